@@ -1,0 +1,381 @@
+"""ORACLE (test infrastructure, never shipped or measured as the product).
+
+Closed-form CPU restatement (numpy fp64) of energy AND functional derivative for every hot-path
+term of SURVEY.md §8a -- i.e. the algorithm the HIP engine implements (shared spectra, minimal FFT
+count, analytic potentials) rather than the reference's autograd.  The formulas follow the
+reference's own analytic potentials in tests/tools_for_tests.py:11-207 and, for WGC99, the closed
+form derived in SURVEY.md §8a-8 from functionals.py:941-985.
+
+Parity status: PINNED -- tests/test_oracle_golden.py checks E and dE/dn of every term here against
+the fixtures produced by the reference itself (tests/golden/make_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import numpy as np
+
+PI = math.pi
+C_TF = 0.3 * (3 * PI * PI) ** (2 / 3)
+C_X = -(3 / 4) * (3 / PI) ** (1 / 3)
+WGC_ALPHA = (5 + math.sqrt(5)) / 6
+WGC_BETA = (5 - math.sqrt(5)) / 6
+
+
+def int_freqs(n, half=False):
+    """Integer frequencies; Nyquist positive on full axes (functional_tools.py:152-155)."""
+    if half:
+        return np.arange(n // 2 + 1, dtype=np.float64)
+    i = np.arange(n)
+    return np.where(i <= n // 2, i, i - n).astype(np.float64)
+
+
+def recip(box, shape):
+    """kx, ky, kz, k^2 on the half grid (functional_tools.py:135-162)."""
+    b = 2 * PI * np.linalg.inv(box.T)
+    ja, jb, jc = np.meshgrid(int_freqs(shape[0]), int_freqs(shape[1]), int_freqs(shape[2], True), indexing='ij')
+    k = [ja * b[0, c] + jb * b[1, c] + jc * b[2, c] for c in range(3)]
+    return k[0], k[1], k[2], k[0] ** 2 + k[1] ** 2 + k[2] ** 2
+
+
+class Grid:
+    """Cell + grid; caches the reciprocal arrays (the engine's 'set_cell')."""
+
+    def __init__(self, box, shape):
+        self.box = np.asarray(box, dtype=np.float64)
+        self.shape = tuple(shape)
+        self.vol = abs(np.linalg.det(self.box))
+        self.npts = int(np.prod(self.shape))
+        self.dV = self.vol / self.npts
+        self.kx, self.ky, self.kz, self.k2 = recip(self.box, self.shape)
+
+    def fwd(self, f):
+        return np.fft.rfftn(f)
+
+    def inv(self, fk):
+        return np.fft.irfftn(fk, s=self.shape, axes=(0, 1, 2))
+
+    def integral(self, e):
+        return float(np.mean(e) * self.vol)
+
+
+# ----------------------------------------------------------------------------- WGC99 kernel
+def wgc_coeffs(nt=100):
+    """Series coefficients A_i, B_i (functionals.py:817-843)."""
+    a = np.zeros(nt + 1)
+    a[0] = 3.0
+    for idx in range(1, nt + 1):
+        i = idx - 1
+        a[idx] = sum(-3.0 * a[j + 1] / (4 * (i - j + 1) ** 2 - 1) for j in range(-1, i))
+    A = np.concatenate([[a[1] - 1.0], a[2:]])
+    b = np.zeros(nt)
+    b[0] = 1.0
+    for i in range(1, nt):
+        b[i] = sum(b[j] / (4 * (i - j) ** 2 - 1) for j in range(i))
+    B = np.concatenate([[0.0, b[1] - 3.0], b[2:]])
+    return A, B
+
+
+def wgc_kernel(eta, alpha=WGC_ALPHA, beta=WGC_BETA, gamma=2.7, nt=100):
+    """w, w', w'' at the given eta values (functionals.py:845-939), Horner form."""
+    eta = np.asarray(eta, dtype=np.float64)
+    u = 3 * (alpha + beta) - gamma / 2
+    v = u * u - 36 * alpha * beta
+    A, B = wgc_coeffs(nt)
+    i = np.arange(nt, dtype=np.float64)
+    ca = A / ((u + 2 * i) ** 2 - v)
+    cb = B / ((u - 2 * i) ** 2 - v)
+    Sd = np.sum(ca - cb)
+    Ss = -2 * np.sum(i * (ca + cb))
+    sgn = np.sign(u)
+    if v > 0:
+        rv = math.sqrt(v)
+        c1, c2 = sgn * ((rv - u) * Sd + Ss), sgn * ((rv + u) * Sd - Ss) / (2 * rv)
+    elif v == 0:
+        c1, c2 = sgn * Sd, sgn * (Ss - u * Sd)
+    else:
+        c1, c2 = sgn * Sd, sgn * (Ss - u * Sd) / math.sqrt(-v)
+    inner = eta <= 1
+    on = inner if u >= 0 else ~inner
+    C1, C2 = np.where(on, c1, 0.0), np.where(on, c2, 0.0)
+    nz = eta != 0
+    e = np.where(nz, eta, 1.0)
+    le = np.log(e)
+    if v > 0:
+        x, y = u + math.sqrt(v), u - math.sqrt(v)
+        H0 = C1 * e ** x + C2 * e ** y
+        H1 = C1 * x * e ** (x - 1) + C2 * y * e ** (y - 1)
+        H2 = C1 * x * (x - 1) * e ** (x - 2) + C2 * y * (y - 1) * e ** (y - 2)
+    elif v == 0:
+        H0 = e ** u * (C2 * le + C1)
+        H1 = C2 * e ** (u - 1) * (1 + u * le) + C1 * u * e ** (u - 1)
+        H2 = C2 * ((u - 1) * e ** (u - 2) * (1 + u * le) + e ** (u - 2)) + C1 * u * (u - 1) * e ** (u - 2)
+    else:
+        rv = math.sqrt(-v)
+        tc, ts = np.cos(rv * le), np.sin(rv * le)
+        p, q = u * tc - rv * ts, u * ts + rv * tc
+        H0 = e ** u * (C1 * tc + C2 * ts)
+        H1 = e ** (u - 1) * (C1 * p + C2 * q)
+        H2 = e ** (u - 2) * ((u - 1) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q))
+    # particular solution: polynomial in eta^2 (inside) / eta^-2 (outside)
+    x = np.where(inner, e * e, 1.0 / (e * e))
+    c0 = np.where(inner[..., None], cb, ca)
+    c1_ = np.where(inner[..., None], 2 * i * cb, -2 * i * ca)
+    c2_ = np.where(inner[..., None], 2 * i * (2 * i - 1) * cb, 2 * i * (2 * i + 1) * ca)
+    P0 = np.zeros(eta.shape)
+    P1 = np.zeros(eta.shape)
+    P2 = np.zeros(eta.shape)
+    for j in range(nt - 1, -1, -1):
+        P0 = P0 * x + c0[..., j]
+        P1 = P1 * x + c1_[..., j]
+        P2 = P2 * x + c2_[..., j]
+    P1 = P1 / e
+    P2 = P2 / (e * e)
+    w0 = np.where(nz, H0 + P0, 0.0)
+    w1 = np.where(nz, H1 + P1, 0.0)
+    w2 = np.where(nz, H2 + P2, 0.0)
+    return w0, w1, w2
+
+
+# ----------------------------------------------------------------------------- per-term closed forms
+def lindhard_kernel_shape(eta):
+    """1/G^-1(eta) - 3 eta^2 - 1 with the eta in {0,1} limits (functionals.py:617-628,648)."""
+    with np.errstate(divide='ignore', invalid='ignore'):
+        g = 0.5 + ((1 - eta ** 2) / (4 * eta)) * np.log(np.abs((1 + eta) / (1 - eta)))
+    g = np.where(eta == 0.0, 1.0, np.where(eta == 1.0, 0.5, g))
+    return 1.0 / g - 3 * eta ** 2 - 1
+
+
+def _pw92(rs):
+    A, a1 = 0.0310907, 0.2137
+    b1, b2, b3, b4 = 7.5957, 3.5876, 1.6382, 0.49294
+    zeta = 2 * A * (b1 * np.sqrt(rs) + b2 * rs + b3 * rs ** 1.5 + b4 * rs * rs)
+    eps = -2 * A * (1 + a1 * rs) * np.log(1 + 1 / zeta)
+    dzeta = 2 * A * (0.5 * b1 / np.sqrt(rs) + b2 + 1.5 * b3 * np.sqrt(rs) + 2 * b4 * rs)
+    deps_drs = -2 * A * a1 * np.log(1 + 1 / zeta) + 2 * A * (1 + a1 * rs) * dzeta / (zeta * (zeta + 1))
+    return eps, deps_drs
+
+
+class Evaluator:
+    """Evaluates a set of terms on one density with shared spectra (engine algorithm)."""
+
+    def __init__(self, grid, wgc_params=(WGC_ALPHA, WGC_BETA, 2.7, 1.0)):
+        self.g = grid
+        self.wgc_params = wgc_params
+        self._wgc_cache = None
+
+    # -- helpers
+    def _wt_kernel(self, nbar, alpha, beta):
+        kf = (3 * PI * PI * nbar) ** (1 / 3)
+        eta = np.where(self.g.k2 != 0, np.sqrt(self.g.k2) / (2 * kf), 0.0)
+        return 5 / (9 * alpha * beta * nbar ** (alpha + beta - 5 / 3)) * lindhard_kernel_shape(eta)
+
+    def _wgc_tables(self, nel_rounded):
+        al, be, ga, ka = self.wgc_params
+        if self._wgc_cache is not None and self._wgc_cache[0] == nel_rounded:
+            return self._wgc_cache[1]
+        nref = ka * nel_rounded / self.g.vol
+        kf = (3 * PI * PI * nref) ** (1 / 3)
+        eta = np.where(self.g.k2 != 0, np.sqrt(self.g.k2) / (2 * kf), 0.0)
+        w0, w1, w2 = wgc_kernel(eta, al, be, ga)
+        pref = 20 * nref ** (5 / 3 - al - be)
+        w0, w1, w2 = pref * w0, pref * w1, pref * w2
+        K1 = -eta * w1 / (6 * nref)
+        K2 = (eta ** 2 * w2 + (7 - ga) * eta * w1) / (36 * nref ** 2)
+        K3 = (eta ** 2 * w2 + (1 + ga) * eta * w1) / (36 * nref ** 2)
+        tabs = (nref, w0, K1, K2, K3)
+        self._wgc_cache = (nel_rounded, tabs)
+        return tabs
+
+    # -- terms: each returns (E, v)
+    def ion_electron(self, n, vext):
+        return self.g.integral(n * vext), vext.copy()
+
+    def hartree(self, n, nk=None):
+        g = self.g
+        nk = g.fwd(n) if nk is None else nk
+        with np.errstate(divide='ignore'):
+            green = np.where(g.k2 != 0, 4 * PI / g.k2, 0.0)
+        vh = g.inv(nk * green)
+        return 0.5 * g.integral(n * vh), vh
+
+    def tf(self, n):
+        return self.g.integral(C_TF * n ** (5 / 3)), (5 / 3) * C_TF * n ** (2 / 3)
+
+    def vw(self, n):
+        g = self.g
+        s = np.sqrt(n)
+        L = g.inv(-g.k2 * g.fwd(s))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            v = np.where(n != 0, -0.5 * L / s, 0.0)
+        return g.integral(-0.5 * s * L), v
+
+    def wt_nl(self, n, alpha=5 / 6, beta=5 / 6):
+        g = self.g
+        nbar = float(np.mean(n) * g.vol) / g.vol
+        K = self._wt_kernel(nbar, alpha, beta)
+        conv_b = g.inv(K * g.fwd(n ** beta))
+        conv_a = conv_b if alpha == beta else g.inv(K * g.fwd(n ** alpha))
+        E = C_TF * g.integral((n ** alpha - nbar ** alpha) * conv_b)
+        v = C_TF * (alpha * n ** (alpha - 1) * conv_b + beta * n ** (beta - 1) * conv_a)
+        return E, v
+
+    def wgc99_nl(self, n):
+        """SURVEY §8a-8 closed form: 6 r2c + 6 c2r for E and potential."""
+        g = self.g
+        al, be, ga, ka = self.wgc_params
+        nel = round(float(np.mean(n) * g.vol))
+        nref, w0, K1, K2, K3 = self._wgc_tables(nel)
+        th = n - nref
+        A = n ** be
+        P = n ** al
+        Ak, Bk, Ck = g.fwd(A), g.fwd(A * th), g.fwd(A * th * th / 2)
+        Pk, Qk, Sk = g.fwd(P), g.fwd(P * th), g.fwd(P * th * th / 2)
+        u0 = g.inv(w0 * Ak + K1 * Bk + K2 * Ck)
+        u1 = g.inv(K1 * Ak + K3 * Bk)
+        u2 = g.inv(K2 * Ak)
+        conv = u0 + th * u1 + th * th / 2 * u2
+        gA = g.inv(w0 * Pk + K1 * Qk + K2 * Sk)
+        gB = g.inv(K1 * Pk + K3 * Qk)
+        gC = g.inv(K2 * Pk)
+        dA = be * n ** (be - 1)
+        v = C_TF * (al * n ** (al - 1) * conv + P * (u1 + th * u2)
+                    + gA * dA + gB * (dA * th + A) + gC * (dA * th * th / 2 + A * th))
+        return C_TF * g.integral(P * conv), v
+
+    def lda_x(self, n):
+        return self.g.integral(C_X * n ** (4 / 3)), (4 / 3) * C_X * n ** (1 / 3)
+
+    def pz_c(self, n):
+        gm, b1, b2 = -0.1423, 1.0529, 0.3334
+        A, B, C, D = 0.0311, -0.048, 0.002, -0.0116
+        rs = (3 / 4 / PI / n) ** (1 / 3)
+        lo = rs < 1
+        lr = np.log(rs)
+        den = 1 + b1 * np.sqrt(rs) + b2 * rs
+        eps = np.where(lo, A * lr + B + C * rs * lr + D * rs, gm / den)
+        v = np.where(lo, lr * (A + 2 / 3 * C * rs) + (B - A / 3) + rs / 3 * (2 * D - C),
+                     gm * (1 + 7 / 6 * b1 * np.sqrt(rs) + 4 / 3 * b2 * rs) / den ** 2)
+        return self.g.integral(eps * n), v
+
+    def pw_c(self, n):
+        rs = (3 / 4 / PI / n) ** (1 / 3)
+        eps, deps_drs = _pw92(rs)
+        return self.g.integral(eps * n), eps - rs / 3 * deps_drs
+
+    def chachiyo_c(self, n):
+        a, b = (math.log(2) - 1) / 2 / PI / PI, 20.4562557
+        rs = (3 / 4 / PI / n) ** (1 / 3)
+        arg = 1 + b / rs + b / rs ** 2
+        eps = a * np.log(arg)
+        deps_drs = a / arg * (-b / rs ** 2 - 2 * b / rs ** 3)
+        return self.g.integral(eps * n), eps - rs / 3 * deps_drs
+
+    def _gradient(self, nk):
+        g = self.g
+        return [g.inv(1j * k * nk) for k in (g.kx, g.ky, g.kz)]
+
+    def _divergence(self, flux):
+        g = self.g
+        acc = 0
+        for k, f in zip((g.kx, g.ky, g.kz), flux):
+            acc = acc + 1j * k * g.fwd(f)
+        return g.inv(acc)
+
+    def pbe_pointwise(self, n, gn2, do_x=True, do_c=True):
+        """energy density f, df/dn and df/d|grad n|^2 of PBE x (+) c
+        (functionals.py:1597-1618; tests/tools_for_tests.py:155-207)."""
+        f = np.zeros_like(n)
+        dfdn = np.zeros_like(n)
+        dfdg = np.zeros_like(n)
+        if do_x:
+            kappa, mu = 0.804, 0.066725 * PI * PI / 3
+            ex = C_X * n ** (1 / 3)                       # per-particle LDA exchange
+            s2 = 0.25 * (3 * PI * PI) ** (-2 / 3) * gn2 / n ** (8 / 3)
+            den = 1 + mu / kappa * s2
+            Fx = 1 + kappa - kappa / den
+            dF = mu / den ** 2
+            f += Fx * ex * n
+            dfdn += Fx * (4 / 3) * ex + dF * (-(8 / 3) * s2 / n) * ex * n
+            dfdg += dF * 0.25 * (3 * PI * PI) ** (-2 / 3) * n ** (-8 / 3) * ex * n
+        if do_c:
+            beta, gam = 0.066725, (1 - math.log(2)) / PI / PI
+            rs = (3 / 4 / PI / n) ** (1 / 3)
+            eps, deps_drs = _pw92(rs)
+            deps_dn = -rs / (3 * n) * deps_drs
+            ex_ = np.exp(-eps / gam)
+            A = beta / gam / (ex_ - 1 + 1e-30)
+            dAdn = A * A / beta * ex_ * deps_dn
+            ct = (1 / 16) * (PI / 3) ** (1 / 3)
+            n73 = n ** (7 / 3) + 1e-30
+            t2 = ct * gn2 / n73
+            dt2dn = -(7 / 3) * ct * gn2 * n ** (4 / 3) / n73 ** 2
+            dt2dg = ct / n73
+            At2 = A * t2
+            num, den = 1 + At2, 1 + At2 + At2 * At2
+            arg = 1 + beta / gam * t2 * num / den
+            H = gam * np.log(arg)
+            num2 = 1 + 2 * At2
+            # d/dX of [t2*num/den] with X in {n, g}: chain through t2 and A
+            def dQ(dt2, dA):
+                return (dt2 * num2 + dA * t2 * t2) / den - t2 * num / den ** 2 * (dt2 * A + dA * t2) * num2
+            dHdn = beta / arg * dQ(dt2dn, dAdn)
+            dHdg = beta / arg * dQ(dt2dg, 0.0)
+            f += (eps + H) * n
+            dfdn += eps + H + n * (deps_dn + dHdn)
+            dfdg += n * dHdg
+        return f, dfdn, dfdg
+
+    def pbe(self, n, nk=None, do_x=True, do_c=True):
+        g = self.g
+        nk = g.fwd(n) if nk is None else nk
+        grad = self._gradient(nk)
+        gn2 = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
+        f, dfdn, dfdg = self.pbe_pointwise(n, gn2, do_x, do_c)
+        v = dfdn - 2 * self._divergence([dfdg * c for c in grad])
+        return g.integral(f), v
+
+    # -- dispatcher over golden-case names
+    def term(self, name, n, vext=None):
+        s5 = math.sqrt(5)
+        if name == 'ion_electron':
+            return self.ion_electron(n, vext)
+        if name in ('hartree', 'tf', 'vw', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c'):
+            return getattr(self, name)(n)
+        if name == 'wt_nl':
+            return self.wt_nl(n)
+        fam = {'wt': (5 / 6, 5 / 6), 'perrot': (1.0, 1.0), 'sm': (0.5, 0.5), 'wgc98': ((5 + s5) / 6, (5 - s5) / 6)}
+        if name in fam or name == 'wgc99':
+            E1, v1 = self.tf(n)
+            E2, v2 = self.vw(n)
+            E3, v3 = self.wgc99_nl(n) if name == 'wgc99' else self.wt_nl(n, *fam[name])
+            return E1 + E2 + E3, v1 + v2 + v3
+        if name == 'pbe_x':
+            return self.pbe(n, do_c=False)
+        if name == 'pbe_c':
+            return self.pbe(n, do_x=False)
+        if name == 'pbe':
+            return self.pbe(n)
+        raise KeyError(name)
+
+    def terms(self, names, n, vext=None):
+        """Sum of terms -> (E_total, dict of E per term, v_total)."""
+        Es, v = {}, np.zeros_like(n)
+        names = list(names)
+        if 'pbe_x' in names and 'pbe_c' in names:          # one shared gradient/divergence
+            names = [x for x in names if x not in ('pbe_x', 'pbe_c')] + ['pbe']
+        for nm in names:
+            E, vt = self.term(nm, n, vext)
+            Es[nm] = E
+            v = v + vt
+        return sum(Es.values()), Es, v
+
+    def closure(self, names, chi, n_elec, vext=None):
+        """chi -> E, chi.grad (system.py:830-838 / explicit form :842-853)."""
+        g = self.g
+        ntilde = float(np.mean(chi * chi) * g.vol)
+        c = n_elec / ntilde
+        n = c * chi * chi
+        E, Es, v = self.terms(names, n, vext)
+        mu = float(np.mean(v * n) * g.vol / n_elec)
+        return E, c * 2 * chi * (v - mu) * g.dV, mu

@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the *reference* (profess-ad) in the build container.
+
+Run from the repo root (needs /root/reference, which exists only here, never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--big] [--cfg1] [--huge]
+
+The reference is imported read-only from /root/reference/src with in-memory stubs for its
+three absent third-party modules (xitorch.integrate / xitorch.optimize / torch_nl), none of
+which is on the hot path.  Only OUTPUTS of the reference are written here
+(fixtures = data); no reference source text is copied.
+
+Fixtures written to tests/golden/:
+  wavevecs.npz            reciprocal-grid arrays on 4^3/5^3/6^3 (+4x5x6) triclinic
+  terms_<case>.npz        per-term E and dE/dn on the small grids
+  fused_<case>.npz        cfg1/cfg2/cfg3 sums (E, dE/dn) and closure outputs (E, chi.grad)
+  wgc99_kernel_g16r.npz   WGC99 w0,w1,w2 on the 16^3 eta grid
+  big_scalars.json        (--big)  64^3/128^3 scalars: E per cfg, potential probe statistics
+  cfg1_fccAl_32.npz       (--cfg1) converged config-1 density, v_ext, E, iteration count
+  huge_scalars.json       (--huge) 256^3 cfg3 scalars (needs ~16 GB RSS, minutes)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+
+def _import_reference():
+    def _absent(*a, **k):
+        raise NotImplementedError('stubbed third-party dependency (not on the hot path)')
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    stub('xitorch')
+    stub('xitorch.integrate', solve_ivp=_absent)
+    stub('xitorch.optimize', minimize=_absent)
+    stub('torch_nl', compute_neighborlist=_absent)
+    sys.path.insert(0, '/root/reference/src')
+    import professad.functionals as F
+    import professad.functional_tools as T
+    return F, T
+
+
+import torch  # noqa: E402
+import cases  # noqa: E402
+
+F, T = _import_reference()
+DT = torch.double
+
+
+def t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=DT)
+
+
+def reference_terms(vext_t):
+    """name -> callable(box, den) built from the reference's own functionals."""
+    wgc99 = F.WangGovindCarter99()
+    s5 = np.sqrt(5)
+    return {
+        'ion_electron': lambda b, d: F.IonElectron(b, d, vext_t),
+        'hartree': F.Hartree,
+        'tf': F.ThomasFermi,
+        'vw': F.Weizsaecker,
+        'wt_nl': lambda b, d: F.non_local_KEF(b, d, 5 / 6, 5 / 6),
+        'wt': F.WangTeter,
+        'perrot': F.Perrot,
+        'sm': F.SmargiassiMadden,
+        'wgc98': F.WangGovindCarter98,
+        'wgc99': wgc99,
+        'lda_x': F.lda_exchange,
+        'pz_c': F.perdew_zunger_correlation,
+        'pw_c': F.perdew_wang_correlation,
+        'chachiyo_c': F.chachiyo_correlation,
+        'pbe_x': F.pbe_exchange,
+        'pbe_c': F.pbe_correlation,
+    }, wgc99
+
+
+def e_and_pot(f, box, den):
+    E = float(f(box, den.clone()).item())
+    v = T.get_functional_derivative(box, den.clone(), f)
+    return E, v.detach().numpy()
+
+
+def closure_outputs(terms, names, box, chi, n_elec):
+    """E and chi.grad exactly as the reference's optimize_density closure produces them
+    (system.py:830-838), composed from reference functionals."""
+    chi = chi.clone().requires_grad_()
+    vol = torch.abs(torch.linalg.det(box))
+    N_tilde = torch.mean(chi.pow(2)) * vol
+    den = (n_elec / N_tilde) * chi.pow(2)
+    E = torch.zeros((1,), dtype=DT)
+    for nm in names:
+        E = E + terms[nm](box, den)
+    E.backward()
+    return float(E.item()), chi.grad.detach().numpy()
+
+
+def gen_wavevecs():
+    out = {}
+    for shape in [(4, 4, 4), (5, 5, 5), (6, 6, 6), (4, 5, 6)]:
+        box = t(cases.make_cell(('tri', 0.3)))
+        kx, ky, kz, k2 = T.wavevecs(box, shape)
+        tag = 'x'.join(map(str, shape))
+        out[tag + '_kx'], out[tag + '_ky'], out[tag + '_kz'], out[tag + '_k2'] = \
+            kx.numpy(), ky.numpy(), kz.numpy(), k2.numpy()
+    np.savez_compressed(os.path.join(HERE, 'wavevecs.npz'), **out)
+    print('wavevecs.npz')
+
+
+def gen_terms(case):
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    terms, wgc99 = reference_terms(t(vext))
+    out = {'input_checksum': np.float64(cases.checksum(den, vext, chi)), 'n_elec': np.float64(n_elec)}
+    vol = abs(np.linalg.det(box))
+    frac = (den.mean() * vol) % 1.0
+    assert abs(frac - 0.5) > 0.05, 'density mean too close to a WGC99 rounding edge'
+    for nm in cases.SINGLE_TERMS:
+        E, v = e_and_pot(terms[nm], t(box), t(den))
+        out['E_' + nm] = np.float64(E)
+        out['v_' + nm] = v
+    np.savez_compressed(os.path.join(HERE, 'terms_%s.npz' % case), **out)
+    if case == 'g16r':
+        np.savez_compressed(os.path.join(HERE, 'wgc99_kernel_g16r.npz'),
+                            eta=wgc99.eta.detach().numpy(), kernel=wgc99.kernel.detach().numpy())
+    print('terms_%s.npz' % case)
+
+
+def gen_fused(case):
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    terms, _ = reference_terms(t(vext))
+    out = {'input_checksum': np.float64(cases.checksum(den, vext, chi)), 'n_elec': np.float64(n_elec)}
+    for cfg, names in cases.CONFIGS.items():
+        def fsum(b, d, names=names):
+            E = torch.zeros((1,), dtype=DT)
+            for nm in names:
+                E = E + terms[nm](b, d)
+            return E
+        E, v = e_and_pot(fsum, t(box), t(den))
+        out['E_' + cfg], out['v_' + cfg] = np.float64(E), v
+        Ec, g = closure_outputs(terms, names, t(box), t(chi), n_elec)
+        out['Ec_' + cfg], out['g_' + cfg] = np.float64(Ec), g
+        for nm in names:   # per-term energies of the fused set (potentials only as the sum)
+            out['E_%s_%s' % (cfg, nm)] = np.float64(terms[nm](t(box), t(den)).item())
+    np.savez_compressed(os.path.join(HERE, 'fused_%s.npz' % case), **out)
+    print('fused_%s.npz' % case)
+
+
+def gen_big(sizes, fname, cfgs):
+    res = {}
+    for n in sizes:
+        shape = (n, n, n)
+        box = cases.synth.cubic_cell(n)
+        den = cases.synth.random_density(shape, seed=1234)
+        vext = cases.synth.random_potential(shape, seed=77)
+        terms, _ = reference_terms(t(vext))
+        for cfg in cfgs:
+            names = cases.CONFIGS[cfg]
+
+            def fsum(b, d, names=names):
+                E = torch.zeros((1,), dtype=DT)
+                for nm in names:
+                    E = E + terms[nm](b, d)
+                return E
+            t0 = time.time()
+            E, v = e_and_pot(fsum, t(box), t(den))
+            dt = time.time() - t0
+            per = {nm: float(terms[nm](t(box), t(den)).item()) for nm in names}
+            res['%s_%d' % (cfg, n)] = dict(E=E, E_terms=per, pot=cases.probe_stats(v),
+                                           input_checksum=cases.checksum(den[:8, :8, :8]),
+                                           seconds_first_call=dt)
+            print(cfg, n, E, '%.1fs' % dt, flush=True)
+    with open(os.path.join(HERE, fname), 'w') as fh:
+        json.dump(res, fh, indent=1)
+
+
+def gen_cfg1():
+    """Converged config-1 state (fcc-Al conventional cell, 32^3, IonElectron+Hartree+TF+vW+PZ)
+    through the reference's own System.optimize_density (system.py:774-908)."""
+    os.chdir('/root/reference/tests')
+    from professad.system import System
+    from professad.crystal_tools import get_cell
+    terms = [F.IonElectron, F.Hartree, F.ThomasFermi, F.Weizsaecker, F.PerdewZunger]
+    box_vecs, frac = get_cell('fcc-c', vol_per_atom=16.8, coord_type='fractional')
+    ions = [['Al', 'potentials/al.gga.recpot', frac]]
+    system = System(box_vecs, (32, 32, 32), ions, terms, units='a', coord_type='fractional')
+    # count outer iterations by wrapping energy evaluation printing
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        system.optimize_density(ntol=1e-7, n_verbose=True)
+    log = buf.getvalue()
+    iters = [ln for ln in log.splitlines() if 'converged in' in ln]
+    den = system.density().detach().numpy()
+    vext = system.ionic_potential().detach().numpy()
+    box_b = system.lattice_vectors('b').detach().numpy()
+    np.savez_compressed(os.path.join(HERE, 'cfg1_fccAl_32.npz'),
+                        box=box_b, den=den, vext=vext,
+                        E_Ha=np.float64(system.energy('Ha')),
+                        n_elec=np.float64(system.electron_count()),
+                        dEdchi_max=np.float64(system.check_density_convergence('dEdchi')),
+                        log=np.array(log))
+    print('cfg1_fccAl_32.npz', system.energy('Ha'), iters)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--big', action='store_true')
+    ap.add_argument('--cfg1', action='store_true')
+    ap.add_argument('--huge', action='store_true')
+    ap.add_argument('--small', action='store_true')
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    if a.small or not (a.big or a.cfg1 or a.huge):
+        gen_wavevecs()
+        for c in cases.PER_TERM_CASES:
+            gen_terms(c)
+        for c in cases.FUSED_CASES:
+            gen_fused(c)
+    if a.big:
+        gen_big([64, 128], 'big_scalars.json', ['cfg2', 'cfg3'])
+    if a.cfg1:
+        gen_cfg1()
+    if a.huge:
+        gen_big([256], 'huge_scalars.json', ['cfg3'])

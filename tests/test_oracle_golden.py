@@ -1,0 +1,86 @@
+"""Pin the oracle: both CPU restatements must reproduce the reference's own outputs
+(fixtures made by tests/golden/make_golden.py running profess-ad itself)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import closed_form as cf
+from oracle import refpath as rp
+
+GOLDEN = os.path.dirname(os.path.abspath(cases.__file__))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def test_recip_grid_matches_reference_wavevecs():
+    gold = load('wavevecs.npz')
+    box = cases.make_cell(('tri', 0.3))
+    for shape in [(4, 4, 4), (5, 5, 5), (6, 6, 6), (4, 5, 6)]:
+        tag = 'x'.join(map(str, shape))
+        got_np = cf.recip(box, shape)
+        got_t = rp.recip_grid(torch.as_tensor(box), shape)
+        for comp, a, b in zip(('kx', 'ky', 'kz', 'k2'), got_np, got_t):
+            ref = gold['%s_%s' % (tag, comp)]
+            assert relerr(a, ref) < 1e-14
+            assert relerr(b.numpy(), ref) < 1e-14
+
+
+def test_wgc99_kernel_matches_reference():
+    gold = load('wgc99_kernel_g16r.npz')
+    w0, w1, w2 = cf.wgc_kernel(gold['eta'])
+    for got, ref in zip((w0, w1, w2), gold['kernel']):
+        assert relerr(got, ref) < 1e-12
+    k = rp.Wgc99().build_kernel(torch.as_tensor(gold['eta'])).numpy()
+    assert relerr(k, gold['kernel']) < 1e-13
+
+
+@pytest.mark.parametrize('case', cases.PER_TERM_CASES)
+def test_per_term_energy_and_potential(case):
+    gold = load('terms_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    assert abs(cases.checksum(den, vext, chi) - float(gold['input_checksum'])) < 1e-9
+    ev = cf.Evaluator(cf.Grid(box, den.shape))
+    table = rp.term_table(torch.as_tensor(vext))
+    tb, td = torch.as_tensor(box), torch.as_tensor(den)
+    for nm in cases.SINGLE_TERMS:
+        Eref, vref = float(gold['E_' + nm]), gold['v_' + nm]
+        # closed form
+        E, v = ev.term(nm, den, vext)
+        assert abs(E - Eref) <= 1e-12 * max(1.0, abs(Eref)), (nm, E, Eref)
+        assert relerr(v, vref) < 2e-11, (nm, relerr(v, vref))
+        # op-for-op autograd restatement
+        E2, v2 = rp.energy_and_potential(tb, td, table[nm])
+        assert abs(float(E2) - Eref) <= 1e-13 * max(1.0, abs(Eref)), (nm, float(E2), Eref)
+        assert relerr(v2.numpy(), vref) < 1e-12, (nm, relerr(v2.numpy(), vref))
+
+
+@pytest.mark.parametrize('case', cases.FUSED_CASES)
+def test_fused_configs_and_closure(case):
+    gold = load('fused_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    assert abs(cases.checksum(den, vext, chi) - float(gold['input_checksum'])) < 1e-9
+    assert n_elec == float(gold['n_elec'])
+    ev = cf.Evaluator(cf.Grid(box, den.shape))
+    for cfg, names in cases.CONFIGS.items():
+        E, Es, v = ev.terms(names, den, vext)
+        Eref = float(gold['E_' + cfg])
+        assert abs(E - Eref) <= 1e-12 * max(1.0, abs(Eref))
+        assert relerr(v, gold['v_' + cfg]) < 2e-11
+        Ec, g, mu = ev.closure(names, chi, n_elec, vext)
+        assert abs(Ec - float(gold['Ec_' + cfg])) <= 1e-12 * max(1.0, abs(Ec))
+        assert relerr(g, gold['g_' + cfg]) < 2e-11
+    if case in ('g16r', 'g17r'):
+        table = rp.term_table(torch.as_tensor(vext))
+        for cfg, names in cases.CONFIGS.items():
+            Ec, g = rp.closure(torch.as_tensor(box), torch.as_tensor(chi), n_elec, [table[n] for n in names])
+            assert abs(float(Ec) - float(gold['Ec_' + cfg])) <= 1e-13 * max(1.0, abs(float(Ec)))
+            assert relerr(g.numpy(), gold['g_' + cfg]) < 1e-12
