@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- energy+gradient evaluations/s of the OFDFT hot path on MI355X.
+
+A "step" is one density-optimisation closure evaluation chi -> (E, dE/dchi) (reference
+system.py:830-838) on the BASELINE.json workload: 256^3 grid, fp64, IonElectron + Hartree +
+WGC99(+TF+vW) + PBE, synthetic density (the converged fcc-Al 32^3 fixture tiled 8^3 times plus a
+seeded low-|k| perturbation, SURVEY.md §8d option A).  Inputs are resident in HBM before the timed
+region.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed in a separate profiling pass) and `cpu_baseline` (the oracle's op-for-op torch-CPU
+restatement of the reference path, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from professad_amd import synth  # noqa: E402
+from professad_amd.engine import Engine  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c']
+CFG2 = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c']
+
+
+def algorithmic_bytes(n, cfg):
+    """SURVEY.md §8d byte model: n_fft (R + 5C) + n_pw R."""
+    R = 8.0 * n ** 3
+    Cc = 16.0 * n * n * (n // 2 + 1)
+    n_fft, n_pw = (23, 25) if cfg == 'cfg3' else (6, 10)
+    return n_fft * (R + 5 * Cc) + n_pw * R, R, Cc
+
+
+def kernel_alg_bytes(name, n):
+    """Algorithmic bytes moved by ONE launch of a kernel class (what it must read + write once)."""
+    R = 8.0 * n ** 3
+    Cc = 16.0 * n * n * (n // 2 + 1)
+    Cmain = 16.0 * n * n * (n // 2)
+    Cnyq = Cc - Cmain
+    table = {
+        'cpass_x': 2 * Cmain, 'cpass_y': 2 * Cmain, 'cpass_x_nyq': 2 * Cnyq, 'cpass_y_nyq': 2 * Cnyq,
+        'zfwd': R + Cc, 'zinv': R + Cc,
+    }
+    return table.get(name)
+
+
+def make_inputs(n, rank=0):
+    """chi, v_ext, box, N_e for an n^3 grid (n multiple of 32)."""
+    fx = os.path.join(ROOT, 'tests', 'golden', 'cfg1_fccAl_32.npz')
+    if os.path.exists(fx) and n % 32 == 0:
+        d = np.load(fx)
+        r = n // 32
+        box = d['box'] * r
+        n_elec = float(d['n_elec']) * r ** 3
+        den = synth.tile_periodic(d['den'], n)
+        vext = synth.tile_periodic(d['vext'], n)
+        den = synth.perturbed(den, box, n_elec, seed=20240601 + rank)
+        src = 'converged fcc-Al 32^3 fixture tiled %d^3 + 1e-3 low-|k| perturbation' % r
+    else:
+        box = synth.cubic_cell(n)
+        den = synth.random_density((n, n, n), seed=1234 + rank)
+        vext = synth.random_potential((n, n, n), seed=77)
+        n_elec = float(round(den.mean() * abs(np.linalg.det(box))))
+        src = 'n0(1+0.2U) random density'
+    return box, np.sqrt(den), vext, n_elec, src
+
+
+def cpu_baseline(sample_n, budget_s=30.0):
+    """The oracle's op-for-op restatement of the reference path (autograd through torch.fft on the host
+    cores), timed on a bounded sample of the same workload."""
+    from oracle import refpath as rp
+    torch.set_num_threads(os.cpu_count() or 1)
+    box, chi, vext, n_elec, _ = make_inputs(sample_n)
+    tb, tc, tv = torch.as_tensor(box), torch.as_tensor(chi), torch.as_tensor(vext)
+    table = rp.term_table(tv)
+    fns = [table[k] for k in ('ion_electron', 'hartree', 'wgc99', 'pbe_x', 'pbe_c')]
+    t0 = time.perf_counter()
+    rp.closure(tb, tc, n_elec, fns)                    # warm-up: includes WGC99 kernel generation
+    first = time.perf_counter() - t0
+    times = []
+    while len(times) < 5 and (sum(times) + first) < budget_s:
+        t0 = time.perf_counter()
+        rp.closure(tb, tc, n_elec, fns)
+        times.append(time.perf_counter() - t0)
+    best = min(times) if times else first
+    return best, first, len(times), torch.get_num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--grid', type=int, default=256)
+    ap.add_argument('--cfg', default='cfg3', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-grid', type=int, default=128)
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    n = a.grid
+    names = CFG3 if a.cfg == 'cfg3' else CFG2
+    box, chi_h, vext_h, n_elec, src = make_inputs(n, rank)
+    chi = torch.as_tensor(chi_h, dtype=torch.double, device=device)
+    vext = torch.as_tensor(vext_h, dtype=torch.double, device=device)
+    eng = Engine((n, n, n), device).set_cell(torch.as_tensor(box)).set_terms(names)
+
+    def step():
+        return eng.energy_grad_chi(chi, n_elec, vext)
+
+    for _ in range(a.warmup):
+        E, mu, g = step()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        E, mu, g = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.double, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / a.steps * 1e3
+    evals_per_s = world * a.steps / dt            # replicas: every rank evaluates its own n^3 system
+    n_fft = int(eng.query(0))
+    n_launch = int(eng.query(4))
+
+    # ---- per-kernel HIP-event profile (separate pass, not inside the timed region)
+    eng.set_profiling(True)
+    nprof = 3
+    for _ in range(nprof):
+        step()
+    prof = eng.profile()
+    eng.set_profiling(False)
+    tot_ms = sum(v[0] for v in prof.values()) or 1.0
+    dom = max((k for k in prof if kernel_alg_bytes(k, n)), key=lambda k: prof[k][0], default=None)
+    roofline = None
+    kernels = {k: {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof,
+                   'share': round(v[0] / tot_ms, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    if dom:
+        avg_ms = prof[dom][0] / prof[dom][1]
+        ach = kernel_alg_bytes(dom, n) / (avg_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n)}
+    alg, R, Cc = algorithmic_bytes(n, a.cfg)
+    eval_gbs = alg * (a.steps / dt) / 1e9          # per GPU
+
+    out = {
+        'metric': 'energy+grad evals/sec', 'value': round(evals_per_s, 3), 'unit': 'evals/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%d^3 grid, fp64, IonElectron+Hartree+WGC99(+TF+vW)+PBE closure chi->(E,dE/dchi)' % n
+                   if a.cfg == 'cfg3' else '%d^3 grid, fp64, IonElectron+Hartree+WT(+TF+vW)+PZ-LDA closure' % n,
+                   'grid': [n, n, n], 'terms': names, 'density': src,
+                   'parallelism': 'single GPU' if world == 1 else 'replicas x%d (one %d^3 system per GPU)' % (world, n)},
+        'roofline': roofline,
+        'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
+                          'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'ffts_executed': n_fft,
+                          'kernel_launches': n_launch, 'device_ms_last_eval': round(eng.query(3), 4)},
+        'kernels': kernels,
+        'energy_Ha': sum(E.values()), 'mu': mu,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        best, first, cnt, cores = cpu_baseline(a.cpu_sample_grid)
+        scale = (a.cpu_sample_grid / n) ** 3
+        out['cpu_baseline'] = {
+            'value': round(scale / best, 5), 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d^3 grid, same terms, best of %d after 1 warm-up (%.2f s/eval; first call %.1f s incl. WGC99 '
+                      'kernel generation); value = measured %d^3 rate x (%d/%d)^3 grid-point scaling to %d^3'
+                      % (a.cpu_sample_grid, cnt, best, first, a.cpu_sample_grid, a.cpu_sample_grid, n, n),
+            'measured_evals_per_s_on_sample': round(1.0 / best, 4)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,119 @@
+/*
+ * ofdft_hip.h -- C ABI of the MI355X-native orbital-free DFT energy/gradient engine.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference (profess-ad) has no FFI: its
+ * plugin points are Python callables.  Each entry point below names the reference interface it
+ * stands behind (paths relative to the reference repo root):
+ *
+ *   ofdft_energy_potential  <->  one or several `terms` callables f(box_vecs, den) -> E evaluated
+ *                                together, plus their functional derivative:
+ *                                System.__compute_energy            src/professad/system.py:759-772
+ *                                get_functional_derivative          src/professad/functional_tools.py:9-31
+ *                                System.functional_derivative       src/professad/system.py:414-447
+ *                                the `potentials=` hook             src/professad/system.py:842-854
+ *   ofdft_energy_grad_chi   <->  the optimize_density closure chi -> (E, chi.grad)
+ *                                                                   src/professad/system.py:830-838
+ *   ofdft_set_cell          <->  wavevecs(box_vecs, shape)          src/professad/functional_tools.py:135-162
+ *   ofdft_set_terms         <->  the `terms=[...]` list of System   src/professad/system.py:35-36,66
+ *   ofdft_rfftn/ofdft_irfftn<->  torch.fft.rfftn / irfftn call sites src/professad/functionals.py:65,71,650,976-981
+ *                                                                   src/professad/functional_tools.py:183,227
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative OFDFT_E* code on failure; nothing throws or
+ *     aborts across the ABI; ofdft_last_error() returns a human-readable message.
+ *   - all grid pointers are DEVICE pointers to C-contiguous arrays owned by the caller
+ *     (real grids [n0][n1][n2]; half spectra [n0][n1][n2/2+1] interleaved re,im); the engine never
+ *     retains them past the call.  Plans, twiddles, kernel tables and workspaces live in the ctx.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Work is enqueued on it and
+ *     the call returns after the scalar results are on the host (one stream sync).
+ *   - a ctx is bound to one device and is not re-entrant.
+ *   - energies are Hartree; lengths bohr; box_vecs rows are the lattice vectors (reference layout).
+ */
+#ifndef OFDFT_HIP_H
+#define OFDFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ofdft_ctx ofdft_ctx;
+
+/* error codes */
+#define OFDFT_OK            0
+#define OFDFT_EINVAL       -1   /* bad argument / shape / unsupported option */
+#define OFDFT_EHIP         -2   /* a HIP runtime call failed */
+#define OFDFT_ESTATE       -3   /* call sequence error (e.g. set_cell not called) */
+#define OFDFT_ENOMEM       -4
+
+/* dtype */
+#define OFDFT_F64 0
+#define OFDFT_F32 1             /* reserved (config 5); not implemented yet */
+
+/* term bits; index of a term in E_terms[] is its bit position */
+#define OFDFT_ION_ELECTRON  (1u << 0)   /* functionals.py:31-46   (needs vext)                    */
+#define OFDFT_HARTREE       (1u << 1)   /* functionals.py:49-72                                  */
+#define OFDFT_TF            (1u << 2)   /* functionals.py:207-224                                */
+#define OFDFT_VW            (1u << 3)   /* functionals.py:227-246                                */
+#define OFDFT_WT_NL         (1u << 4)   /* non_local_KEF functionals.py:644-652, params alpha,beta */
+#define OFDFT_WGC99_NL      (1u << 5)   /* WGC99 nonlocal part functionals.py:941-983            */
+#define OFDFT_LDA_X         (1u << 6)   /* functionals.py:1510-1512                              */
+#define OFDFT_PZ_C          (1u << 7)   /* functionals.py:1515-1521                              */
+#define OFDFT_PW_C          (1u << 8)   /* functionals.py:1524-1530                              */
+#define OFDFT_CHACHIYO_C    (1u << 9)   /* functionals.py:1533-1537                              */
+#define OFDFT_PBE_X         (1u << 10)  /* functionals.py:1597-1603                              */
+#define OFDFT_PBE_C         (1u << 11)  /* functionals.py:1606-1618                              */
+#define OFDFT_NTERMS        12
+
+/* params[] slots for ofdft_set_terms (missing trailing slots keep their defaults) */
+#define OFDFT_P_WT_ALPHA    0   /* default 5/6 */
+#define OFDFT_P_WT_BETA     1   /* default 5/6 */
+#define OFDFT_P_WGC_ALPHA   2   /* default (5+sqrt5)/6 */
+#define OFDFT_P_WGC_BETA    3   /* default (5-sqrt5)/6 */
+#define OFDFT_P_WGC_GAMMA   4   /* default 2.7 */
+#define OFDFT_P_WGC_KAPPA   5   /* default 1.0 */
+#define OFDFT_NPARAMS       6
+
+/* ofdft_query selectors */
+#define OFDFT_Q_FFT_COUNT        0  /* 3-D FFTs executed by the last energy call              */
+#define OFDFT_Q_WORKSPACE_BYTES  1  /* device bytes held by the ctx                            */
+#define OFDFT_Q_FAST_PATH        2  /* 1 if the LDS radix FFT path is used, 0 = generic DFT    */
+#define OFDFT_Q_KERNEL_MS        3  /* HIP-event time of the last energy call's device work    */
+#define OFDFT_Q_LAUNCH_COUNT     4  /* kernel launches of the last energy call                 */
+
+int  ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id);
+void ofdft_destroy(ofdft_ctx* ctx);
+const char* ofdft_last_error(const ofdft_ctx* ctx);   /* ctx may be NULL: last create() error */
+
+int  ofdft_set_cell(ofdft_ctx* ctx, const double box_vecs[9]);
+int  ofdft_set_terms(ofdft_ctx* ctx, uint32_t term_mask, const double* params, int nparams);
+
+/* E_terms_host[OFDFT_NTERMS] (entries of unset terms are 0); dEdn_dev may be NULL (energy only).
+ * vext_dev is required iff OFDFT_ION_ELECTRON is set. */
+int  ofdft_energy_potential(ofdft_ctx* ctx, const void* den_dev, const void* vext_dev,
+                            double* E_terms_host, void* dEdn_dev, void* stream);
+
+/* The density-optimisation closure: n = N_e chi^2 / int chi^2; returns per-term energies,
+ * the chemical potential mu = int (dE/dn) n / N_e, and grad_dev = dE/dchi * dV, i.e. exactly what
+ * the reference leaves in chi.grad (system.py:836-837,853).  grad_dev may be NULL. */
+int  ofdft_energy_grad_chi(ofdft_ctx* ctx, const void* chi_dev, const void* vext_dev, double n_electrons,
+                           double* E_terms_host, double* mu_host, void* grad_dev, void* stream);
+
+/* Validation / building-block entry points: same semantics as torch.fft.rfftn / irfftn(s=shape). */
+int  ofdft_rfftn(ofdft_ctx* ctx, const void* real_dev, void* spec_dev, void* stream);
+int  ofdft_irfftn(ofdft_ctx* ctx, const void* spec_dev, void* real_dev, void* stream);
+
+int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
+
+/* Measurement support (bench.py): when on, every kernel launch of the energy calls is bracketed by HIP
+ * events on the caller's stream and the durations are accumulated per kernel class.  Adds launch overhead:
+ * never on inside a timed region. */
+int  ofdft_set_profiling(ofdft_ctx* ctx, int on);
+int  ofdft_profile_count(ofdft_ctx* ctx);
+int  ofdft_profile_get(ofdft_ctx* ctx, int idx, char* name_buf, int buflen, double* total_ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDFT_HIP_H */

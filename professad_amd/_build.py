@@ -1,0 +1,42 @@
+"""Build recipe for the HIP engine (gfx950 only).  `python -m professad_amd._build` rebuilds in-tree."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIBDIR = os.path.join(PKG, 'lib')
+LIB = os.path.join(LIBDIR, 'libofdft_hip.so')
+SOURCES = ['engine.hip']
+HEADERS = ['fft_radix.h', 'fft_kernels.h', 'pointwise_kernels.h', os.path.join('..', '..', 'include', 'ofdft_hip.h')]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=True):
+    """Compile csrc/*.hip into lib/libofdft_hip.so with hipcc (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
+           '-ffp-contract=on', '-Wall', '-Wno-unused-function',
+           '-I', os.path.join(PKG, '..', 'include')]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

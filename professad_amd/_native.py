@@ -1,0 +1,85 @@
+"""ctypes binding of libofdft_hip.so (include/ofdft_hip.h).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+# torch first, always: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64 (same SONAMEs as
+# /opt/rocm).  Loading our library before torch binds the process to the system runtime and the
+# two then disagree about the device ("no ROCm-capable device"); loading torch first makes the
+# whole process -- torch tensors, streams and this engine -- share ONE HIP runtime.
+import torch  # noqa: F401,E402
+
+from . import _build
+
+_LIB = None
+
+# mirror of the #defines in include/ofdft_hip.h
+OK, EINVAL, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4
+F64, F32 = 0, 1
+TERM_BITS = {
+    'ion_electron': 1 << 0, 'hartree': 1 << 1, 'tf': 1 << 2, 'vw': 1 << 3, 'wt_nl': 1 << 4, 'wgc99_nl': 1 << 5,
+    'lda_x': 1 << 6, 'pz_c': 1 << 7, 'pw_c': 1 << 8, 'chachiyo_c': 1 << 9, 'pbe_x': 1 << 10, 'pbe_c': 1 << 11,
+}
+TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c',
+              'pbe_x', 'pbe_c']
+NTERMS = 12
+NPARAMS = 6
+Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1, 2, 3, 4
+
+EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
+           'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
+           'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building if stale and hipcc is present) the HIP engine.  Raises if it cannot."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path) or (os.path.exists('/opt/rocm/bin/hipcc') and _build._stale()):
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise NativeLibraryError('libofdft_hip.so is missing and could not be built: %r' % (e,))
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise NativeLibraryError('cannot load %s: %s (the HIP engine is required; there is no CPU fallback)'
+                                 % (path, e))
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.c_int
+    lib.ofdft_create.argtypes = [C.POINTER(vp), ip, ip, ip, ip, ip]
+    lib.ofdft_create.restype = ip
+    lib.ofdft_destroy.argtypes = [vp]
+    lib.ofdft_destroy.restype = None
+    lib.ofdft_last_error.argtypes = [vp]
+    lib.ofdft_last_error.restype = C.c_char_p
+    lib.ofdft_set_cell.argtypes = [vp, dp]
+    lib.ofdft_set_cell.restype = ip
+    lib.ofdft_set_terms.argtypes = [vp, C.c_uint32, dp, ip]
+    lib.ofdft_set_terms.restype = ip
+    lib.ofdft_energy_potential.argtypes = [vp, vp, vp, dp, vp, vp]
+    lib.ofdft_energy_potential.restype = ip
+    lib.ofdft_energy_grad_chi.argtypes = [vp, vp, vp, C.c_double, dp, dp, vp, vp]
+    lib.ofdft_energy_grad_chi.restype = ip
+    lib.ofdft_rfftn.argtypes = [vp, vp, vp, vp]
+    lib.ofdft_rfftn.restype = ip
+    lib.ofdft_irfftn.argtypes = [vp, vp, vp, vp]
+    lib.ofdft_irfftn.restype = ip
+    lib.ofdft_query.argtypes = [vp, ip, dp]
+    lib.ofdft_query.restype = ip
+    lib.ofdft_set_profiling.argtypes = [vp, ip]
+    lib.ofdft_set_profiling.restype = ip
+    lib.ofdft_profile_count.argtypes = [vp]
+    lib.ofdft_profile_count.restype = ip
+    lib.ofdft_profile_get.argtypes = [vp, ip, C.c_char_p, ip, dp, C.POINTER(C.c_longlong)]
+    lib.ofdft_profile_get.restype = ip
+    _LIB = lib
+    return lib

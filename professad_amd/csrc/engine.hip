@@ -1,0 +1,844 @@
+// C-ABI implementation of the OFDFT energy/gradient engine (include/ofdft_hip.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ofdft_hip.h"
+#include "pointwise_kernels.h"
+
+using namespace ofdft;
+
+namespace {
+
+thread_local char g_create_error[512] = "";
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct ofdft_ctx {
+    int n0 = 0, n1 = 0, n2 = 0, device = 0;
+    SpecGeom g{};
+    KGeom kg{};
+    long long npts = 0;
+    bool fast = false, cell_set = false;
+    double box[9] = {0}, vol = 0.0, dV = 0.0;
+    unsigned mask = 0;
+    double params[OFDFT_NPARAMS];
+    // twiddle tables by length
+    std::map<int, cplx*> tw;
+    // named workspaces
+    std::map<std::string, DevBuf> ws;
+    size_t ws_bytes = 0;
+    // reduction partials (device) + pinned host mirror
+    double* d_partial = nullptr;
+    double* h_partial = nullptr;
+    // WGC tables
+    double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
+    long long wgc_key_nel = -1;
+    bool wgc_valid = false;
+    // stats
+    int fft_count = 0, launch_count = 0;
+    float last_ms = 0.f;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // optional per-kernel-class profiling (HIP events around every launch)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Pending { const char* name; size_t a, b; };
+    std::vector<Pending> pending;
+    struct Acc { double ms = 0.0; long long launches = 0; };
+    std::map<std::string, Acc> prof;
+    char err[512] = "";
+};
+
+namespace {
+
+int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_create_error, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, OFDFT_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+
+void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name);
+void prof_end(ofdft_ctx* c, hipStream_t st);
+
+#define OFDFT_LAUNCH(c, st, name, kern, grid, block, lds, ...)            \
+    do {                                                                  \
+        prof_begin(c, st, name);                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);      \
+        prof_end(c, st);                                                  \
+        (c)->launch_count++;                                              \
+    } while (0)
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+int grid_for(long long n, int tpb = 256, int cap = 2048) {
+    long long b = (n + tpb - 1) / tpb;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int get_twiddle(ofdft_ctx* c, int n, cplx** out) {
+    auto it = c->tw.find(n);
+    if (it != c->tw.end()) {
+        *out = it->second;
+        return 0;
+    }
+    std::vector<cplx> h(n);
+    for (int m = 0; m < n; ++m) {
+        const long double ph = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+        h[m] = make_double2((double)cosl(ph), (double)sinl(ph));
+    }
+    // exact values on the axes
+    h[0] = make_double2(1.0, 0.0);
+    if (n % 2 == 0) h[n / 2] = make_double2(-1.0, 0.0);
+    if (n % 4 == 0) {
+        h[n / 4] = make_double2(0.0, -1.0);
+        h[3 * n / 4] = make_double2(0.0, 1.0);
+    }
+    cplx* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, sizeof(cplx) * n));
+    HIP_TRY(c, hipMemcpy(d, h.data(), sizeof(cplx) * n, hipMemcpyHostToDevice));
+    c->tw[n] = d;
+    c->ws_bytes += sizeof(cplx) * n;
+    *out = d;
+    return 0;
+}
+
+int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out) {
+    DevBuf& b = c->ws[name];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            HIP_TRY(c, hipFree(b.p));
+            c->ws_bytes -= b.bytes;
+        }
+        b.p = nullptr;
+        b.bytes = 0;
+        HIP_TRY(c, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+        c->ws_bytes += bytes;
+    }
+    *out = b.p;
+    return 0;
+}
+int real_ws(ofdft_ctx* c, const char* name, double** out) {
+    return get_ws(c, std::string("r:") + name, sizeof(double) * (size_t)c->npts, (void**)out);
+}
+int spec_ws(ofdft_ctx* c, const char* name, cplx** out) {
+    return get_ws(c, std::string("s:") + name, sizeof(cplx) * (size_t)c->g.total, (void**)out);
+}
+
+// ---------------------------------------------------------------------------------- profiling
+hipEvent_t prof_event(ofdft_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name) {
+    if (!c->profiling) return;
+    hipEvent_t e = prof_event(c);
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    c->pending.push_back({name, c->ev_used - 1, 0});
+}
+void prof_end(ofdft_ctx* c, hipStream_t st) {
+    if (!c->profiling || c->pending.empty()) return;
+    hipEvent_t e = prof_event(c);
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    c->pending.back().b = c->ev_used - 1;
+}
+// after a stream sync: fold the pending event pairs into the per-name accumulators
+void prof_collect(ofdft_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (p.b && hipEventElapsedTime(&ms, c->ev_pool[p.a], c->ev_pool[p.b]) == hipSuccess) {
+            auto& a = c->prof[p.name];
+            a.ms += ms;
+            a.launches += 1;
+        }
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+}
+
+// ---------------------------------------------------------------------------------- FFT drivers
+template <int LEN, bool INV>
+int launch_cpass_t(ofdft_ctx* c, cplx* data, const LineMap& m, hipStream_t st, const char* nm) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    const int blocks = (m.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, data, m, tw);
+    return 0;
+}
+
+template <bool INV>
+int launch_cpass(ofdft_ctx* c, int len, cplx* data, const LineMap& m, hipStream_t st, const char* nm) {
+    switch (len) {
+        case 8: return launch_cpass_t<8, INV>(c, data, m, st, nm);
+        case 16: return launch_cpass_t<16, INV>(c, data, m, st, nm);
+        case 32: return launch_cpass_t<32, INV>(c, data, m, st, nm);
+        case 64: return launch_cpass_t<64, INV>(c, data, m, st, nm);
+        case 128: return launch_cpass_t<128, INV>(c, data, m, st, nm);
+        case 256: return launch_cpass_t<256, INV>(c, data, m, st, nm);
+        case 512: return launch_cpass_t<512, INV>(c, data, m, st, nm);
+        case 1024: return launch_cpass_t<1024, INV>(c, data, m, st, nm);
+    }
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
+}
+
+// line maps of the block-8 layout (see fft_kernels.h)
+void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
+    const SpecGeom& g = c->g;
+    const int nb = g.nzm / 8, nrem = g.nzc - g.nzm;
+    if (axis == 0) {   // x lines: base = b*n0*n1*8 + (y*8+kin), stride n1*8
+        main.d = g.n1 * 8; main.sb = (long long)g.n0 * g.n1 * 8; main.sl = 1; main.se = (long long)g.n1 * 8;
+        main.nlines = nb * g.n1 * 8; main.lf = 0;  // lf filled by caller (LPW)
+        rem.d = g.n1; rem.sb = (long long)g.n0 * g.n1; rem.sl = 1; rem.se = g.n1; rem.nlines = nrem * g.n1; rem.lf = 0;
+    } else {           // y lines: base = (b*n0+x)*n1*8 + kin, stride 8
+        main.d = 8; main.sb = (long long)g.n1 * 8; main.sl = 1; main.se = 8; main.nlines = nb * g.n0 * 8; main.lf = 8;
+        rem.d = 1; rem.sb = g.n1; rem.sl = 0; rem.se = 1; rem.nlines = nrem * g.n0; rem.lf = 1;
+    }
+}
+
+template <bool INV>
+int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
+    LineMap main, rem;
+    pass_maps(c, axis, main, rem);
+    const int len = axis == 0 ? c->n0 : c->n1;
+    int lpw;
+    switch (len) {
+        case 8: lpw = PassCfg<8>::LPW; break;
+        case 16: lpw = PassCfg<16>::LPW; break;
+        case 32: lpw = PassCfg<32>::LPW; break;
+        case 64: lpw = PassCfg<64>::LPW; break;
+        case 128: lpw = PassCfg<128>::LPW; break;
+        case 256: lpw = PassCfg<256>::LPW; break;
+        case 512: lpw = PassCfg<512>::LPW; break;
+        default: lpw = PassCfg<1024>::LPW; break;
+    }
+    if (axis == 0) {
+        main.lf = lpw;
+        rem.lf = lpw;
+    }
+    if (main.nlines > 0)
+        if (int rc = launch_cpass<INV>(c, len, spec, main, st, axis == 0 ? "cpass_x" : "cpass_y")) return rc;
+    if (rem.nlines > 0)
+        if (int rc = launch_cpass<INV>(c, len, spec + c->g.main_count, rem, st, axis == 0 ? "cpass_x_nyq" : "cpass_y_nyq")) return rc;
+    return 0;
+}
+
+template <int M>
+int launch_zfwd_t(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = get_twiddle(c, M, &twM)) return rc;
+    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
+    using Cfg = ZCfg<M>;
+    const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+    OFDFT_LAUNCH(c, st, "zfwd", (zfwd_kernel<M, PreIdentity>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, in, spec, c->g, twM,
+                       twN, PreIdentity());
+    return 0;
+}
+template <int M>
+int launch_zinv_t(ofdft_ctx* c, const cplx* spec, double* out, double scale, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = get_twiddle(c, M, &twM)) return rc;
+    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
+    using Cfg = ZCfg<M>;
+    const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+    PostScale post{scale};
+    OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
+                       twN, post);
+    return 0;
+}
+
+int gen_axis(ofdft_ctx* c, int axis, int inv, cplx*& cur, cplx*& other, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, axis == 0 ? c->n0 : c->n1, &tw)) return rc;
+    OFDFT_LAUNCH(c, st, "gen_c2c", gen_c2c_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, cur, other, c->g,
+                       axis, inv, tw);
+    std::swap(cur, other);
+    return 0;
+}
+
+// real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
+int rfftn_internal(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+    c->fft_count++;
+    if (c->fast) {
+        int rc;
+        switch (c->n2 / 2) {
+            case 8: rc = launch_zfwd_t<8>(c, in, spec, st); break;
+            case 16: rc = launch_zfwd_t<16>(c, in, spec, st); break;
+            case 32: rc = launch_zfwd_t<32>(c, in, spec, st); break;
+            case 64: rc = launch_zfwd_t<64>(c, in, spec, st); break;
+            case 128: rc = launch_zfwd_t<128>(c, in, spec, st); break;
+            case 256: rc = launch_zfwd_t<256>(c, in, spec, st); break;
+            case 512: rc = launch_zfwd_t<512>(c, in, spec, st); break;
+            case 1024: rc = launch_zfwd_t<1024>(c, in, spec, st); break;
+            default: rc = fail(c, OFDFT_EINVAL, "bad n2");
+        }
+        if (rc) return rc;
+        if ((rc = fast_axis_pass<false>(c, 1, spec, st))) return rc;
+        return fast_axis_pass<false>(c, 0, spec, st);
+    }
+    cplx *tw2, *tmp;
+    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
+    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
+    // z into tmp, y: tmp -> spec, x: spec -> tmp, then copy back (two swaps leave the result in tmp)
+    OFDFT_LAUNCH(c, st, "gen_r2c_z", gen_r2c_z_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, in, spec, c->g, tw2);
+    cplx *cur = spec, *other = tmp;
+    if (int rc = gen_axis(c, 1, 0, cur, other, st)) return rc;
+    if (int rc = gen_axis(c, 0, 0, cur, other, st)) return rc;
+    if (cur != spec) HIP_TRY(c, hipMemcpyAsync(spec, cur, sizeof(cplx) * c->g.total, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// internal half spectrum (destroyed) -> real, scaled by `scale` (1/N for irfftn semantics)
+int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) {
+    c->fft_count++;
+    if (c->fast) {
+        int rc;
+        if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;
+        if ((rc = fast_axis_pass<true>(c, 1, spec, st))) return rc;
+        switch (c->n2 / 2) {
+            case 8: return launch_zinv_t<8>(c, spec, out, scale, st);
+            case 16: return launch_zinv_t<16>(c, spec, out, scale, st);
+            case 32: return launch_zinv_t<32>(c, spec, out, scale, st);
+            case 64: return launch_zinv_t<64>(c, spec, out, scale, st);
+            case 128: return launch_zinv_t<128>(c, spec, out, scale, st);
+            case 256: return launch_zinv_t<256>(c, spec, out, scale, st);
+            case 512: return launch_zinv_t<512>(c, spec, out, scale, st);
+            case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
+        }
+        return fail(c, OFDFT_EINVAL, "bad n2");
+    }
+    cplx *tw2, *tmp;
+    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
+    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
+    cplx *cur = spec, *other = tmp;
+    if (int rc = gen_axis(c, 0, 1, cur, other, st)) return rc;
+    if (int rc = gen_axis(c, 1, 1, cur, other, st)) return rc;
+    PostScale post{scale};
+    OFDFT_LAUNCH(c, st, "gen_c2r_z", (gen_c2r_z_kernel<PostScale>), dim3((unsigned)((c->npts + 255) / 256)), dim3(256), 0, cur, out,
+                       c->g, tw2, post);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- reductions
+// copy `rows` x `ns` partials to the host and sum them in a fixed order
+int fetch_partials(ofdft_ctx* c, int rows, int ns, double* sums, hipStream_t st) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_partial, sizeof(double) * rows * ns, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int s = 0; s < ns; ++s) {
+        long double t = 0.0L;
+        for (int r = 0; r < rows; ++r) t += (long double)c->h_partial[(size_t)r * ns + s];
+        sums[s] = (double)t;
+    }
+    return 0;
+}
+
+int device_sum(ofdft_ctx* c, const double* a, bool square, double* out, hipStream_t st) {
+    const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+    if (square)
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, a, c->npts, c->d_partial);
+    else
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, a, c->npts, c->d_partial);
+    return fetch_partials(c, blocks, 1, out, st);
+}
+
+// ---------------------------------------------------------------------------------- WGC tables
+void wgc_series_coeffs(int nt, std::vector<double>& A, std::vector<double>& B) {
+    // functionals.py:817-843
+    std::vector<double> a(nt + 1, 0.0), b(nt, 0.0);
+    a[0] = 3.0;
+    for (int idx = 1; idx <= nt; ++idx) {
+        const int i = idx - 1;
+        double s = 0.0;
+        for (int j = -1; j < i; ++j) s += -3.0 * a[j + 1] / (4.0 * (i - j + 1) * (i - j + 1) - 1.0);
+        a[idx] = s;
+    }
+    A.assign(nt, 0.0);
+    A[0] = a[1] - 1.0;
+    for (int i = 1; i < nt; ++i) A[i] = a[i + 1];
+    b[0] = 1.0;
+    for (int i = 1; i < nt; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < i; ++j) s += b[j] / (4.0 * (i - j) * (i - j) - 1.0);
+        b[i] = s;
+    }
+    B.assign(nt, 0.0);
+    B[0] = 0.0;
+    if (nt > 1) B[1] = b[1] - 3.0;
+    for (int i = 2; i < nt; ++i) B[i] = b[i];
+}
+
+int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out) {
+    const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+    const double ga = c->params[OFDFT_P_WGC_GAMMA], ka = c->params[OFDFT_P_WGC_KAPPA];
+    const double nref = ka * ((double)nel_rounded / c->vol);
+    *nref_out = nref;
+    if (c->wgc_valid && c->wgc_key_nel == nel_rounded) return 0;
+    const int nt = 100;
+    const double u = 3.0 * (al + be) - ga / 2.0, v = u * u - 36.0 * al * be;
+    std::vector<double> A, B, coef(2 * nt);
+    wgc_series_coeffs(nt, A, B);
+    double Sd = 0.0, Ss = 0.0;
+    for (int i = 0; i < nt; ++i) {
+        const double da = (u + 2.0 * i) * (u + 2.0 * i) - v, db = (u - 2.0 * i) * (u - 2.0 * i) - v;
+        coef[i] = A[i] / da;
+        coef[nt + i] = B[i] / db;
+        Sd += coef[i] - coef[nt + i];
+        Ss += i * (coef[i] + coef[nt + i]);
+    }
+    Ss *= -2.0;
+    const double sgn = (u > 0) - (u < 0);
+    WgcSeries s{};
+    s.u = u;
+    s.v = v;
+    if (v > 0) {
+        const double rv = std::sqrt(v);
+        s.c1 = sgn * ((rv - u) * Sd + Ss);
+        s.c2 = sgn * ((rv + u) * Sd - Ss) / (2.0 * rv);
+    } else if (v == 0) {
+        s.c1 = sgn * Sd;
+        s.c2 = sgn * (Ss - u * Sd);
+    } else {
+        s.c1 = sgn * Sd;
+        s.c2 = sgn * (Ss - u * Sd) / std::sqrt(-v);
+    }
+    s.gamma = ga;
+    s.nref = nref;
+    s.pref = 20.0 * std::pow(nref, 5.0 / 3.0 - al - be);
+    s.inv2kf = 1.0 / (2.0 * std::cbrt(3.0 * kPi * kPi * nref));
+    s.nt = nt;
+    if (!c->d_wgc_coef) HIP_TRY(c, hipMalloc((void**)&c->d_wgc_coef, sizeof(double) * 2 * nt));
+    HIP_TRY(c, hipMemcpyAsync(c->d_wgc_coef, coef.data(), sizeof(double) * 2 * nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));   // coef is a stack-backed vector
+    s.ca = c->d_wgc_coef;
+    s.cb = c->d_wgc_coef + nt;
+    double *w0, *K1, *K2, *K3;
+    const size_t tb = sizeof(double) * (size_t)c->g.total;
+    if (int rc = get_ws(c, "t:w0", tb, (void**)&w0)) return rc;
+    if (int rc = get_ws(c, "t:K1", tb, (void**)&K1)) return rc;
+    if (int rc = get_ws(c, "t:K2", tb, (void**)&K2)) return rc;
+    if (int rc = get_ws(c, "t:K3", tb, (void**)&K3)) return rc;
+    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s);
+    c->wgc_key_nel = nel_rounded;
+    c->wgc_valid = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- the energy pipeline
+// den: density on device.  Fills E_terms (host), writes v_out (device, may be NULL), returns sum(v n) dV.
+int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out, double* vn_int,
+              hipStream_t st) {
+    const unsigned mask = c->mask;
+    const long long npts = c->npts;
+    const double inv_n = 1.0 / (double)npts;
+    const int pw_grid = grid_for(npts);
+    const int sp_grid = grid_for(c->g.total);
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+
+    double nsum = 0.0;
+    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL))
+        if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
+    const double nel = nsum * inv_n * c->vol;       // mean(den) * vol   functionals.py:634,646,952
+
+    CombineArgs ca{};
+    ca.n = den;
+    ca.vext = vext;
+    ca.v_out = v_out;
+    ca.npts = npts;
+    ca.mask = mask;
+    double pbe_sums[2] = {0.0, 0.0};
+
+    cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
+    if (int rc = spec_ws(c, "s0", &s0)) return rc;
+
+    if (mask & (OFDFT_HARTREE | OFDFT_PBE_X | OFDFT_PBE_C)) {
+        if (int rc = rfftn_internal(c, den, s0, st)) return rc;             // n^ (shared)
+        if (int rc = spec_ws(c, "s1", &s1)) return rc;
+        if (mask & OFDFT_HARTREE) {
+            double* vh;
+            if (int rc = real_ws(c, "vh", &vh)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, s1, c->kg, 0.0, 0.0);
+            if (int rc = irfftn_internal(c, s1, vh, inv_n, st)) return rc;
+            ca.vh = vh;
+        }
+        if (mask & (OFDFT_PBE_X | OFDFT_PBE_C)) {
+            double *gx, *gy, *gz, *dfdn, *dv;
+            if (int rc = spec_ws(c, "s2", &s2)) return rc;
+            if (int rc = spec_ws(c, "s3", &s3)) return rc;
+            if (int rc = real_ws(c, "gx", &gx)) return rc;
+            if (int rc = real_ws(c, "gy", &gy)) return rc;
+            if (int rc = real_ws(c, "gz", &gz)) return rc;
+            if (int rc = real_ws(c, "dfdn", &dfdn)) return rc;
+            if (int rc = real_ws(c, "div", &dv)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
+            if (int rc = irfftn_internal(c, s1, gx, inv_n, st)) return rc;
+            if (int rc = irfftn_internal(c, s2, gy, inv_n, st)) return rc;
+            if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
+            const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
+            OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
+                               (mask & OFDFT_PBE_X) ? 1 : 0, (mask & OFDFT_PBE_C) ? 1 : 0, c->d_partial);
+            if (int rc = fetch_partials(c, blocks, 2, pbe_sums, st)) return rc;
+            if (int rc = rfftn_internal(c, gx, s1, st)) return rc;
+            if (int rc = rfftn_internal(c, gy, s2, st)) return rc;
+            if (int rc = rfftn_internal(c, gz, s3, st)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
+            if (int rc = irfftn_internal(c, s0, dv, inv_n, st)) return rc;
+            ca.dfdn = dfdn;
+            ca.div = dv;
+        }
+    }
+    if (mask & OFDFT_VW) {
+        double *tmp, *lap;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        if (int rc = real_ws(c, "lap", &lap)) return rc;
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
+        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
+        OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, 0.0, 0.0);
+        if (int rc = irfftn_internal(c, s0, lap, inv_n, st)) return rc;
+        ca.lap_s = lap;
+    }
+    if (mask & OFDFT_WT_NL) {
+        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+        const double nbar = nel / c->vol;                                    // functionals.py:646-647
+        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        double *tmp, *cb;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        if (int rc = real_ws(c, "conv_b", &cb)) return rc;
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
+        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
+        OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, pref,
+                           1.0 / (2.0 * kf));
+        if (int rc = irfftn_internal(c, s0, cb, inv_n, st)) return rc;
+        ca.conv_b = cb;
+        ca.conv_a = nullptr;
+        if (al != be) {
+            double* cva;
+            if (int rc = real_ws(c, "conv_a", &cva)) return rc;
+            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
+            if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, pref,
+                               1.0 / (2.0 * kf));
+            if (int rc = irfftn_internal(c, s0, cva, inv_n, st)) return rc;
+            ca.conv_a = cva;
+        }
+        ca.wt_alpha = al;
+        ca.wt_beta = be;
+        ca.wt_nbar_pa = std::pow(nbar, al);
+    }
+    if (mask & OFDFT_WGC99_NL) {
+        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+        const long long nel_r = std::llround(nel);                           // functionals.py:952
+        double nref;
+        if (int rc = ensure_wgc_tables(c, nel_r, st, &nref)) return rc;
+        double *t0, *t1, *t2, *o[6];
+        if (int rc = real_ws(c, "t0", &t0)) return rc;
+        if (int rc = real_ws(c, "t1", &t1)) return rc;
+        if (int rc = real_ws(c, "t2", &t2)) return rc;
+        const char* names[6] = {"u0", "u1", "u2", "gA", "gB", "gC"};
+        for (int i = 0; i < 6; ++i)
+            if (int rc = real_ws(c, names[i], &o[i])) return rc;
+        if (int rc = spec_ws(c, "s1", &s1)) return rc;
+        if (int rc = spec_ws(c, "s2", &s2)) return rc;
+        const double *w0 = (double*)c->ws["t:w0"].p, *K1 = (double*)c->ws["t:K1"].p, *K2 = (double*)c->ws["t:K2"].p,
+                     *K3 = (double*)c->ws["t:K3"].p;
+        for (int pass = 0; pass < 2; ++pass) {
+            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
+                               nref);
+            if (int rc = rfftn_internal(c, t0, s0, st)) return rc;
+            if (int rc = rfftn_internal(c, t1, s1, st)) return rc;
+            if (int rc = rfftn_internal(c, t2, s2, st)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, w0, K1, K2, K3, c->g.total);
+            if (int rc = irfftn_internal(c, s0, o[3 * pass + 0], inv_n, st)) return rc;
+            if (int rc = irfftn_internal(c, s1, o[3 * pass + 1], inv_n, st)) return rc;
+            if (int rc = irfftn_internal(c, s2, o[3 * pass + 2], inv_n, st)) return rc;
+        }
+        ca.u0 = o[0]; ca.u1 = o[1]; ca.u2 = o[2];
+        ca.gA = o[3]; ca.gB = o[4]; ca.gC = o[5];
+        ca.wgc_alpha = al;
+        ca.wgc_beta = be;
+        ca.nref = nref;
+    }
+    // ---- combine
+    const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
+    OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, ca, c->d_partial);
+    double sums[kCombineScalars];
+    if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
+    const double dV = c->dV;
+    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
+    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
+    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
+    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
+    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
+    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
+    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
+    // one local correlation flavour is expected; if several are set their sum is split evenly
+    {
+        int nc = 0;
+        for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
+        for (int b = 7; b <= 9; ++b)
+            if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
+    }
+    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
+    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    *vn_int = sums[8] * dV;
+    return 0;
+}
+
+int begin_call(ofdft_ctx* c, hipStream_t st) {
+    if (!c) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
+    c->fft_count = 0;
+    c->launch_count = 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    return 0;
+}
+int end_call(ofdft_ctx* c, hipStream_t st) {
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return 0;
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" {
+
+int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id) {
+    if (!out) return OFDFT_EINVAL;
+    *out = nullptr;
+    if (n0 < 2 || n1 < 2 || n2 < 2) return fail(nullptr, OFDFT_EINVAL, "grid extents must be >= 2 (got %d %d %d)", n0, n1, n2);
+    if (dtype != OFDFT_F64) return fail(nullptr, OFDFT_EINVAL, "only OFDFT_F64 is implemented");
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev <= 0)
+        return fail(nullptr, OFDFT_EHIP, "no HIP device available (hipGetDeviceCount: %s, count %d)",
+                    hipGetErrorString(e0), ndev);
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, OFDFT_EINVAL, "bad device id %d", device_id);
+    ofdft_ctx* c = new (std::nothrow) ofdft_ctx();
+    if (!c) return fail(nullptr, OFDFT_ENOMEM, "out of host memory");
+    c->n0 = n0; c->n1 = n1; c->n2 = n2; c->device = device_id;
+    c->npts = (long long)n0 * n1 * n2;
+    SpecGeom& g = c->g;
+    g.n0 = n0; g.n1 = n1; g.n2 = n2;
+    g.nzc = n2 / 2 + 1;
+    g.nzm = (g.nzc / 8) * 8;
+    g.nrows = (long long)n0 * n1;
+    g.main_count = (long long)g.nzm * g.nrows;
+    g.total = (long long)g.nzc * g.nrows;
+    c->fast = is_pow2(n0) && is_pow2(n1) && is_pow2(n2) && n0 >= 8 && n0 <= 1024 && n1 >= 8 && n1 <= 1024 &&
+              n2 >= 16 && n2 <= 2048;
+    const double s5 = std::sqrt(5.0);
+    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0};
+    std::memcpy(c->params, defaults, sizeof(defaults));
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * kRedBlocks * kMaxScalars);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        fail(nullptr, OFDFT_EHIP, "context allocation failed: %s", hipGetErrorString(e));
+        ofdft_destroy(c);
+        return OFDFT_EHIP;
+    }
+    *out = c;
+    return OFDFT_OK;
+}
+
+void ofdft_destroy(ofdft_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto& kv : c->tw) (void)hipFree(kv.second);
+    for (auto& kv : c->ws)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->h_partial) (void)hipHostFree(c->h_partial);
+    if (c->d_wgc_coef) (void)hipFree(c->d_wgc_coef);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char* ofdft_last_error(const ofdft_ctx* c) { return c ? c->err : g_create_error; }
+
+int ofdft_set_cell(ofdft_ctx* c, const double box[9]) {
+    if (!c || !box) return OFDFT_EINVAL;
+    // det and inverse-transpose of the 3x3 (rows = lattice vectors)
+    const double* a = box;
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                       a[2] * (a[3] * a[7] - a[4] * a[6]);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det))
+        return fail(c, OFDFT_EINVAL, "Lattice vector matrix is not invertible.");   // functional_tools.py:150
+    // inv(box^T)[i][j] = cofactor(box)[i][j] / det   (inverse of the transpose = transpose of the inverse)
+    double cof[9];
+    cof[0] = a[4] * a[8] - a[5] * a[7];
+    cof[1] = -(a[3] * a[8] - a[5] * a[6]);
+    cof[2] = a[3] * a[7] - a[4] * a[6];
+    cof[3] = -(a[1] * a[8] - a[2] * a[7]);
+    cof[4] = a[0] * a[8] - a[2] * a[6];
+    cof[5] = -(a[0] * a[7] - a[1] * a[6]);
+    cof[6] = a[1] * a[5] - a[2] * a[4];
+    cof[7] = -(a[0] * a[5] - a[2] * a[3]);
+    cof[8] = a[0] * a[4] - a[1] * a[3];
+    for (int i = 0; i < 9; ++i) {
+        c->box[i] = box[i];
+        c->kg.b[i] = 2.0 * kPi * cof[i] / det;                                       // functional_tools.py:149
+    }
+    c->kg.g = c->g;
+    c->vol = std::fabs(det);
+    c->dV = c->vol / (double)c->npts;
+    c->cell_set = true;
+    c->wgc_valid = false;
+    return OFDFT_OK;
+}
+
+int ofdft_set_terms(ofdft_ctx* c, uint32_t mask, const double* params, int nparams) {
+    if (!c) return OFDFT_EINVAL;
+    if (mask == 0 || (mask >> OFDFT_NTERMS)) return fail(c, OFDFT_EINVAL, "bad term mask 0x%x", mask);
+    if (nparams < 0 || nparams > OFDFT_NPARAMS || (nparams > 0 && !params)) return fail(c, OFDFT_EINVAL, "bad params");
+    for (int i = 0; i < nparams; ++i) {
+        if (i >= OFDFT_P_WGC_ALPHA && c->params[i] != params[i]) c->wgc_valid = false;
+        c->params[i] = params[i];
+    }
+    c->mask = mask;
+    return OFDFT_OK;
+}
+
+int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, double* E_terms, void* dEdn, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = begin_call(c, st)) return rc;
+    if (!den || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    double vn;
+    if (int rc = run_terms(c, (const double*)den, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
+    return end_call(c, st);
+}
+
+int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, double n_electrons, double* E_terms,
+                          double* mu_host, void* grad, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = begin_call(c, st)) return rc;
+    if (!chi || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
+    double s2;
+    if (int rc = device_sum(c, (const double*)chi, true, &s2, st)) return rc;
+    const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
+    const double cfac = n_electrons / ntilde;                                         // system.py:834
+    double *den, *v;
+    if (int rc = real_ws(c, "den", &den)) return rc;
+    if (int rc = real_ws(c, "v", &v)) return rc;
+    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts)), dim3(256), 0, (const double*)chi, den,
+                       c->npts, cfac);
+    double vn;
+    if (int rc = run_terms(c, den, (const double*)vext, E_terms, v, &vn, st)) return rc;
+    const double mu = vn / n_electrons;                                               // system.py:851
+    if (mu_host) *mu_host = mu;
+    if (grad) {
+        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)chi, v, (double*)grad,
+                           c->npts, cfac * 2.0 * c->dV, mu);
+    }
+    return end_call(c, st);
+}
+
+int ofdft_rfftn(ofdft_ctx* c, const void* real_dev, void* spec_dev, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !real_dev || !spec_dev) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    cplx* s;
+    if (int rc = spec_ws(c, "io", &s)) return rc;
+    if (int rc = rfftn_internal(c, (const double*)real_dev, s, st)) return rc;
+    OFDFT_LAUNCH(c, st, "spec_to_standard", spec_to_standard_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, s,
+                       (cplx*)spec_dev, c->g);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !real_dev || !spec_dev) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    cplx* s;
+    if (int rc = spec_ws(c, "io", &s)) return rc;
+    OFDFT_LAUNCH(c, st, "spec_to_internal", spec_to_internal_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0,
+                 (const cplx*)spec_dev, s, c->g);
+    if (int rc = irfftn_internal(c, s, (double*)real_dev, 1.0 / (double)c->npts, st)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+int ofdft_set_profiling(ofdft_ctx* c, int on) {
+    if (!c) return OFDFT_EINVAL;
+    c->profiling = on != 0;
+    c->prof.clear();
+    c->pending.clear();
+    c->ev_used = 0;
+    return OFDFT_OK;
+}
+
+int ofdft_profile_count(ofdft_ctx* c) { return c ? (int)c->prof.size() : OFDFT_EINVAL; }
+
+int ofdft_profile_get(ofdft_ctx* c, int idx, char* name_buf, int buflen, double* total_ms, long long* launches) {
+    if (!c || idx < 0 || idx >= (int)c->prof.size() || !name_buf || buflen < 2) return OFDFT_EINVAL;
+    auto it = c->prof.begin();
+    std::advance(it, idx);
+    std::snprintf(name_buf, (size_t)buflen, "%s", it->first.c_str());
+    if (total_ms) *total_ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+    return OFDFT_OK;
+}
+
+int ofdft_query(ofdft_ctx* c, int what, double* out) {
+    if (!c || !out) return OFDFT_EINVAL;
+    switch (what) {
+        case OFDFT_Q_FFT_COUNT: *out = c->fft_count; return OFDFT_OK;
+        case OFDFT_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; return OFDFT_OK;
+        case OFDFT_Q_FAST_PATH: *out = c->fast ? 1.0 : 0.0; return OFDFT_OK;
+        case OFDFT_Q_KERNEL_MS: *out = c->last_ms; return OFDFT_OK;
+        case OFDFT_Q_LAUNCH_COUNT: *out = c->launch_count; return OFDFT_OK;
+    }
+    return fail(c, OFDFT_EINVAL, "unknown query %d", what);
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// In-register radix butterflies and the multi-stage Stockham line FFT (fp64) for gfx950.
+//
+// A line of LEN complex points is owned by P = LEN/E threads, E points per thread.  On entry and
+// on exit thread j holds v[q] = x[j + P*q], q = 0..E-1 (so global loads/stores with consecutive j
+// are coalesced and no bit-reversal pass exists).  Stages are radix-R_s Stockham steps done in
+// registers; between stages the line is exchanged through an LDS line buffer (real and imaginary
+// parts separately, so the buffer is LEN doubles + padding).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ofdft {
+
+typedef double2 cplx;
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) {
+    return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+// cos(2 pi k / 16), sin(2 pi k / 16)
+__device__ constexpr double kCos16[16] = {
+    1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
+    -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173,
+    0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
+__device__ constexpr double kSin16[16] = {
+    0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
+    1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
+    -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173};
+
+// a * W_R^K  (W = exp(-2 pi i / R) forward, conjugate for inverse), K, R compile-time
+template <int R, int K, bool INV> __device__ __forceinline__ cplx mul_w(cplx a) {
+    constexpr int idx = (K * (16 / R)) & 15;
+    if constexpr (idx == 0) return a;
+    else if constexpr (idx == 4) return mul_mi<INV>(a);
+    else if constexpr (idx == 8) return make_double2(-a.x, -a.y);
+    else if constexpr (idx == 12) return mul_mi<!INV>(a);
+    else {
+        constexpr double c = kCos16[idx];
+        constexpr double s = INV ? kSin16[idx] : -kSin16[idx];
+        return make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+// natural-order in-place DFT of R points held in registers
+template <int R, bool INV> struct Dft;
+
+template <bool INV> struct Dft<1, INV> {
+    static __device__ __forceinline__ void run(cplx*) {}
+};
+template <bool INV> struct Dft<2, INV> {
+    static __device__ __forceinline__ void run(cplx* a) {
+        cplx t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    }
+};
+template <bool INV> struct Dft<4, INV> {
+    static __device__ __forceinline__ void run(cplx* a) {
+        cplx s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+        cplx s13 = cadd(a[1], a[3]), d13 = mul_mi<INV>(csub(a[1], a[3]));
+        a[0] = cadd(s02, s13);
+        a[1] = cadd(d02, d13);
+        a[2] = csub(s02, s13);
+        a[3] = csub(d02, d13);
+    }
+};
+
+template <int R, int K, bool INV> struct Combine {
+    static __device__ __forceinline__ void run(cplx* a, const cplx* e, const cplx* o) {
+        cplx t = mul_w<R, K, INV>(o[K]);
+        a[K] = cadd(e[K], t);
+        a[K + R / 2] = csub(e[K], t);
+        if constexpr (K + 1 < R / 2) Combine<R, K + 1, INV>::run(a, e, o);
+    }
+};
+
+template <int R, bool INV> struct Dft {
+    static_assert(R == 8 || R == 16, "radix");
+    static __device__ __forceinline__ void run(cplx* a) {
+        cplx e[R / 2], o[R / 2];
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) { e[i] = a[2 * i]; o[i] = a[2 * i + 1]; }
+        Dft<R / 2, INV>::run(e);
+        Dft<R / 2, INV>::run(o);
+        Combine<R, 0, INV>::run(a, e, o);
+    }
+};
+
+// ---- per-length plan: stage radices, points per thread E, threads per line P = LEN / E
+template <int LEN> struct Plan;
+#define OFDFT_PLAN(LEN_, NST_, R0_, R1_, R2_, E_)                                   \
+    template <> struct Plan<LEN_> {                                                \
+        static constexpr int NST = NST_;                                           \
+        static constexpr int E = E_;                                               \
+        static constexpr int P = LEN_ / E_;                                        \
+        static __host__ __device__ constexpr int radix(int s) { return s == 0 ? R0_ : (s == 1 ? R1_ : R2_); } \
+    };
+OFDFT_PLAN(8, 1, 8, 1, 1, 8)
+OFDFT_PLAN(16, 1, 16, 1, 1, 16)
+OFDFT_PLAN(32, 2, 8, 4, 1, 8)
+OFDFT_PLAN(64, 2, 8, 8, 1, 8)
+OFDFT_PLAN(128, 2, 16, 8, 1, 16)
+OFDFT_PLAN(256, 2, 16, 16, 1, 16)
+OFDFT_PLAN(512, 3, 8, 8, 8, 8)
+OFDFT_PLAN(1024, 3, 16, 8, 8, 16)
+#undef OFDFT_PLAN
+
+// padded position inside an LDS line buffer (breaks the power-of-two strides of the exchange)
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+template <int LEN> struct LineBuf {
+    // doubles per line buffer; +2 staggers consecutive lines over the banks
+    static constexpr int STRIDE = LEN + (LEN >> 4) + 2;
+};
+
+template <int LEN, int S, int NS, bool INV> struct Stage {
+    static constexpr int R = Plan<LEN>::radix(S);
+    static constexpr int E = Plan<LEN>::E;
+    static constexpr int P = Plan<LEN>::P;
+    static constexpr int NB = E / R;       // butterflies per thread in this stage (also register stride)
+
+    static __device__ __forceinline__ void run(cplx (&v)[E], int j, double* line, const cplx* __restrict__ tw) {
+        // ---- twiddle + butterflies
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            cplx a[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) a[t] = v[b + t * NB];
+            if constexpr (NS > 1) {
+                const int k = (j + b * P) % NS;
+                constexpr int TSTEP = LEN / (NS * R);
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    cplx w = tw[t * k * TSTEP];
+                    if (INV) w.y = -w.y;
+                    a[t] = cmul(a[t], w);
+                }
+            }
+            Dft<R, INV>::run(a);
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[b + t * NB] = a[t];
+        }
+        // ---- exchange through LDS (not after the last stage)
+        if constexpr (S + 1 < Plan<LEN>::NST) {
+            int base[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int jb = j + b * P;
+                base[b] = (jb / NS) * (NS * R) + (jb % NS);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
+            __syncthreads();
+            double re[E];
+#pragma unroll
+            for (int q = 0; q < E; ++q) re[q] = line[lpad(j + P * q)];
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = make_double2(re[q], line[lpad(j + P * q)]);
+            Stage<LEN, S + 1, NS * R, INV>::run(v, j, line, tw);
+        }
+    }
+};
+
+// Full line transform.  `line` = this line's LDS buffer (LineBuf<LEN>::STRIDE doubles; unused when
+// the plan has one stage).  `tw` = forward table W_LEN^m, m = 0..LEN-1 (global memory).
+// Every thread of the workgroup must call this (it contains __syncthreads()).
+template <int LEN, bool INV>
+__device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, double* line, const cplx* __restrict__ tw) {
+    Stage<LEN, 0, 1, INV>::run(v, j, line, tw);
+}
+
+}  // namespace ofdft

@@ -1,0 +1,447 @@
+// Real-space and reciprocal-space pointwise kernels + wavefront-shuffle reductions (fp64, gfx950).
+// The math follows the closed forms listed in SURVEY.md §8a (reference: src/professad/functionals.py
+// and tests/tools_for_tests.py; exact lines cited at each functor).
+#pragma once
+#include "fft_kernels.h"
+
+namespace ofdft {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
+constexpr int kRedThreads = 256;
+constexpr int kMaxScalars = 12;    // scalars reduced by one kernel
+
+// ---- block reduction of NS scalars; thread 0 writes partial[blockIdx.x * NS + s]
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __restrict__ partial) {
+    __shared__ double red[kRedThreads / 64][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double v = acc[s];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[s] = v;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) red[w][s] = acc[s];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < kRedThreads / 64; ++ww) t += red[ww][s];
+            partial[(long long)blockIdx.x * NS + s] = t;
+        }
+    }
+}
+
+// sum(a) or sum(a^2)
+template <bool SQUARE>
+__global__ __launch_bounds__(kRedThreads) void sum_kernel(const double* __restrict__ a, long long n,
+                                                          double* __restrict__ partial) {
+    double acc[1] = {0.0};
+    const long long n2 = n >> 1;
+    const double2* a2 = reinterpret_cast<const double2*>(a);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 t = a2[i];
+        acc[0] += SQUARE ? (t.x * t.x + t.y * t.y) : (t.x + t.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc[0] += SQUARE ? a[n - 1] * a[n - 1] : a[n - 1];
+    block_reduce_store<1>(acc, partial);
+}
+
+// elementwise unary maps (prep of FFT inputs)
+enum { MAP_SQRT = 0, MAP_POW = 1, MAP_SCALE_SQ = 2 };
+template <int OP>
+__global__ void map_kernel(const double* __restrict__ a, double* __restrict__ out, long long n, double p) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double x = a[i];
+        double r;
+        if (OP == MAP_SQRT) r = (x != 0.0) ? sqrt(x) : 0.0;        // functionals.py:242-243
+        else if (OP == MAP_POW) r = pow(x, p);
+        else r = p * x * x;                                         // n = c chi^2, system.py:834
+        out[i] = r;
+    }
+}
+
+// WGC99 real-space inputs: A = n^e, B = A theta, C = A theta^2 / 2 (functionals.py:974-981)
+__global__ void wgc_prep_kernel(const double* __restrict__ n, double* __restrict__ A, double* __restrict__ B,
+                                double* __restrict__ C, long long npts, double expo, double nref) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+        const double d = n[i], th = d - nref, a = pow(d, expo);
+        A[i] = a;
+        B[i] = a * th;
+        C[i] = 0.5 * a * th * th;
+    }
+}
+
+// ---- reciprocal space -------------------------------------------------------------------------
+struct KGeom {
+    SpecGeom g;
+    double b[9];   // b = 2 pi inv(box^T), row-major (functional_tools.py:149)
+};
+
+__device__ __forceinline__ double ifreq(int i, int n) { return (double)(i <= n / 2 ? i : i - n); }   // :152-154
+
+__device__ __forceinline__ void kvec(const KGeom& kg, long long i, double& kx, double& ky, double& kz, double& k2) {
+    int x, y, z;
+    spec_decode(kg.g, i, x, y, z);
+    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y, kg.g.n1), fc = (double)z;     // :155 rfftfreq
+    kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];                                  // :158-160
+    ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
+    kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
+    k2 = kx * kx + ky * ky + kz * kz;
+}
+
+// 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648)
+__device__ __forceinline__ double lindhard_shape(double eta) {
+    double ginv;
+    if (eta == 0.0) ginv = 1.0;
+    else if (eta == 1.0) ginv = 0.5;
+    else ginv = 0.5 + ((1.0 - eta * eta) / (4.0 * eta)) * log(fabs((1.0 + eta) / (1.0 - eta)));
+    return 1.0 / ginv - 3.0 * eta * eta - 1.0;
+}
+
+enum { SPEC_HARTREE = 0, SPEC_LAPLACE = 1, SPEC_LINDHARD = 2 };
+// out = in * f(k); p0,p1 parameters (LINDHARD: p0 = prefactor, p1 = 1/(2 kF))
+template <int OP>
+__global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict__ out, KGeom kg, double p0, double p1) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        double kx, ky, kz, k2;
+        kvec(kg, i, kx, ky, kz, k2);
+        double f;
+        if (OP == SPEC_HARTREE) f = (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;              // functionals.py:67-70
+        else if (OP == SPEC_LAPLACE) f = -k2;                                       // functional_tools.py:227
+        else f = p0 * lindhard_shape((k2 != 0.0) ? sqrt(k2) * p1 : 0.0);            // functionals.py:637-638,648
+        const cplx a = in[i];
+        out[i] = make_double2(a.x * f, a.y * f);
+    }
+}
+
+// g_j = i k_j * in (functional_tools.py:183)
+__global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__ gx, cplx* __restrict__ gy,
+                                 cplx* __restrict__ gz, KGeom kg) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        double kx, ky, kz, k2;
+        kvec(kg, i, kx, ky, kz, k2);
+        const cplx a = in[i];
+        gx[i] = make_double2(-kx * a.y, kx * a.x);
+        gy[i] = make_double2(-ky * a.y, ky * a.x);
+        gz[i] = make_double2(-kz * a.y, kz * a.x);
+    }
+}
+
+// out = sum_j i k_j f_j
+__global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* __restrict__ fy, const cplx* __restrict__ fz,
+                                cplx* __restrict__ out, KGeom kg) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        double kx, ky, kz, k2;
+        kvec(kg, i, kx, ky, kz, k2);
+        const cplx a = fx[i], b = fy[i], c = fz[i];
+        out[i] = make_double2(-(kx * a.y + ky * b.y + kz * c.y), kx * a.x + ky * b.x + kz * c.x);
+    }
+}
+
+// WGC99 spectral mixing, in place: (A,B,C) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A)   SURVEY §8a-8
+__global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, cplx* __restrict__ C,
+                                    const double* __restrict__ w0, const double* __restrict__ K1,
+                                    const double* __restrict__ K2, const double* __restrict__ K3, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const cplx a = A[i], b = B[i], c = C[i];
+        const double t0 = w0[i], t1 = K1[i], t2 = K2[i], t3 = K3[i];
+        A[i] = make_double2(t0 * a.x + t1 * b.x + t2 * c.x, t0 * a.y + t1 * b.y + t2 * c.y);
+        B[i] = make_double2(t1 * a.x + t3 * b.x, t1 * a.y + t3 * b.y);
+        C[i] = make_double2(t2 * a.x, t2 * a.y);
+    }
+}
+
+// WGC99 kernel tables on the k grid (functionals.py:845-939 for w,w',w''; :968-972 for T,K1,K2,K3).
+struct WgcSeries {
+    double u, v, c1, c2;      // homogeneous-solution constants
+    double gamma, nref, pref; // pref = 20 nref^(5/3-alpha-beta)
+    double inv2kf;
+    const double* ca;         // [nt] A_i / ((u+2i)^2 - v)
+    const double* cb;         // [nt] B_i / ((u-2i)^2 - v)
+    int nt;
+};
+
+__global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ K1o, double* __restrict__ K2o,
+                                 double* __restrict__ K3o, KGeom kg, WgcSeries s) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        double kx, ky, kz, k2;
+        kvec(kg, i, kx, ky, kz, k2);
+        const double eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        if (eta != 0.0) {
+            const bool inner = eta <= 1.0;
+            const bool on = (s.u >= 0.0) ? inner : !inner;
+            const double C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
+            const double le = log(eta);
+            double H0, H1, H2;
+            if (s.v > 0.0) {
+                const double rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
+                const double px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
+                H0 = (C1 * px + C2 * py) * eta * eta;
+                H1 = (C1 * x * px + C2 * y * py) * eta;
+                H2 = C1 * x * (x - 1.0) * px + C2 * y * (y - 1.0) * py;
+            } else if (s.v == 0.0) {
+                const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+                H0 = pu * (C2 * le + C1);
+                H1 = C2 * pu1 * (1.0 + s.u * le) + C1 * s.u * pu1;
+                H2 = C2 * ((s.u - 1.0) * pu2 * (1.0 + s.u * le) + pu2) + C1 * s.u * (s.u - 1.0) * pu2;
+            } else {
+                const double rv = sqrt(-s.v);
+                const double tc = cos(rv * le), ts = sin(rv * le);
+                const double p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
+                const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+                H0 = pu * (C1 * tc + C2 * ts);
+                H1 = pu1 * (C1 * p + C2 * q);
+                H2 = pu2 * ((s.u - 1.0) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q));
+            }
+            // particular solution: Horner in eta^2 (inside) or eta^-2 (outside)
+            const double x = inner ? eta * eta : 1.0 / (eta * eta);
+            double P0 = 0.0, P1 = 0.0, P2 = 0.0;
+            for (int t = s.nt - 1; t >= 0; --t) {
+                const double ti = 2.0 * t;
+                const double c = inner ? s.cb[t] : s.ca[t];
+                const double d1 = inner ? ti * c : -ti * c;
+                const double d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
+                P0 = P0 * x + c;
+                P1 = P1 * x + d1;
+                P2 = P2 * x + d2;
+            }
+            P1 /= eta;
+            P2 /= eta * eta;
+            w0 = H0 + P0;
+            w1 = H1 + P1;
+            w2 = H2 + P2;
+        }
+        w0 *= s.pref;
+        w1 *= s.pref;
+        w2 *= s.pref;
+        w0o[i] = w0;
+        K1o[i] = -eta * w1 / (6.0 * s.nref);
+        K2o[i] = (eta * eta * w2 + (7.0 - s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
+        K3o[i] = (eta * eta * w2 + (1.0 + s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
+    }
+}
+
+// ---- XC pointwise math -------------------------------------------------------------------------
+// PW92 eps_c(rs) and d eps_c / d rs (functionals.py:1524-1530; tests/tools_for_tests.py:136-144)
+__device__ __forceinline__ void pw92(double rs, double& eps, double& deps_drs) {
+    const double A = 0.0310907, a1 = 0.2137, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    const double sr = sqrt(rs);
+    const double zeta = 2.0 * A * (b1 * sr + b2 * rs + b3 * rs * sr + b4 * rs * rs);
+    const double lg = log(1.0 + 1.0 / zeta);
+    eps = -2.0 * A * (1.0 + a1 * rs) * lg;
+    const double dzeta = 2.0 * A * (0.5 * b1 / sr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
+    deps_drs = -2.0 * A * a1 * lg + 2.0 * A * (1.0 + a1 * rs) * dzeta / (zeta * (zeta + 1.0));
+}
+
+struct XcLocal { double ex, vx, ec, vc; };   // energy densities (per volume) and potentials
+
+// LDA exchange + one of PZ / PW / Chachiyo correlation (functionals.py:1510-1537; tools_for_tests.py:121-152)
+__device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
+    XcLocal r = {0.0, 0.0, 0.0, 0.0};
+    const double cx = -0.75 * cbrt(3.0 / kPi);
+    const double n13 = cbrt(n);
+    if (mask & (1u << 6)) {
+        r.ex = cx * n13 * n;
+        r.vx = (4.0 / 3.0) * cx * n13;
+    }
+    if (mask & ((1u << 7) | (1u << 8) | (1u << 9))) {
+        const double rs = cbrt(3.0 / (4.0 * kPi * n));
+        if (mask & (1u << 7)) {
+            const double gm = -0.1423, b1 = 1.0529, b2 = 0.3334, A = 0.0311, B = -0.048, C = 0.002, D = -0.0116;
+            double eps, v;
+            if (rs < 1.0) {
+                const double lr = log(rs);
+                eps = A * lr + B + C * rs * lr + D * rs;
+                v = lr * (A + (2.0 / 3.0) * C * rs) + (B - A / 3.0) + rs / 3.0 * (2.0 * D - C);
+            } else {
+                const double sr = sqrt(rs), den = 1.0 + b1 * sr + b2 * rs;
+                eps = gm / den;
+                v = gm * (1.0 + (7.0 / 6.0) * b1 * sr + (4.0 / 3.0) * b2 * rs) / (den * den);
+            }
+            r.ec += eps * n;
+            r.vc += v;
+        }
+        if (mask & (1u << 8)) {
+            double eps, d;
+            pw92(rs, eps, d);
+            r.ec += eps * n;
+            r.vc += eps - rs / 3.0 * d;
+        }
+        if (mask & (1u << 9)) {
+            const double a = (log(2.0) - 1.0) / (2.0 * kPi * kPi), b = 20.4562557;
+            const double arg = 1.0 + b / rs + b / (rs * rs);
+            const double eps = a * log(arg);
+            const double d = a / arg * (-b / (rs * rs) - 2.0 * b / (rs * rs * rs));
+            r.ec += eps * n;
+            r.vc += eps - rs / 3.0 * d;
+        }
+    }
+    return r;
+}
+
+struct PbePoint { double fx, fc, dfdn, dfdg; };
+
+// PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
+__device__ __forceinline__ PbePoint pbe_point(double n, double gn2, bool do_x, bool do_c) {
+    PbePoint r = {0.0, 0.0, 0.0, 0.0};
+    const double n13 = cbrt(n);
+    if (do_x) {
+        const double kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
+        const double cx = -0.75 * cbrt(3.0 / kPi);
+        const double ex = cx * n13;
+        const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);     // 0.25 (3 pi^2)^(-2/3)
+        const double n83i = 1.0 / (n13 * n13 * n * n);                   // n^(-8/3)
+        const double s2 = cs * gn2 * n83i;
+        const double den = 1.0 + mu / kappa * s2;
+        const double Fx = 1.0 + kappa - kappa / den;
+        const double dF = mu / (den * den);
+        r.fx = Fx * ex * n;
+        r.dfdn += Fx * (4.0 / 3.0) * ex + dF * (-(8.0 / 3.0) * s2 / n) * ex * n;
+        r.dfdg += dF * cs * n83i * ex * n;
+    }
+    if (do_c) {
+        const double beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi);
+        const double rs = cbrt(3.0 / (4.0 * kPi)) / n13;
+        double eps, deps_drs;
+        pw92(rs, eps, deps_drs);
+        const double deps_dn = -rs / (3.0 * n) * deps_drs;
+        const double ee = exp(-eps / gam);
+        const double A = beta / gam / (ee - 1.0 + 1e-30);
+        const double dAdn = A * A / beta * ee * deps_dn;
+        const double ct = (1.0 / 16.0) * cbrt(kPi / 3.0);
+        const double n43 = n13 * n, n73 = n43 * n + 1e-30;
+        const double t2 = ct * gn2 / n73;
+        const double dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 / (n73 * n73);
+        const double dt2dg = ct / n73;
+        const double At2 = A * t2;
+        const double num = 1.0 + At2, den = 1.0 + At2 + At2 * At2, num2 = 1.0 + 2.0 * At2;
+        const double arg = 1.0 + beta / gam * t2 * num / den;
+        const double H = gam * log(arg);
+        const double dQn = (dt2dn * num2 + dAdn * t2 * t2) / den - t2 * num / (den * den) * (dt2dn * A + dAdn * t2) * num2;
+        const double dQg = (dt2dg * num2) / den - t2 * num / (den * den) * (dt2dg * A) * num2;
+        r.fc = (eps + H) * n;
+        r.dfdn += eps + H + n * (deps_dn + beta / arg * dQn);
+        r.dfdg += n * beta / arg * dQg;
+    }
+    return r;
+}
+
+// PBE mid stage: grad n -> energy partials (x, c), df/dn, flux_j = df/dg * grad_j n (in place)
+__global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restrict__ n, double* __restrict__ gx,
+                                                          double* __restrict__ gy, double* __restrict__ gz,
+                                                          double* __restrict__ dfdn, long long npts, int do_x,
+                                                          int do_c, double* __restrict__ partial) {
+    double acc[2] = {0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+        const double a = gx[i], b = gy[i], c = gz[i];
+        const PbePoint p = pbe_point(n[i], a * a + b * b + c * c, do_x != 0, do_c != 0);
+        acc[0] += p.fx;
+        acc[1] += p.fc;
+        dfdn[i] = p.dfdn;
+        gx[i] = p.dfdg * a;
+        gy[i] = p.dfdg * b;
+        gz[i] = p.dfdg * c;
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// ---- final combine: potential + all energy integrands -------------------------------------------
+struct CombineArgs {
+    const double* n;
+    const double* vext;
+    const double* vh;
+    const double* lap_s;
+    const double* conv_b;
+    const double* conv_a;
+    const double* u0; const double* u1; const double* u2;
+    const double* gA; const double* gB; const double* gC;
+    const double* dfdn;
+    const double* div;
+    double* v_out;
+    long long npts;
+    unsigned mask;
+    double wt_alpha, wt_beta, wt_nbar_pa;     // nbar^alpha
+    double wgc_alpha, wgc_beta, nref;
+};
+// partial scalars: 0 ion-electron, 1 hartree, 2 tf, 3 vw, 4 wt-nl, 5 wgc-nl, 6 lda-x, 7 local-c, 8 sum(v*n)
+constexpr int kCombineScalars = 9;
+
+__global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, double* __restrict__ partial) {
+    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);   // 0.3 (3 pi^2)^(2/3)
+    double acc[kCombineScalars];
+#pragma unroll
+    for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.npts; i += (long long)gridDim.x * blockDim.x) {
+        const double n = a.n[i];
+        double v = 0.0;
+        if (a.mask & 1u) {                                  // ion-electron  functionals.py:46
+            const double ve = a.vext[i];
+            acc[0] += n * ve;
+            v += ve;
+        }
+        if (a.mask & 2u) {                                  // Hartree  functionals.py:72
+            const double vh = a.vh[i];
+            acc[1] += 0.5 * n * vh;
+            v += vh;
+        }
+        if (a.mask & 4u) {                                  // TF  functionals.py:223; tools_for_tests.py:19-20
+            const double n13 = cbrt(n), n23 = n13 * n13;
+            acc[2] += ctf * n23 * n;
+            v += (5.0 / 3.0) * ctf * n23;
+        }
+        if (a.mask & 8u) {                                  // vW  functionals.py:245; tools_for_tests.py:23-26
+            const double s = (n != 0.0) ? sqrt(n) : 0.0, L = a.lap_s[i];
+            acc[3] += -0.5 * s * L;
+            if (n != 0.0) v += -0.5 * L / s;
+        }
+        if (a.mask & 16u) {                                 // WT-family NL  functionals.py:650-651; tools_for_tests.py:29-39
+            const double cb = a.conv_b[i];
+            const double pa1 = pow(n, a.wt_alpha - 1.0);
+            acc[4] += ctf * (pa1 * n - a.wt_nbar_pa) * cb;
+            if (a.conv_a) {
+                const double pb1 = pow(n, a.wt_beta - 1.0);
+                v += ctf * (a.wt_alpha * pa1 * cb + a.wt_beta * pb1 * a.conv_a[i]);
+            } else {
+                v += ctf * 2.0 * a.wt_alpha * pa1 * cb;
+            }
+        }
+        if (a.mask & 32u) {                                 // WGC99 NL  SURVEY §8a-8
+            const double th = n - a.nref;
+            const double pa1 = pow(n, a.wgc_alpha - 1.0), pb1 = pow(n, a.wgc_beta - 1.0);
+            const double P = pa1 * n, A = pb1 * n, dA = a.wgc_beta * pb1;
+            const double u1 = a.u1[i], u2 = a.u2[i];
+            const double conv = a.u0[i] + th * u1 + 0.5 * th * th * u2;
+            acc[5] += ctf * P * conv;
+            v += ctf * (a.wgc_alpha * pa1 * conv + P * (u1 + th * u2) + a.gA[i] * dA + a.gB[i] * (dA * th + A)
+                        + a.gC[i] * (0.5 * dA * th * th + A * th));
+        }
+        if (a.mask & (0xFu << 6)) {                         // local XC
+            const XcLocal x = lda_point(n, a.mask);
+            acc[6] += x.ex;
+            acc[7] += x.ec;
+            v += x.vx + x.vc;
+        }
+        if (a.mask & (3u << 10)) v += a.dfdn[i] - 2.0 * a.div[i];   // PBE  tools_for_tests.py:168-170
+        acc[8] += v * n;
+        if (a.v_out) a.v_out[i] = v;
+    }
+    block_reduce_store<kCombineScalars>(acc, partial);
+}
+
+// chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
+__global__ void chi_grad_kernel(const double* __restrict__ chi, const double* __restrict__ v, double* __restrict__ g,
+                                long long npts, double c2dV, double mu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x)
+        g[i] = c2dV * chi[i] * (v[i] - mu);
+}
+
+}  // namespace ofdft

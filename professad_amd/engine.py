@@ -1,0 +1,173 @@
+"""Python host object over one ofdft_ctx (one grid shape on one GPU).
+
+PyTorch is used only as plumbing: it owns the device tensors and the HIP stream; every number is
+produced by the HIP library behind the C ABI.  There is no CPU path: construction raises when the
+library or a GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """energy + functional derivative of a set of OFDFT terms on a fixed grid shape."""
+
+    def __init__(self, shape, device=None):
+        if not torch.cuda.is_available():
+            raise N.NativeLibraryError('professad_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
+                                       'there is no CPU fallback')
+        self.lib = N.load()
+        self.device = torch.device(device if device is not None else 'cuda:0')
+        if self.device.type != 'cuda':
+            raise ValueError('Engine tensors must live on a GPU device, got %s' % self.device)
+        self.shape = tuple(int(s) for s in shape)
+        if len(self.shape) != 3:
+            raise ValueError('shape must be (n0, n1, n2)')
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._ctx = C.c_void_p(0)
+        rc = self.lib.ofdft_create(C.byref(self._ctx), *self.shape, N.F64, idx)
+        if rc != 0:
+            raise RuntimeError('ofdft_create failed (%d): %s' % (rc, self.lib.ofdft_last_error(None).decode()))
+        self._box_key = None
+        self._terms_key = None
+        self.npts = int(np.prod(self.shape))
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            self.lib.ofdft_destroy(self._ctx)
+            self._ctx = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- helpers
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (what, rc, self.lib.ofdft_last_error(self._ctx).decode()))
+
+    def _grid_tensor(self, t, name):
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            raise TypeError('%s must be a torch.Tensor' % name)
+        if t.device != self.device and not (t.device.type == 'cuda' and self.device.type == 'cuda'
+                                            and (t.device.index or 0) == (self.device.index or 0)):
+            raise ValueError('%s is on %s, engine is on %s' % (name, t.device, self.device))
+        if t.dtype != torch.double:
+            raise TypeError('%s must be torch.double (the reference is fp64 throughout)' % name)
+        if tuple(t.shape) != self.shape:
+            raise ValueError('%s has shape %s, engine grid is %s' % (name, tuple(t.shape), self.shape))
+        return t.detach().contiguous()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- configuration
+    def set_cell(self, box_vecs):
+        box = np.ascontiguousarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64).reshape(9)
+        key = box.tobytes()
+        if key != self._box_key:
+            self._check(self.lib.ofdft_set_cell(self._ctx, box.ctypes.data_as(C.POINTER(C.c_double))), 'ofdft_set_cell')
+            self._box_key = key
+        return self
+
+    def set_terms(self, names, params=None):
+        """names: iterable of keys of _native.TERM_BITS; params: dict slot->value
+        (wt_alpha, wt_beta, wgc_alpha, wgc_beta, wgc_gamma, wgc_kappa)."""
+        mask = 0
+        for nm in names:
+            mask |= N.TERM_BITS[nm]
+        slots = ['wt_alpha', 'wt_beta', 'wgc_alpha', 'wgc_beta', 'wgc_gamma', 'wgc_kappa']
+        s5 = np.sqrt(5.0)
+        vals = np.array([5 / 6, 5 / 6, (5 + s5) / 6, (5 - s5) / 6, 2.7, 1.0], dtype=np.float64)
+        for k, v in (params or {}).items():
+            vals[slots.index(k)] = float(v)
+        key = (mask, vals.tobytes())
+        if key != self._terms_key:
+            self._check(self.lib.ofdft_set_terms(self._ctx, mask, vals.ctypes.data_as(C.POINTER(C.c_double)), len(vals)),
+                        'ofdft_set_terms')
+            self._terms_key = key
+        return self
+
+    # -- hot path
+    def energy_potential(self, den, vext=None, want_potential=True):
+        """-> (dict term -> E [Ha], dE/dn tensor or None)."""
+        den = self._grid_tensor(den, 'den')
+        vext = self._grid_tensor(vext, 'v_ext')
+        out = torch.empty_like(den) if want_potential else None
+        E = (C.c_double * N.NTERMS)()
+        self._check(self.lib.ofdft_energy_potential(self._ctx, _ptr(den), _ptr(vext), E, _ptr(out), self._stream()),
+                    'ofdft_energy_potential')
+        return {nm: E[i] for i, nm in enumerate(N.TERM_ORDER)}, out
+
+    def energy_grad_chi(self, chi, n_elec, vext=None, want_grad=True):
+        """The optimize_density closure: -> (dict term -> E, mu, chi.grad tensor or None)."""
+        chi = self._grid_tensor(chi, 'chi')
+        vext = self._grid_tensor(vext, 'v_ext')
+        out = torch.empty_like(chi) if want_grad else None
+        E = (C.c_double * N.NTERMS)()
+        mu = C.c_double(0.0)
+        self._check(self.lib.ofdft_energy_grad_chi(self._ctx, _ptr(chi), _ptr(vext), float(n_elec), E, C.byref(mu),
+                                                   _ptr(out), self._stream()), 'ofdft_energy_grad_chi')
+        return {nm: E[i] for i, nm in enumerate(N.TERM_ORDER)}, mu.value, out
+
+    # -- validation entry points
+    def rfftn(self, x):
+        x = self._grid_tensor(x, 'x')
+        out = torch.empty(self.shape[0], self.shape[1], self.shape[2] // 2 + 1, dtype=torch.complex128, device=self.device)
+        self._check(self.lib.ofdft_rfftn(self._ctx, _ptr(x), _ptr(out), self._stream()), 'ofdft_rfftn')
+        return out
+
+    def irfftn(self, xk):
+        want = (self.shape[0], self.shape[1], self.shape[2] // 2 + 1)
+        if tuple(xk.shape) != want or xk.dtype != torch.complex128:
+            raise ValueError('spectrum must be complex128 of shape %s' % (want,))
+        xk = xk.detach().contiguous()
+        out = torch.empty(self.shape, dtype=torch.double, device=self.device)
+        self._check(self.lib.ofdft_irfftn(self._ctx, _ptr(xk), _ptr(out), self._stream()), 'ofdft_irfftn')
+        return out
+
+    def query(self, what):
+        v = C.c_double(0.0)
+        self._check(self.lib.ofdft_query(self._ctx, int(what), C.byref(v)), 'ofdft_query')
+        return v.value
+
+    def set_profiling(self, on):
+        self._check(self.lib.ofdft_set_profiling(self._ctx, 1 if on else 0), 'ofdft_set_profiling')
+
+    def profile(self):
+        """-> {kernel class: (total ms, launches)} accumulated since set_profiling(True)."""
+        out = {}
+        buf = C.create_string_buffer(64)
+        for i in range(self.lib.ofdft_profile_count(self._ctx)):
+            ms, n = C.c_double(0.0), C.c_longlong(0)
+            self._check(self.lib.ofdft_profile_get(self._ctx, i, buf, 64, C.byref(ms), C.byref(n)), 'ofdft_profile_get')
+            out[buf.value.decode()] = (ms.value, n.value)
+        return out
+
+    @property
+    def fast_path(self):
+        return bool(self.query(N.Q_FAST_PATH))
+
+
+_ENGINES = {}
+
+
+def engine_for(shape, device):
+    """One cached Engine per (shape, device)."""
+    dev = torch.device(device)
+    key = (tuple(int(s) for s in shape), dev.type, dev.index if dev.index is not None else 0)
+    e = _ENGINES.get(key)
+    if e is None:
+        e = _ENGINES[key] = Engine(shape, dev)
+    return e

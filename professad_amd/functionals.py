@@ -1,0 +1,222 @@
+"""Drop-in energy terms with the reference's names and call signatures, backed by the HIP engine.
+
+Every callable here has the reference protocol ``f(box_vecs, den) -> torch scalar`` (``IonElectron``
+takes ``v_ext`` as a third argument) of src/professad/functionals.py, keeps the reference's
+``__name__``/``__qualname__`` (professad's System dispatches on them, system.py:199-203,761-771,
+917-921) and supports ``E.backward()`` / ``torch.autograd.grad`` w.r.t. ``den`` -- once-differentiable,
+with the analytic functional derivative computed by the engine (no autograd through FFTs).
+
+So ``terms=[IonElectron, Hartree, WangTeter, PerdewBurkeErnzerhof]`` built from THIS module can be
+handed to professad's ``System`` unchanged, and ``get_functional_derivative(box_vecs, den, f)``
+(functional_tools.py:9-31) works on them.  ``NativeTerms`` fuses several terms into one engine call
+(shared spectra; System only sums its terms, system.py:771).
+
+Gradients w.r.t. ``box_vecs`` (stress) are not produced natively: asking for them raises.
+"""
+import numpy as np
+import torch
+
+from . import _native as N
+from .engine import engine_for
+
+_S5 = np.sqrt(5.0)
+
+
+class _NativeEnergy(torch.autograd.Function):
+    """forward: C-ABI call (energy + dE/dn); backward: gE * dE/dn * dV  (functional_tools.py:31)."""
+
+    @staticmethod
+    def forward(ctx, box_vecs, den, v_ext, term_names, params):
+        if box_vecs.requires_grad:
+            raise NotImplementedError('native terms do not provide dE/d(box_vecs) (stress); '
+                                      'use the reference torch terms for System.stress()')
+        eng = engine_for(den.shape, den.device)
+        eng.set_cell(box_vecs)
+        eng.set_terms(term_names, dict(params))
+        need_v = den.requires_grad
+        E_terms, v = eng.energy_potential(den, v_ext, want_potential=need_v)
+        dV = float(torch.abs(torch.linalg.det(box_vecs.detach().double().cpu()))) / den.numel()
+        ctx.dV = dV
+        ctx.has_vext = v_ext is not None
+        ctx.save_for_backward(v if need_v else None, den.detach() if (v_ext is not None and v_ext.requires_grad) else None)
+        ctx.E_terms = E_terms
+        return torch.tensor(sum(E_terms.values()), dtype=torch.double, device=den.device)
+
+    @staticmethod
+    def backward(ctx, gE):
+        v, den = ctx.saved_tensors
+        g_den = gE * v * ctx.dV if v is not None else None
+        g_vext = gE * den * ctx.dV if den is not None else None       # d/dv_ext of mean(n v) vol
+        return None, g_den, g_vext, None, None
+
+
+def _evaluate(box_vecs, den, names, params=(), v_ext=None):
+    return _NativeEnergy.apply(box_vecs, den, v_ext, tuple(names), tuple(params))
+
+
+class NativeTerms:
+    """Several reference terms fused into ONE engine evaluation.
+
+    ``NativeTerms(['hartree', 'wgc99', 'pbe'])`` behaves like a single reference functional
+    f(box_vecs, den); with ``'ion_electron'`` in the list it takes the reference's IonElectron
+    signature f(box_vecs, den, v_ext) and carries ``__qualname__ == 'IonElectron'`` so that professad's
+    System passes v_ext (system.py:762-763)."""
+
+    ALIASES = {
+        'wt': ('tf', 'vw', 'wt_nl'), 'wgc99': ('tf', 'vw', 'wgc99_nl'),
+        'pz': ('lda_x', 'pz_c'), 'pw': ('lda_x', 'pw_c'), 'chachiyo': ('lda_x', 'chachiyo_c'),
+        'pbe': ('pbe_x', 'pbe_c'),
+    }
+
+    def __init__(self, names, **params):
+        flat = []
+        for nm in names:
+            for t in self.ALIASES.get(nm, (nm,)):
+                if t not in N.TERM_BITS:
+                    raise KeyError('unknown term %r' % (t,))
+                if t not in flat:
+                    flat.append(t)
+        self.names = tuple(flat)
+        self.params = tuple(sorted(params.items()))
+        self.needs_vext = 'ion_electron' in flat
+        self.__name__ = self.__qualname__ = 'IonElectron' if self.needs_vext else 'NativeTerms'
+        self.last_energies = None
+
+    def __call__(self, box_vecs, den, v_ext=None):
+        if self.needs_vext and v_ext is None:
+            raise TypeError('this NativeTerms includes ion_electron and needs v_ext')
+        return _evaluate(box_vecs, den, self.names, self.params, v_ext if self.needs_vext else None)
+
+    def potential(self, box_vecs, den, v_ext=None):
+        """dE/dn grid -- the reference's ``potentials=`` hook signature f(box_vecs, den) (system.py:849)."""
+        eng = engine_for(den.shape, den.device)
+        eng.set_cell(box_vecs)
+        eng.set_terms(self.names, dict(self.params))
+        self.last_energies, v = eng.energy_potential(den, v_ext if self.needs_vext else None)
+        return v
+
+
+# ----------------------------------------------------------------- reference-named functionals
+def IonIon():
+    """Marker term, handled by System (functionals.py:21-28)."""
+    return None
+
+
+def IonElectron(box_vecs, den, v_ext):
+    """functionals.py:31-46"""
+    return _evaluate(box_vecs, den, ('ion_electron',), v_ext=v_ext)
+
+
+def Hartree(box_vecs, den):
+    """functionals.py:49-72"""
+    return _evaluate(box_vecs, den, ('hartree',))
+
+
+def ThomasFermi(box_vecs, den):
+    """functionals.py:207-224"""
+    return _evaluate(box_vecs, den, ('tf',))
+
+
+def Weizsaecker(box_vecs, den):
+    """functionals.py:227-246"""
+    return _evaluate(box_vecs, den, ('vw',))
+
+
+def non_local_KEF(box_vecs, den, alpha, beta):
+    """functionals.py:644-652"""
+    return _evaluate(box_vecs, den, ('wt_nl',), (('wt_alpha', float(alpha)), ('wt_beta', float(beta))))
+
+
+def _wt_style(alpha, beta):
+    p = (('wt_alpha', float(alpha)), ('wt_beta', float(beta)))
+
+    def f(box_vecs, den):
+        return _evaluate(box_vecs, den, ('tf', 'vw', 'wt_nl'), p)
+    return f
+
+
+WangTeter = _wt_style(5 / 6, 5 / 6)                        # functionals.py:655-670
+Perrot = _wt_style(1.0, 1.0)                               # functionals.py:673-689
+SmargiassiMadden = _wt_style(0.5, 0.5)                     # functionals.py:692-707
+WangGovindCarter98 = _wt_style((5 + _S5) / 6, (5 - _S5) / 6)   # functionals.py:710-725
+for _f, _n in ((WangTeter, 'WangTeter'), (Perrot, 'Perrot'), (SmargiassiMadden, 'SmargiassiMadden'),
+               (WangGovindCarter98, 'WangGovindCarter98')):
+    _f.__name__ = _f.__qualname__ = _n
+
+
+class WangGovindCarter99:
+    """functionals.py:787-985.  ``init_args=(alpha, beta, gamma, kappa)`` as in the reference (:795-815);
+    call the instance or its ``forward``.  The kernel tables are generated on the GPU and cached in the
+    engine while the cell and the rounded electron count are unchanged (reference rule :961-966)."""
+
+    def __init__(self, init_args=None):
+        if init_args is None:
+            init_args = ((5 + _S5) / 6, (5 - _S5) / 6, 2.7, 1.0)
+        self.alpha, self.beta, self.gamma, self.kappa = (float(x) for x in init_args)
+        self.__name__ = self.__qualname__ = 'WangGovindCarter99'
+
+    def _params(self):
+        return (('wgc_alpha', self.alpha), ('wgc_beta', self.beta), ('wgc_gamma', self.gamma), ('wgc_kappa', self.kappa))
+
+    def forward(self, box_vecs, den):
+        return _evaluate(box_vecs, den, ('tf', 'vw', 'wgc99_nl'), self._params())
+
+    __call__ = forward
+
+
+def lda_exchange(box_vecs, den):
+    """functionals.py:1510-1512"""
+    return _evaluate(box_vecs, den, ('lda_x',))
+
+
+def perdew_zunger_correlation(box_vecs, den):
+    """functionals.py:1515-1521"""
+    return _evaluate(box_vecs, den, ('pz_c',))
+
+
+def perdew_wang_correlation(box_vecs, den):
+    """functionals.py:1524-1530"""
+    return _evaluate(box_vecs, den, ('pw_c',))
+
+
+def chachiyo_correlation(box_vecs, den):
+    """functionals.py:1533-1537"""
+    return _evaluate(box_vecs, den, ('chachiyo_c',))
+
+
+def PerdewZunger(box_vecs, den):
+    """functionals.py:1540-1554"""
+    return _evaluate(box_vecs, den, ('lda_x', 'pz_c'))
+
+
+def PerdewWang(box_vecs, den):
+    """functionals.py:1557-1571"""
+    return _evaluate(box_vecs, den, ('lda_x', 'pw_c'))
+
+
+def Chachiyo(box_vecs, den):
+    """functionals.py:1574-1588"""
+    return _evaluate(box_vecs, den, ('lda_x', 'chachiyo_c'))
+
+
+def pbe_exchange(box_vecs, den):
+    """functionals.py:1597-1603"""
+    return _evaluate(box_vecs, den, ('pbe_x',))
+
+
+def pbe_correlation(box_vecs, den):
+    """functionals.py:1606-1618"""
+    return _evaluate(box_vecs, den, ('pbe_c',))
+
+
+def PerdewBurkeErnzerhof(box_vecs, den):
+    """functionals.py:1621-1635"""
+    return _evaluate(box_vecs, den, ('pbe_x', 'pbe_c'))
+
+
+def get_functional_derivative(box_vecs, den, functional):
+    """functional_tools.py:9-31 for native terms (same result as autograd on them, one engine call)."""
+    den = den.detach().requires_grad_()
+    E = functional(box_vecs, den)
+    (g,) = torch.autograd.grad(E, den)
+    return g / (torch.abs(torch.linalg.det(box_vecs)) / den.numel())

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against
+  (1) the reference's own outputs committed as golden fixtures,
+  (2) the pinned CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at larger sizes.
+Tolerances: fp64 everywhere; energies within 1e-10 relative (north-star bar: 1e-8 Ha/atom),
+potentials within 5e-10 of the max magnitude."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import closed_form as cf
+from professad_amd import functionals as F
+from professad_amd import synth
+from professad_amd.engine import Engine, engine_for
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.dirname(os.path.abspath(cases.__file__))
+DEV = 'cuda:0'
+E_RTOL = 1e-10
+V_RTOL = 5e-10
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=DEV)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+# ------------------------------------------------------------------------------- FFT building block
+FFT_SHAPES = [(8, 8, 16), (16, 16, 16), (16, 32, 64), (64, 64, 64), (32, 16, 128), (8, 128, 32), (256, 8, 32),
+              (128, 128, 128), (512, 8, 16), (8, 1024, 16), (8, 8, 1024), (8, 8, 2048),
+              (17, 17, 17), (18, 20, 16), (5, 6, 7), (20, 20, 20), (9, 8, 12)]
+
+
+@pytest.mark.parametrize('shape', FFT_SHAPES)
+def test_rfftn_irfftn_match_numpy(shape):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape)
+    eng = Engine(shape, DEV)
+    got = eng.rfftn(dev(x)).cpu().numpy()
+    ref = np.fft.rfftn(x)
+    assert relerr(got, ref) < 1e-13
+    # non-Hermitian spectrum: imaginary parts at kz=0 / Nyquist must be ignored exactly like irfftn
+    yk = rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape)
+    got_r = eng.irfftn(torch.as_tensor(yk, device=DEV)).cpu().numpy()
+    ref_r = np.fft.irfftn(yk, s=shape, axes=(0, 1, 2))
+    assert relerr(got_r, ref_r) < 1e-13
+    assert eng.fast_path == all((s & (s - 1)) == 0 for s in shape)
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- golden: per term
+_REF_NAME = {
+    'hartree': F.Hartree, 'tf': F.ThomasFermi, 'vw': F.Weizsaecker,
+    'wt_nl': lambda b, d: F.non_local_KEF(b, d, 5 / 6, 5 / 6),
+    'wt': F.WangTeter, 'perrot': F.Perrot, 'sm': F.SmargiassiMadden, 'wgc98': F.WangGovindCarter98,
+    'wgc99': F.WangGovindCarter99(), 'lda_x': F.lda_exchange, 'pz_c': F.perdew_zunger_correlation,
+    'pw_c': F.perdew_wang_correlation, 'chachiyo_c': F.chachiyo_correlation,
+    'pbe_x': F.pbe_exchange, 'pbe_c': F.pbe_correlation,
+}
+
+
+@pytest.mark.parametrize('case', cases.PER_TERM_CASES)
+def test_terms_match_reference_golden(case):
+    gold = load('terms_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    tb, td, tv = dev(box), dev(den), dev(vext)
+    for nm in cases.SINGLE_TERMS:
+        f = (lambda b, d: F.IonElectron(b, d, tv)) if nm == 'ion_electron' else _REF_NAME[nm]
+        E = float(f(tb, td))
+        v = F.get_functional_derivative(tb, td, f).cpu().numpy()
+        Eref, vref = float(gold['E_' + nm]), gold['v_' + nm]
+        assert abs(E - Eref) <= E_RTOL * max(1.0, abs(Eref)), (nm, E, Eref)
+        assert relerr(v, vref) < V_RTOL, (nm, relerr(v, vref))
+
+
+# ------------------------------------------------------------------------------- golden: fused + closure
+_CFG_TERMS = {
+    'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'],
+    'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
+    'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe'],
+}
+
+
+@pytest.mark.parametrize('case', cases.FUSED_CASES)
+def test_fused_configs_and_closure_match_reference_golden(case):
+    gold = load('fused_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    tb, td, tv, tc = dev(box), dev(den), dev(vext), dev(chi)
+    for cfg, names in _CFG_TERMS.items():
+        fused = F.NativeTerms(names)
+        d = td.clone().requires_grad_()
+        E = fused(tb, d, tv)
+        E.backward()
+        dV = abs(np.linalg.det(box)) / den.size
+        Eref = float(gold['E_' + cfg])
+        assert abs(float(E) - Eref) <= E_RTOL * max(1.0, abs(Eref))
+        assert relerr(d.grad.cpu().numpy() / dV, gold['v_' + cfg]) < V_RTOL
+        # `potentials=` hook form
+        assert relerr(fused.potential(tb, td, tv).cpu().numpy(), gold['v_' + cfg]) < V_RTOL
+        # the optimize_density closure
+        eng = engine_for(den.shape, DEV).set_cell(tb).set_terms(fused.names)
+        Et, mu, g = eng.energy_grad_chi(tc, n_elec, tv)
+        Ecl = float(gold['Ec_' + cfg])
+        assert abs(sum(Et.values()) - Ecl) <= E_RTOL * max(1.0, abs(Ecl))
+        assert relerr(g.cpu().numpy(), gold['g_' + cfg]) < V_RTOL
+
+
+def test_big_scalars_match_reference_golden():
+    import json
+    path = os.path.join(GOLDEN, 'big_scalars.json')
+    if not os.path.exists(path):
+        pytest.skip('big_scalars.json not generated')
+    big = json.load(open(path))
+    for key, rec in big.items():
+        cfg, n = key.split('_')
+        n = int(n)
+        if n > 128:
+            continue
+        shape = (n, n, n)
+        box = synth.cubic_cell(n)
+        den = synth.random_density(shape, seed=1234)
+        vext = synth.random_potential(shape, seed=77)
+        assert abs(cases.checksum(den[:8, :8, :8]) - rec['input_checksum']) < 1e-9
+        fused = F.NativeTerms(_CFG_TERMS[cfg])
+        v = fused.potential(dev(box), dev(den), dev(vext)).cpu().numpy()
+        E = sum(fused.last_energies.values())
+        assert abs(E - rec['E']) <= E_RTOL * abs(rec['E']), (key, E, rec['E'])
+        st = cases.probe_stats(v)
+        assert abs(st['sum'] - rec['pot']['sum']) <= 1e-9 * abs(rec['pot']['l2']) * np.sqrt(v.size)
+        assert abs(st['l2'] - rec['pot']['l2']) <= 1e-10 * rec['pot']['l2']
+        assert np.allclose(st['probes'], rec['pot']['probes'], rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------- oracle on seeded inputs
+@pytest.mark.parametrize('shape,cell', [((64, 64, 64), ('cubic', 64)), ((32, 64, 16), ('tri', 1.3)),
+                                        ((24, 20, 18), ('tri', 0.8)), ((33, 32, 31), ('cubic', 32))])
+def test_configs_match_oracle_on_seeded_inputs(shape, cell):
+    box = cases.make_cell(cell)
+    den = synth.smooth_density(shape, seed=11) * (1 + 0.05 * np.random.default_rng(5).random(shape))
+    vext = synth.random_potential(shape, seed=12)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(6).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
+    ev = cf.Evaluator(cf.Grid(box, shape))
+    for cfg, names in _CFG_TERMS.items():
+        fused = F.NativeTerms(names)
+        v = fused.potential(dev(box), dev(den), dev(vext)).cpu().numpy()
+        Eo, Es, vo = ev.terms(cases.CONFIGS[cfg], den, vext)
+        assert abs(sum(fused.last_energies.values()) - Eo) <= E_RTOL * max(1.0, abs(Eo))
+        assert relerr(v, vo) < V_RTOL
+        eng = engine_for(shape, DEV).set_cell(dev(box)).set_terms(fused.names)
+        Et, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+        Ec, go, muo = ev.closure(cases.CONFIGS[cfg], chi, n_elec, vext)
+        assert abs(sum(Et.values()) - Ec) <= E_RTOL * max(1.0, abs(Ec))
+        assert abs(mu - muo) <= 1e-9 * max(1.0, abs(muo))
+        assert relerr(g.cpu().numpy(), go) < V_RTOL
+
+
+# ------------------------------------------------------------------------------- size-independent properties
+@pytest.mark.parametrize('n', [128, 256])
+def test_periodic_tiling_gives_extensive_energy_and_tiled_potential(n):
+    """A 32^3 state tiled (n/32)^3 times on the (n/32)x cell: every term is extensive, so E scales by the
+    tile count and the potential is the tiled 32^3 potential (needs no reference on the GPU box)."""
+    base = 32
+    box32 = synth.cubic_cell(base)
+    den32 = synth.smooth_density((base,) * 3, seed=21) * (1 + 0.02 * np.random.default_rng(8).random((base,) * 3))
+    vext32 = synth.random_potential((base,) * 3, seed=22)
+    # make the 32^3 electron count an exact integer so that WGC99's rounding commutes with tiling
+    vol32 = abs(np.linalg.det(box32))
+    den32 *= 3.0 / (den32.mean() * vol32)
+    r = n // base
+    fused = F.NativeTerms(_CFG_TERMS['cfg3'])
+    v32 = fused.potential(dev(box32), dev(den32), dev(vext32)).cpu().numpy()
+    E32 = dict(fused.last_energies)
+    vN = fused.potential(dev(synth.cubic_cell(n)), dev(synth.tile_periodic(den32, n)),
+                         dev(synth.tile_periodic(vext32, n)))
+    EN = dict(fused.last_energies)
+    for k in E32:
+        assert abs(EN[k] - r ** 3 * E32[k]) <= 2e-10 * max(1.0, abs(EN[k])), (k, EN[k], r ** 3 * E32[k])
+    assert relerr(vN[:base, :base, :base].cpu().numpy(), v32) < V_RTOL
+    assert relerr(vN[-base:, base:2 * base, -base:].cpu().numpy(), v32) < V_RTOL
+
+
+def test_round_trip_and_linearity_256():
+    shape = (256, 256, 256)
+    eng = engine_for(shape, DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = torch.randn(shape, dtype=torch.double, device=DEV, generator=g)
+    b = torch.randn(shape, dtype=torch.double, device=DEV, generator=g)
+    ak = eng.rfftn(a)
+    assert float((eng.irfftn(ak) - a).abs().max()) < 1e-12
+    lin = eng.rfftn(a + 2 * b) - (ak + 2 * eng.rfftn(b))
+    assert float(lin.abs().max()) < 1e-9 * float(ak.abs().max())
+    # Parseval on the half spectrum
+    w = torch.full((129,), 2.0, dtype=torch.double, device=DEV)
+    w[0] = w[-1] = 1.0
+    lhs = float((a * a).sum())
+    rhs = float(((ak.real ** 2 + ak.imag ** 2) * w).sum()) / a.numel()
+    assert abs(lhs - rhs) < 1e-11 * lhs
+
+
+# ------------------------------------------------------------------------------- edge cases / errors
+def test_zero_density_point_vw_guard_and_errors():
+    box, den, vext, chi, n_elec = cases.make_inputs('g16r')
+    tb = dev(box)
+    d0 = den.copy()
+    d0[3, 4, 5] = 0.0
+    v = F.get_functional_derivative(tb, dev(d0), F.Weizsaecker).cpu().numpy()
+    assert np.isfinite(v).all() and v[3, 4, 5] == 0.0              # functionals.py:242-243 guard
+    with pytest.raises(RuntimeError):
+        engine_for(den.shape, DEV).set_cell(tb).set_terms(['ion_electron']).energy_potential(dev(den), None)
+    with pytest.raises(TypeError):
+        F.Hartree(tb, dev(den).float())
+    with pytest.raises(ValueError):
+        engine_for(den.shape, DEV).energy_potential(dev(den)[:8])
+    with pytest.raises(NotImplementedError):
+        F.Hartree(tb.clone().requires_grad_(), dev(den))
+    with pytest.raises(RuntimeError):
+        engine_for(den.shape, DEV).set_cell(torch.zeros(3, 3, dtype=torch.double))
+
+
+def test_reference_system_protocol_sum_of_terms():
+    """Mimics System.__compute_energy's dispatch (system.py:759-772) over native terms."""
+    box, den, vext, chi, n_elec = cases.make_inputs('g16r')
+    gold = load('fused_g16r.npz')
+    tb, tv = dev(box), dev(vext)
+    terms = [F.IonIon, F.IonElectron, F.Hartree, F.WangGovindCarter99().forward, F.PerdewBurkeErnzerhof]
+    d = dev(den).requires_grad_()
+    E = torch.zeros((1,), dtype=torch.double, device=DEV)
+    for f in terms:
+        if f.__qualname__ == 'IonElectron':
+            E = E + f(tb, d, tv)
+        elif f.__qualname__ == 'IonIon':
+            continue
+        else:
+            E = E + f(tb, d)
+    E.backward()
+    assert abs(float(E) - float(gold['E_cfg3'])) <= E_RTOL * abs(float(gold['E_cfg3']))
+    dV = abs(np.linalg.det(box)) / den.size
+    assert relerr(d.grad.cpu().numpy() / dV, gold['v_cfg3']) < V_RTOL

@@ -1,0 +1,65 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every declared symbol; host logic."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from professad_amd import _native as N
+from professad_amd import functionals as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.load()
+    header = open(os.path.join(ROOT, 'include', 'ofdft_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(ofdft_[a-z_]+)\s*\(', header)))
+    assert declared == sorted(N.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_header_constants_match_python_mirror():
+    header = open(os.path.join(ROOT, 'include', 'ofdft_hip.h')).read()
+    bits = dict(re.findall(r'#define OFDFT_([A-Z0-9_]+)\s+\(1u << (\d+)\)', header))
+    for nm, bit in N.TERM_BITS.items():
+        assert int(bits[nm.upper()]) == bit.bit_length() - 1
+    assert N.TERM_ORDER == sorted(N.TERM_BITS, key=lambda k: N.TERM_BITS[k])
+    assert int(re.search(r'#define OFDFT_NTERMS\s+(\d+)', header).group(1)) == N.NTERMS == len(N.TERM_ORDER)
+
+
+def test_error_paths_without_gpu():
+    lib = N.load()
+    ctx = ctypes.c_void_p(0)
+    # invalid extents are rejected before any device work
+    assert lib.ofdft_create(ctypes.byref(ctx), 1, 8, 8, N.F64, 0) == N.EINVAL
+    assert b'extents' in lib.ofdft_last_error(None)
+    assert lib.ofdft_create(ctypes.byref(ctx), 8, 8, 16, N.F32, 0) == N.EINVAL
+    assert lib.ofdft_set_cell(None, None) == N.EINVAL
+    if not torch.cuda.is_available():
+        rc = lib.ofdft_create(ctypes.byref(ctx), 16, 16, 16, N.F64, 0)
+        assert rc == N.EHIP and not ctx.value
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_path_fails_loudly_without_gpu():
+    box = torch.eye(3, dtype=torch.double) * 5
+    den = torch.full((16, 16, 16), 0.03, dtype=torch.double)
+    with pytest.raises(N.NativeLibraryError):
+        F.Hartree(box, den)
+
+
+def test_reference_protocol_names():
+    assert F.IonElectron.__qualname__ == 'IonElectron' and F.IonElectron.__name__ == 'IonElectron'
+    assert F.IonIon.__qualname__ == 'IonIon'
+    assert F.WangTeter.__qualname__ == 'WangTeter'
+    w = F.WangGovindCarter99()
+    assert w.__qualname__ == 'WangGovindCarter99' and (w.alpha, w.gamma) == ((5 + 5 ** 0.5) / 6, 2.7)
+    fused = F.NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe'])
+    assert fused.__qualname__ == 'IonElectron' and fused.needs_vext
+    assert fused.names == ('ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c')
+    assert F.NativeTerms(['wt', 'pz']).__qualname__ == 'NativeTerms'
+    with pytest.raises(KeyError):
+        F.NativeTerms(['nope'])
