@@ -80,7 +80,12 @@ def cpu_baseline(sample_n, budget_s=30.0):
     """The oracle's op-for-op restatement of the reference path (autograd through torch.fft on the host
     cores), timed on a bounded sample of the same workload."""
     from oracle import refpath as rp
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # a 1-GPU box grants a 16-core CPU share even when more cores are visible
+    torch.set_num_threads(int(os.environ.get('OFDFT_CPU_THREADS', min(avail, 16))))
     box, chi, vext, n_elec, _ = make_inputs(sample_n)
     tb, tc, tv = torch.as_tensor(box), torch.as_tensor(chi), torch.as_tensor(vext)
     table = rp.term_table(tv)

@@ -106,6 +106,11 @@ int  ofdft_irfftn(ofdft_ctx* ctx, const void* spec_dev, void* real_dev, void* st
 
 int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
 
+/* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (fused x passes on power-of-two grids),
+ * 1 = force the unfused reference pipeline (separate forward, multiply and inverse passes). */
+#define OFDFT_OPT_PIPELINE 0
+int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
+
 /* Measurement support (bench.py): when on, every kernel launch of the energy calls is bracketed by HIP
  * events on the caller's stream and the durations are accumulated per kernel class.  Adds launch overhead:
  * never on inside a timed region. */

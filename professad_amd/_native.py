@@ -27,7 +27,7 @@ Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1,
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
-           'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
+           'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
 class NativeLibraryError(RuntimeError):
@@ -75,6 +75,8 @@ def load():
     lib.ofdft_irfftn.restype = ip
     lib.ofdft_query.argtypes = [vp, ip, dp]
     lib.ofdft_query.restype = ip
+    lib.ofdft_set_option.argtypes = [vp, ip, C.c_double]
+    lib.ofdft_set_option.restype = ip
     lib.ofdft_set_profiling.argtypes = [vp, ip]
     lib.ofdft_set_profiling.restype = ip
     lib.ofdft_profile_count.argtypes = [vp]

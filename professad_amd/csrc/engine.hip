@@ -30,7 +30,7 @@ struct ofdft_ctx {
     SpecGeom g{};
     KGeom kg{};
     long long npts = 0;
-    bool fast = false, cell_set = false;
+    bool fast = false, cell_set = false, force_unfused = false;
     double box[9] = {0}, vol = 0.0, dV = 0.0;
     unsigned mask = 0;
     double params[OFDFT_NPARAMS];
@@ -190,28 +190,14 @@ void prof_collect(ofdft_ctx* c) {
 
 // ---------------------------------------------------------------------------------- FFT drivers
 template <int LEN, bool INV>
-int launch_cpass_t(ofdft_ctx* c, cplx* data, const LineMap& m, hipStream_t st, const char* nm) {
+int launch_cpass_t(ofdft_ctx* c, cplx* data, const LineMap& main, const LineMap& rem, hipStream_t st, const char* nm) {
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     using Cfg = PassCfg<LEN>;
-    const int blocks = (m.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, data, m, tw);
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, data, main, rem, mb,
+                 c->g.main_count, tw);
     return 0;
-}
-
-template <bool INV>
-int launch_cpass(ofdft_ctx* c, int len, cplx* data, const LineMap& m, hipStream_t st, const char* nm) {
-    switch (len) {
-        case 8: return launch_cpass_t<8, INV>(c, data, m, st, nm);
-        case 16: return launch_cpass_t<16, INV>(c, data, m, st, nm);
-        case 32: return launch_cpass_t<32, INV>(c, data, m, st, nm);
-        case 64: return launch_cpass_t<64, INV>(c, data, m, st, nm);
-        case 128: return launch_cpass_t<128, INV>(c, data, m, st, nm);
-        case 256: return launch_cpass_t<256, INV>(c, data, m, st, nm);
-        case 512: return launch_cpass_t<512, INV>(c, data, m, st, nm);
-        case 1024: return launch_cpass_t<1024, INV>(c, data, m, st, nm);
-    }
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
 }
 
 // line maps of the block-8 layout (see fft_kernels.h)
@@ -226,6 +212,8 @@ void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
         main.d = 8; main.sb = (long long)g.n1 * 8; main.sl = 1; main.se = 8; main.nlines = nb * g.n0 * 8; main.lf = 8;
         rem.d = 1; rem.sb = g.n1; rem.sl = 0; rem.se = 1; rem.nlines = nrem * g.n0; rem.lf = 1;
     }
+    if (main.nlines == 0) { main.d = 1; main.lf = 1; }
+    if (rem.nlines == 0) { rem.d = 1; rem.lf = 1; }
 }
 
 template <bool INV>
@@ -233,26 +221,17 @@ int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
     LineMap main, rem;
     pass_maps(c, axis, main, rem);
     const int len = axis == 0 ? c->n0 : c->n1;
-    int lpw;
+    const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
+#define OFDFT_CASE(L)                                                   \
+    case L:                                                             \
+        if (axis == 0) main.lf = rem.lf = PassCfg<L>::LPW;              \
+        return launch_cpass_t<L, INV>(c, spec, main, rem, st, nm);
     switch (len) {
-        case 8: lpw = PassCfg<8>::LPW; break;
-        case 16: lpw = PassCfg<16>::LPW; break;
-        case 32: lpw = PassCfg<32>::LPW; break;
-        case 64: lpw = PassCfg<64>::LPW; break;
-        case 128: lpw = PassCfg<128>::LPW; break;
-        case 256: lpw = PassCfg<256>::LPW; break;
-        case 512: lpw = PassCfg<512>::LPW; break;
-        default: lpw = PassCfg<1024>::LPW; break;
+        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
+        OFDFT_CASE(1024)
     }
-    if (axis == 0) {
-        main.lf = lpw;
-        rem.lf = lpw;
-    }
-    if (main.nlines > 0)
-        if (int rc = launch_cpass<INV>(c, len, spec, main, st, axis == 0 ? "cpass_x" : "cpass_y")) return rc;
-    if (rem.nlines > 0)
-        if (int rc = launch_cpass<INV>(c, len, spec + c->g.main_count, rem, st, axis == 0 ? "cpass_x_nyq" : "cpass_y_nyq")) return rc;
-    return 0;
+#undef OFDFT_CASE
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
 }
 
 template <int M>
@@ -349,6 +328,75 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStre
     OFDFT_LAUNCH(c, st, "gen_c2r_z", (gen_c2r_z_kernel<PostScale>), dim3((unsigned)((c->npts + 255) / 256)), dim3(256), 0, cur, out,
                        c->g, tw2, post);
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------- fused-pipeline pieces
+// z-forward + y-forward (the x transform is left to the fused x pass)
+int fwd_zy(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+    c->fft_count++;
+    int rc;
+    switch (c->n2 / 2) {
+        case 8: rc = launch_zfwd_t<8>(c, in, spec, st); break;
+        case 16: rc = launch_zfwd_t<16>(c, in, spec, st); break;
+        case 32: rc = launch_zfwd_t<32>(c, in, spec, st); break;
+        case 64: rc = launch_zfwd_t<64>(c, in, spec, st); break;
+        case 128: rc = launch_zfwd_t<128>(c, in, spec, st); break;
+        case 256: rc = launch_zfwd_t<256>(c, in, spec, st); break;
+        case 512: rc = launch_zfwd_t<512>(c, in, spec, st); break;
+        case 1024: rc = launch_zfwd_t<1024>(c, in, spec, st); break;
+        default: rc = fail(c, OFDFT_EINVAL, "bad n2");
+    }
+    if (rc) return rc;
+    return fast_axis_pass<false>(c, 1, spec, st);
+}
+
+// y-inverse + z-inverse (c2r) of a spectrum whose x axis is already back in real space
+int inv_yz(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) {
+    c->fft_count++;
+    if (int rc = fast_axis_pass<true>(c, 1, spec, st)) return rc;
+    switch (c->n2 / 2) {
+        case 8: return launch_zinv_t<8>(c, spec, out, scale, st);
+        case 16: return launch_zinv_t<16>(c, spec, out, scale, st);
+        case 32: return launch_zinv_t<32>(c, spec, out, scale, st);
+        case 64: return launch_zinv_t<64>(c, spec, out, scale, st);
+        case 128: return launch_zinv_t<128>(c, spec, out, scale, st);
+        case 256: return launch_zinv_t<256>(c, spec, out, scale, st);
+        case 512: return launch_zinv_t<512>(c, spec, out, scale, st);
+        case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
+    }
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+template <int LEN, int NIN, int NOUT, class Mix>
+int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
+    constexpr int G = NIN > NOUT ? NIN : NOUT;
+    using Cfg = XfCfg<LEN, G>;
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    LineMap main, rem;
+    pass_maps(c, 0, main, rem);
+    main.lf = rem.lf = Cfg::LPW;
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
+                 c->g, tw, mix);
+    return 0;
+}
+
+// forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
+template <int NIN, int NOUT, class Mix>
+int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
+    switch (c->n0) {
+        case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 64: return launch_xfused_t<64, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 128: return launch_xfused_t<128, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, st, nm);
+    }
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0);
 }
 
 // ---------------------------------------------------------------------------------- reductions
@@ -455,14 +503,54 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- combine / energies
+// launch the combine kernel and turn its partial sums into per-term energies
+int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, double* E_terms, double* vn_int,
+                 hipStream_t st) {
+    const unsigned mask = c->mask;
+    const long long npts = c->npts;
+    const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
+    CombineArgs cb = ca;     // every pointer valid: unused inputs alias the density (their terms are masked off)
+    const double* d = cb.n;
+    if (!cb.vext) cb.vext = d;
+    if (!cb.vh) cb.vh = d;
+    if (!cb.lap_s) cb.lap_s = d;
+    if (!cb.conv_b) cb.conv_b = d;
+    if (!cb.u0) cb.u0 = cb.u1 = cb.u2 = cb.gA = cb.gB = cb.gC = d;
+    if (!cb.dfdn) cb.dfdn = cb.div = d;
+    OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, cb, c->d_partial);
+    double sums[kCombineScalars];
+    if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
+    const double dV = c->dV;
+    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
+    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
+    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
+    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
+    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
+    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
+    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
+    // one local correlation flavour is expected; if several are set their sum is split evenly
+    {
+        int nc = 0;
+        for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
+        for (int b = 7; b <= 9; ++b)
+            if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
+    }
+    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
+    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    *vn_int = sums[8] * dV;
+    return 0;
+}
+
+
 // ---------------------------------------------------------------------------------- the energy pipeline
 // den: density on device.  Fills E_terms (host), writes v_out (device, may be NULL), returns sum(v n) dV.
-int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out, double* vn_int,
-              hipStream_t st) {
+int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out,
+                      double* vn_int, hipStream_t st) {
     const unsigned mask = c->mask;
     const long long npts = c->npts;
     const double inv_n = 1.0 / (double)npts;
-    const int pw_grid = grid_for(npts);
+    const int pw_grid = grid_for(npts / 2 + 1);
     const int sp_grid = grid_for(c->g.total);
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
@@ -506,7 +594,7 @@ int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_ter
             if (int rc = irfftn_internal(c, s1, gx, inv_n, st)) return rc;
             if (int rc = irfftn_internal(c, s2, gy, inv_n, st)) return rc;
             if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
-            const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
+            const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
             OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
                                (mask & OFDFT_PBE_X) ? 1 : 0, (mask & OFDFT_PBE_C) ? 1 : 0, c->d_partial);
             if (int rc = fetch_partials(c, blocks, 2, pbe_sums, st)) return rc;
@@ -557,6 +645,7 @@ int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_ter
         ca.wt_alpha = al;
         ca.wt_beta = be;
         ca.wt_nbar_pa = std::pow(nbar, al);
+        ca.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
     }
     if (mask & OFDFT_WGC99_NL) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
@@ -590,31 +679,177 @@ int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_ter
         ca.wgc_alpha = al;
         ca.wgc_beta = be;
         ca.nref = nref;
+        ca.wgc_sum_53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
     }
-    // ---- combine
-    const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
-    OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, ca, c->d_partial);
-    double sums[kCombineScalars];
-    if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
-    const double dV = c->dV;
-    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
-    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
-    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
-    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
-    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
-    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
-    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
-    // one local correlation flavour is expected; if several are set their sum is split evenly
-    {
-        int nc = 0;
-        for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
-        for (int b = 7; b <= 9; ++b)
-            if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
+    return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
+}
+
+
+// Fused pipeline (power-of-two grids): every spectral multiply rides inside the x pass (xfused_kernel), so a
+// forward/inverse FFT pair costs  z + y + (x fused) + y + z  = 5 passes instead of 6 + a multiply pass.
+int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out,
+                   double* vn_int, hipStream_t st) {
+    const unsigned mask = c->mask;
+    const long long npts = c->npts;
+    const double inv_n = 1.0 / (double)npts;
+    const int pw_grid = grid_for(npts / 2 + 1);
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+
+    double nsum = 0.0;
+    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL))
+        if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
+    const double nel = nsum * inv_n * c->vol;
+
+    CombineArgs ca{};
+    ca.n = den;
+    ca.vext = vext;
+    ca.v_out = v_out;
+    ca.npts = npts;
+    ca.mask = mask;
+    double pbe_sums[2] = {0.0, 0.0};
+    cplx* s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const char* sn[5] = {"s0", "s1", "s2", "s3", "s4"};
+    if (int rc = spec_ws(c, sn[0], &s[0])) return rc;
+
+    const bool has_h = mask & OFDFT_HARTREE, has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
+    if (has_h || has_g) {
+        if (int rc = fwd_zy(c, den, s[0], st)) return rc;
+        XfIo io{};
+        io.in[0] = s[0];
+        int no = 0;
+        double *vh = nullptr, *gr[3] = {nullptr, nullptr, nullptr}, *dfdn = nullptr, *dv = nullptr;
+        if (has_h) {
+            if (int rc = spec_ws(c, sn[1], &s[1])) return rc;
+            if (int rc = real_ws(c, "vh", &vh)) return rc;
+            io.out[no++] = s[1];
+        }
+        if (has_g) {
+            const char* gn[3] = {"gx", "gy", "gz"};
+            for (int k = 0; k < 3; ++k) {
+                if (int rc = spec_ws(c, sn[2 + k], &s[2 + k])) return rc;
+                if (int rc = real_ws(c, gn[k], &gr[k])) return rc;
+                io.out[no++] = s[2 + k];
+            }
+            if (int rc = real_ws(c, "dfdn", &dfdn)) return rc;
+            if (int rc = real_ws(c, "div", &dv)) return rc;
+        }
+        int rc;
+        if (has_h && has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n");
+        else if (has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n");
+        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n");
+        if (rc) return rc;
+        if (has_h) {
+            if ((rc = inv_yz(c, s[1], vh, inv_n, st))) return rc;
+            ca.vh = vh;
+        }
+        if (has_g) {
+            for (int k = 0; k < 3; ++k)
+                if ((rc = inv_yz(c, s[2 + k], gr[k], inv_n, st))) return rc;
+            const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
+            OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gr[0], gr[1], gr[2], dfdn, npts,
+                         (mask & OFDFT_PBE_X) ? 1 : 0, (mask & OFDFT_PBE_C) ? 1 : 0, c->d_partial);
+            if ((rc = fetch_partials(c, blocks, 2, pbe_sums, st))) return rc;
+            for (int k = 0; k < 3; ++k)
+                if ((rc = fwd_zy(c, gr[k], s[2 + k], st))) return rc;
+            XfIo dio{};
+            for (int k = 0; k < 3; ++k) dio.in[k] = s[2 + k];
+            dio.out[0] = s[0];
+            if ((rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div"))) return rc;
+            if ((rc = inv_yz(c, s[0], dv, inv_n, st))) return rc;
+            ca.dfdn = dfdn;
+            ca.div = dv;
+        }
     }
-    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
-    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
-    *vn_int = sums[8] * dV;
-    return 0;
+    if (mask & OFDFT_VW) {
+        double *tmp, *lap;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        if (int rc = real_ws(c, "lap", &lap)) return rc;
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
+        if (int rc = fwd_zy(c, tmp, s[0], st)) return rc;
+        XfIo io{};
+        io.in[0] = s[0];
+        io.out[0] = s[0];
+        if (int rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, st, "xfused_lap")) return rc;
+        if (int rc = inv_yz(c, s[0], lap, inv_n, st)) return rc;
+        ca.lap_s = lap;
+    }
+    if (mask & OFDFT_WT_NL) {
+        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+        const double nbar = nel / c->vol;
+        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        double *tmp, *cb;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        if (int rc = real_ws(c, "conv_b", &cb)) return rc;
+        const MixScale<SPEC_LINDHARD> lind{c->kg, pref, 1.0 / (2.0 * kf)};
+        XfIo io{};
+        io.in[0] = s[0];
+        io.out[0] = s[0];
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
+        if (int rc = fwd_zy(c, tmp, s[0], st)) return rc;
+        if (int rc = xfused<1, 1>(c, io, lind, st, "xfused_lind")) return rc;
+        if (int rc = inv_yz(c, s[0], cb, inv_n, st)) return rc;
+        ca.conv_b = cb;
+        ca.conv_a = nullptr;
+        if (al != be) {
+            double* cva;
+            if (int rc = real_ws(c, "conv_a", &cva)) return rc;
+            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
+            if (int rc = fwd_zy(c, tmp, s[0], st)) return rc;
+            if (int rc = xfused<1, 1>(c, io, lind, st, "xfused_lind")) return rc;
+            if (int rc = inv_yz(c, s[0], cva, inv_n, st)) return rc;
+            ca.conv_a = cva;
+        }
+        ca.wt_alpha = al;
+        ca.wt_beta = be;
+        ca.wt_nbar_pa = std::pow(nbar, al);
+        ca.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+    }
+    if (mask & OFDFT_WGC99_NL) {
+        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+        const long long nel_r = std::llround(nel);
+        double nref;
+        if (int rc = ensure_wgc_tables(c, nel_r, st, &nref)) return rc;
+        double *t[3], *o[6];
+        const char* tn[3] = {"t0", "t1", "t2"};
+        const char* names[6] = {"u0", "u1", "u2", "gA", "gB", "gC"};
+        for (int i = 0; i < 3; ++i)
+            if (int rc = real_ws(c, tn[i], &t[i])) return rc;
+        for (int i = 0; i < 6; ++i)
+            if (int rc = real_ws(c, names[i], &o[i])) return rc;
+        for (int i = 1; i < 3; ++i)
+            if (int rc = spec_ws(c, sn[i], &s[i])) return rc;
+        const MixWgc mix{(double*)c->ws["t:w0"].p, (double*)c->ws["t:K1"].p, (double*)c->ws["t:K2"].p,
+                         (double*)c->ws["t:K3"].p};
+        XfIo io{};
+        for (int i = 0; i < 3; ++i) {
+            io.in[i] = s[i];
+            io.out[i] = s[i];
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t[0], t[1], t[2], npts,
+                         pass == 0 ? be : al, nref);
+            for (int i = 0; i < 3; ++i)
+                if (int rc = fwd_zy(c, t[i], s[i], st)) return rc;
+            if (int rc = xfused<3, 3>(c, io, mix, st, "xfused_wgc")) return rc;
+            for (int i = 0; i < 3; ++i)
+                if (int rc = inv_yz(c, s[i], o[3 * pass + i], inv_n, st)) return rc;
+        }
+        ca.u0 = o[0]; ca.u1 = o[1]; ca.u2 = o[2];
+        ca.gA = o[3]; ca.gB = o[4]; ca.gC = o[5];
+        ca.wgc_alpha = al;
+        ca.wgc_beta = be;
+        ca.nref = nref;
+        ca.wgc_sum_53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+    }
+    return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
+}
+
+int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out, double* vn_int,
+              hipStream_t st) {
+    if (c->fast && !c->force_unfused) return run_terms_fast(c, den, vext, E_terms, v_out, vn_int, st);
+    return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st);
 }
 
 int begin_call(ofdft_ctx* c, hipStream_t st) {
@@ -765,14 +1000,14 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     double *den, *v;
     if (int rc = real_ws(c, "den", &den)) return rc;
     if (int rc = real_ws(c, "v", &v)) return rc;
-    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts)), dim3(256), 0, (const double*)chi, den,
+    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, den,
                        c->npts, cfac);
     double vn;
     if (int rc = run_terms(c, den, (const double*)vext, E_terms, v, &vn, st)) return rc;
     const double mu = vn / n_electrons;                                               // system.py:851
     if (mu_host) *mu_host = mu;
     if (grad) {
-        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)chi, v, (double*)grad,
+        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, v, (double*)grad,
                            c->npts, cfac * 2.0 * c->dV, mu);
     }
     return end_call(c, st);
@@ -806,6 +1041,16 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
     return OFDFT_OK;
+}
+
+int ofdft_set_option(ofdft_ctx* c, int option, double value) {
+    if (!c) return OFDFT_EINVAL;
+    switch (option) {
+        case OFDFT_OPT_PIPELINE:
+            c->force_unfused = value == 1.0;
+            return OFDFT_OK;
+    }
+    return fail(c, OFDFT_EINVAL, "unknown option %d", option);
 }
 
 int ofdft_set_profiling(ofdft_ctx* c, int on) {

@@ -65,22 +65,37 @@ template <int LEN> struct PassCfg {
     static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(double) * LPW * LineBuf<LEN>::STRIDE : 0;
 };
 
+// uniform base of a tile (first line of the workgroup) and the per-lane byte offset of line L, element j
+__device__ __forceinline__ long long line_base(const LineMap& m, long long L) {
+    return (L / m.d) * m.sb + (L % m.d) * (long long)m.sl;
+}
+
 template <int LEN, bool INV>
-__global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(cplx* __restrict__ data, LineMap m,
+__global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(cplx* __restrict__ data, LineMap m_main, LineMap m_rem,
+                                                                   int main_blocks, long long rem_offset,
                                                                    const cplx* __restrict__ tw) {
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
+    // one grid covers the block-8 main part and the dense remainder planes (Nyquist plane)
+    const bool in_rem = (int)blockIdx.x >= main_blocks;
+    const LineMap m = in_rem ? m_rem : m_main;
+    if (in_rem) data += rem_offset;
+    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
     const int l_lo = tid % m.lf;
     const int j = (tid / m.lf) % P;
     const int l = (tid / (m.lf * P)) * m.lf + l_lo;
-    const long long L = (long long)blockIdx.x * LPW + l;
+    const long long L0 = (long long)bid * LPW;
+    const long long L = L0 + l;
     const bool valid = L < m.nlines;
-    cplx* p = data + (valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0);
+    const long long b0 = uniform64(line_base(m, L0));
+    cplx* ub = data + b0;                                   // wave-uniform
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const long long qstep = uniform64((long long)P * m.se); // uniform element stride between a thread's points
     cplx v[E];
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = p[(long long)(j + P * q) * m.se];
+        for (int q = 0; q < E; ++q) v[q] = buf_load_c(ub + q * qstep, voff);
     } else {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(cplx* __restri
     line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) p[(long long)(j + P * q) * m.se] = v[q];
+        for (int q = 0; q < E; ++q) buf_store_c(ub + q * qstep, voff, v[q]);
     }
 }
 
@@ -121,10 +136,11 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const double* __rest
     const bool valid = row < g.nrows;
     cplx v[E];
     if (valid) {
-        const double2* src = reinterpret_cast<const double2*>(in + row * N2);
+        const cplx* ub = reinterpret_cast<const cplx*>(in + row0 * N2);       // wave-uniform
+        const unsigned voff = (unsigned)((r * M + j) * 16);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            double2 t = src[j + P * q];
+            const cplx t = buf_load_c(ub + q * P, voff);
             const long long e = row * N2 + 2 * (j + P * q);
             v[q] = make_double2(pre(t.x, e), pre(t.y, e + 1));
         }
@@ -165,7 +181,11 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const double* __rest
         const cplx od = make_double2(0.5 * (ci_k + ci_m), -0.5 * (cr_k[it] - cr_m[it]));
         const cplx X = cadd(ev, cmul(twN[k], od));
         const long long rg = row0 + rr;
-        if (rg < g.nrows) spec[((long long)b * g.nrows + rg) * 8 + kin] = X;
+        // block b of rows row0.. is one contiguous 128-B-per-row run: uniform base + (rr*8+kin)*16
+        const int bu = (it * TPB) / (8 * RPW);          // compile-time after unrolling: uniform part of b
+        if (rg < g.nrows)
+            buf_store_c(spec + ((long long)bu * g.nrows + row0) * 8,
+                        (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * 16), X);
     }
     if (tid < RPW) {
         c0i = lds[tid * RS];
@@ -199,7 +219,10 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
         const int idx = tid + it * TPB;
         const int kin = idx & 7, rr = (idx >> 3) % RPW, b = idx / (8 * RPW);
         const long long rg = row0 + rr;
-        xs[it] = (rg < g.nrows) ? spec[((long long)b * g.nrows + rg) * 8 + kin] : make_double2(0.0, 0.0);
+        const int bu = (it * TPB) / (8 * RPW);
+        xs[it] = (rg < g.nrows) ? buf_load_c(spec + ((long long)bu * g.nrows + row0) * 8,
+                                             (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * 16))
+                                : make_double2(0.0, 0.0);
     }
     const double nyq = (valid && j == 0) ? spec[g.main_count + row].x : 0.0;
 #pragma unroll
@@ -241,11 +264,12 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
     }
     line_fft<M, true>(v, j, mine, twM);
     if (valid) {
-        double2* dst = reinterpret_cast<double2*>(out + row * N2);
+        cplx* ub = reinterpret_cast<cplx*>(out + row0 * N2);                  // wave-uniform
+        const unsigned voff = (unsigned)((r * M + j) * 16);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const long long e = row * N2 + 2 * (j + P * q);
-            dst[j + P * q] = make_double2(post(v[q].x, e), post(v[q].y, e + 1));
+            buf_store_c(ub + q * P, voff, make_double2(post(v[q].x, e), post(v[q].y, e + 1)));
         }
     }
 }
@@ -331,6 +355,170 @@ __global__ void spec_to_standard_kernel(const cplx* __restrict__ intl, cplx* __r
     int x, y, kz;
     spec_decode(g, i, x, y, kz);
     stdl[((long long)x * g.n1 + y) * g.nzc + kz] = intl[i];
+}
+
+}  // namespace ofdft
+
+// ----------------------------------------------------------------------------------------------
+// Fused x pass:  forward x-FFT of NIN spectra  ->  k-space mixing  ->  inverse x-FFT of NOUT spectra.
+// One workgroup owns LPW memory-contiguous x-lines; G = max(NIN,NOUT) thread groups work array-parallel:
+// group g transforms input g, the groups trade their spectra through LDS (real and imaginary parts in
+// turn -- every mixing coefficient is either real or purely imaginary, so the parts never need each
+// other), group g then builds output g and transforms it back.  HBM traffic: NIN reads + NOUT writes of a
+// spectrum instead of 2*NIN + (mix) + 2*NOUT for separate forward / multiply / inverse passes.
+namespace ofdft {
+
+constexpr int kMaxXf = 4;
+struct XfIo {
+    const cplx* in[kMaxXf];
+    cplx* out[kMaxXf];
+};
+
+// pick element g (wave-uniform) of a small kernel-argument pointer array without dynamic indexing
+template <class T> __device__ __forceinline__ T* xf_pick(T* const (&a)[kMaxXf], int g) {
+    T* p = a[0];
+    if (g == 1) p = a[1];
+    if (g == 2) p = a[2];
+    if (g == 3) p = a[3];
+    return p;
+}
+
+template <int LEN, int G> struct XfCfg {
+    static constexpr int P = Plan<LEN>::P;
+    static constexpr int E = Plan<LEN>::E;
+    // lines per workgroup: >= 8 (128-B runs) and a whole number of waves per group (LPW*P % 64 == 0)
+    // multi-group workgroups are kept small (4 lines = 64-B runs) so that several fit a CU and their
+    // load / transform / store phases overlap; single-group ones take 8 lines (128-B runs)
+    static constexpr int WANT = 8;
+    static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
+    static constexpr int TPB = G * LPW * P;
+    static constexpr size_t LDS = sizeof(double) * G * LPW * LineBuf<LEN>::STRIDE;
+};
+
+
+// Mix functor contract (all indices compile-time, so every workgroup runs straight-line code):
+//   static constexpr bool imag(int o)              coefficient of output o is i*c (else c)
+//   template<int O,int I> static constexpr bool present()   whether input I contributes to output O
+//   template<int O,int I> double coef(x, y, kz, uoff, loff)  the real number c at that k-point; uoff + loff =
+//        element offset of the k-point in a spectrum array (uoff wave-uniform) for buffer-load table lookups
+template <int LEN, int G> struct XfMixCtx {
+    int j, l, y, kz;
+    long long b0, qstep;
+    unsigned loff;      // per-lane element offset of the thread's first point (table lookups)
+};
+
+// acc += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish)
+template <int LEN, int G, int NIN, int O, int I, class Mix>
+__device__ __forceinline__ void xf_mix_inputs(double& acc, const double* lds, const XfMixCtx<LEN, G>& c, const Mix& mix,
+                                              int q, int x) {
+    constexpr int LPW = XfCfg<LEN, G>::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+    if constexpr (I < NIN) {
+        if constexpr (Mix::template present<O, I>())
+            acc += mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff) * lds[(I * LPW + c.l) * STRIDE + lpad(x)];
+        xf_mix_inputs<LEN, G, NIN, O, I + 1, Mix>(acc, lds, c, mix, q, x);
+    }
+}
+
+// one output (compile-time O) from all inputs, one part (real or imaginary) of the inputs at a time
+template <int LEN, int G, int NIN, int O, class Mix, bool IMPART>
+__device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const double* lds, const XfMixCtx<LEN, G>& c,
+                                            const Mix& mix) {
+    constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E, LPW = XfCfg<LEN, G>::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int x = c.j + P * q;
+        double acc = 0.0;
+        xf_mix_inputs<LEN, G, NIN, O, 0, Mix>(acc, lds, c, mix, q, x);
+        if (Mix::imag(O)) {
+            if (IMPART) o[q].x = -acc;      // (i c)(i im) = -c im
+            else o[q].y = acc;              // (i c)(re)
+        } else {
+            if (IMPART) o[q].y = acc;
+            else o[q].x = acc;
+        }
+    }
+}
+
+template <int LEN, int G, int NIN, int NOUT, class Mix, bool IMPART>
+__device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const double* lds,
+                                                const XfMixCtx<LEN, G>& c, const Mix& mix) {
+    // grp is wave-uniform: a scalar branch into straight-line code specialised per output
+    if (grp == 0) xf_mix_part<LEN, G, NIN, 0, Mix, IMPART>(o, lds, c, mix);
+    if constexpr (NOUT > 1) { if (grp == 1) xf_mix_part<LEN, G, NIN, 1, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 2) { if (grp == 2) xf_mix_part<LEN, G, NIN, 2, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, G, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
+}
+
+template <int LEN, int NIN, int NOUT, class Mix>
+__global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void xfused_kernel(
+    XfIo io, LineMap m_main, LineMap m_rem, int main_blocks, SpecGeom g, const cplx* __restrict__ tw, Mix mix) {
+    constexpr int G = NIN > NOUT ? NIN : NOUT;
+    using Cfg = XfCfg<LEN, G>;
+    constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    static_assert((LPW * P) % 64 == 0, "a thread group must be whole waves");
+    const int grp = __builtin_amdgcn_readfirstlane(tid / (LPW * P));   // wave-uniform by construction
+    const int t = tid % (LPW * P);
+    const int l = t % LPW;          // lines fastest over the lanes: memory-contiguous direction
+    const int j = t / LPW;
+    const bool is_rem = (int)blockIdx.x >= main_blocks;    // one grid: main part, then the remainder planes
+    const LineMap m = is_rem ? m_rem : m_main;
+    const int bid = is_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    const long long L = (long long)bid * LPW + l;
+    const bool valid = L < m.nlines;
+    const long long base = valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0;
+    // k-point coordinates of this line
+    int y, kz;
+    if (is_rem) {
+        y = (int)(L % g.n1);
+        kz = g.nzm + (int)(L / g.n1);
+    } else {
+        const int c = (int)(L % m.d);
+        y = c >> 3;
+        kz = (int)(L / m.d) * 8 + (c & 7);
+    }
+    const long long region = is_rem ? g.main_count : 0;   // offset of this launch's region in the full array
+
+    const long long L0 = (long long)bid * LPW;
+    const long long b0 = uniform64(region + line_base(m, L0));                 // wave-uniform
+    const unsigned voff = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * m.se) * 16) : 0u;
+    const long long qstep = uniform64((long long)P * m.se);
+    cplx v[E];
+    if (valid && grp < NIN) {
+        // the group index is wave-uniform only when a group is a whole number of waves; select the pointer
+        // with scalar-friendly code: each wave belongs to exactly one group when LPW*P % 64 == 0
+        const cplx* ub = xf_pick(io.in, grp) + b0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = buf_load_c(ub + q * qstep, voff);
+    } else {
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+    }
+    double* mine = lds + (grp * LPW + l) * STRIDE;
+    line_fft<LEN, false>(v, j, mine, tw);
+
+    cplx o[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) o[q] = make_double2(0.0, 0.0);
+    XfMixCtx<LEN, G> mc{j, l, y, kz, b0, qstep, voff >> 4};
+    // ---- real parts of the inputs
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < E; ++q) mine[lpad(j + P * q)] = v[q].x;
+    __syncthreads();
+    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, false>(grp, o, lds, mc, mix);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < E; ++q) mine[lpad(j + P * q)] = v[q].y;
+    __syncthreads();
+    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, true>(grp, o, lds, mc, mix);
+    line_fft<LEN, true>(o, j, mine, tw);
+    if (valid && grp < NOUT) {
+        cplx* ub = xf_pick(io.out, grp) + b0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) buf_store_c(ub + q * qstep, voff, o[q]);
+    }
 }
 
 }  // namespace ofdft

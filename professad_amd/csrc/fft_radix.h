@@ -49,6 +49,34 @@ template <int R, int K, bool INV> __device__ __forceinline__ cplx mul_w(cplx a) 
     }
 }
 
+// ---- buffer (SRD) addressing: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset.
+// All uniform strides are folded into the base pointer, so a thread keeps ONE offset VGPR for a whole
+// line instead of a 64-bit address per element (that alone was ~60 VGPRs in the 16-point-per-thread
+// kernels).  The base must be built from kernel arguments / blockIdx only (provably uniform).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// tell the compiler a 64-bit value is wave-uniform (it is, by construction, wherever this is used)
+__device__ __forceinline__ long long uniform64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000);
+}
+__device__ __forceinline__ cplx buf_load_c(const cplx* ubase, unsigned voff_bytes) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, 0);
+    return *reinterpret_cast<cplx*>(&t);
+}
+__device__ __forceinline__ void buf_store_c(cplx* ubase, unsigned voff_bytes, cplx v) {
+    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, 0);
+}
+__device__ __forceinline__ double buf_load_d(const double* ubase, unsigned voff_bytes) {
+    u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(ubase), (int)voff_bytes, 0, 0);
+    return *reinterpret_cast<double*>(&t);
+}
+
 // natural-order in-place DFT of R points held in registers
 template <int R, bool INV> struct Dft;
 
@@ -134,14 +162,20 @@ template <int LEN, int S, int NS, bool INV> struct Stage {
 #pragma unroll
             for (int t = 0; t < R; ++t) a[t] = v[b + t * NB];
             if constexpr (NS > 1) {
+                // twiddles W^(t k), t = 1..R-1: ONE table load (W^k) and a depth-<=4 product tree for the
+                // powers (<= ~5 ulp), instead of R-1 loads whose prefetch would pin 4(R-1) VGPRs
                 const int k = (j + b * P) % NS;
                 constexpr int TSTEP = LEN / (NS * R);
+                cplx w[R];
+                w[1] = tw[k * TSTEP];
+                if (INV) w[1].y = -w[1].y;
 #pragma unroll
-                for (int t = 1; t < R; ++t) {
-                    cplx w = tw[t * k * TSTEP];
-                    if (INV) w.y = -w.y;
-                    a[t] = cmul(a[t], w);
+                for (int t = 2; t < R; ++t) {
+                    const int hi = (t >= 8) ? 8 : ((t >= 4) ? 4 : 2);   // largest power of two <= t
+                    w[t] = (t == hi) ? cmul(w[t / 2], w[t / 2]) : cmul(w[hi], w[t - hi]);
                 }
+#pragma unroll
+                for (int t = 1; t < R; ++t) a[t] = cmul(a[t], w[t]);
             }
             Dft<R, INV>::run(a);
 #pragma unroll

@@ -54,24 +54,36 @@ __global__ __launch_bounds__(kRedThreads) void sum_kernel(const double* __restri
     block_reduce_store<1>(acc, partial);
 }
 
-// elementwise unary maps (prep of FFT inputs)
+// elementwise unary maps (prep of FFT inputs); 16-byte accesses, scalar tail for odd sizes
 enum { MAP_SQRT = 0, MAP_POW = 1, MAP_SCALE_SQ = 2 };
+template <int OP> __device__ __forceinline__ double map_op(double x, double p) {
+    if (OP == MAP_SQRT) return (x != 0.0) ? sqrt(x) : 0.0;        // functionals.py:242-243
+    if (OP == MAP_POW) return pow(x, p);
+    return p * x * x;                                               // n = c chi^2, system.py:834
+}
 template <int OP>
 __global__ void map_kernel(const double* __restrict__ a, double* __restrict__ out, long long n, double p) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const double x = a[i];
-        double r;
-        if (OP == MAP_SQRT) r = (x != 0.0) ? sqrt(x) : 0.0;        // functionals.py:242-243
-        else if (OP == MAP_POW) r = pow(x, p);
-        else r = p * x * x;                                         // n = c chi^2, system.py:834
-        out[i] = r;
+    const long long n2 = n >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 x = reinterpret_cast<const double2*>(a)[i];
+        reinterpret_cast<double2*>(out)[i] = make_double2(map_op<OP>(x.x, p), map_op<OP>(x.y, p));
     }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = map_op<OP>(a[n - 1], p);
 }
 
 // WGC99 real-space inputs: A = n^e, B = A theta, C = A theta^2 / 2 (functionals.py:974-981)
 __global__ void wgc_prep_kernel(const double* __restrict__ n, double* __restrict__ A, double* __restrict__ B,
                                 double* __restrict__ C, long long npts, double expo, double nref) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+    const long long n2 = npts >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 d = reinterpret_cast<const double2*>(n)[i];
+        const double t0 = d.x - nref, t1 = d.y - nref, a0 = pow(d.x, expo), a1 = pow(d.y, expo);
+        reinterpret_cast<double2*>(A)[i] = make_double2(a0, a1);
+        reinterpret_cast<double2*>(B)[i] = make_double2(a0 * t0, a1 * t1);
+        reinterpret_cast<double2*>(C)[i] = make_double2(0.5 * a0 * t0 * t0, 0.5 * a1 * t1 * t1);
+    }
+    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long i = npts - 1;
         const double d = n[i], th = d - nref, a = pow(d, expo);
         A[i] = a;
         B[i] = a * th;
@@ -230,6 +242,73 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
     }
 }
 
+// ---- mixing functors of the fused x pass (see xfused_kernel in fft_kernels.h) ----------------------
+__device__ __forceinline__ void kvec_xyz(const KGeom& kg, int x, int y, int z, double& kx, double& ky, double& kz,
+                                         double& k2) {
+    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y, kg.g.n1), fc = (double)z;
+    kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];
+    ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
+    kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
+    k2 = kx * kx + ky * ky + kz * kz;
+}
+
+// n^ -> [v_H^ = 4 pi/k^2 n^] [, i k_x n^, i k_y n^, i k_z n^]
+template <bool HAS_H, bool HAS_G> struct MixDensity {
+    KGeom kg;
+    static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        if (HAS_H && O == 0) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+        constexpr int c = O - (HAS_H ? 1 : 0);
+        return c == 0 ? kx : (c == 1 ? ky : kz);
+    }
+};
+
+// one spectrum times a real f(k): OP as spec_scale_kernel
+template <int OP> struct MixScale {
+    KGeom kg;
+    double p0, p1;
+    static __device__ __forceinline__ constexpr bool imag(int) { return false; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        if (OP == SPEC_HARTREE) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+        if (OP == SPEC_LAPLACE) return -k2;
+        return p0 * lindhard_shape((k2 != 0.0) ? sqrt(k2) * p1 : 0.0);
+    }
+};
+
+// (F_x^, F_y^, F_z^) -> sum_j i k_j F_j^
+struct MixDiv {
+    KGeom kg;
+    static __device__ __forceinline__ constexpr bool imag(int) { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        return I == 0 ? kx : (I == 1 ? ky : kz);
+    }
+};
+
+// WGC99: (A^,B^,C^) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) with tables in the spectrum layout
+struct MixWgc {
+    const double* w0; const double* K1; const double* K2; const double* K3;
+    static __device__ __forceinline__ constexpr bool imag(int) { return false; }
+    // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return O + I <= 2; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int, int, int, long long uoff, unsigned loff) const {
+        const double* t = (O + I == 0) ? w0 : ((O + I == 1) ? K1 : ((O == 1) ? K3 : K2));
+        return buf_load_d(t + uoff, loff * 8);
+    }
+};
+
 // ---- XC pointwise math -------------------------------------------------------------------------
 // PW92 eps_c(rs) and d eps_c / d rs (functionals.py:1524-1530; tests/tools_for_tests.py:136-144)
 __device__ __forceinline__ void pw92(double rs, double& eps, double& deps_drs) {
@@ -341,7 +420,22 @@ __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restri
                                                           double* __restrict__ dfdn, long long npts, int do_x,
                                                           int do_c, double* __restrict__ partial) {
     double acc[2] = {0.0, 0.0};
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+    const long long n2 = npts >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 d = reinterpret_cast<const double2*>(n)[i];
+        const double2 a = reinterpret_cast<double2*>(gx)[i], b = reinterpret_cast<double2*>(gy)[i],
+                      c = reinterpret_cast<double2*>(gz)[i];
+        const PbePoint p0 = pbe_point(d.x, a.x * a.x + b.x * b.x + c.x * c.x, do_x != 0, do_c != 0);
+        const PbePoint p1 = pbe_point(d.y, a.y * a.y + b.y * b.y + c.y * c.y, do_x != 0, do_c != 0);
+        acc[0] += p0.fx + p1.fx;
+        acc[1] += p0.fc + p1.fc;
+        reinterpret_cast<double2*>(dfdn)[i] = make_double2(p0.dfdn, p1.dfdn);
+        reinterpret_cast<double2*>(gx)[i] = make_double2(p0.dfdg * a.x, p1.dfdg * a.y);
+        reinterpret_cast<double2*>(gy)[i] = make_double2(p0.dfdg * b.x, p1.dfdg * b.y);
+        reinterpret_cast<double2*>(gz)[i] = make_double2(p0.dfdg * c.x, p1.dfdg * c.y);
+    }
+    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long i = npts - 1;
         const double a = gx[i], b = gy[i], c = gz[i];
         const PbePoint p = pbe_point(n[i], a * a + b * b + c * c, do_x != 0, do_c != 0);
         acc[0] += p.fx;
@@ -371,67 +465,96 @@ struct CombineArgs {
     unsigned mask;
     double wt_alpha, wt_beta, wt_nbar_pa;     // nbar^alpha
     double wgc_alpha, wgc_beta, nref;
+    int wt_is_56;        // alpha = beta = 5/6: n^(-1/6) = 1/sqrt(cbrt n), no pow
+    int wgc_sum_53;      // alpha + beta = 5/3: n^(alpha-1) = 1/(cbrt(n) n^(beta-1)), one pow instead of two
 };
 // partial scalars: 0 ion-electron, 1 hartree, 2 tf, 3 vw, 4 wt-nl, 5 wgc-nl, 6 lda-x, 7 local-c, 8 sum(v*n)
 constexpr int kCombineScalars = 9;
 
+// one grid point of the combine: all inputs already in registers
+struct CombinePoint {
+    double n, vext, vh, lap, cb, cva, u0, u1, u2, gA, gB, gC, dfdn, div;
+};
+__device__ __forceinline__ double combine_point(const CombineArgs& a, const CombinePoint& p, double ctf,
+                                                double (&acc)[kCombineScalars]) {
+    const double n = p.n;
+    double v = 0.0;
+    if (a.mask & 1u) {                                  // ion-electron  functionals.py:46
+        acc[0] += n * p.vext;
+        v += p.vext;
+    }
+    if (a.mask & 2u) {                                  // Hartree  functionals.py:72
+        acc[1] += 0.5 * n * p.vh;
+        v += p.vh;
+    }
+    const double n13 = cbrt(n);
+    if (a.mask & 4u) {                                  // TF  functionals.py:223; tools_for_tests.py:19-20
+        const double n23 = n13 * n13;
+        acc[2] += ctf * n23 * n;
+        v += (5.0 / 3.0) * ctf * n23;
+    }
+    if (a.mask & 8u) {                                  // vW  functionals.py:245; tools_for_tests.py:23-26
+        const double s = (n != 0.0) ? sqrt(n) : 0.0;
+        acc[3] += -0.5 * s * p.lap;
+        if (n != 0.0) v += -0.5 * p.lap / s;
+    }
+    if (a.mask & 16u) {                                 // WT-family NL  functionals.py:650-651; tools_for_tests.py:29-39
+        const double pa1 = a.wt_is_56 ? 1.0 / sqrt(n13) : pow(n, a.wt_alpha - 1.0);
+        acc[4] += ctf * (pa1 * n - a.wt_nbar_pa) * p.cb;
+        if (a.conv_a) {
+            const double pb1 = pow(n, a.wt_beta - 1.0);
+            v += ctf * (a.wt_alpha * pa1 * p.cb + a.wt_beta * pb1 * p.cva);
+        } else {
+            v += ctf * 2.0 * a.wt_alpha * pa1 * p.cb;
+        }
+    }
+    if (a.mask & 32u) {                                 // WGC99 NL  SURVEY §8a-8
+        const double th = n - a.nref;
+        const double pb1 = pow(n, a.wgc_beta - 1.0);
+        const double pa1 = a.wgc_sum_53 ? 1.0 / (n13 * pb1) : pow(n, a.wgc_alpha - 1.0);
+        const double P = pa1 * n, A = pb1 * n, dA = a.wgc_beta * pb1;
+        const double conv = p.u0 + th * p.u1 + 0.5 * th * th * p.u2;
+        acc[5] += ctf * P * conv;
+        v += ctf * (a.wgc_alpha * pa1 * conv + P * (p.u1 + th * p.u2) + p.gA * dA + p.gB * (dA * th + A)
+                    + p.gC * (0.5 * dA * th * th + A * th));
+    }
+    if (a.mask & (0xFu << 6)) {                         // local XC
+        const XcLocal x = lda_point(n, a.mask);
+        acc[6] += x.ex;
+        acc[7] += x.ec;
+        v += x.vx + x.vc;
+    }
+    if (a.mask & (3u << 10)) v += p.dfdn - 2.0 * p.div;   // PBE  tools_for_tests.py:168-170
+    acc[8] += v * n;
+    return v;
+}
+
+// Every array pointer in CombineArgs is valid (the host points unused ones at `n`), so all loads of an
+// iteration are issued together as 16-byte loads ahead of the arithmetic instead of one dependent load
+// per term behind a branch.
 __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, double* __restrict__ partial) {
     const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);   // 0.3 (3 pi^2)^(2/3)
     double acc[kCombineScalars];
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.npts; i += (long long)gridDim.x * blockDim.x) {
-        const double n = a.n[i];
-        double v = 0.0;
-        if (a.mask & 1u) {                                  // ion-electron  functionals.py:46
-            const double ve = a.vext[i];
-            acc[0] += n * ve;
-            v += ve;
-        }
-        if (a.mask & 2u) {                                  // Hartree  functionals.py:72
-            const double vh = a.vh[i];
-            acc[1] += 0.5 * n * vh;
-            v += vh;
-        }
-        if (a.mask & 4u) {                                  // TF  functionals.py:223; tools_for_tests.py:19-20
-            const double n13 = cbrt(n), n23 = n13 * n13;
-            acc[2] += ctf * n23 * n;
-            v += (5.0 / 3.0) * ctf * n23;
-        }
-        if (a.mask & 8u) {                                  // vW  functionals.py:245; tools_for_tests.py:23-26
-            const double s = (n != 0.0) ? sqrt(n) : 0.0, L = a.lap_s[i];
-            acc[3] += -0.5 * s * L;
-            if (n != 0.0) v += -0.5 * L / s;
-        }
-        if (a.mask & 16u) {                                 // WT-family NL  functionals.py:650-651; tools_for_tests.py:29-39
-            const double cb = a.conv_b[i];
-            const double pa1 = pow(n, a.wt_alpha - 1.0);
-            acc[4] += ctf * (pa1 * n - a.wt_nbar_pa) * cb;
-            if (a.conv_a) {
-                const double pb1 = pow(n, a.wt_beta - 1.0);
-                v += ctf * (a.wt_alpha * pa1 * cb + a.wt_beta * pb1 * a.conv_a[i]);
-            } else {
-                v += ctf * 2.0 * a.wt_alpha * pa1 * cb;
-            }
-        }
-        if (a.mask & 32u) {                                 // WGC99 NL  SURVEY §8a-8
-            const double th = n - a.nref;
-            const double pa1 = pow(n, a.wgc_alpha - 1.0), pb1 = pow(n, a.wgc_beta - 1.0);
-            const double P = pa1 * n, A = pb1 * n, dA = a.wgc_beta * pb1;
-            const double u1 = a.u1[i], u2 = a.u2[i];
-            const double conv = a.u0[i] + th * u1 + 0.5 * th * th * u2;
-            acc[5] += ctf * P * conv;
-            v += ctf * (a.wgc_alpha * pa1 * conv + P * (u1 + th * u2) + a.gA[i] * dA + a.gB[i] * (dA * th + A)
-                        + a.gC[i] * (0.5 * dA * th * th + A * th));
-        }
-        if (a.mask & (0xFu << 6)) {                         // local XC
-            const XcLocal x = lda_point(n, a.mask);
-            acc[6] += x.ex;
-            acc[7] += x.ec;
-            v += x.vx + x.vc;
-        }
-        if (a.mask & (3u << 10)) v += a.dfdn[i] - 2.0 * a.div[i];   // PBE  tools_for_tests.py:168-170
-        acc[8] += v * n;
+    const long long n2 = a.npts >> 1;
+#define LD2(ptr) reinterpret_cast<const double2*>(ptr)[i]
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 n = LD2(a.n), ve = LD2(a.vext), vh = LD2(a.vh), lp = LD2(a.lap_s), cb = LD2(a.conv_b),
+                      cva = LD2(a.conv_a ? a.conv_a : a.n), u0 = LD2(a.u0), u1 = LD2(a.u1), u2 = LD2(a.u2),
+                      gA = LD2(a.gA), gB = LD2(a.gB), gC = LD2(a.gC), df = LD2(a.dfdn), dv = LD2(a.div);
+        const CombinePoint p0{n.x, ve.x, vh.x, lp.x, cb.x, cva.x, u0.x, u1.x, u2.x, gA.x, gB.x, gC.x, df.x, dv.x};
+        const CombinePoint p1{n.y, ve.y, vh.y, lp.y, cb.y, cva.y, u0.y, u1.y, u2.y, gA.y, gB.y, gC.y, df.y, dv.y};
+        const double v0 = combine_point(a, p0, ctf, acc);
+        const double v1 = combine_point(a, p1, ctf, acc);
+        if (a.v_out) reinterpret_cast<double2*>(a.v_out)[i] = make_double2(v0, v1);
+    }
+#undef LD2
+    if ((a.npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long i = a.npts - 1;
+        const CombinePoint p{a.n[i], a.vext[i], a.vh[i], a.lap_s[i], a.conv_b[i], (a.conv_a ? a.conv_a : a.n)[i], a.u0[i],
+                             a.u1[i], a.u2[i], a.gA[i], a.gB[i], a.gC[i], a.dfdn[i], a.div[i]};
+        const double v = combine_point(a, p, ctf, acc);
         if (a.v_out) a.v_out[i] = v;
     }
     block_reduce_store<kCombineScalars>(acc, partial);
@@ -440,8 +563,12 @@ __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, dou
 // chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
 __global__ void chi_grad_kernel(const double* __restrict__ chi, const double* __restrict__ v, double* __restrict__ g,
                                 long long npts, double c2dV, double mu) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x)
-        g[i] = c2dV * chi[i] * (v[i] - mu);
+    const long long n2 = npts >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 x = reinterpret_cast<const double2*>(chi)[i], w = reinterpret_cast<const double2*>(v)[i];
+        reinterpret_cast<double2*>(g)[i] = make_double2(c2dV * x.x * (w.x - mu), c2dV * x.y * (w.y - mu));
+    }
+    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) g[npts - 1] = c2dV * chi[npts - 1] * (v[npts - 1] - mu);
 }
 
 }  // namespace ofdft

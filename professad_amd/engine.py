@@ -142,6 +142,10 @@ class Engine:
         self._check(self.lib.ofdft_query(self._ctx, int(what), C.byref(v)), 'ofdft_query')
         return v.value
 
+    def set_option(self, option, value):
+        self._check(self.lib.ofdft_set_option(self._ctx, int(option), float(value)), 'ofdft_set_option')
+        return self
+
     def set_profiling(self, on):
         self._check(self.lib.ofdft_set_profiling(self._ctx, 1 if on else 0), 'ofdft_set_profiling')
 

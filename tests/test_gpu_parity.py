@@ -248,3 +248,24 @@ def test_reference_system_protocol_sum_of_terms():
     assert abs(float(E) - float(gold['E_cfg3'])) <= E_RTOL * abs(float(gold['E_cfg3']))
     dV = abs(np.linalg.det(box)) / den.size
     assert relerr(d.grad.cpu().numpy() / dV, gold['v_cfg3']) < V_RTOL
+
+
+def test_fused_and_unfused_pipelines_agree():
+    """The fused x-pass pipeline against the engine's own unfused pipeline (separate passes) on one input."""
+    shape = (64, 32, 128)
+    box = cases.make_cell(('tri', 1.7))
+    den = synth.random_density(shape, seed=31)
+    vext = synth.random_potential(shape, seed=32)
+    eng = Engine(shape, DEV).set_cell(dev(box))
+    for cfg, names in _CFG_TERMS.items():
+        eng.set_terms(F.NativeTerms(names).names)
+        eng.set_option(0, 0)
+        Ef, vf = eng.energy_potential(dev(den), dev(vext))
+        nf = eng.query(0)
+        eng.set_option(0, 1)
+        Eu, vu = eng.energy_potential(dev(den), dev(vext))
+        assert eng.query(0) == nf
+        for k in Ef:
+            assert abs(Ef[k] - Eu[k]) <= 1e-12 * max(1.0, abs(Eu[k])), (cfg, k)
+        assert relerr(vf.cpu().numpy(), vu.cpu().numpy()) < 1e-12
+    eng.close()
