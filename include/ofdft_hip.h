@@ -106,8 +106,9 @@ int  ofdft_irfftn(ofdft_ctx* ctx, const void* spec_dev, void* real_dev, void* st
 
 int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
 
-/* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (fused x passes on power-of-two grids),
- * 1 = force the unfused reference pipeline (separate forward, multiply and inverse passes). */
+/* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (power-of-two grids: fused x passes and z
+ * passes that keep every real-space intermediate on chip), 1 = force the unfused pipeline (separate forward,
+ * multiply, inverse and pointwise passes; the only one for other grids), 2 = fused x passes only. */
 #define OFDFT_OPT_PIPELINE 0
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 

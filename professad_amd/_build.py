@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'libofdft_hip.so')
 SOURCES = ['engine.hip']
-HEADERS = ['fft_radix.h', 'fft_kernels.h', 'pointwise_kernels.h', os.path.join('..', '..', 'include', 'ofdft_hip.h')]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'ofdft_hip.h')]
 
 
 def _stale():

@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "../../include/ofdft_hip.h"
-#include "pointwise_kernels.h"
+#include "zpass.h"
 
 using namespace ofdft;
 
@@ -31,6 +31,7 @@ struct ofdft_ctx {
     KGeom kg{};
     long long npts = 0;
     bool fast = false, cell_set = false, force_unfused = false;
+    int pipeline = 0;   // 0 = z-fused (default on power-of-two grids), 1 = unfused, 2 = x-fused only
     double box[9] = {0}, vol = 0.0, dV = 0.0;
     unsigned mask = 0;
     double params[OFDFT_NPARAMS];
@@ -41,7 +42,9 @@ struct ofdft_ctx {
     size_t ws_bytes = 0;
     // reduction partials (device) + pinned host mirror
     double* d_partial = nullptr;
+    double* d_reduced = nullptr;     // second-level sums [kMaxScalars]
     double* h_partial = nullptr;
+    long long partial_rows = 0;
     // WGC tables
     double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
     long long wgc_key_nel = -1;
@@ -402,6 +405,14 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
 // ---------------------------------------------------------------------------------- reductions
 // copy `rows` x `ns` partials to the host and sum them in a fixed order
 int fetch_partials(ofdft_ctx* c, int rows, int ns, double* sums, hipStream_t st) {
+    if (rows > kRedBlocks) {     // many rows: reduce on the device first (fixed order), copy ns numbers
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(ns), dim3(kRedThreads), 0, c->d_partial, rows, ns,
+                     c->d_reduced);
+        HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int s = 0; s < ns; ++s) sums[s] = c->h_partial[s];
+        return 0;
+    }
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_partial, sizeof(double) * rows * ns, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     for (int s = 0; s < ns; ++s) {
@@ -852,6 +863,262 @@ int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_ter
     return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st);
 }
 
+
+// ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
+#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
+constexpr int EZ = 4;   // points per lane wanted by the register-hungry fused z kernels
+
+int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
+    if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;
+    return get_twiddle(c, c->n2, twN);
+}
+template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nrows + ZW<M, E>::RPB - 1) / ZW<M, E>::RPB); }
+
+int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
+#define X(M_)                                                                                                       \
+    case M_:                                                                                                        \
+        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(z_blocks<M_, 8>(c)), dim3(256),          \
+                     (ZW<M_, 8>::LDS), ds, out_n, out_s, c->g, twM, twN);                                           \
+        return 0;
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
+#define X(M_)                                                                                                      \
+    case M_:                                                                                                       \
+        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>),                                \
+                     dim3(z_blocks<M_, ZPick<M_, EZ>::E>(c)), dim3(256), (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, c->g,  \
+                     twM, twN);                                                                                    \
+        return 0;
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n, int do_x,
+                int do_c, int* blocks_out, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    c->fft_count += 6;    // three c2r finished + three r2c started on chip
+#define X(M_)                                                                                                   \
+    case M_:                                                                                                    \
+        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
+        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256),          \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, do_x, do_c, c->g, twM, twN,  \
+                     c->d_partial);                                                                             \
+        return 0;
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+#define X(M_)                                                                                                     \
+    case M_:                                                                                                      \
+        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                          \
+        OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256), \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), a, c->g, twM, twN, c->d_partial);                           \
+        return 0;
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pbe_sums, double* E_terms, double* vn_int) {
+    const unsigned mask = c->mask;
+    const double dV = c->dV;
+    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
+    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
+    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
+    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
+    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
+    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
+    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
+    int nc = 0;
+    for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
+    for (int b = 7; b <= 9; ++b)
+        if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
+    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
+    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    *vn_int = sums[8] * dV;
+}
+
+// Pipeline with every real-space intermediate kept on chip: z kernels compute their inputs from chi|n on the
+// fly and consume the convolution results straight out of the inverse transform.  `nel` = mean(n)*vol.
+int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
+                     double* vn_int, hipStream_t st) {
+    const unsigned mask = c->mask;
+    const double inv_n = 1.0 / (double)c->npts;
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    ZCombineArgs za{};
+    za.ds = ds;
+    za.vext = vext;
+    za.v_out = v_out;
+    za.mask = mask;
+    za.inv_n = inv_n;
+    double pbe_sums[2] = {0.0, 0.0};
+    auto spec = [&](const char* nm, cplx** p) { return spec_ws(c, nm, p); };
+    int rc;
+    const bool has_h = mask & OFDFT_HARTREE, has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C), has_vw = mask & OFDFT_VW;
+    cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
+    if (has_h || has_g)
+        if ((rc = spec("zn", &s_n))) return rc;
+    if (has_vw)
+        if ((rc = spec("zs", &s_s))) return rc;
+    if (s_n || s_s) {
+        if ((rc = launch_zf_density(c, ds, s_n, s_s, st))) return rc;
+        if (s_n && (rc = fast_axis_pass<false>(c, 1, s_n, st))) return rc;
+        if (s_s && (rc = fast_axis_pass<false>(c, 1, s_s, st))) return rc;
+    }
+    if (s_n) {
+        XfIo io{};
+        io.in[0] = s_n;
+        int no = 0;
+        if (has_h) {
+            if ((rc = spec("zvh", &s_vh))) return rc;
+            io.out[no++] = s_vh;
+        }
+        if (has_g) {
+            const char* gn[3] = {"zgx", "zgy", "zgz"};
+            for (int k = 0; k < 3; ++k) {
+                if ((rc = spec(gn[k], &s_g[k]))) return rc;
+                io.out[no++] = s_g[k];
+            }
+        }
+        if (has_h && has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n");
+        else if (has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n");
+        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n");
+        if (rc) return rc;
+        if (has_h) {
+            if ((rc = fast_axis_pass<true>(c, 1, s_vh, st))) return rc;
+            c->fft_count++;
+            za.vh = s_vh;
+        }
+        if (has_g) {
+            double* dfdn;
+            if ((rc = real_ws(c, "dfdn", &dfdn))) return rc;
+            for (int k = 0; k < 3; ++k)
+                if ((rc = fast_axis_pass<true>(c, 1, s_g[k], st))) return rc;
+            int blocks = 0;
+            if ((rc = launch_zpbe(c, ds, s_g[0], s_g[1], s_g[2], dfdn, inv_n, (mask & OFDFT_PBE_X) ? 1 : 0,
+                                  (mask & OFDFT_PBE_C) ? 1 : 0, &blocks, st)))
+                return rc;
+            if ((rc = fetch_partials(c, blocks, 2, pbe_sums, st))) return rc;
+            for (int k = 0; k < 3; ++k)
+                if ((rc = fast_axis_pass<false>(c, 1, s_g[k], st))) return rc;
+            XfIo dio{};
+            for (int k = 0; k < 3; ++k) dio.in[k] = s_g[k];
+            dio.out[0] = s_n;      // n^ is no longer needed
+            if ((rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div"))) return rc;
+            if ((rc = fast_axis_pass<true>(c, 1, s_n, st))) return rc;
+            c->fft_count++;
+            za.div = s_n;
+            za.dfdn = dfdn;
+        }
+    }
+    if (s_s) {
+        XfIo io{};
+        io.in[0] = s_s;
+        io.out[0] = s_s;
+        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, st, "xfused_lap"))) return rc;
+        if ((rc = fast_axis_pass<true>(c, 1, s_s, st))) return rc;
+        c->fft_count++;
+        za.lap = s_s;
+    }
+    if (mask & OFDFT_WT_NL) {
+        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+        const double nbar = nel / c->vol;                                    // functionals.py:646-647
+        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        const MixScale<SPEC_LINDHARD> lind{c->kg, pref, 1.0 / (2.0 * kf)};
+        cplx *s_b = nullptr, *s_a = nullptr;
+        if ((rc = spec("zwb", &s_b))) return rc;
+        if (al != be && (rc = spec("zwa", &s_a))) return rc;
+        PowersArgs pa{};
+        pa.out[0] = s_b;
+        pa.out[3] = s_a;
+        pa.e0 = be;
+        pa.e1 = al;
+        pa.nref = 0.0;
+        pa.sum53 = 0;
+        if ((rc = launch_zf_powers(c, ds, pa, st))) return rc;
+        for (cplx* sp : {s_b, s_a}) {
+            if (!sp) continue;
+            XfIo io{};
+            io.in[0] = sp;
+            io.out[0] = sp;
+            if ((rc = fast_axis_pass<false>(c, 1, sp, st))) return rc;
+            if ((rc = xfused<1, 1>(c, io, lind, st, "xfused_lind"))) return rc;
+            if ((rc = fast_axis_pass<true>(c, 1, sp, st))) return rc;
+            c->fft_count++;
+        }
+        za.conv_b = s_b;
+        za.conv_a = s_a;
+        za.wt_alpha = al;
+        za.wt_beta = be;
+        za.wt_nbar_pa = std::pow(nbar, al);
+        za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+    }
+    if (mask & OFDFT_WGC99_NL) {
+        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+        const long long nel_r = std::llround(nel);                           // functionals.py:952
+        double nref;
+        if ((rc = ensure_wgc_tables(c, nel_r, st, &nref))) return rc;
+        cplx* sw[6];
+        const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
+        PowersArgs pa{};
+        for (int i = 0; i < 6; ++i) {
+            if ((rc = spec(wn[i], &sw[i]))) return rc;
+            pa.out[i] = sw[i];
+        }
+        pa.e0 = be;
+        pa.e1 = al;
+        pa.nref = nref;
+        pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+        if ((rc = launch_zf_powers(c, ds, pa, st))) return rc;
+        const MixWgc mix{(double*)c->ws["t:w0"].p, (double*)c->ws["t:K1"].p, (double*)c->ws["t:K2"].p,
+                         (double*)c->ws["t:K3"].p};
+        for (int half = 0; half < 2; ++half) {
+            XfIo io{};
+            for (int i = 0; i < 3; ++i) {
+                if ((rc = fast_axis_pass<false>(c, 1, sw[3 * half + i], st))) return rc;
+                io.in[i] = sw[3 * half + i];
+                io.out[i] = sw[3 * half + i];
+            }
+            if ((rc = xfused<3, 3>(c, io, mix, st, "xfused_wgc"))) return rc;
+            for (int i = 0; i < 3; ++i) {
+                if ((rc = fast_axis_pass<true>(c, 1, sw[3 * half + i], st))) return rc;
+                c->fft_count++;
+            }
+        }
+        for (int i = 0; i < 3; ++i) {
+            za.u[i] = sw[i];
+            za.gw[i] = sw[3 + i];
+        }
+        za.wgc_alpha = al;
+        za.wgc_beta = be;
+        za.nref = nref;
+        za.wgc_sum_53 = pa.sum53;
+    }
+    int blocks = 0;
+    if ((rc = launch_zi_combine(c, za, &blocks, st))) return rc;
+    double sums[kCombineScalars];
+    if ((rc = fetch_partials(c, blocks, kCombineScalars, sums, st))) return rc;
+    energies_from_sums(c, sums, pbe_sums, E_terms, vn_int);
+    return 0;
+}
+
 int begin_call(ofdft_ctx* c, hipStream_t st) {
     if (!c) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -903,7 +1170,14 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
     const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     hipError_t e = hipSetDevice(device_id);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * kRedBlocks * kMaxScalars);
+    // partial-sum rows: the pointwise kernels use <= kRedBlocks blocks, the z kernels one block per row group
+    c->partial_rows = kRedBlocks;
+    if (c->fast && c->n2 / 2 <= 512) {
+        const long long zb = (g.nrows + 3) / 4;      // >= blocks of any z kernel (RPB >= 4)
+        if (zb > c->partial_rows) c->partial_rows = zb;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * c->partial_rows * kMaxScalars);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_reduced, sizeof(double) * kMaxScalars);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -923,6 +1197,7 @@ void ofdft_destroy(ofdft_ctx* c) {
     for (auto& kv : c->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_reduced) (void)hipFree(c->d_reduced);
     if (c->h_partial) (void)hipHostFree(c->h_partial);
     if (c->d_wgc_coef) (void)hipFree(c->d_wgc_coef);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -982,6 +1257,17 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     if (!den || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     double vn;
+    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
+        double nel = 0.0;
+        if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) {
+            double nsum;
+            if (int rc = device_sum(c, (const double*)den, false, &nsum, st)) return rc;
+            nel = nsum / (double)c->npts * c->vol;
+        }
+        const DenSrc ds{(const double*)den, 1.0, 0};
+        if (int rc = run_terms_zfused(c, ds, nel, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
+        return end_call(c, st);
+    }
     if (int rc = run_terms(c, (const double*)den, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
     return end_call(c, st);
 }
@@ -998,8 +1284,21 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
     const double cfac = n_electrons / ntilde;                                         // system.py:834
     double *den, *v;
-    if (int rc = real_ws(c, "den", &den)) return rc;
     if (int rc = real_ws(c, "v", &v)) return rc;
+    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
+        // n = cfac chi^2 is formed on the fly inside the z kernels; mean(n) vol = N_e by construction
+        const DenSrc ds{(const double*)chi, cfac, 1};
+        double vn;
+        if (int rc = run_terms_zfused(c, ds, n_electrons, (const double*)vext, E_terms, v, &vn, st)) return rc;
+        const double mu = vn / n_electrons;
+        if (mu_host) *mu_host = mu;
+        if (grad) {
+            OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi,
+                         v, (double*)grad, c->npts, cfac * 2.0 * c->dV, mu);
+        }
+        return end_call(c, st);
+    }
+    if (int rc = real_ws(c, "den", &den)) return rc;
     OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, den,
                        c->npts, cfac);
     double vn;
@@ -1048,6 +1347,7 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
     switch (option) {
         case OFDFT_OPT_PIPELINE:
             c->force_unfused = value == 1.0;
+            c->pipeline = (int)value;
             return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);

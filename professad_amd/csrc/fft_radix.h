@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace ofdft {
 
 typedef double2 cplx;
@@ -126,6 +128,7 @@ template <int R, bool INV> struct Dft {
 template <int LEN> struct Plan;
 #define OFDFT_PLAN(LEN_, NST_, R0_, R1_, R2_, E_)                                   \
     template <> struct Plan<LEN_> {                                                \
+        static constexpr int LEN = LEN_;                                           \
         static constexpr int NST = NST_;                                           \
         static constexpr int E = E_;                                               \
         static constexpr int P = LEN_ / E_;                                        \
@@ -148,10 +151,23 @@ template <int LEN> struct LineBuf {
     static constexpr int STRIDE = LEN + (LEN >> 4) + 2;
 };
 
-template <int LEN, int S, int NS, bool INV> struct Stage {
-    static constexpr int R = Plan<LEN>::radix(S);
-    static constexpr int E = Plan<LEN>::E;
-    static constexpr int P = Plan<LEN>::P;
+// workgroup-wide or wave-local synchronisation of the LDS exchange.  WAVE = true is legal when all P
+// threads of a line are lanes of ONE wavefront: a wave's LDS instructions execute in program order, so a
+// ds_write followed by a ds_read of the same wave needs no s_barrier -- only a compiler-level fence.
+template <bool WAVE> __device__ __forceinline__ void exchange_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
+    static constexpr int LEN = PL::LEN;
+    static constexpr int R = PL::radix(S);
+    static constexpr int E = PL::E;
+    static constexpr int P = PL::P;
     static constexpr int NB = E / R;       // butterflies per thread in this stage (also register stride)
 
     static __device__ __forceinline__ void run(cplx (&v)[E], int j, double* line, const cplx* __restrict__ tw) {
@@ -182,31 +198,31 @@ template <int LEN, int S, int NS, bool INV> struct Stage {
             for (int t = 0; t < R; ++t) v[b + t * NB] = a[t];
         }
         // ---- exchange through LDS (not after the last stage)
-        if constexpr (S + 1 < Plan<LEN>::NST) {
+        if constexpr (S + 1 < PL::NST) {
             int base[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int jb = j + b * P;
                 base[b] = (jb / NS) * (NS * R) + (jb % NS);
             }
-            __syncthreads();
+            exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
-            __syncthreads();
+            exchange_sync<WAVE>();
             double re[E];
 #pragma unroll
             for (int q = 0; q < E; ++q) re[q] = line[lpad(j + P * q)];
-            __syncthreads();
+            exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
-            __syncthreads();
+            exchange_sync<WAVE>();
 #pragma unroll
             for (int q = 0; q < E; ++q) v[q] = make_double2(re[q], line[lpad(j + P * q)]);
-            Stage<LEN, S + 1, NS * R, INV>::run(v, j, line, tw);
+            StageP<PL, S + 1, NS * R, INV, WAVE>::run(v, j, line, tw);
         }
     }
 };
@@ -216,7 +232,54 @@ template <int LEN, int S, int NS, bool INV> struct Stage {
 // Every thread of the workgroup must call this (it contains __syncthreads()).
 template <int LEN, bool INV>
 __device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, double* line, const cplx* __restrict__ tw) {
-    Stage<LEN, 0, 1, INV>::run(v, j, line, tw);
+    StageP<Plan<LEN>, 0, 1, INV, false>::run(v, j, line, tw);
 }
+
+// ---- small-footprint plans for the z kernels: E = 8 or 4 complex points per lane.  A line's P = LEN/E
+// threads are lanes of one wave, so the exchanges need no barrier (extra stages only cost LDS traffic), and
+// the small register footprint leaves room for fused pointwise math.
+template <int LEN_, int E_> struct ZPlan;
+#define OFDFT_ZPLAN(LEN_, E_, NST_, R0_, R1_, R2_, R3_)                             \
+    template <> struct ZPlan<LEN_, E_> {                                           \
+        static constexpr int LEN = LEN_;                                           \
+        static constexpr int NST = NST_;                                           \
+        static constexpr int E = E_;                                               \
+        static constexpr int P = LEN_ / E_;                                        \
+        static __host__ __device__ constexpr int radix(int s) {                    \
+            return s == 0 ? R0_ : (s == 1 ? R1_ : (s == 2 ? R2_ : R3_));           \
+        }                                                                          \
+    };
+OFDFT_ZPLAN(8, 8, 1, 8, 1, 1, 1)
+OFDFT_ZPLAN(16, 8, 2, 8, 2, 1, 1)
+OFDFT_ZPLAN(32, 8, 2, 8, 4, 1, 1)
+OFDFT_ZPLAN(64, 8, 2, 8, 8, 1, 1)
+OFDFT_ZPLAN(128, 8, 3, 8, 4, 4, 1)
+OFDFT_ZPLAN(256, 8, 3, 8, 8, 4, 1)
+OFDFT_ZPLAN(512, 8, 3, 8, 8, 8, 1)
+OFDFT_ZPLAN(8, 4, 2, 4, 2, 1, 1)
+OFDFT_ZPLAN(16, 4, 2, 4, 4, 1, 1)
+OFDFT_ZPLAN(32, 4, 3, 4, 4, 2, 1)
+OFDFT_ZPLAN(64, 4, 3, 4, 4, 4, 1)
+OFDFT_ZPLAN(128, 4, 4, 4, 4, 4, 2)
+OFDFT_ZPLAN(256, 4, 4, 4, 4, 4, 4)
+#undef OFDFT_ZPLAN
+
+// E to use for a z kernel that wants `want` points per lane: lines longer than 64*want need more
+template <int M, int WANT> struct ZPick { static constexpr int E = (M / WANT <= 64) ? WANT : 8; };
+
+template <int LEN, int E, bool INV>
+__device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, double* line, const cplx* __restrict__ tw) {
+    static_assert(ZPlan<LEN, E>::P <= 64, "a line must fit one wavefront");
+    StageP<ZPlan<LEN, E>, 0, 1, INV, true>::run(v, j, line, tw);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1
+template <int I, int N, class F> __device__ __forceinline__ void static_for_impl(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
 
 }  // namespace ofdft

@@ -2,6 +2,8 @@
 // The math follows the closed forms listed in SURVEY.md §8a (reference: src/professad/functionals.py
 // and tests/tools_for_tests.py; exact lines cited at each functor).
 #pragma once
+#include <type_traits>
+
 #include "fft_kernels.h"
 
 namespace ofdft {
@@ -37,6 +39,22 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __
             partial[(long long)blockIdx.x * NS + s] = t;
         }
     }
+}
+
+// second level: partial[rows][ns] -> out[ns], fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const double* __restrict__ partial, int rows, int ns,
+                                                                      double* __restrict__ out) {
+    const int s = blockIdx.x;
+    double acc[1] = {0.0};
+    for (int r = threadIdx.x; r < rows; r += kRedThreads) acc[0] += partial[(long long)r * ns + s];
+    __shared__ double red[kRedThreads];
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    for (int off = kRedThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[s] = red[0];
 }
 
 // sum(a) or sum(a^2)

@@ -1,0 +1,482 @@
+// Wave-local z passes with fused real-space math (fp64, gfx950).
+//
+// A real row of N2 = 2M points is transformed by the M/8 lanes that own it (ZPlan<M>, 8 complex = 16 real
+// points per lane); the lanes of a row sit in ONE wavefront, so every LDS exchange is ordered by the wave's
+// own program order and the kernels contain no s_barrier.  A 256-thread workgroup is four independent waves.
+// Because a lane keeps only 16 points, the kernels have registers left to do the pointwise physics while a
+// row is on chip:
+//   zf_density_kernel   chi|n row -> spectra of n and sqrt(n)                 (1 read, 2 spectrum writes)
+//   zf_powers_kernel    chi|n row -> spectra of up to six n^e theta^m/m! terms (WT / WGC99 inputs, ONE pow)
+//   zpbe_kernel         (d_x n, d_y n, d_z n)^ rows -> real space -> PBE -> flux rows -> spectra, in place
+//   zi_combine_kernel   all convolution spectra of a row -> real space -> potential + energy integrands
+// so none of the real-space intermediates (sqrt n, n^beta theta..., grad n, flux, v_H, u_i, g_i, div) ever
+// exists in HBM.
+#pragma once
+#include "pointwise_kernels.h"
+
+namespace ofdft {
+
+template <int M, int E_> struct ZW {
+    using PL = ZPlan<M, E_>;
+    static constexpr int E = E_;
+    static constexpr int P = PL::P;                 // lanes per row
+    static constexpr int RPWV = 64 / P;             // rows per wave
+    static constexpr int TPB = 256;
+    static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
+    static constexpr int RS = LineBuf<M>::STRIDE;   // LDS doubles per row
+    static constexpr size_t LDS = sizeof(double) * RPB * RS;
+    static constexpr int N2 = 2 * M;
+};
+
+// lane geometry of the z kernels
+template <int M, int E> struct ZLane {
+    int j;            // lane's position inside its row group
+    int rw;           // row inside the wave
+    long long row_u;  // first row of this wave (wave-uniform)
+    long long row;    // this lane's row
+    bool valid;
+    double* mine;     // LDS buffer of this row
+    __device__ __forceinline__ ZLane(const SpecGeom& g, double* lds) {
+        using W = ZW<M, E>;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        j = lane % W::P;
+        rw = lane / W::P;
+        row_u = uniform64((long long)blockIdx.x * W::RPB + (long long)wave * W::RPWV);
+        row = row_u + rw;
+        valid = row < g.nrows;
+        mine = lds + (wave * W::RPWV + rw) * W::RS;
+    }
+};
+
+// ---- real rows: lane holds (a[2(j+Pq)], a[2(j+Pq)+1]) for q = 0..7
+template <int M, int E>
+__device__ __forceinline__ void z_load_real(cplx (&v)[E], const ZLane<M, E>& z, const double* __restrict__ a) {
+    using W = ZW<M, E>;
+    const cplx* ub = reinterpret_cast<const cplx*>(a + z.row_u * W::N2);
+    const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c(ub + q * W::P, voff) : make_double2(0.0, 0.0);
+}
+template <int M, int E>
+__device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, E>& z, double* __restrict__ a) {
+    using W = ZW<M, E>;
+    cplx* ub = reinterpret_cast<cplx*>(a + z.row_u * W::N2);
+    const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
+    if (z.valid) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) buf_store_c(ub + q * W::P, voff, v[q]);
+    }
+}
+
+// spectrum element k = j + P q of row `row` lives at ((k>>3)*nrows + row)*8 + (k&7); the (P q)>>3 part of
+// the block index is wave-uniform (folded into the base), the rest is the per-lane offset
+template <int M, int E> __device__ __forceinline__ unsigned z_spec_voff(const ZLane<M, E>& z, const SpecGeom& g) {
+    return (unsigned)((((long long)(z.j >> 3) * g.nrows + z.rw) * 8 + (z.j & 7)) * 16);
+}
+template <int M, int E, int Q> __device__ __forceinline__ long long z_spec_ubase(const ZLane<M, E>& z, const SpecGeom& g) {
+    constexpr int bu = (ZW<M, E>::P * Q) >> 3;
+    constexpr int kin_u = (ZW<M, E>::P * Q) & 7;     // non-zero only when P < 8
+    return ((long long)bu * g.nrows + z.row_u) * 8 + kin_u;
+}
+
+// forward: real pairs in v -> half-spectrum row written to `spec` (block-8 layout + Nyquist plane)
+template <int M, int E>
+__device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>& z, cplx* __restrict__ spec,
+                                                const SpecGeom& g, const cplx* __restrict__ twM,
+                                                const cplx* __restrict__ twN) {
+    using W = ZW<M, E>;
+    constexpr int P = W::P;
+    wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
+    double cr_m[E], c0r;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    c0r = z.mine[0];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    exchange_sync<true>();
+    const unsigned voff = z_spec_voff<M, E>(z, g);
+    static_for<E>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const int k = z.j + P * q;
+        const double ci_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx ev = make_double2(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+        const cplx od = make_double2(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+        const cplx X = cadd(ev, cmul(twN[k], od));
+        if (z.valid) buf_store_c(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
+    });
+    if (z.j == 0 && z.valid) {
+        const double c0i = z.mine[0];
+        spec[g.main_count + z.row] = make_double2(c0r - c0i, 0.0);
+    }
+    exchange_sync<true>();
+}
+
+// inverse: half-spectrum row of `spec` -> unscaled real pairs in v (imaginary parts of kz = 0 / Nyquist ignored)
+template <int M, int E>
+__device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ spec,
+                                               const SpecGeom& g, const cplx* __restrict__ twM,
+                                               const cplx* __restrict__ twN) {
+    using W = ZW<M, E>;
+    constexpr int P = W::P;
+    // keep this row's loads below the previous array's work: hoisting the loads of ALL arrays to the kernel top
+    // (the compiler's default) costs 16 VGPRs per array and collapses the occupancy that hides their latency
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned voff = z_spec_voff<M, E>(z, g);
+    static_for<E>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        v[q] = z.valid ? buf_load_c(spec + z_spec_ubase<M, E, q>(z, g), voff) : make_double2(0.0, 0.0);
+    });
+    const double nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
+    double xr_m[E];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) xr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int k = z.j + P * q;
+        const double xi_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx x = v[q];
+        if (k == 0) {
+            v[q] = make_double2(x.x + nyq, x.x - nyq);
+        } else {
+            const cplx ev = make_double2(x.x + xr_m[q], x.y - xi_m);
+            const cplx d = make_double2(x.x - xr_m[q], x.y + xi_m);
+            const cplx od = cmul(d, cconj(twN[k]));
+            v[q] = make_double2(ev.x - od.y, ev.y + od.x);
+        }
+    }
+    exchange_sync<true>();
+    wave_line_fft<M, E, true>(v, z.j, z.mine, twM);
+    exchange_sync<true>();
+}
+
+// x^y for x >= 0 as exp(y log x): ~2 ulp for the |y log x| = O(1..10) met here, a fraction of the instructions
+// and registers of the fully-general pow() (which the unfused pipeline keeps using as an independent check).
+__device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
+
+// density of a point from the kernel's source array: n = cscale * x^2 (source = chi) or n = x (source = den)
+struct DenSrc {
+    const double* src;
+    double cscale;
+    int from_chi;
+    __device__ __forceinline__ double operator()(double x) const { return from_chi ? cscale * x * x : x; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// chi|n -> n^ and (sqrt n)^      (functionals.py:65 rfftn(den); :245 laplacian(k2, sqrt_den))
+template <int M, int E>
+__global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
+                                                         SpecGeom g, const cplx* __restrict__ twM,
+                                                         const cplx* __restrict__ twN) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    cplx x[E], v[E];
+    z_load_real<M, E>(x, z, ds.src);
+    if (out_n) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = make_double2(ds(x[q].x), ds(x[q].y));
+        z_forward_store<M, E>(v, z, out_n, g, twM, twN);
+    }
+    if (out_s) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const double a = ds(x[q].x), b = ds(x[q].y);
+            v[q] = make_double2(a != 0.0 ? sqrt(a) : 0.0, b != 0.0 ? sqrt(b) : 0.0);     // functionals.py:242-243
+        }
+        z_forward_store<M, E>(v, z, out_s, g, twM, twN);
+    }
+}
+
+// chi|n -> spectra of  n^e0 theta^m / m!  (m = 0,1,2; out[0..2])  and  n^e1 theta^m / m!  (out[3..5]).
+// WGC99: e0 = beta, e1 = alpha (functionals.py:976-981 and the closed form SURVEY §8a-8); WT: only out[0]
+// (and out[3] when alpha != beta), theta unused.  One pow per point when e0 + e1 = 5/3.
+struct PowersArgs {
+    cplx* out[6];
+    double e0, e1, nref;
+    int sum53;       // e0 + e1 == 5/3: n^e1 = n^(5/3) / n^e0
+};
+template <int M, int E>
+__global__ __launch_bounds__(256, 3) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
+                                                        const cplx* __restrict__ twM, const cplx* __restrict__ twN) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    cplx n[E], a[E], v[E];
+    z_load_real<M, E>(n, z, ds.src);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        n[q] = make_double2(ds(n[q].x), ds(n[q].y));
+        a[q] = make_double2(pow_pos(n[q].x, pa.e0), pow_pos(n[q].y, pa.e0));
+    }
+    for (int half = 0; half < 2; ++half) {
+        if (half == 1) {
+            if (!pa.out[3] && !pa.out[4] && !pa.out[5]) break;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                if (pa.sum53) {
+                    const double cx = cbrt(n[q].x), cy = cbrt(n[q].y);
+                    a[q] = make_double2(n[q].x * cx * cx / a[q].x, n[q].y * cy * cy / a[q].y);
+                } else {
+                    a[q] = make_double2(pow_pos(n[q].x, pa.e1), pow_pos(n[q].y, pa.e1));
+                }
+            }
+        }
+        cplx* const* o = pa.out + 3 * half;
+        if (o[0]) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = a[q];
+            z_forward_store<M, E>(v, z, o[0], g, twM, twN);
+        }
+        if (o[1]) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[q] = make_double2(a[q].x * (n[q].x - pa.nref), a[q].y * (n[q].y - pa.nref));
+            z_forward_store<M, E>(v, z, o[1], g, twM, twN);
+        }
+        if (o[2]) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const double tx = n[q].x - pa.nref, ty = n[q].y - pa.nref;
+                v[q] = make_double2(0.5 * a[q].x * tx * tx, 0.5 * a[q].y * ty * ty);
+            }
+            z_forward_store<M, E>(v, z, o[2], g, twM, twN);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PBE mid stage on chip: spectra of grad n (x already in real space, y done) -> real space -> f, df/dn,
+// flux_j = df/d|grad n|^2 * d_j n -> spectra again, in place.  (functionals.py:1597-1618;
+// tests/tools_for_tests.py:155-207)
+template <int M, int E>
+__global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
+                                                   cplx* __restrict__ gz, double* __restrict__ dfdn, double inv_n,
+                                                   int do_x, int do_c, SpecGeom g, const cplx* __restrict__ twM,
+                                                   const cplx* __restrict__ twN, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    cplx a[E], b[E], c[E], n[E];
+    z_load_inverse<M, E>(a, z, gx, g, twM, twN);
+    z_load_inverse<M, E>(b, z, gy, g, twM, twN);
+    z_load_inverse<M, E>(c, z, gz, g, twM, twN);
+    z_load_real<M, E>(n, z, ds.src);
+    double acc[2] = {0.0, 0.0};
+    cplx d[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double ax = a[q].x * inv_n, bx = b[q].x * inv_n, cx = c[q].x * inv_n;
+        const double ay = a[q].y * inv_n, by = b[q].y * inv_n, cy = c[q].y * inv_n;
+        PbePoint p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+        if (z.valid) {
+            p0 = pbe_point(ds(n[q].x), ax * ax + bx * bx + cx * cx, do_x != 0, do_c != 0);
+            p1 = pbe_point(ds(n[q].y), ay * ay + by * by + cy * cy, do_x != 0, do_c != 0);
+        }
+        acc[0] += p0.fx + p1.fx;
+        acc[1] += p0.fc + p1.fc;
+        d[q] = make_double2(p0.dfdn, p1.dfdn);
+        a[q] = make_double2(p0.dfdg * ax, p1.dfdg * ay);
+        b[q] = make_double2(p0.dfdg * bx, p1.dfdg * by);
+        c[q] = make_double2(p0.dfdg * cx, p1.dfdg * cy);
+    }
+    z_store_real<M, E>(d, z, dfdn);
+    z_forward_store<M, E>(a, z, gx, g, twM, twN);
+    z_forward_store<M, E>(b, z, gy, g, twM, twN);
+    z_forward_store<M, E>(c, z, gz, g, twM, twN);
+    block_reduce_store<2>(acc, partial);
+}
+
+// ------------------------------------------------------------------------------------------------
+// final stage: every convolution spectrum of a row -> real space -> potential and energy integrands.
+struct ZCombineArgs {
+    DenSrc ds;
+    const double* vext;
+    const double* dfdn;       // real array from zpbe
+    const cplx* vh;
+    const cplx* lap;
+    const cplx* conv_b;
+    const cplx* conv_a;
+    const cplx* u[3];
+    const cplx* gw[3];
+    const cplx* div;
+    double* v_out;
+    unsigned mask;
+    double inv_n;
+    double wt_alpha, wt_beta, wt_nbar_pa;
+    double wgc_alpha, wgc_beta, nref;
+    int wt_is_56, wgc_sum_53;
+};
+
+template <int M, int E>
+__global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
+                                                         const cplx* __restrict__ twN, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    double acc[kCombineScalars];
+#pragma unroll
+    for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
+    cplx n[E], vacc[E], w[E];
+    z_load_real<M, E>(n, z, a.ds.src);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        n[q] = z.valid ? make_double2(a.ds(n[q].x), a.ds(n[q].y)) : make_double2(1.0, 1.0);
+        vacc[q] = make_double2(0.0, 0.0);
+    }
+    const double sc = a.inv_n;
+    if (a.mask & 2u) {                                   // Hartree  functionals.py:72
+        z_load_inverse<M, E>(w, z, a.vh, g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            acc[1] += 0.5 * (n[q].x * x0 + n[q].y * x1);
+            vacc[q].x += x0;
+            vacc[q].y += x1;
+        }
+    }
+    if (a.mask & 8u) {                                   // vW  functionals.py:245; tools_for_tests.py:23-26
+        z_load_inverse<M, E>(w, z, a.lap, g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            const double s0 = n[q].x != 0.0 ? sqrt(n[q].x) : 0.0, s1 = n[q].y != 0.0 ? sqrt(n[q].y) : 0.0;
+            acc[3] += -0.5 * (s0 * x0 + s1 * x1);
+            if (n[q].x != 0.0) vacc[q].x += -0.5 * x0 / s0;
+            if (n[q].y != 0.0) vacc[q].y += -0.5 * x1 / s1;
+        }
+    }
+    if (a.mask & 16u) {                                  // WT family  functionals.py:650-651; tools_for_tests.py:29-39
+        z_load_inverse<M, E>(w, z, a.conv_b, g, twM, twN);
+        cplx pa1[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            __builtin_amdgcn_sched_barrier(0);
+            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            pa1[q] = a.wt_is_56 ? make_double2(1.0 / sqrt(cbrt(n[q].x)), 1.0 / sqrt(cbrt(n[q].y)))
+                                : make_double2(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
+            acc[4] += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
+            const double f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
+            vacc[q].x += ctf * f * pa1[q].x * x0;
+            vacc[q].y += ctf * f * pa1[q].y * x1;
+        }
+        if (a.conv_a) {
+            z_load_inverse<M, E>(w, z, a.conv_a, g, twM, twN);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                vacc[q].x += ctf * a.wt_beta * pow_pos(n[q].x, a.wt_beta - 1.0) * w[q].x * sc;
+                vacc[q].y += ctf * a.wt_beta * pow_pos(n[q].y, a.wt_beta - 1.0) * w[q].y * sc;
+            }
+        }
+    }
+    if (a.mask & 32u) {                                  // WGC99  SURVEY §8a-8 closed form
+        cplx t1[E], t2[E];
+        z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) t1[q] = make_double2(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
+        z_load_inverse<M, E>(w, z, a.u[1], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            t1[q].x += (n[q].x - a.nref) * x0;
+            t1[q].y += (n[q].y - a.nref) * x1;
+            t2[q] = make_double2(x0, x1);                                                            // S_1 = u1 + ...
+        }
+        z_load_inverse<M, E>(w, z, a.u[2], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            __builtin_amdgcn_sched_barrier(0);      // one point pair at a time: pow_pos() is register-hungry
+            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+            t1[q].x += 0.5 * h0 * h0 * x0;
+            t1[q].y += 0.5 * h1 * h1 * x1;
+            t2[q].x += h0 * x0;
+            t2[q].y += h1 * x1;
+            // fold: e_NL = ctf n^alpha S_e ; v += ctf n^(alpha-1) (alpha S_e + n S_1); keep n^(beta-1) in t2
+            const double pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
+            const double pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
+            const double pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
+            acc[5] += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
+            vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
+            vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
+            t2[q] = make_double2(pb0, pb1);
+        }
+        z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) t1[q] = make_double2(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
+        z_load_inverse<M, E>(w, z, a.gw[1], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            t1[q].x += (a.wgc_beta * (n[q].x - a.nref) + n[q].x) * w[q].x * sc;
+            t1[q].y += (a.wgc_beta * (n[q].y - a.nref) + n[q].y) * w[q].y * sc;
+        }
+        z_load_inverse<M, E>(w, z, a.gw[2], g, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+            t1[q].x += (0.5 * a.wgc_beta * h0 * h0 + n[q].x * h0) * w[q].x * sc;
+            t1[q].y += (0.5 * a.wgc_beta * h1 * h1 + n[q].y * h1) * w[q].y * sc;
+            vacc[q].x += ctf * t2[q].x * t1[q].x;
+            vacc[q].y += ctf * t2[q].y * t1[q].y;
+        }
+    }
+    if (a.mask & (3u << 10)) {                           // PBE: v += df/dn - 2 div  (tools_for_tests.py:168-170)
+        z_load_inverse<M, E>(w, z, a.div, g, twM, twN);
+        cplx d[E];
+        z_load_real<M, E>(d, z, a.dfdn);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            vacc[q].x += d[q].x - 2.0 * w[q].x * sc;
+            vacc[q].y += d[q].y - 2.0 * w[q].y * sc;
+        }
+    }
+    // ---- local terms and the sum of v n
+    if (a.mask & 1u) {
+        cplx ve[E];
+        z_load_real<M, E>(ve, z, a.vext);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            acc[0] += n[q].x * ve[q].x + n[q].y * ve[q].y;
+            vacc[q].x += ve[q].x;
+            vacc[q].y += ve[q].y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.mask & 4u) {                               // TF  functionals.py:223
+            const double c0 = cbrt(n[q].x), c1 = cbrt(n[q].y);
+            acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
+            vacc[q].x += (5.0 / 3.0) * ctf * c0 * c0;
+            vacc[q].y += (5.0 / 3.0) * ctf * c1 * c1;
+        }
+        if (a.mask & (0xFu << 6)) {                      // local XC
+            const XcLocal x0 = lda_point(n[q].x, a.mask), x1 = lda_point(n[q].y, a.mask);
+            acc[6] += x0.ex + x1.ex;
+            acc[7] += x0.ec + x1.ec;
+            vacc[q].x += x0.vx + x0.vc;
+            vacc[q].y += x1.vx + x1.vc;
+        }
+        acc[8] += vacc[q].x * n[q].x + vacc[q].y * n[q].y;
+    }
+    if (!z.valid) {
+#pragma unroll
+        for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
+    }
+    if (a.v_out) z_store_real<M, E>(vacc, z, a.v_out);
+    block_reduce_store<kCombineScalars>(acc, partial);
+}
+
+}  // namespace ofdft

@@ -250,22 +250,30 @@ def test_reference_system_protocol_sum_of_terms():
     assert relerr(d.grad.cpu().numpy() / dV, gold['v_cfg3']) < V_RTOL
 
 
-def test_fused_and_unfused_pipelines_agree():
-    """The fused x-pass pipeline against the engine's own unfused pipeline (separate passes) on one input."""
-    shape = (64, 32, 128)
+@pytest.mark.parametrize('shape', [(64, 32, 128), (16, 8, 16), (8, 64, 32), (32, 32, 1024)])
+def test_all_pipelines_agree(shape):
+    """z-fused (default), x-fused-only and unfused pipelines of the engine on one input, energy_potential and
+    closure forms."""
     box = cases.make_cell(('tri', 1.7))
     den = synth.random_density(shape, seed=31)
     vext = synth.random_potential(shape, seed=32)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(33).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
     eng = Engine(shape, DEV).set_cell(dev(box))
     for cfg, names in _CFG_TERMS.items():
         eng.set_terms(F.NativeTerms(names).names)
-        eng.set_option(0, 0)
-        Ef, vf = eng.energy_potential(dev(den), dev(vext))
-        nf = eng.query(0)
-        eng.set_option(0, 1)
-        Eu, vu = eng.energy_potential(dev(den), dev(vext))
-        assert eng.query(0) == nf
-        for k in Ef:
-            assert abs(Ef[k] - Eu[k]) <= 1e-12 * max(1.0, abs(Eu[k])), (cfg, k)
-        assert relerr(vf.cpu().numpy(), vu.cpu().numpy()) < 1e-12
+        res = {}
+        for mode in (0, 1, 2):
+            eng.set_option(0, mode)
+            E, v = eng.energy_potential(dev(den), dev(vext))
+            Ec, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+            res[mode] = (E, v.cpu().numpy(), Ec, mu, g.cpu().numpy(), eng.query(0))
+        for mode in (0, 2):
+            for k in res[1][0]:
+                assert abs(res[mode][0][k] - res[1][0][k]) <= 1e-12 * max(1.0, abs(res[1][0][k])), (cfg, mode, k)
+                assert abs(res[mode][2][k] - res[1][2][k]) <= 1e-12 * max(1.0, abs(res[1][2][k])), (cfg, mode, k)
+            assert relerr(res[mode][1], res[1][1]) < 1e-12, (cfg, mode)
+            assert relerr(res[mode][4], res[1][4]) < 1e-12, (cfg, mode)
+            assert abs(res[mode][3] - res[1][3]) < 1e-12 * max(1.0, abs(res[1][3]))
+            assert res[mode][5] == res[1][5]          # same number of 3-D FFTs
     eng.close()
