@@ -27,7 +27,8 @@ Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1,
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
-           'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
+           'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish',
+           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
 class NativeLibraryError(RuntimeError):
@@ -75,6 +76,20 @@ def load():
     lib.ofdft_irfftn.restype = ip
     lib.ofdft_query.argtypes = [vp, ip, dp]
     lib.ofdft_query.restype = ip
+    lib.ofdft_create_dist.argtypes = [C.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]
+    lib.ofdft_create_dist.restype = ip
+    lib.ofdft_dist_sumsq.argtypes = [vp, vp, ip, dp, vp]
+    lib.ofdft_dist_sumsq.restype = ip
+    lib.ofdft_dist_begin.argtypes = [vp, vp, ip, C.c_double, C.c_double, vp, vp, vp]
+    lib.ofdft_dist_begin.restype = ip
+    lib.ofdft_dist_stage.argtypes = [vp, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
+    lib.ofdft_dist_stage.restype = ip
+    lib.ofdft_dist_finish.argtypes = [vp, dp, vp]
+    lib.ofdft_dist_finish.restype = ip
+    lib.ofdft_dist_energies.argtypes = [vp, dp, dp, dp]
+    lib.ofdft_dist_energies.restype = ip
+    lib.ofdft_dist_chi_grad.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp]
+    lib.ofdft_dist_chi_grad.restype = ip
     lib.ofdft_set_option.argtypes = [vp, ip, C.c_double]
     lib.ofdft_set_option.restype = ip
     lib.ofdft_set_profiling.argtypes = [vp, ip]

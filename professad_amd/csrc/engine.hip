@@ -26,10 +26,14 @@ struct DevBuf {
 }  // namespace
 
 struct ofdft_ctx {
-    int n0 = 0, n1 = 0, n2 = 0, device = 0;
-    SpecGeom g{};
-    KGeom kg{};
-    long long npts = 0;
+    int n0 = 0, n1 = 0, n2 = 0, device = 0;     // LOCAL real-space extents (x-slab: n0 = n0g / nranks)
+    int n0g = 0, n1g = 0, nranks = 1, rank = 0; // global extents and slab decomposition
+    SpecGeom g{};      // spectrum geometry of the z and y passes (x-slab: n0 local, n1 global)
+    SpecGeom gx{};     // spectrum geometry of the x pass (y-slab: n0 global, n1 local); == g on one GPU
+    KGeom kg{};        // k-vectors in the x-pass geometry
+    SlabGeom sg{};
+    long long npts = 0;      // local points
+    long long npts_g = 0;    // global points (normalisation, dV)
     bool fast = false, cell_set = false, force_unfused = false;
     int pipeline = 0;   // 0 = z-fused (default on power-of-two grids), 1 = unfused, 2 = x-fused only
     double box[9] = {0}, vol = 0.0, dV = 0.0;
@@ -61,6 +65,7 @@ struct ofdft_ctx {
     std::vector<Pending> pending;
     struct Acc { double ms = 0.0; long long launches = 0; };
     std::map<std::string, Acc> prof;
+    struct ofdft_zrun_holder* zr = nullptr;
     char err[512] = "";
 };
 
@@ -205,7 +210,7 @@ int launch_cpass_t(ofdft_ctx* c, cplx* data, const LineMap& main, const LineMap&
 
 // line maps of the block-8 layout (see fft_kernels.h)
 void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
-    const SpecGeom& g = c->g;
+    const SpecGeom& g = axis == 0 ? c->gx : c->g;
     const int nb = g.nzm / 8, nrem = g.nzc - g.nzm;
     if (axis == 0) {   // x lines: base = b*n0*n1*8 + (y*8+kin), stride n1*8
         main.d = g.n1 * 8; main.sb = (long long)g.n0 * g.n1 * 8; main.sl = 1; main.se = (long long)g.n1 * 8;
@@ -223,7 +228,7 @@ template <bool INV>
 int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
     LineMap main, rem;
     pass_maps(c, axis, main, rem);
-    const int len = axis == 0 ? c->n0 : c->n1;
+    const int len = axis == 0 ? c->n0g : c->n1;
     const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
 #define OFDFT_CASE(L)                                                   \
     case L:                                                             \
@@ -382,14 +387,14 @@ int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st
     main.lf = rem.lf = Cfg::LPW;
     const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
     OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
-                 c->g, tw, mix);
+                 c->gx, tw, mix);
     return 0;
 }
 
 // forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
 template <int NIN, int NOUT, class Mix>
 int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
-    switch (c->n0) {
+    switch (c->n0g) {
         case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, st, nm);
         case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, st, nm);
         case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, st, nm);
@@ -399,7 +404,7 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
         case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, st, nm);
         case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, st, nm);
     }
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0);
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
 }
 
 // ---------------------------------------------------------------------------------- reductions
@@ -954,169 +959,314 @@ void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pb
 }
 
 // Pipeline with every real-space intermediate kept on chip: z kernels compute their inputs from chi|n on the
-// fly and consume the convolution results straight out of the inverse transform.  `nel` = mean(n)*vol.
-int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
-                     double* vn_int, hipStream_t st) {
-    const unsigned mask = c->mask;
-    const double inv_n = 1.0 / (double)c->npts;
-    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
-    if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+// fly and consume the convolution results straight out of the inverse transform.  It is written as five
+// stages separated by the four points where the spectra change between the x-slab geometry (z, y passes) and
+// the x-pass geometry: on one GPU the two coincide and the stages simply run back to back; on several GPUs
+// each boundary is one all-to-all over the listed arrays (the host does the collective, see ofdft_dist_*).
+//   stage 1  z-forward (+pointwise pre-ops) and y-forward of every input spectrum          -> exchange
+//   stage 2  fused x passes (Hartree, gradient, Laplacian, Lindhard / WGC99 mixing)         -> exchange
+//   stage 3  y-inverse of the results; PBE mid stage on chip; y-forward of the flux          -> exchange
+//   stage 4  fused x pass of the divergence                                                  -> exchange
+//   stage 5  y-inverse of the divergence; combine kernel (potential + energy integrands)
+struct ZRun {
+    DenSrc ds{};
+    double nel = 0.0;
+    const double* vext = nullptr;
+    double* v_out = nullptr;
     ZCombineArgs za{};
-    za.ds = ds;
-    za.vext = vext;
-    za.v_out = v_out;
-    za.mask = mask;
-    za.inv_n = inv_n;
     double pbe_sums[2] = {0.0, 0.0};
-    auto spec = [&](const char* nm, cplx** p) { return spec_ws(c, nm, p); };
-    int rc;
-    const bool has_h = mask & OFDFT_HARTREE, has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C), has_vw = mask & OFDFT_VW;
+    bool has_h = false, has_g = false, has_vw = false, has_wt = false, has_wgc = false;
     cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
-    if (has_h || has_g)
-        if ((rc = spec("zn", &s_n))) return rc;
-    if (has_vw)
-        if ((rc = spec("zs", &s_s))) return rc;
-    if (s_n || s_s) {
-        if ((rc = launch_zf_density(c, ds, s_n, s_s, st))) return rc;
-        if (s_n && (rc = fast_axis_pass<false>(c, 1, s_n, st))) return rc;
-        if (s_s && (rc = fast_axis_pass<false>(c, 1, s_s, st))) return rc;
+    cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* dfdn = nullptr;
+    double wt_pref = 0.0, wt_kf = 1.0;
+    std::vector<cplx*> xlist;      // arrays that cross the next geometry boundary
+    int stage = 0;
+    int combine_blocks = 0, pbe_blocks = 0;
+};
+
+}  // namespace
+struct ofdft_zrun_holder { ZRun r; };
+namespace {
+
+ZRun& zrun(ofdft_ctx* c);
+
+int zstage1(ofdft_ctx* c, hipStream_t st) {
+    ZRun& r = zrun(c);
+    const unsigned mask = c->mask;
+    int rc;
+    r.has_h = mask & OFDFT_HARTREE;
+    r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
+    r.has_vw = mask & OFDFT_VW;
+    r.has_wt = mask & OFDFT_WT_NL;
+    r.has_wgc = mask & OFDFT_WGC99_NL;
+    r.xlist.clear();
+    r.za = ZCombineArgs{};
+    r.za.ds = r.ds;
+    r.za.vext = r.vext;
+    r.za.v_out = r.v_out;
+    r.za.mask = mask;
+    r.za.inv_n = 1.0 / (double)c->npts_g;
+    r.pbe_sums[0] = r.pbe_sums[1] = 0.0;
+    r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
+    if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    if (r.has_h || r.has_g)
+        if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
+    if (r.has_vw)
+        if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
+    if (r.s_n || r.s_s) {
+        if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) return rc;
+        if (r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+        if (r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, st))) return rc;
+        if (r.s_n) r.xlist.push_back(r.s_n);
+        if (r.s_s) r.xlist.push_back(r.s_s);
     }
-    if (s_n) {
-        XfIo io{};
-        io.in[0] = s_n;
-        int no = 0;
-        if (has_h) {
-            if ((rc = spec("zvh", &s_vh))) return rc;
-            io.out[no++] = s_vh;
-        }
-        if (has_g) {
-            const char* gn[3] = {"zgx", "zgy", "zgz"};
-            for (int k = 0; k < 3; ++k) {
-                if ((rc = spec(gn[k], &s_g[k]))) return rc;
-                io.out[no++] = s_g[k];
-            }
-        }
-        if (has_h && has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n");
-        else if (has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n");
-        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n");
-        if (rc) return rc;
-        if (has_h) {
-            if ((rc = fast_axis_pass<true>(c, 1, s_vh, st))) return rc;
-            c->fft_count++;
-            za.vh = s_vh;
-        }
-        if (has_g) {
-            double* dfdn;
-            if ((rc = real_ws(c, "dfdn", &dfdn))) return rc;
-            for (int k = 0; k < 3; ++k)
-                if ((rc = fast_axis_pass<true>(c, 1, s_g[k], st))) return rc;
-            int blocks = 0;
-            if ((rc = launch_zpbe(c, ds, s_g[0], s_g[1], s_g[2], dfdn, inv_n, (mask & OFDFT_PBE_X) ? 1 : 0,
-                                  (mask & OFDFT_PBE_C) ? 1 : 0, &blocks, st)))
-                return rc;
-            if ((rc = fetch_partials(c, blocks, 2, pbe_sums, st))) return rc;
-            for (int k = 0; k < 3; ++k)
-                if ((rc = fast_axis_pass<false>(c, 1, s_g[k], st))) return rc;
-            XfIo dio{};
-            for (int k = 0; k < 3; ++k) dio.in[k] = s_g[k];
-            dio.out[0] = s_n;      // n^ is no longer needed
-            if ((rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div"))) return rc;
-            if ((rc = fast_axis_pass<true>(c, 1, s_n, st))) return rc;
-            c->fft_count++;
-            za.div = s_n;
-            za.dfdn = dfdn;
-        }
-    }
-    if (s_s) {
-        XfIo io{};
-        io.in[0] = s_s;
-        io.out[0] = s_s;
-        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, st, "xfused_lap"))) return rc;
-        if ((rc = fast_axis_pass<true>(c, 1, s_s, st))) return rc;
-        c->fft_count++;
-        za.lap = s_s;
-    }
-    if (mask & OFDFT_WT_NL) {
+    if (r.has_wt) {
         const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-        const double nbar = nel / c->vol;                                    // functionals.py:646-647
-        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-        const MixScale<SPEC_LINDHARD> lind{c->kg, pref, 1.0 / (2.0 * kf)};
-        cplx *s_b = nullptr, *s_a = nullptr;
-        if ((rc = spec("zwb", &s_b))) return rc;
-        if (al != be && (rc = spec("zwa", &s_a))) return rc;
+        const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
+        r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
+        if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
         PowersArgs pa{};
-        pa.out[0] = s_b;
-        pa.out[3] = s_a;
+        pa.out[0] = r.s_b;
+        pa.out[3] = r.s_a;
         pa.e0 = be;
         pa.e1 = al;
-        pa.nref = 0.0;
-        pa.sum53 = 0;
-        if ((rc = launch_zf_powers(c, ds, pa, st))) return rc;
-        for (cplx* sp : {s_b, s_a}) {
+        if ((rc = launch_zf_powers(c, r.ds, pa, st))) return rc;
+        for (cplx* sp : {r.s_b, r.s_a}) {
             if (!sp) continue;
-            XfIo io{};
-            io.in[0] = sp;
-            io.out[0] = sp;
             if ((rc = fast_axis_pass<false>(c, 1, sp, st))) return rc;
-            if ((rc = xfused<1, 1>(c, io, lind, st, "xfused_lind"))) return rc;
-            if ((rc = fast_axis_pass<true>(c, 1, sp, st))) return rc;
-            c->fft_count++;
+            r.xlist.push_back(sp);
         }
-        za.conv_b = s_b;
-        za.conv_a = s_a;
-        za.wt_alpha = al;
-        za.wt_beta = be;
-        za.wt_nbar_pa = std::pow(nbar, al);
-        za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+        r.za.wt_alpha = al;
+        r.za.wt_beta = be;
+        r.za.wt_nbar_pa = std::pow(nbar, al);
+        r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
     }
-    if (mask & OFDFT_WGC99_NL) {
+    if (r.has_wgc) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
-        const long long nel_r = std::llround(nel);                           // functionals.py:952
+        const long long nel_r = std::llround(r.nel);                         // functionals.py:952
         double nref;
         if ((rc = ensure_wgc_tables(c, nel_r, st, &nref))) return rc;
-        cplx* sw[6];
         const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
         PowersArgs pa{};
         for (int i = 0; i < 6; ++i) {
-            if ((rc = spec(wn[i], &sw[i]))) return rc;
-            pa.out[i] = sw[i];
+            if ((rc = spec_ws(c, wn[i], &r.sw[i]))) return rc;
+            pa.out[i] = r.sw[i];
         }
         pa.e0 = be;
         pa.e1 = al;
         pa.nref = nref;
         pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
-        if ((rc = launch_zf_powers(c, ds, pa, st))) return rc;
+        if ((rc = launch_zf_powers(c, r.ds, pa, st))) return rc;
+        for (int i = 0; i < 6; ++i) {
+            if ((rc = fast_axis_pass<false>(c, 1, r.sw[i], st))) return rc;
+            r.xlist.push_back(r.sw[i]);
+        }
+        r.za.wgc_alpha = al;
+        r.za.wgc_beta = be;
+        r.za.nref = nref;
+        r.za.wgc_sum_53 = pa.sum53;
+    }
+    r.stage = 1;
+    return 0;
+}
+
+int zstage2(ofdft_ctx* c, hipStream_t st) {
+    ZRun& r = zrun(c);
+    int rc;
+    r.xlist.clear();
+    if (r.s_n) {
+        XfIo io{};
+        io.in[0] = r.s_n;
+        int no = 0;
+        if (r.has_h) {
+            if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
+            io.out[no++] = r.s_vh;
+            r.xlist.push_back(r.s_vh);
+        }
+        if (r.has_g) {
+            const char* gn[3] = {"zgx", "zgy", "zgz"};
+            for (int k = 0; k < 3; ++k) {
+                if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
+                io.out[no++] = r.s_g[k];
+                r.xlist.push_back(r.s_g[k]);
+            }
+        }
+        if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n");
+        else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n");
+        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n");
+        if (rc) return rc;
+    }
+    if (r.s_s) {
+        XfIo io{};
+        io.in[0] = r.s_s;
+        io.out[0] = r.s_s;
+        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, st, "xfused_lap"))) return rc;
+        r.xlist.push_back(r.s_s);
+    }
+    if (r.has_wt) {
+        const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
+        for (cplx* sp : {r.s_b, r.s_a}) {
+            if (!sp) continue;
+            XfIo io{};
+            io.in[0] = sp;
+            io.out[0] = sp;
+            if ((rc = xfused<1, 1>(c, io, lind, st, "xfused_lind"))) return rc;
+            r.xlist.push_back(sp);
+        }
+    }
+    if (r.has_wgc) {
         const MixWgc mix{(double*)c->ws["t:w0"].p, (double*)c->ws["t:K1"].p, (double*)c->ws["t:K2"].p,
                          (double*)c->ws["t:K3"].p};
         for (int half = 0; half < 2; ++half) {
             XfIo io{};
             for (int i = 0; i < 3; ++i) {
-                if ((rc = fast_axis_pass<false>(c, 1, sw[3 * half + i], st))) return rc;
-                io.in[i] = sw[3 * half + i];
-                io.out[i] = sw[3 * half + i];
+                io.in[i] = r.sw[3 * half + i];
+                io.out[i] = r.sw[3 * half + i];
             }
             if ((rc = xfused<3, 3>(c, io, mix, st, "xfused_wgc"))) return rc;
-            for (int i = 0; i < 3; ++i) {
-                if ((rc = fast_axis_pass<true>(c, 1, sw[3 * half + i], st))) return rc;
-                c->fft_count++;
-            }
         }
-        for (int i = 0; i < 3; ++i) {
-            za.u[i] = sw[i];
-            za.gw[i] = sw[3 + i];
-        }
-        za.wgc_alpha = al;
-        za.wgc_beta = be;
-        za.nref = nref;
-        za.wgc_sum_53 = pa.sum53;
+        for (int i = 0; i < 6; ++i) r.xlist.push_back(r.sw[i]);
     }
-    int blocks = 0;
-    if ((rc = launch_zi_combine(c, za, &blocks, st))) return rc;
-    double sums[kCombineScalars];
-    if ((rc = fetch_partials(c, blocks, kCombineScalars, sums, st))) return rc;
-    energies_from_sums(c, sums, pbe_sums, E_terms, vn_int);
+    r.stage = 2;
     return 0;
+}
+
+int zstage3(ofdft_ctx* c, hipStream_t st) {
+    ZRun& r = zrun(c);
+    int rc;
+    // y-inverse of everything that came back from the x passes (each completes one c2r except grad n)
+    for (cplx* sp : r.xlist) {
+        if ((rc = fast_axis_pass<true>(c, 1, sp, st))) return rc;
+        if (sp != r.s_g[0] && sp != r.s_g[1] && sp != r.s_g[2]) c->fft_count++;
+    }
+    r.xlist.clear();
+    if (r.has_h) r.za.vh = r.s_vh;
+    if (r.s_s) r.za.lap = r.s_s;
+    if (r.has_wt) {
+        r.za.conv_b = r.s_b;
+        r.za.conv_a = r.s_a;
+    }
+    if (r.has_wgc)
+        for (int i = 0; i < 3; ++i) {
+            r.za.u[i] = r.sw[i];
+            r.za.gw[i] = r.sw[3 + i];
+        }
+    if (r.has_g) {
+        if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
+        if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
+                              (c->mask & OFDFT_PBE_C) ? 1 : 0, &r.pbe_blocks, st)))
+            return rc;
+        if (c->nranks == 1) {
+            if ((rc = fetch_partials(c, r.pbe_blocks, 2, r.pbe_sums, st))) return rc;
+        } else {    // keep the stream asynchronous between collectives: reduce on the device, read at the end
+            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
+                         c->d_reduced + kCombineScalars);
+        }
+        for (int k = 0; k < 3; ++k) {
+            if ((rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
+            r.xlist.push_back(r.s_g[k]);
+        }
+    }
+    r.stage = 3;
+    return 0;
+}
+
+int zstage4(ofdft_ctx* c, hipStream_t st) {
+    ZRun& r = zrun(c);
+    r.xlist.clear();
+    if (r.has_g) {
+        XfIo dio{};
+        for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
+        dio.out[0] = r.s_n;      // n^ is no longer needed
+        if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div")) return rc;
+        r.xlist.push_back(r.s_n);
+    }
+    r.stage = 4;
+    return 0;
+}
+
+// local sums: sums[0..8] combine scalars, sums[9..10] PBE x / c
+int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
+    ZRun& r = zrun(c);
+    int rc;
+    if (r.has_g) {
+        if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) return rc;
+        c->fft_count++;
+        r.za.div = r.s_n;
+        r.za.dfdn = r.dfdn;
+    }
+    r.xlist.clear();
+    if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) return rc;
+    if (c->nranks == 1) {
+        if ((rc = fetch_partials(c, r.combine_blocks, kCombineScalars, sums, st))) return rc;
+        sums[kCombineScalars] = r.pbe_sums[0];
+        sums[kCombineScalars + 1] = r.pbe_sums[1];
+    } else {
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
+                     r.combine_blocks, kCombineScalars, c->d_reduced);
+        HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
+        if (!r.has_g) sums[kCombineScalars] = sums[kCombineScalars + 1] = 0.0;
+    }
+    r.stage = 5;
+    return 0;
+}
+
+int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
+                     double* vn_int, hipStream_t st) {
+    ZRun& r = zrun(c);
+    r.ds = ds;
+    r.nel = nel;
+    r.vext = vext;
+    r.v_out = v_out;
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    int rc;
+    if ((rc = zstage1(c, st))) return rc;
+    if ((rc = zstage2(c, st))) return rc;
+    if ((rc = zstage3(c, st))) return rc;
+    if ((rc = zstage4(c, st))) return rc;
+    double sums[kCombineScalars + 2];
+    if ((rc = zstage5(c, sums, st))) return rc;
+    energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
+    return 0;
+}
+
+// ---- slab transpose helpers (multi-GPU): pack the stage's arrays for the all-to-all / unpack what came back
+int dist_buffers(ofdft_ctx* c, size_t narr, cplx** send, cplx** recv) {
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
+    if (int rc = get_ws(c, "x:send", bytes, (void**)send)) return rc;
+    return get_ws(c, "x:recv", bytes, (void**)recv);
+}
+int dist_pack(ofdft_ctx* c, int dir, hipStream_t st) {
+    ZRun& r = zrun(c);
+    cplx *send, *recv;
+    const int narr = (int)r.xlist.size();
+    if (narr == 0) return 0;
+    if (int rc = dist_buffers(c, 11, &send, &recv)) return rc;
+    for (int a = 0; a < narr; ++a)
+        OFDFT_LAUNCH(c, st, "slab_pack", slab_copy_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, r.xlist[a], send,
+                     c->sg, narr, a, dir);
+    return 0;
+}
+int dist_unpack(ofdft_ctx* c, int dir, hipStream_t st) {
+    ZRun& r = zrun(c);
+    cplx *send, *recv;
+    const int narr = (int)r.xlist.size();
+    if (narr == 0) return 0;
+    if (int rc = dist_buffers(c, 11, &send, &recv)) return rc;
+    for (int a = 0; a < narr; ++a)
+        OFDFT_LAUNCH(c, st, "slab_unpack", slab_copy_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, r.xlist[a], recv,
+                     c->sg, narr, a, dir);
+    return 0;
+}
+
+ZRun& zrun(ofdft_ctx* c) {
+    if (!c->zr) c->zr = new ofdft_zrun_holder();
+    return c->zr->r;
 }
 
 int begin_call(ofdft_ctx* c, hipStream_t st) {
@@ -1142,10 +1292,15 @@ int end_call(ofdft_ctx* c, hipStream_t st) {
 // ====================================================================================== C ABI
 extern "C" {
 
-int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id) {
+int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int device_id, int nranks, int rank) {
     if (!out) return OFDFT_EINVAL;
     *out = nullptr;
-    if (n0 < 2 || n1 < 2 || n2 < 2) return fail(nullptr, OFDFT_EINVAL, "grid extents must be >= 2 (got %d %d %d)", n0, n1, n2);
+    if (n0g < 2 || n1g < 2 || n2 < 2)
+        return fail(nullptr, OFDFT_EINVAL, "grid extents must be >= 2 (got %d %d %d)", n0g, n1g, n2);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, OFDFT_EINVAL, "bad rank %d of %d", rank, nranks);
+    if (nranks > 1 && (n0g % nranks || n1g % nranks))
+        return fail(nullptr, OFDFT_EINVAL, "slab decomposition needs n0 and n1 divisible by the rank count %d", nranks);
+    const int n0 = n0g / nranks, n1 = n1g;
     if (dtype != OFDFT_F64) return fail(nullptr, OFDFT_EINVAL, "only OFDFT_F64 is implemented");
     int ndev = 0;
     hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -1156,7 +1311,9 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
     ofdft_ctx* c = new (std::nothrow) ofdft_ctx();
     if (!c) return fail(nullptr, OFDFT_ENOMEM, "out of host memory");
     c->n0 = n0; c->n1 = n1; c->n2 = n2; c->device = device_id;
+    c->n0g = n0g; c->n1g = n1g; c->nranks = nranks; c->rank = rank;
     c->npts = (long long)n0 * n1 * n2;
+    c->npts_g = (long long)n0g * n1g * n2;
     SpecGeom& g = c->g;
     g.n0 = n0; g.n1 = n1; g.n2 = n2;
     g.nzc = n2 / 2 + 1;
@@ -1164,8 +1321,18 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
     g.nrows = (long long)n0 * n1;
     g.main_count = (long long)g.nzm * g.nrows;
     g.total = (long long)g.nzc * g.nrows;
-    c->fast = is_pow2(n0) && is_pow2(n1) && is_pow2(n2) && n0 >= 8 && n0 <= 1024 && n1 >= 8 && n1 <= 1024 &&
-              n2 >= 16 && n2 <= 2048;
+    c->gx = g;
+    c->gx.n0 = n0g;
+    c->gx.n1 = n1g / nranks;        // same nrows / totals as g
+    c->fast = is_pow2(n0g) && is_pow2(n1g) && is_pow2(n2) && is_pow2(nranks) && n0g >= 8 && n0g <= 1024 && n1g >= 8 &&
+              n1g <= 1024 && n2 >= 16 && n2 <= 2048;
+    if (nranks > 1 && !(c->fast && n2 / 2 <= 512 && c->gx.n1 >= 1)) {
+        delete c;
+        return fail(nullptr, OFDFT_EINVAL, "the slab-decomposed path needs power-of-two extents (n2 <= 1024)");
+    }
+    c->sg.nxl = n0; c->sg.nyl = c->gx.n1; c->sg.nranks = nranks; c->sg.n0g = n0g; c->sg.n1g = n1g;
+    c->sg.nzm = g.nzm; c->sg.nrem = g.nzc - g.nzm;
+    c->sg.chunk = (long long)g.nzc * n0 * c->gx.n1;
     const double s5 = std::sqrt(5.0);
     const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
@@ -1190,6 +1357,10 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
     return OFDFT_OK;
 }
 
+int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id) {
+    return ofdft_create_dist(out, n0, n1, n2, dtype, device_id, 1, 0);
+}
+
 void ofdft_destroy(ofdft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -1201,6 +1372,7 @@ void ofdft_destroy(ofdft_ctx* c) {
     if (c->h_partial) (void)hipHostFree(c->h_partial);
     if (c->d_wgc_coef) (void)hipFree(c->d_wgc_coef);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c->zr;
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -1231,9 +1403,11 @@ int ofdft_set_cell(ofdft_ctx* c, const double box[9]) {
         c->box[i] = box[i];
         c->kg.b[i] = 2.0 * kPi * cof[i] / det;                                       // functional_tools.py:149
     }
-    c->kg.g = c->g;
+    c->kg.g = c->gx;
+    c->kg.y0 = c->rank * c->gx.n1;
+    c->kg.n1g = c->n1g;
     c->vol = std::fabs(det);
-    c->dV = c->vol / (double)c->npts;
+    c->dV = c->vol / (double)c->npts_g;
     c->cell_set = true;
     c->wgc_valid = false;
     return OFDFT_OK;
@@ -1256,6 +1430,7 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     if (int rc = begin_call(c, st)) return rc;
     if (!den || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     double vn;
     if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
         double nel = 0.0;
@@ -1278,6 +1453,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (int rc = begin_call(c, st)) return rc;
     if (!chi || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
     double s2;
     if (int rc = device_sum(c, (const double*)chi, true, &s2, st)) return rc;
@@ -1339,6 +1515,97 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+// ------------------------------------------------------------------------------ slab-decomposed (multi-GPU) API
+int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* local_sum, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !x_local || !local_sum) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return device_sum(c, (const double*)x_local, square != 0, local_sum, st);
+}
+
+int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double cscale, double nel_global,
+                     const void* vext_local, void* v_out_local, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = begin_call(c, st)) return rc;
+    if (!src_local) return fail(c, OFDFT_EINVAL, "null argument");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
+    ZRun& r = zrun(c);
+    r.ds = DenSrc{(const double*)src_local, cscale, from_chi};
+    r.nel = nel_global;
+    r.vext = (const double*)vext_local;
+    r.v_out = (double*)v_out_local;
+    r.stage = 0;
+    r.xlist.clear();
+    return OFDFT_OK;
+}
+
+// Runs stage `stage` (1..4): un-packs the previous exchange, does the stage's local work, packs its outputs.
+// On return *bytes_per_peer is the all-to-all message size (0: nothing to exchange) and the buffers to use.
+int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* bytes_per_peer, void** sendbuf,
+                     void** recvbuf) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !bytes_per_peer || !sendbuf || !recvbuf) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ZRun& r = zrun(c);
+    if (stage != r.stage + 1 || stage < 1 || stage > 4) return fail(c, OFDFT_ESTATE, "stage %d out of order", stage);
+    int rc;
+    if (c->nranks > 1 && stage > 1)
+        if ((rc = dist_unpack(c, (stage % 2 == 0) ? 1 : 3, st))) return rc;
+    switch (stage) {
+        case 1: rc = zstage1(c, st); break;
+        case 2: rc = zstage2(c, st); break;
+        case 3: rc = zstage3(c, st); break;
+        default: rc = zstage4(c, st); break;
+    }
+    if (rc) return rc;
+    *bytes_per_peer = 0;
+    *sendbuf = *recvbuf = nullptr;
+    if (c->nranks > 1 && !r.xlist.empty()) {
+        if ((rc = dist_pack(c, (stage % 2 == 1) ? 0 : 2, st))) return rc;
+        cplx *send, *recv;
+        if ((rc = dist_buffers(c, 11, &send, &recv))) return rc;
+        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->sg.chunk * r.xlist.size());
+        *sendbuf = send;
+        *recvbuf = recv;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return OFDFT_OK;
+}
+
+// Stage 5: un-pack the last exchange, combine; local_sums[11] = 9 combine scalars + PBE x, c (to be summed
+// over ranks by the caller, then turned into energies by ofdft_dist_energies).
+int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !local_sums) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ZRun& r = zrun(c);
+    if (r.stage != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4");
+    int rc;
+    if (c->nranks > 1)
+        if ((rc = dist_unpack(c, 3, st))) return rc;
+    if ((rc = zstage5(c, local_sums, st))) return rc;
+    return end_call(c, st);
+}
+
+int ofdft_dist_energies(ofdft_ctx* c, const double* global_sums, double* E_terms, double* vn_int) {
+    if (!c || !global_sums || !E_terms || !vn_int) return OFDFT_EINVAL;
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    energies_from_sums(c, global_sums, global_sums + kCombineScalars, E_terms, vn_int);
+    return OFDFT_OK;
+}
+
+int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local, void* grad_local, double cscale,
+                        double mu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !chi_local || !v_local || !grad_local) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi_local,
+                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV, mu);
+    HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
 

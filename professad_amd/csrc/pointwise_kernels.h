@@ -113,6 +113,8 @@ __global__ void wgc_prep_kernel(const double* __restrict__ n, double* __restrict
 struct KGeom {
     SpecGeom g;
     double b[9];   // b = 2 pi inv(box^T), row-major (functional_tools.py:149)
+    int y0;        // first global y index held by this rank in the x-pass (y-slab) geometry; 0 on one GPU
+    int n1g;       // global extent of axis 1 (= g.n1 on one GPU)
 };
 
 __device__ __forceinline__ double ifreq(int i, int n) { return (double)(i <= n / 2 ? i : i - n); }   // :152-154
@@ -120,7 +122,7 @@ __device__ __forceinline__ double ifreq(int i, int n) { return (double)(i <= n /
 __device__ __forceinline__ void kvec(const KGeom& kg, long long i, double& kx, double& ky, double& kz, double& k2) {
     int x, y, z;
     spec_decode(kg.g, i, x, y, z);
-    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y, kg.g.n1), fc = (double)z;     // :155 rfftfreq
+    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (double)z;     // :155 rfftfreq
     kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];                                  // :158-160
     ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
     kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
@@ -263,7 +265,7 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
 // ---- mixing functors of the fused x pass (see xfused_kernel in fft_kernels.h) ----------------------
 __device__ __forceinline__ void kvec_xyz(const KGeom& kg, int x, int y, int z, double& kx, double& ky, double& kz,
                                          double& k2) {
-    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y, kg.g.n1), fc = (double)z;
+    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (double)z;
     kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];
     ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
     kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
@@ -326,6 +328,54 @@ struct MixWgc {
         return buf_load_d(t + uoff, loff * 8);
     }
 };
+
+// ---- slab transpose (multi-GPU): x-slab spectrum [b][xl][y][8] (+ planes [xl][y]) <-> y-slab [b][x][yl][8].
+// The exchange buffer is [peer][array][chunk], chunk = the (xl, yl) sub-block in block-8 order:
+//   main (b, xl, yl, kin) -> ((b*nxl + xl)*nyl + yl)*8 + kin ;  planes (p, xl, yl) -> main_chunk + (p*nxl + xl)*nyl + yl
+struct SlabGeom {
+    int nxl, nyl, nranks;      // local x extent in x-slab form, local y extent in y-slab form
+    int n0g, n1g, nzm, nrem;   // global extents, blocked kz count, remainder planes
+    long long chunk;           // elements per (peer, array)
+};
+// dir 0: x-slab array -> send buffer (peer = y / nyl);   dir 1: recv buffer -> y-slab array (peer = x / nxl)
+// dir 2: y-slab array -> send buffer (peer = x / nxl);   dir 3: recv buffer -> x-slab array (peer = y / nyl)
+__global__ void slab_copy_kernel(cplx* __restrict__ arr, cplx* __restrict__ buf, SlabGeom sg, int narr, int a, int dir) {
+    const long long total = (long long)(sg.nzm + sg.nrem) * sg.nxl * sg.nyl * sg.nranks;   // local elements
+    const long long main_chunk = (long long)sg.nzm * sg.nxl * sg.nyl;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // enumerate (peer, chunk offset): i = peer*chunk + off
+        const int peer = (int)(i / sg.chunk);
+        const long long off = i % sg.chunk;
+        int b, xl, yl, kin;
+        bool in_main = off < main_chunk;
+        if (in_main) {
+            kin = (int)(off & 7);
+            const long long r = off >> 3;
+            yl = (int)(r % sg.nyl);
+            xl = (int)((r / sg.nyl) % sg.nxl);
+            b = (int)(r / ((long long)sg.nyl * sg.nxl));
+        } else {
+            const long long r = off - main_chunk;
+            kin = 0;
+            yl = (int)(r % sg.nyl);
+            xl = (int)((r / sg.nyl) % sg.nxl);
+            b = (int)(r / ((long long)sg.nyl * sg.nxl));      // plane index
+        }
+        cplx* pb = buf + ((long long)peer * narr + a) * sg.chunk + off;
+        long long ai;
+        if (dir == 0 || dir == 3) {           // x-slab array: [b][xl][y][8], y = peer*nyl + yl, rows = nxl*n1g
+            const long long rows = (long long)sg.nxl * sg.n1g;
+            const long long row = (long long)xl * sg.n1g + (long long)peer * sg.nyl + yl;
+            ai = in_main ? ((long long)b * rows + row) * 8 + kin : (long long)sg.nzm * rows + (long long)b * rows + row;
+        } else {                              // y-slab array: [b][x][yl][8], x = peer*nxl + xl, rows = n0g*nyl
+            const long long rows = (long long)sg.n0g * sg.nyl;
+            const long long row = ((long long)peer * sg.nxl + xl) * sg.nyl + yl;
+            ai = in_main ? ((long long)b * rows + row) * 8 + kin : (long long)sg.nzm * rows + (long long)b * rows + row;
+        }
+        if (dir == 0 || dir == 2) *pb = arr[ai];
+        else arr[ai] = *pb;
+    }
+}
 
 // ---- XC pointwise math -------------------------------------------------------------------------
 // PW92 eps_c(rs) and d eps_c / d rs (functionals.py:1524-1530; tests/tools_for_tests.py:136-144)

@@ -1,0 +1,228 @@
+"""Slab-decomposed evaluation over the GPUs of one node: one process per GPU.
+
+Rank r of P owns the real-space x-slab ``[n0/P, n1, n2]`` of chi / n / v_ext and gets back its slab of the
+potential / gradient.  The engine (C ABI ``ofdft_dist_*``) does all local work -- z and y passes on x-slabs,
+fused x passes on y-slabs, pack / un-pack of the exchange buffers -- and this module only sequences the
+stages and performs the collectives through ``torch.distributed``: four equal-split all-to-alls (the FFT
+transposes, every array of a stage in ONE message per peer) and two small all-reduces per evaluation.  With
+the ``nccl`` backend (= RCCL) the all-to-all runs device-to-device over xGMI; with ``gloo`` the buffers are
+staged through the host (used for tests, including two ranks sharing one GPU).
+
+The orchestration (`run_closure`, `run_potential`) is written against a tiny "stages" interface so that the
+CPU-only test-suite can drive it with a numpy double under gloo; the product implementation of that
+interface is `HipStages` (ctypes -> libofdft_hip.so), which has no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from .engine import Engine
+
+NSUMS = 11   # 9 combine scalars + PBE exchange, correlation
+
+
+class SlabPlan:
+    """Index bookkeeping of the decomposition (host logic only)."""
+
+    def __init__(self, shape, nranks, rank):
+        n0, n1, n2 = (int(s) for s in shape)
+        if n0 % nranks or n1 % nranks:
+            raise ValueError('slab decomposition needs n0 and n1 divisible by the number of ranks')
+        self.shape = (n0, n1, n2)
+        self.nranks, self.rank = int(nranks), int(rank)
+        self.nxl, self.nyl = n0 // nranks, n1 // nranks
+        self.nzc = n2 // 2 + 1
+        self.local_shape = (self.nxl, n1, n2)                  # real-space slab of this rank
+        self.x0, self.y0 = self.rank * self.nxl, self.rank * self.nyl
+        self.chunk = self.nzc * self.nxl * self.nyl            # complex elements per (peer, array)
+
+    def x_range(self, r=None):
+        r = self.rank if r is None else r
+        return slice(r * self.nxl, (r + 1) * self.nxl)
+
+    def y_range(self, r=None):
+        r = self.rank if r is None else r
+        return slice(r * self.nyl, (r + 1) * self.nyl)
+
+    def scatter(self, full):
+        """this rank's slab of a global real array"""
+        return full[self.x_range()]
+
+
+class Comm:
+    """The two collectives the path needs, over a torch.distributed group (or trivially for one rank)."""
+
+    def __init__(self, group=None):
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.nranks = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.backend = dist.get_backend(group) if self.active else None
+
+    def all_reduce_sum(self, vec, device):
+        """vec: 1-D numpy fp64 -> summed over ranks (numpy)"""
+        if not self.active:
+            return vec
+        t = torch.as_tensor(vec, dtype=torch.double, device=device if self.backend == 'nccl' else 'cpu').clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def all_to_all(self, send_t, recv_t):
+        """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo)"""
+        if not self.active:
+            recv_t.copy_(send_t)
+            return
+        if self.backend == 'nccl':
+            dist.all_to_all_single(recv_t, send_t, group=self.group)
+        else:
+            # gloo has no all-to-all: host-staged pairwise exchange (test / fallback transport only)
+            hs = send_t.cpu()
+            hr = torch.empty_like(hs)
+            ins = list(hs.chunk(self.nranks))
+            outs = list(hr.chunk(self.nranks))
+            reqs = []
+            for p in range(self.nranks):
+                if p == self.rank:
+                    outs[p].copy_(ins[p])
+                else:
+                    reqs.append(dist.isend(ins[p].contiguous(), p, group=self.group))
+                    reqs.append(dist.irecv(outs[p], p, group=self.group))
+            for r in reqs:
+                r.wait()
+            recv_t.copy_(hr)
+
+
+class _RawDeviceBuffer:
+    """Zero-copy view of engine-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(ptr), False), 'version': 2}
+
+
+class HipStages(Engine):
+    """`stages` interface on top of the ofdft_dist_* C ABI (one slab per rank)."""
+
+    def __init__(self, shape, device, nranks=1, rank=0):
+        self.plan = SlabPlan(shape, nranks, rank)
+        super().__init__(shape, device, nranks=nranks, rank=rank)
+
+    def sumsq(self, x, square=True):
+        x = self._grid_tensor(x, 'x')
+        out = C.c_double(0.0)
+        self._check(self.lib.ofdft_dist_sumsq(self._ctx, C.c_void_p(x.data_ptr()), 1 if square else 0, C.byref(out),
+                                              self._stream()), 'ofdft_dist_sumsq')
+        return out.value
+
+    def begin(self, src, from_chi, cscale, nel, vext, v_out):
+        self._keep = (src, vext, v_out)          # keep the tensors alive for the duration of the evaluation
+        self._check(self.lib.ofdft_dist_begin(self._ctx, C.c_void_p(src.data_ptr()), 1 if from_chi else 0, float(cscale),
+                                              float(nel), C.c_void_p(vext.data_ptr() if vext is not None else 0),
+                                              C.c_void_p(v_out.data_ptr() if v_out is not None else 0), self._stream()),
+                    'ofdft_dist_begin')
+
+    def stage(self, k):
+        """-> None or (send, recv) flat uint8 device tensors of nranks * bytes_per_peer bytes"""
+        nbytes, sp, rp = C.c_ulonglong(0), C.c_void_p(0), C.c_void_p(0)
+        self._check(self.lib.ofdft_dist_stage(self._ctx, int(k), self._stream(), C.byref(nbytes), C.byref(sp), C.byref(rp)),
+                    'ofdft_dist_stage')
+        if nbytes.value == 0:
+            return None
+        tot = nbytes.value * self.plan.nranks
+        send = torch.as_tensor(_RawDeviceBuffer(sp.value, tot), device=self.device)
+        recv = torch.as_tensor(_RawDeviceBuffer(rp.value, tot), device=self.device)
+        return send, recv
+
+    def finish(self):
+        sums = (C.c_double * NSUMS)()
+        self._check(self.lib.ofdft_dist_finish(self._ctx, sums, self._stream()), 'ofdft_dist_finish')
+        return np.array(list(sums), dtype=np.float64)
+
+    def energies(self, global_sums):
+        E = (C.c_double * N.NTERMS)()
+        vn = C.c_double(0.0)
+        g = (C.c_double * NSUMS)(*[float(x) for x in global_sums])
+        self._check(self.lib.ofdft_dist_energies(self._ctx, g, E, C.byref(vn)), 'ofdft_dist_energies')
+        return {nm: E[i] for i, nm in enumerate(N.TERM_ORDER)}, vn.value
+
+    def chi_grad(self, chi, v, cscale, mu):
+        out = torch.empty_like(chi)
+        self._check(self.lib.ofdft_dist_chi_grad(self._ctx, C.c_void_p(chi.data_ptr()), C.c_void_p(v.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), float(cscale), float(mu), self._stream()),
+                    'ofdft_dist_chi_grad')
+        return out
+
+    def sync(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+
+def _run_stages(stages, comm):
+    for k in (1, 2, 3, 4):
+        ex = stages.stage(k)
+        if ex is not None:
+            comm.all_to_all(ex[0], ex[1])
+    local = stages.finish()
+    return comm.all_reduce_sum(local, getattr(stages, 'device', 'cpu'))
+
+
+def run_closure(stages, comm, chi, n_elec, vext, vol, npts_global, new_like):
+    """The optimize_density closure (system.py:830-838) over slabs -> (E_terms, mu, grad slab)."""
+    s2 = comm.all_reduce_sum(np.array([stages.sumsq(chi, True)]), getattr(stages, 'device', 'cpu'))[0]
+    ntilde = s2 / npts_global * vol                     # system.py:833
+    cscale = n_elec / ntilde                            # system.py:834
+    v = new_like(chi)
+    stages.begin(chi, True, cscale, n_elec, vext, v)
+    gsums = _run_stages(stages, comm)
+    E_terms, vn = stages.energies(gsums)
+    mu = vn / n_elec                                    # system.py:851
+    return E_terms, mu, stages.chi_grad(chi, v, cscale, mu)
+
+
+def run_potential(stages, comm, den, vext, vol, npts_global, new_like):
+    """energy + dE/dn for a given density slab (functional_tools.py:9-31 semantics)."""
+    nsum = comm.all_reduce_sum(np.array([stages.sumsq(den, False)]), getattr(stages, 'device', 'cpu'))[0]
+    nel = nsum / npts_global * vol
+    v = new_like(den)
+    stages.begin(den, False, 1.0, nel, vext, v)
+    gsums = _run_stages(stages, comm)
+    E_terms, _ = stages.energies(gsums)
+    return E_terms, v
+
+
+class DistEngine:
+    """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
+    as `Engine`, on this rank's slab."""
+
+    def __init__(self, shape, device, group=None):
+        self.comm = Comm(group)
+        self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank)
+        self.plan = self.stages.plan
+        self.npts_global = int(np.prod(self.plan.shape))
+        self._vol = None
+
+    def set_cell(self, box_vecs):
+        self.stages.set_cell(box_vecs)
+        self._vol = float(abs(np.linalg.det(np.asarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64))))
+        return self
+
+    def set_terms(self, names, params=None):
+        self.stages.set_terms(names, params)
+        return self
+
+    def energy_grad_chi(self, chi, n_elec, vext=None):
+        chi = self.stages._grid_tensor(chi, 'chi')
+        vext = self.stages._grid_tensor(vext, 'v_ext')
+        return run_closure(self.stages, self.comm, chi, n_elec, vext, self._vol, self.npts_global, torch.empty_like)
+
+    def energy_potential(self, den, vext=None):
+        den = self.stages._grid_tensor(den, 'den')
+        vext = self.stages._grid_tensor(vext, 'v_ext')
+        return run_potential(self.stages, self.comm, den, vext, self._vol, self.npts_global, torch.empty_like)
+
+    def query(self, what):
+        return self.stages.query(what)
+
+    def close(self):
+        self.stages.close()

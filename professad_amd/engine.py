@@ -19,7 +19,7 @@ def _ptr(t):
 class Engine:
     """energy + functional derivative of a set of OFDFT terms on a fixed grid shape."""
 
-    def __init__(self, shape, device=None):
+    def __init__(self, shape, device=None, nranks=1, rank=0):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError('professad_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
                                        'there is no CPU fallback')
@@ -27,12 +27,14 @@ class Engine:
         self.device = torch.device(device if device is not None else 'cuda:0')
         if self.device.type != 'cuda':
             raise ValueError('Engine tensors must live on a GPU device, got %s' % self.device)
-        self.shape = tuple(int(s) for s in shape)
-        if len(self.shape) != 3:
+        self.global_shape = tuple(int(s) for s in shape)
+        if len(self.global_shape) != 3:
             raise ValueError('shape must be (n0, n1, n2)')
+        # `shape` of the tensors this engine takes: the rank's x-slab (the whole grid on one GPU)
+        self.shape = (self.global_shape[0] // int(nranks),) + self.global_shape[1:]
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._ctx = C.c_void_p(0)
-        rc = self.lib.ofdft_create(C.byref(self._ctx), *self.shape, N.F64, idx)
+        rc = self.lib.ofdft_create_dist(C.byref(self._ctx), *self.global_shape, N.F64, idx, int(nranks), int(rank))
         if rc != 0:
             raise RuntimeError('ofdft_create failed (%d): %s' % (rc, self.lib.ofdft_last_error(None).decode()))
         self._box_key = None

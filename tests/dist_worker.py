@@ -1,0 +1,72 @@
+"""Worker of the multi-rank tests: `python dist_worker.py <case> <outfile>` with RANK/WORLD_SIZE/MASTER_* set.
+All ranks share cuda:0 (gloo backend, host-staged exchange) so the slab-decomposed path -- HIP kernels, pack /
+un-pack, stage sequencing, collectives -- is exercised with several ranks on a one-GPU box."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+import cases  # noqa: E402
+from professad_amd import synth  # noqa: E402
+from professad_amd.distributed import DistEngine  # noqa: E402
+from professad_amd.engine import Engine  # noqa: E402
+from professad_amd.functionals import NativeTerms  # noqa: E402
+
+CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
+       'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe'], 'wgc98': ['wgc98x']}
+
+
+def main():
+    shape = tuple(int(x) for x in sys.argv[1].split('x'))
+    out = sys.argv[2]
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device('cuda:0')
+    box = cases.make_cell(('tri', 1.3))
+    den = synth.random_density(shape, seed=41)
+    vext = synth.random_potential(shape, seed=42)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(43).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=dev)  # noqa: E731
+    eng = DistEngine(shape, dev).set_cell(torch.as_tensor(box))
+    plan = eng.plan
+    worst = {}
+    for cfg in ('cfg1', 'cfg2', 'cfg3'):
+        names = NativeTerms(CFG[cfg]).names
+        eng.set_terms(names)
+        E, mu, g = eng.energy_grad_chi(t(plan.scatter(chi)), n_elec, t(plan.scatter(vext)))
+        E2, v = eng.energy_potential(t(plan.scatter(den)), t(plan.scatter(vext)))
+        parts_g = [torch.empty(plan.local_shape, dtype=torch.double) for _ in range(world)]
+        parts_v = [torch.empty(plan.local_shape, dtype=torch.double) for _ in range(world)]
+        dist.all_gather(parts_g, g.cpu())
+        dist.all_gather(parts_v, v.cpu())
+        if rank == 0:
+            ref = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(names)
+            Er, mur, gr = ref.energy_grad_chi(t(chi), n_elec, t(vext))
+            Er2, vr = ref.energy_potential(t(den), t(vext))
+            gfull, vfull = torch.cat(parts_g).numpy(), torch.cat(parts_v).numpy()
+            worst[cfg] = dict(
+                dE=max(abs(E[k] - Er[k]) / max(1.0, abs(Er[k])) for k in E),
+                dE2=max(abs(E2[k] - Er2[k]) / max(1.0, abs(Er2[k])) for k in E2),
+                dmu=abs(mu - mur) / max(1.0, abs(mur)),
+                dg=float(np.abs(gfull - gr.cpu().numpy()).max() / np.abs(gr.cpu().numpy()).max()),
+                dv=float(np.abs(vfull - vr.cpu().numpy()).max() / np.abs(vr.cpu().numpy()).max()),
+                ffts=eng.query(0), ffts_ref=ref.query(0))
+            ref.close()
+    if rank == 0:
+        with open(out, 'w') as fh:
+            json.dump(worst, fh)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
