@@ -47,6 +47,7 @@ struct ofdft_ctx {
     // reduction partials (device) + pinned host mirror
     double* d_partial = nullptr;
     double* d_reduced = nullptr;     // second-level sums [kMaxScalars]
+    double* d_scal = nullptr;        // device-resident scalars: [0] = closure scale c
     double* h_partial = nullptr;
     long long partial_rows = 0;
     // WGC tables
@@ -1159,12 +1160,9 @@ int zstage3(ofdft_ctx* c, hipStream_t st) {
         if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
                               (c->mask & OFDFT_PBE_C) ? 1 : 0, &r.pbe_blocks, st)))
             return rc;
-        if (c->nranks == 1) {
-            if ((rc = fetch_partials(c, r.pbe_blocks, 2, r.pbe_sums, st))) return rc;
-        } else {    // keep the stream asynchronous between collectives: reduce on the device, read at the end
-            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
-                         c->d_reduced + kCombineScalars);
-        }
+        // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
+                     c->d_reduced + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
             if ((rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             r.xlist.push_back(r.s_g[k]);
@@ -1200,18 +1198,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     }
     r.xlist.clear();
     if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) return rc;
-    if (c->nranks == 1) {
-        if ((rc = fetch_partials(c, r.combine_blocks, kCombineScalars, sums, st))) return rc;
-        sums[kCombineScalars] = r.pbe_sums[0];
-        sums[kCombineScalars + 1] = r.pbe_sums[1];
-    } else {
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
-                     r.combine_blocks, kCombineScalars, c->d_reduced);
-        HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
-        if (!r.has_g) sums[kCombineScalars] = sums[kCombineScalars + 1] = 0.0;
-    }
+    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
+                 r.combine_blocks, kCombineScalars, c->d_reduced);
+    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
+    if (!r.has_g) sums[kCombineScalars] = sums[kCombineScalars + 1] = 0.0;
     r.stage = 5;
     return 0;
 }
@@ -1345,6 +1337,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * c->partial_rows * kMaxScalars);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_reduced, sizeof(double) * kMaxScalars);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_scal, sizeof(double) * 4);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -1369,6 +1362,7 @@ void ofdft_destroy(ofdft_ctx* c) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_reduced) (void)hipFree(c->d_reduced);
+    if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_partial) (void)hipHostFree(c->h_partial);
     if (c->d_wgc_coef) (void)hipFree(c->d_wgc_coef);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1439,7 +1433,7 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
             if (int rc = device_sum(c, (const double*)den, false, &nsum, st)) return rc;
             nel = nsum / (double)c->npts * c->vol;
         }
-        const DenSrc ds{(const double*)den, 1.0, 0};
+        const DenSrc ds{(const double*)den, 1.0, 0, nullptr};
         if (int rc = run_terms_zfused(c, ds, nel, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
         return end_call(c, st);
     }
@@ -1455,25 +1449,33 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
-    double s2;
-    if (int rc = device_sum(c, (const double*)chi, true, &s2, st)) return rc;
-    const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
-    const double cfac = n_electrons / ntilde;                                         // system.py:834
     double *den, *v;
     if (int rc = real_ws(c, "v", &v)) return rc;
     if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
-        // n = cfac chi^2 is formed on the fly inside the z kernels; mean(n) vol = N_e by construction
-        const DenSrc ds{(const double*)chi, cfac, 1};
+        // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
+        // z kernels; mean(n) vol = N_e by construction.  One host sync per evaluation (the final sums).
+        const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)chi, c->npts,
+                     c->d_partial);
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
+                     c->d_reduced + 11);
+        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + 11, c->d_scal, n_electrons,
+                     c->vol / (double)c->npts);
+        const DenSrc ds{(const double*)chi, 0.0, 1, c->d_scal};
         double vn;
         if (int rc = run_terms_zfused(c, ds, n_electrons, (const double*)vext, E_terms, v, &vn, st)) return rc;
         const double mu = vn / n_electrons;
         if (mu_host) *mu_host = mu;
         if (grad) {
             OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi,
-                         v, (double*)grad, c->npts, cfac * 2.0 * c->dV, mu);
+                         v, (double*)grad, c->npts, 0.0, (const double*)c->d_scal, 2.0 * c->dV, mu);
         }
         return end_call(c, st);
     }
+    double s2;
+    if (int rc = device_sum(c, (const double*)chi, true, &s2, st)) return rc;
+    const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
+    const double cfac = n_electrons / ntilde;                                         // system.py:834
     if (int rc = real_ws(c, "den", &den)) return rc;
     OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, den,
                        c->npts, cfac);
@@ -1483,7 +1485,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (mu_host) *mu_host = mu;
     if (grad) {
         OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, v, (double*)grad,
-                           c->npts, cfac * 2.0 * c->dV, mu);
+                           c->npts, cfac * 2.0 * c->dV, (const double*)nullptr, 0.0, mu);
     }
     return end_call(c, st);
 }
@@ -1534,7 +1536,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
     ZRun& r = zrun(c);
-    r.ds = DenSrc{(const double*)src_local, cscale, from_chi};
+    r.ds = DenSrc{(const double*)src_local, cscale, from_chi, nullptr};
     r.nel = nel_global;
     r.vext = (const double*)vext_local;
     r.v_out = (double*)v_out_local;
@@ -1604,7 +1606,7 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
     if (!c || !chi_local || !v_local || !grad_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi_local,
-                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV, mu);
+                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV, (const double*)nullptr, 0.0, mu);
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }

@@ -407,39 +407,39 @@ template <int LEN, int G> struct XfMixCtx {
     unsigned loff;      // per-lane element offset of the thread's first point (table lookups)
 };
 
-// acc += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish)
+// (re, im) += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish).  Both parts
+// of the inputs are in LDS at once (re at pos, im at pos + LEN/2), so every coefficient is fetched ONCE.
 template <int LEN, int G, int NIN, int O, int I, class Mix>
-__device__ __forceinline__ void xf_mix_inputs(double& acc, const double* lds, const XfMixCtx<LEN, G>& c, const Mix& mix,
-                                              int q, int x) {
+__device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const double* lds, const XfMixCtx<LEN, G>& c,
+                                              const Mix& mix, int q, int x, int pos) {
     constexpr int LPW = XfCfg<LEN, G>::LPW, STRIDE = LineBuf<LEN>::STRIDE;
     if constexpr (I < NIN) {
-        if constexpr (Mix::template present<O, I>())
-            acc += mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff) * lds[(I * LPW + c.l) * STRIDE + lpad(x)];
-        xf_mix_inputs<LEN, G, NIN, O, I + 1, Mix>(acc, lds, c, mix, q, x);
+        if constexpr (Mix::template present<O, I>()) {
+            const double cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
+            const double* lb = lds + (I * LPW + c.l) * STRIDE;
+            acr += cf * lb[lpad(pos)];
+            aci += cf * lb[lpad(pos + LEN / 2)];
+        }
+        xf_mix_inputs<LEN, G, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
     }
 }
 
-// one output (compile-time O) from all inputs, one part (real or imaginary) of the inputs at a time
-template <int LEN, int G, int NIN, int O, class Mix, bool IMPART>
+// one output (compile-time O) from all inputs for the half of the thread's points with index HALF
+template <int LEN, int G, int NIN, int O, class Mix, int HALF>
 __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const double* lds, const XfMixCtx<LEN, G>& c,
                                             const Mix& mix) {
-    constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E, LPW = XfCfg<LEN, G>::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+    constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E;
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
+    for (int qq = 0; qq < E / 2; ++qq) {
+        const int q = qq + HALF * (E / 2);
         const int x = c.j + P * q;
-        double acc = 0.0;
-        xf_mix_inputs<LEN, G, NIN, O, 0, Mix>(acc, lds, c, mix, q, x);
-        if (Mix::imag(O)) {
-            if (IMPART) o[q].x = -acc;      // (i c)(i im) = -c im
-            else o[q].y = acc;              // (i c)(re)
-        } else {
-            if (IMPART) o[q].y = acc;
-            else o[q].x = acc;
-        }
+        double acr = 0.0, aci = 0.0;
+        xf_mix_inputs<LEN, G, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
+        o[q] = Mix::imag(O) ? make_double2(-aci, acr) : make_double2(acr, aci);     // (i c)(re + i im) = -c im + i c re
     }
 }
 
-template <int LEN, int G, int NIN, int NOUT, class Mix, bool IMPART>
+template <int LEN, int G, int NIN, int NOUT, class Mix, int IMPART>
 __device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const double* lds,
                                                 const XfMixCtx<LEN, G>& c, const Mix& mix) {
     // grp is wave-uniform: a scalar branch into straight-line code specialised per output
@@ -502,17 +502,25 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void 
 #pragma unroll
     for (int q = 0; q < E; ++q) o[q] = make_double2(0.0, 0.0);
     XfMixCtx<LEN, G> mc{j, l, y, kz, b0, qstep, voff >> 4};
-    // ---- real parts of the inputs
+    // ---- mix in two halves of the k-points (x < LEN/2, then the rest): the line buffer holds the real parts of a
+    // half at [0, LEN/2) and the imaginary parts at [LEN/2, LEN)
+    static_assert(E % 2 == 0, "points per thread must be even");
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < E; ++q) mine[lpad(j + P * q)] = v[q].x;
+    for (int q = 0; q < E / 2; ++q) {
+        mine[lpad(j + P * q)] = v[q].x;
+        mine[lpad(j + P * q + LEN / 2)] = v[q].y;
+    }
     __syncthreads();
-    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, false>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, 0>(grp, o, lds, mc, mix);
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < E; ++q) mine[lpad(j + P * q)] = v[q].y;
+    for (int q = E / 2; q < E; ++q) {
+        mine[lpad(j + P * q - LEN / 2)] = v[q].x;
+        mine[lpad(j + P * q)] = v[q].y;
+    }
     __syncthreads();
-    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, true>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, 1>(grp, o, lds, mc, mix);
     line_fft<LEN, true>(o, j, mine, tw);
     if (valid && grp < NOUT) {
         cplx* ub = xf_pick(io.out, grp) + b0;

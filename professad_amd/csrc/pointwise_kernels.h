@@ -629,8 +629,16 @@ __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, dou
 }
 
 // chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
+// c = N_e / (mean(chi^2) vol) from the reduced sum of chi^2, left on the device (system.py:833-834)
+__global__ void closure_scale_kernel(const double* __restrict__ sumsq, double* __restrict__ cscale, double n_elec,
+                                     double vol_over_npts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
+}
+
 __global__ void chi_grad_kernel(const double* __restrict__ chi, const double* __restrict__ v, double* __restrict__ g,
-                                long long npts, double c2dV, double mu) {
+                                long long npts, double c2dV_host, const double* __restrict__ cscale_dev, double two_dV,
+                                double mu) {
+    const double c2dV = cscale_dev ? cscale_dev[0] * two_dV : c2dV_host;
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const double2 x = reinterpret_cast<const double2*>(chi)[i], w = reinterpret_cast<const double2*>(v)[i];

@@ -173,7 +173,10 @@ struct DenSrc {
     const double* src;
     double cscale;
     int from_chi;
-    __device__ __forceinline__ double operator()(double x) const { return from_chi ? cscale * x * x : x; }
+    const double* cscale_dev;    // when set, the scale is read from device memory (no host round trip after sum chi^2)
+    __device__ __forceinline__ double operator()(double x) const {
+        return from_chi ? (cscale_dev ? *cscale_dev : cscale) * x * x : x;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
