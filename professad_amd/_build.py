@@ -22,20 +22,22 @@ def _stale():
     return False
 
 
-def build(force=False, verbose=True):
-    """Compile csrc/*.hip into lib/libofdft_hip.so with hipcc (cross-compiles without a GPU)."""
-    if not force and not _stale():
+def build(force=False, verbose=True, extra_flags=(), out=None):
+    """Compile csrc/*.hip into lib/libofdft_hip.so with hipcc (cross-compiles without a GPU).
+    `extra_flags` / `out` build an experiment variant (A/B runs select it with OFDFT_LIB=<path>)."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
            '-ffp-contract=on', '-Wall', '-Wno-unused-function',
            '-I', os.path.join(PKG, '..', 'include')]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    cmd += list(extra_flags)
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out or LIB]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out or LIB
 
 
 if __name__ == '__main__':

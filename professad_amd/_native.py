@@ -44,8 +44,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
-    if not os.path.exists(path) or (os.path.exists('/opt/rocm/bin/hipcc') and _build._stale()):
+    path = os.environ.get('OFDFT_LIB') or _build.LIB      # OFDFT_LIB: an experiment build for A/B measurements
+    if os.environ.get('OFDFT_LIB'):
+        pass
+    elif not os.path.exists(path) or (os.path.exists('/opt/rocm/bin/hipcc') and _build._stale()):
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001

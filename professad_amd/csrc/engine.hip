@@ -380,7 +380,7 @@ int inv_yz(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) 
 template <int LEN, int NIN, int NOUT, class Mix>
 int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
-    using Cfg = XfCfg<LEN, G>;
+    using Cfg = XfCfg<LEN, G, NOUT>;
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     LineMap main, rem;

@@ -383,13 +383,18 @@ template <class T> __device__ __forceinline__ T* xf_pick(T* const (&a)[kMaxXf], 
     return p;
 }
 
-template <int LEN, int G> struct XfCfg {
+template <int LEN, int G, int NOUT> struct XfCfg {
     static constexpr int P = Plan<LEN>::P;
     static constexpr int E = Plan<LEN>::E;
     // lines per workgroup: >= 8 (128-B runs) and a whole number of waves per group (LPW*P % 64 == 0)
     // multi-group workgroups are kept small (4 lines = 64-B runs) so that several fit a CU and their
     // load / transform / store phases overlap; single-group ones take 8 lines (128-B runs)
-    static constexpr int WANT = 8;
+    // measured at 256^3: 4-line tiles (more, smaller workgroups; pairs placed on one XCD) win when several
+    // spectra are written (1->4: 0.20 -> 0.17 ms, 3->3: 0.38 -> 0.30 ms) and lose for 3->1 (0.20 -> 0.46 ms)
+#ifndef OFDFT_XF_WANT4
+#define OFDFT_XF_WANT4 1
+#endif
+    static constexpr int WANT = (OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8;
     static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
     static constexpr int TPB = G * LPW * P;
     static constexpr size_t LDS = sizeof(double) * G * LPW * LineBuf<LEN>::STRIDE;
@@ -401,7 +406,7 @@ template <int LEN, int G> struct XfCfg {
 //   template<int O,int I> static constexpr bool present()   whether input I contributes to output O
 //   template<int O,int I> double coef(x, y, kz, uoff, loff)  the real number c at that k-point; uoff + loff =
 //        element offset of the k-point in a spectrum array (uoff wave-uniform) for buffer-load table lookups
-template <int LEN, int G> struct XfMixCtx {
+template <int LEN, int LPW_> struct XfMixCtx {
     int j, l, y, kz;
     long long b0, qstep;
     unsigned loff;      // per-lane element offset of the thread's first point (table lookups)
@@ -409,10 +414,10 @@ template <int LEN, int G> struct XfMixCtx {
 
 // (re, im) += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish).  Both parts
 // of the inputs are in LDS at once (re at pos, im at pos + LEN/2), so every coefficient is fetched ONCE.
-template <int LEN, int G, int NIN, int O, int I, class Mix>
-__device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const double* lds, const XfMixCtx<LEN, G>& c,
+template <int LEN, int LPW, int NIN, int O, int I, class Mix>
+__device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const double* lds, const XfMixCtx<LEN, LPW>& c,
                                               const Mix& mix, int q, int x, int pos) {
-    constexpr int LPW = XfCfg<LEN, G>::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+    constexpr int STRIDE = LineBuf<LEN>::STRIDE;
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
             const double cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
@@ -420,13 +425,13 @@ __device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const do
             acr += cf * lb[lpad(pos)];
             aci += cf * lb[lpad(pos + LEN / 2)];
         }
-        xf_mix_inputs<LEN, G, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
+        xf_mix_inputs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
     }
 }
 
 // one output (compile-time O) from all inputs for the half of the thread's points with index HALF
-template <int LEN, int G, int NIN, int O, class Mix, int HALF>
-__device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const double* lds, const XfMixCtx<LEN, G>& c,
+template <int LEN, int LPW, int NIN, int O, class Mix, int HALF>
+__device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const double* lds, const XfMixCtx<LEN, LPW>& c,
                                             const Mix& mix) {
     constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E;
 #pragma unroll
@@ -434,26 +439,26 @@ __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const doubl
         const int q = qq + HALF * (E / 2);
         const int x = c.j + P * q;
         double acr = 0.0, aci = 0.0;
-        xf_mix_inputs<LEN, G, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
+        xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
         o[q] = Mix::imag(O) ? make_double2(-aci, acr) : make_double2(acr, aci);     // (i c)(re + i im) = -c im + i c re
     }
 }
 
-template <int LEN, int G, int NIN, int NOUT, class Mix, int IMPART>
+template <int LEN, int LPW, int NIN, int NOUT, class Mix, int IMPART>
 __device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const double* lds,
-                                                const XfMixCtx<LEN, G>& c, const Mix& mix) {
+                                                const XfMixCtx<LEN, LPW>& c, const Mix& mix) {
     // grp is wave-uniform: a scalar branch into straight-line code specialised per output
-    if (grp == 0) xf_mix_part<LEN, G, NIN, 0, Mix, IMPART>(o, lds, c, mix);
-    if constexpr (NOUT > 1) { if (grp == 1) xf_mix_part<LEN, G, NIN, 1, Mix, IMPART>(o, lds, c, mix); }
-    if constexpr (NOUT > 2) { if (grp == 2) xf_mix_part<LEN, G, NIN, 2, Mix, IMPART>(o, lds, c, mix); }
-    if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, G, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
+    if (grp == 0) xf_mix_part<LEN, LPW, NIN, 0, Mix, IMPART>(o, lds, c, mix);
+    if constexpr (NOUT > 1) { if (grp == 1) xf_mix_part<LEN, LPW, NIN, 1, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 2) { if (grp == 2) xf_mix_part<LEN, LPW, NIN, 2, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, LPW, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
 }
 
 template <int LEN, int NIN, int NOUT, class Mix>
-__global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void xfused_kernel(
+__global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB)) void xfused_kernel(
     XfIo io, LineMap m_main, LineMap m_rem, int main_blocks, SpecGeom g, const cplx* __restrict__ tw, Mix mix) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
-    using Cfg = XfCfg<LEN, G>;
+    using Cfg = XfCfg<LEN, G, NOUT>;
     constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = LineBuf<LEN>::STRIDE;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -464,7 +469,12 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void 
     const int j = t / LPW;
     const bool is_rem = (int)blockIdx.x >= main_blocks;    // one grid: main part, then the remainder planes
     const LineMap m = is_rem ? m_rem : m_main;
-    const int bid = is_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    int bid = is_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    if (LPW < 8 && !is_rem && bid < (main_blocks & ~15)) {
+        // two 4-line tiles share every 128-B line: put the pair on ONE XCD (blocks are dealt round-robin over
+        // the 8 XCDs, so blocks b and b+8 share an L2) -- speed only, never correctness
+        bid = (bid & ~15) + ((bid & 7) << 1) + ((bid >> 3) & 1);
+    }
     const long long L = (long long)bid * LPW + l;
     const bool valid = L < m.nlines;
     const long long base = valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void 
     cplx o[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) o[q] = make_double2(0.0, 0.0);
-    XfMixCtx<LEN, G> mc{j, l, y, kz, b0, qstep, voff >> 4};
+    XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, qstep, voff >> 4};
     // ---- mix in two halves of the k-points (x < LEN/2, then the rest): the line buffer holds the real parts of a
     // half at [0, LEN/2) and the imaginary parts at [LEN/2, LEN)
     static_assert(E % 2 == 0, "points per thread must be even");
@@ -512,7 +522,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void 
         mine[lpad(j + P * q + LEN / 2)] = v[q].y;
     }
     __syncthreads();
-    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, 0>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, LPW, NIN, NOUT, Mix, 0>(grp, o, lds, mc, mix);
     __syncthreads();
 #pragma unroll
     for (int q = E / 2; q < E; ++q) {
@@ -520,7 +530,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT)>::TPB)) void 
         mine[lpad(j + P * q)] = v[q].y;
     }
     __syncthreads();
-    xf_mix_dispatch<LEN, G, NIN, NOUT, Mix, 1>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, LPW, NIN, NOUT, Mix, 1>(grp, o, lds, mc, mix);
     line_fft<LEN, true>(o, j, mine, tw);
     if (valid && grp < NOUT) {
         cplx* ub = xf_pick(io.out, grp) + b0;
