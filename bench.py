@@ -140,6 +140,8 @@ def main():
         raw = eng
     chi = torch.as_tensor(chi_h, dtype=torch.double, device=device)
     vext = torch.as_tensor(vext_h, dtype=torch.double, device=device)
+    if os.environ.get('OFDFT_SIDE_STREAM') == '0':       # A/B switch: everything on one stream
+        raw.set_option(1, 0)
 
     def step():
         return eng.energy_grad_chi(chi, n_elec, vext)

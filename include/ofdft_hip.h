@@ -131,6 +131,9 @@ int  ofdft_dist_chi_grad(ofdft_ctx* ctx, const void* chi_local_dev, const void* 
  * passes that keep every real-space intermediate on chip), 1 = force the unfused pipeline (separate forward,
  * multiply, inverse and pointwise passes; the only one for other grids), 2 = fused x passes only. */
 #define OFDFT_OPT_PIPELINE 0
+/* OFDFT_OPT_SIDE_STREAM: 1 (default) = run the nonlocal-KEDF chain of the z-fused pipeline on a second HIP stream so
+ * that it overlaps the Hartree/vW/PBE chain (they only meet in the combine kernel); 0 = everything on the caller's stream. */
+#define OFDFT_OPT_SIDE_STREAM 1
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 
 /* Measurement support (bench.py): when on, every kernel launch of the energy calls is bracketed by HIP

@@ -57,7 +57,9 @@ struct ofdft_ctx {
     // stats
     int fft_count = 0, launch_count = 0;
     float last_ms = 0.f;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+    bool use_side_stream = true;
     // optional per-kernel-class profiling (HIP events around every launch)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -984,6 +986,9 @@ struct ZRun {
     std::vector<cplx*> xlist;      // arrays that cross the next geometry boundary
     int stage = 0;
     int combine_blocks = 0, pbe_blocks = 0;
+    hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
+    hipStream_t sc = nullptr;      // second side stream: vW chain and the second half of the WGC99 chain
+    bool forked = false;
 };
 
 }  // namespace
@@ -996,6 +1001,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
     int rc;
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     r.has_h = mask & OFDFT_HARTREE;
     r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
     r.has_vw = mask & OFDFT_VW;
@@ -1017,8 +1023,12 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
         if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
     if (r.s_n || r.s_s) {
         if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) return rc;
+        if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
+            HIP_TRY(c, hipEventRecord(c->ev_a, st));
+            HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
+        }
         if (r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
-        if (r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, st))) return rc;
+        if (r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
         if (r.s_n) r.xlist.push_back(r.s_n);
         if (r.s_s) r.xlist.push_back(r.s_s);
     }
@@ -1034,10 +1044,10 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
         pa.out[3] = r.s_a;
         pa.e0 = be;
         pa.e1 = al;
-        if ((rc = launch_zf_powers(c, r.ds, pa, st))) return rc;
+        if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
         for (cplx* sp : {r.s_b, r.s_a}) {
             if (!sp) continue;
-            if ((rc = fast_axis_pass<false>(c, 1, sp, st))) return rc;
+            if ((rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
             r.xlist.push_back(sp);
         }
         r.za.wt_alpha = al;
@@ -1049,7 +1059,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
         const long long nel_r = std::llround(r.nel);                         // functionals.py:952
         double nref;
-        if ((rc = ensure_wgc_tables(c, nel_r, st, &nref))) return rc;
+        if ((rc = ensure_wgc_tables(c, nel_r, sb, &nref))) return rc;
         const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
         PowersArgs pa{};
         for (int i = 0; i < 6; ++i) {
@@ -1060,9 +1070,13 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
         pa.e1 = al;
         pa.nref = nref;
         pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
-        if ((rc = launch_zf_powers(c, r.ds, pa, st))) return rc;
+        if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
+        if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
+            HIP_TRY(c, hipEventRecord(c->ev_b, sb));
+            HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
+        }
         for (int i = 0; i < 6; ++i) {
-            if ((rc = fast_axis_pass<false>(c, 1, r.sw[i], st))) return rc;
+            if ((rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
             r.xlist.push_back(r.sw[i]);
         }
         r.za.wgc_alpha = al;
@@ -1077,6 +1091,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
 int zstage2(ofdft_ctx* c, hipStream_t st) {
     ZRun& r = zrun(c);
     int rc;
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     r.xlist.clear();
     if (r.s_n) {
         XfIo io{};
@@ -1104,7 +1119,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
         XfIo io{};
         io.in[0] = r.s_s;
         io.out[0] = r.s_s;
-        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, st, "xfused_lap"))) return rc;
+        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap"))) return rc;
         r.xlist.push_back(r.s_s);
     }
     if (r.has_wt) {
@@ -1114,7 +1129,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
             XfIo io{};
             io.in[0] = sp;
             io.out[0] = sp;
-            if ((rc = xfused<1, 1>(c, io, lind, st, "xfused_lind"))) return rc;
+            if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind"))) return rc;
             r.xlist.push_back(sp);
         }
     }
@@ -1127,7 +1142,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
                 io.in[i] = r.sw[3 * half + i];
                 io.out[i] = r.sw[3 * half + i];
             }
-            if ((rc = xfused<3, 3>(c, io, mix, st, "xfused_wgc"))) return rc;
+            if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc"))) return rc;
         }
         for (int i = 0; i < 6; ++i) r.xlist.push_back(r.sw[i]);
     }
@@ -1139,8 +1154,11 @@ int zstage3(ofdft_ctx* c, hipStream_t st) {
     ZRun& r = zrun(c);
     int rc;
     // y-inverse of everything that came back from the x passes (each completes one c2r except grad n)
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     for (cplx* sp : r.xlist) {
-        if ((rc = fast_axis_pass<true>(c, 1, sp, st))) return rc;
+        const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
+        const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
+        if ((rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) return rc;
         if (sp != r.s_g[0] && sp != r.s_g[1] && sp != r.s_g[2]) c->fft_count++;
     }
     r.xlist.clear();
@@ -1197,6 +1215,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
         r.za.dfdn = r.dfdn;
     }
     r.xlist.clear();
+    if (r.forked) {       // the combine needs both chains
+        HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
+    }
     if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) return rc;
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
@@ -1217,6 +1241,17 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     r.v_out = v_out;
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     int rc;
+    // two independent chains meet only in the combine kernel: {Hartree, vW, PBE} and the nonlocal KEDF.  Forking
+    // the second onto its own stream lets its latency-bound fused kernels overlap the other's bandwidth-bound passes.
+    r.forked = c->use_side_stream && c->side_stream && c->side_stream2 && (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) &&
+               (c->mask & (OFDFT_HARTREE | OFDFT_VW | OFDFT_PBE_X | OFDFT_PBE_C));
+    if (r.forked) {
+        r.sb = c->side_stream;
+        r.sc = c->side_stream2;
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(r.sb, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(r.sc, c->ev_fork, 0));
+    }
     if ((rc = zstage1(c, st))) return rc;
     if ((rc = zstage2(c, st))) return rc;
     if ((rc = zstage3(c, st))) return rc;
@@ -1341,6 +1376,13 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream2, hipStreamNonBlocking);
     if (e != hipSuccess) {
         fail(nullptr, OFDFT_EHIP, "context allocation failed: %s", hipGetErrorString(e));
         ofdft_destroy(c);
@@ -1369,6 +1411,13 @@ void ofdft_destroy(ofdft_ctx* c) {
     delete c->zr;
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->side_stream2) (void)hipStreamDestroy(c->side_stream2);
     delete c;
 }
 
@@ -1541,6 +1590,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.vext = (const double*)vext_local;
     r.v_out = (double*)v_out_local;
     r.stage = 0;
+    r.forked = false;
     r.xlist.clear();
     return OFDFT_OK;
 }
@@ -1617,6 +1667,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
         case OFDFT_OPT_PIPELINE:
             c->force_unfused = value == 1.0;
             c->pipeline = (int)value;
+            return OFDFT_OK;
+        case OFDFT_OPT_SIDE_STREAM:
+            c->use_side_stream = value != 0.0;
             return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);

@@ -454,8 +454,11 @@ __device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E]
     if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, LPW, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
 }
 
+#ifndef OFDFT_XF_MINWAVES
+#define OFDFT_XF_MINWAVES 1
+#endif
 template <int LEN, int NIN, int NOUT, class Mix>
-__global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB)) void xfused_kernel(
+__global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB), OFDFT_XF_MINWAVES) void xfused_kernel(
     XfIo io, LineMap m_main, LineMap m_rem, int main_blocks, SpecGeom g, const cplx* __restrict__ tw, Mix mix) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
     using Cfg = XfCfg<LEN, G, NOUT>;
