@@ -512,10 +512,10 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     s.cb = c->d_wgc_coef + nt;
     double *w0, *K1, *K2, *K3;
     const size_t tb = sizeof(double) * (size_t)c->g.total;
-    if (int rc = get_ws(c, "t:w0", tb, (void**)&w0)) return rc;
-    if (int rc = get_ws(c, "t:K1", tb, (void**)&K1)) return rc;
-    if (int rc = get_ws(c, "t:K2", tb, (void**)&K2)) return rc;
-    if (int rc = get_ws(c, "t:K3", tb, (void**)&K3)) return rc;
+    if (int rc = get_ws(c, "t:wgc", 4 * tb, (void**)&w0)) return rc;      // interleaved (w0,K1,K2,K3) per k-point
+    K1 = w0 + 1;
+    K2 = w0 + 2;
+    K3 = w0 + 3;
     OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s);
     c->wgc_key_nel = nel_rounded;
     c->wgc_valid = true;
@@ -680,8 +680,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         if (int rc = spec_ws(c, "s1", &s1)) return rc;
         if (int rc = spec_ws(c, "s2", &s2)) return rc;
-        const double *w0 = (double*)c->ws["t:w0"].p, *K1 = (double*)c->ws["t:K1"].p, *K2 = (double*)c->ws["t:K2"].p,
-                     *K3 = (double*)c->ws["t:K3"].p;
+        const double *w0 = (double*)c->ws["t:wgc"].p, *K1 = w0 + 1, *K2 = w0 + 2, *K3 = w0 + 3;
         for (int pass = 0; pass < 2; ++pass) {
             OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
                                nref);
@@ -839,8 +838,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         for (int i = 1; i < 3; ++i)
             if (int rc = spec_ws(c, sn[i], &s[i])) return rc;
-        const MixWgc mix{(double*)c->ws["t:w0"].p, (double*)c->ws["t:K1"].p, (double*)c->ws["t:K2"].p,
-                         (double*)c->ws["t:K3"].p};
+        const MixWgc mix{(double*)c->ws["t:wgc"].p};
         XfIo io{};
         for (int i = 0; i < 3; ++i) {
             io.in[i] = s[i];
@@ -1134,8 +1132,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
         }
     }
     if (r.has_wgc) {
-        const MixWgc mix{(double*)c->ws["t:w0"].p, (double*)c->ws["t:K1"].p, (double*)c->ws["t:K2"].p,
-                         (double*)c->ws["t:K3"].p};
+        const MixWgc mix{(double*)c->ws["t:wgc"].p};
         for (int half = 0; half < 2; ++half) {
             XfIo io{};
             for (int i = 0; i < 3; ++i) {

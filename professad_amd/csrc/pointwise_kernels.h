@@ -184,7 +184,7 @@ __global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, 
                                     const double* __restrict__ K2, const double* __restrict__ K3, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const cplx a = A[i], b = B[i], c = C[i];
-        const double t0 = w0[i], t1 = K1[i], t2 = K2[i], t3 = K3[i];
+        const double t0 = w0[4 * i], t1 = K1[4 * i], t2 = K2[4 * i], t3 = K3[4 * i];   // interleaved (w0,K1,K2,K3) per k-point
         A[i] = make_double2(t0 * a.x + t1 * b.x + t2 * c.x, t0 * a.y + t1 * b.y + t2 * c.y);
         B[i] = make_double2(t1 * a.x + t3 * b.x, t1 * a.y + t3 * b.y);
         C[i] = make_double2(t2 * a.x, t2 * a.y);
@@ -255,10 +255,11 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
         w0 *= s.pref;
         w1 *= s.pref;
         w2 *= s.pref;
-        w0o[i] = w0;
-        K1o[i] = -eta * w1 / (6.0 * s.nref);
-        K2o[i] = (eta * eta * w2 + (7.0 - s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
-        K3o[i] = (eta * eta * w2 + (1.0 + s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
+        // interleaved per k-point (32 B): a 4-line x tile then reads whole 128-B lines of the table
+        w0o[4 * i] = w0;
+        K1o[4 * i] = -eta * w1 / (6.0 * s.nref);
+        K2o[4 * i] = (eta * eta * w2 + (7.0 - s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
+        K3o[4 * i] = (eta * eta * w2 + (1.0 + s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
     }
 }
 
@@ -318,14 +319,16 @@ struct MixDiv {
 
 // WGC99: (A^,B^,C^) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) with tables in the spectrum layout
 struct MixWgc {
-    const double* w0; const double* K1; const double* K2; const double* K3;
+    const double* tab;     // interleaved (w0, K1, K2, K3) per k-point, spectrum order
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return O + I <= 2; }
     template <int O, int I>
     __device__ __forceinline__ double coef(int, int, int, long long uoff, unsigned loff) const {
-        const double* t = (O + I == 0) ? w0 : ((O + I == 1) ? K1 : ((O == 1) ? K3 : K2));
-        return buf_load_d(t + uoff, loff * 8);
+        // 16-byte loads of (w0,K1) or (K2,K3): identical loads of one k-point are merged by the compiler
+        const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff + ((O + I == 2) ? 1 : 0);
+        const cplx pr = buf_load_c(t2, loff * 32);
+        return (O + I == 0) ? pr.x : ((O + I == 1) ? pr.y : ((O == 1) ? pr.y : pr.x));
     }
 };
 
