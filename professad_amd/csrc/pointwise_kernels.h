@@ -386,10 +386,11 @@ __device__ __forceinline__ void pw92(double rs, double& eps, double& deps_drs) {
     const double A = 0.0310907, a1 = 0.2137, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
     const double sr = sqrt(rs);
     const double zeta = 2.0 * A * (b1 * sr + b2 * rs + b3 * rs * sr + b4 * rs * rs);
-    const double lg = log(1.0 + 1.0 / zeta);
+    const double izeta = 1.0 / zeta;
+    const double lg = log(1.0 + izeta);
     eps = -2.0 * A * (1.0 + a1 * rs) * lg;
     const double dzeta = 2.0 * A * (0.5 * b1 / sr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
-    deps_drs = -2.0 * A * a1 * lg + 2.0 * A * (1.0 + a1 * rs) * dzeta / (zeta * (zeta + 1.0));
+    deps_drs = -2.0 * A * a1 * lg + 2.0 * A * (1.0 + a1 * rs) * dzeta * izeta / (zeta + 1.0);
 }
 
 struct XcLocal { double ex, vx, ec, vc; };   // energy densities (per volume) and potentials
@@ -441,46 +442,52 @@ __device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
 struct PbePoint { double fx, fc, dfdn, dfdg; };
 
 // PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
+// (fp64 division costs ~10x a multiply on gfx950, so every quotient below goes through a shared reciprocal)
 __device__ __forceinline__ PbePoint pbe_point(double n, double gn2, bool do_x, bool do_c) {
     PbePoint r = {0.0, 0.0, 0.0, 0.0};
     const double n13 = cbrt(n);
+    const double inv_n = 1.0 / n;
     if (do_x) {
         const double kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
         const double cx = -0.75 * cbrt(3.0 / kPi);
         const double ex = cx * n13;
         const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);     // 0.25 (3 pi^2)^(-2/3)
-        const double n83i = 1.0 / (n13 * n13 * n * n);                   // n^(-8/3)
+        const double n83i = inv_n * inv_n * inv_n * n13;                 // n^(-8/3)
         const double s2 = cs * gn2 * n83i;
-        const double den = 1.0 + mu / kappa * s2;
-        const double Fx = 1.0 + kappa - kappa / den;
-        const double dF = mu / (den * den);
+        const double iden = 1.0 / (1.0 + (mu / kappa) * s2);
+        const double Fx = 1.0 + kappa - kappa * iden;
+        const double dF = mu * iden * iden;
         r.fx = Fx * ex * n;
-        r.dfdn += Fx * (4.0 / 3.0) * ex + dF * (-(8.0 / 3.0) * s2 / n) * ex * n;
+        r.dfdn += Fx * (4.0 / 3.0) * ex + dF * (-(8.0 / 3.0) * s2 * inv_n) * ex * n;
         r.dfdg += dF * cs * n83i * ex * n;
     }
     if (do_c) {
-        const double beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi);
-        const double rs = cbrt(3.0 / (4.0 * kPi)) / n13;
+        const double beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi), igam = 1.0 / gam;
+        const double rs = cbrt(3.0 / (4.0 * kPi)) * (n13 * n13 * inv_n);  // c n^(-1/3)
         double eps, deps_drs;
         pw92(rs, eps, deps_drs);
-        const double deps_dn = -rs / (3.0 * n) * deps_drs;
-        const double ee = exp(-eps / gam);
-        const double A = beta / gam / (ee - 1.0 + 1e-30);
-        const double dAdn = A * A / beta * ee * deps_dn;
+        const double deps_dn = -rs * (1.0 / 3.0) * inv_n * deps_drs;
+        const double ee = exp(-eps * igam);
+        const double A = beta * igam / (ee - 1.0 + 1e-30);
+        const double dAdn = A * A * (1.0 / beta) * ee * deps_dn;
         const double ct = (1.0 / 16.0) * cbrt(kPi / 3.0);
-        const double n43 = n13 * n, n73 = n43 * n + 1e-30;
-        const double t2 = ct * gn2 / n73;
-        const double dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 / (n73 * n73);
-        const double dt2dg = ct / n73;
+        const double n43 = n13 * n;
+        const double in73 = 1.0 / (n43 * n + 1e-30);
+        const double t2 = ct * gn2 * in73;
+        const double dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 * in73 * in73;
+        const double dt2dg = ct * in73;
         const double At2 = A * t2;
-        const double num = 1.0 + At2, den = 1.0 + At2 + At2 * At2, num2 = 1.0 + 2.0 * At2;
-        const double arg = 1.0 + beta / gam * t2 * num / den;
+        const double num = 1.0 + At2, num2 = 1.0 + 2.0 * At2;
+        const double iden = 1.0 / (1.0 + At2 + At2 * At2);
+        const double arg = 1.0 + beta * igam * t2 * num * iden;
         const double H = gam * log(arg);
-        const double dQn = (dt2dn * num2 + dAdn * t2 * t2) / den - t2 * num / (den * den) * (dt2dn * A + dAdn * t2) * num2;
-        const double dQg = (dt2dg * num2) / den - t2 * num / (den * den) * (dt2dg * A) * num2;
+        const double common = t2 * num * iden * iden * num2;
+        const double dQn = (dt2dn * num2 + dAdn * t2 * t2) * iden - common * (dt2dn * A + dAdn * t2);
+        const double dQg = dt2dg * num2 * iden - common * (dt2dg * A);
+        const double boa = beta / arg;
         r.fc = (eps + H) * n;
-        r.dfdn += eps + H + n * (deps_dn + beta / arg * dQn);
-        r.dfdg += n * beta / arg * dQg;
+        r.dfdn += eps + H + n * (deps_dn + boa * dQn);
+        r.dfdg += n * boa * dQg;
     }
     return r;
 }
