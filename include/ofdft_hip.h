@@ -127,6 +127,17 @@ int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[11]*/, dou
 int  ofdft_dist_chi_grad(ofdft_ctx* ctx, const void* chi_local_dev, const void* v_local_dev, void* grad_local_dev,
                          double cscale, double mu, void* stream);
 
+/* Ionic (external) potential of one species on the grid: v(r) = irfftn(S(k) v~(|k|), norm='forward') / vol with the
+ * exact structure factor (pme_order = 0) or its particle-mesh-Ewald approximation of even order >= 2, and v~ the
+ * cubic-Hermite interpolation of a reciprocal-space pseudopotential table (uniform k grid from 0; the Coulomb tail
+ * 4 pi z / k^2 already ADDED to the table for k > 0, exactly as the reference prepares it).  Stands behind
+ * System.__potential_from_ions (system.py:183-194) = lattice_sum + structure_factor[_spline] + interpolate_recpot
+ * (ion_utils.py:49-286).  frac_coords_host: [nions][3] fractional coordinates (host); vext_dev: [n0][n1][n2] device
+ * array that receives (accumulate = 0) or is incremented by (accumulate = 1) the potential. */
+int  ofdft_ionic_potential(ofdft_ctx* ctx, const double* frac_coords_host, int nions, const double* table_k_host,
+                           const double* table_v_host, int ntable, double z_ion, int pme_order, void* vext_dev,
+                           int accumulate, void* stream);
+
 /* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (power-of-two grids: fused x passes and z
  * passes that keep every real-space intermediate on chip), 1 = force the unfused pipeline (separate forward,
  * multiply, inverse and pointwise passes; the only one for other grids), 2 = fused x passes only. */

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ofdft_hip.h"
+#include "ion_kernels.h"
 #include "zpass.h"
 
 using namespace ofdft;
@@ -1655,6 +1656,107 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
     OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi_local,
                  (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV, (const double*)nullptr, 0.0, mu);
     HIP_TRY(c, hipGetLastError());
+    return OFDFT_OK;
+}
+
+// ------------------------------------------------------------------------------ ionic potential
+int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, const double* tab_k, const double* tab_v,
+                          int ntab, double z_ion, int pme_order, void* vext_dev, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !frac_host || !tab_k || !tab_v || !vext_dev) return OFDFT_EINVAL;
+    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
+    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_ionic_potential: single-GPU contexts only");
+    if (nions < 1 || ntab < 2) return fail(c, OFDFT_EINVAL, "need at least one ion and two table points");
+    if (pme_order != 0 && (pme_order < 2 || pme_order > kMaxPmeOrder || (pme_order & 1)))
+        return fail(c, OFDFT_EINVAL, "Requires even order n >= 2 (<= %d)", kMaxPmeOrder);       // ion_utils.py:116
+    HIP_TRY(c, hipSetDevice(c->device));
+    // ---- host-side small tables: fractional coordinates in [0,1), Hermite slopes, spline b factors
+    std::vector<double> frac(3 * (size_t)nions), cart(3 * (size_t)nions);
+    for (int a = 0; a < nions; ++a) {
+        for (int d = 0; d < 3; ++d) {
+            double f = frac_host[3 * a + d];
+            f -= std::floor(f);
+            f -= std::floor(f);                                                      // ion_utils.py:241-242
+            frac[3 * a + d] = f;
+        }
+        for (int d = 0; d < 3; ++d)     // cart = frac @ box (the un-wrapped coordinates, as the reference's exact sum uses)
+            cart[3 * a + d] = frac_host[3 * a] * c->box[d] + frac_host[3 * a + 1] * c->box[3 + d] +
+                              frac_host[3 * a + 2] * c->box[6 + d];
+    }
+    std::vector<double> slopes(ntab);
+    {
+        std::vector<double> m(ntab - 1);
+        for (int i = 0; i + 1 < ntab; ++i) m[i] = (tab_v[i + 1] - tab_v[i]) / (tab_k[i + 1] - tab_k[i]);
+        slopes[0] = m[0];
+        for (int i = 1; i + 1 < ntab; ++i) slopes[i] = (m[i] + m[i - 1]) / 2;
+        slopes[ntab - 1] = m[ntab - 2];
+    }
+    double *d_frac, *d_cart, *d_k, *d_y, *d_m;
+    if (int rc = get_ws(c, "i:frac", sizeof(double) * frac.size(), (void**)&d_frac)) return rc;
+    if (int rc = get_ws(c, "i:cart", sizeof(double) * cart.size(), (void**)&d_cart)) return rc;
+    if (int rc = get_ws(c, "i:k", sizeof(double) * ntab, (void**)&d_k)) return rc;
+    if (int rc = get_ws(c, "i:y", sizeof(double) * ntab, (void**)&d_y)) return rc;
+    if (int rc = get_ws(c, "i:m", sizeof(double) * ntab, (void**)&d_m)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_frac, frac.data(), sizeof(double) * frac.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * cart.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_k, tab_k, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_y, tab_v, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_m, slopes.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, st));
+    RecpotTable tab{d_k, d_y, d_m, ntab, z_ion, 1.0 / (tab_k[1] - tab_k[0])};
+    cplx *sQ, *sF;
+    double* tmp;
+    if (int rc = spec_ws(c, "i:F", &sF)) return rc;
+    if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
+    const int sp_grid = grid_for(c->g.total);
+    std::vector<cplx> hb;
+    if (pme_order == 0) {
+        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)nullptr, sF, c->kg,
+                     (const cplx*)nullptr, (const cplx*)nullptr, (const cplx*)nullptr, (const double*)d_cart, nions, tab,
+                     1.0 / c->vol);
+    } else {
+        // b(m) = exp(2 pi i m (n-1)/N) / sum_i M_n(i) exp(2 pi i m (i-1)/N)        ion_utils.py:207-215
+        std::vector<double> M(pme_order, 0.0);
+        M[0] = 0.0;
+        M[1] = 1.0;
+        for (int n = 3; n <= pme_order; ++n) {
+            for (int i = n - 1; i >= 1; --i) M[i] = ((0.0 + i) * M[i] + (n - 0.0 - i) * M[i - 1]) / (n - 1);
+            M[0] = 0.0;
+        }
+        const int cnt[3] = {c->n0, c->n1, c->g.nzc}, Ns[3] = {c->n0, c->n1, c->n2};
+        hb.resize((size_t)cnt[0] + cnt[1] + cnt[2]);
+        size_t off = 0;
+        for (int d = 0; d < 3; ++d) {
+            for (int m = 0; m < cnt[d]; ++m) {
+                double br = 0.0, bi = 0.0;
+                for (int i = 0; i < pme_order; ++i) {
+                    const double ph = 2.0 * kPi * m * (i - 1.0) / Ns[d];
+                    br += M[i] * std::cos(ph);
+                    bi += M[i] * std::sin(ph);
+                }
+                const double ph = 2.0 * kPi * m * (pme_order - 1.0) / Ns[d];
+                const double nr = std::cos(ph), ni = std::sin(ph), den = br * br + bi * bi;
+                hb[off + m] = make_double2((nr * br + ni * bi) / den, (ni * br - nr * bi) / den);
+            }
+            off += cnt[d];
+        }
+        cplx* d_b;
+        if (int rc = get_ws(c, "i:b", sizeof(cplx) * hb.size(), (void**)&d_b)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d_b, hb.data(), sizeof(cplx) * hb.size(), hipMemcpyHostToDevice, st));
+        if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
+        HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
+        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)d_frac, nions, pme_order,
+                     tmp, c->n0, c->n1, c->n2);
+        if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
+        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)sQ, sF, c->kg,
+                     (const cplx*)d_b, (const cplx*)(d_b + cnt[0]), (const cplx*)(d_b + cnt[0] + cnt[1]),
+                     (const double*)nullptr, nions, tab, 1.0 / c->vol);
+    }
+    if (int rc = irfftn_internal(c, sF, tmp, 1.0, st)) return rc;              // norm='forward': no 1/N  (ion_utils.py:118)
+    OFDFT_LAUNCH(c, st, "axpy", axpy_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)tmp, (double*)vext_dev,
+                 c->npts, accumulate);
+    HIP_TRY(c, hipStreamSynchronize(st));      // host vectors above must outlive the async copies
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
     return OFDFT_OK;
 }
 

@@ -1,0 +1,106 @@
+// Ionic (external) potential on the grid from ion positions: exact or particle-mesh-Ewald structure factor times
+// the interpolated reciprocal-space pseudopotential (reference: src/professad/ion_utils.py:49-286,
+// src/professad/system.py:183-194).  fp64, gfx950.
+#pragma once
+#include "pointwise_kernels.h"
+
+namespace ofdft {
+
+constexpr int kMaxPmeOrder = 32;
+
+// cardinal B-spline values [M_n(x+i), i = 0..n-1], 0 <= x < 1 (ion_utils.py:140-204: the recursion of its docstring)
+__device__ __forceinline__ void bspline_values(double x, int order, double* M) {
+    M[0] = x;
+    M[1] = 1.0 - x;
+    for (int n = 3; n <= order; ++n) {
+        M[n - 1] = 0.0;
+        for (int i = n - 1; i >= 1; --i) M[i] = ((x + i) * M[i] + (n - x - i) * M[i - 1]) / (n - 1);
+        M[0] = x / (n - 1) * M[0];
+    }
+}
+
+// Q(l0,l1,l2) += M0 M1 M2 with periodic wrap (ion_utils.py:249-273); one workgroup per ion
+__global__ __launch_bounds__(256) void pme_spread_kernel(const double* __restrict__ frac, int nion, int order,
+                                                         double* __restrict__ Q, int n0, int n1, int n2) {
+    __shared__ double M[3][kMaxPmeOrder];
+    __shared__ int L[3][kMaxPmeOrder];
+    const int a = blockIdx.x;
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        const int N = d == 0 ? n0 : (d == 1 ? n1 : n2);
+        const double u = frac[3 * a + d] * N;
+        const long long fl = (long long)floor(u);
+        bspline_values(u - (double)fl, order, M[d]);
+        for (int i = 0; i < order; ++i) {
+            long long l = (i - fl) % N;
+            if (l < 0) l += N;
+            L[d][i] = (int)l;
+        }
+    }
+    __syncthreads();
+    const int tot = order * order * order;
+    for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+        const int i2 = t % order, i1 = (t / order) % order, i0 = t / (order * order);
+        atomicAdd(&Q[((long long)L[0][i0] * n1 + L[1][i1]) * n2 + L[2][i2]], M[0][i0] * M[1][i1] * M[2][i2]);
+    }
+}
+
+struct RecpotTable {
+    const double* ks;    // [n] uniform grid from 0
+    const double* y;     // [n] table with the Coulomb tail 4 pi z/k^2 added for k > 0 (ion_utils.py:67-68)
+    const double* m;     // [n] Hermite slopes (functional_tools.py:309-310)
+    int n;
+    double z;
+    double inv_dk;
+};
+
+// interpolate_recpot at |k| (ion_utils.py:74-81; functional_tools.py:311-334)
+__device__ __forceinline__ double recpot_value(const RecpotTable& t, double kabs) {
+    const double xs = fmin(kabs, t.ks[t.n - 1]);
+    int idx = (int)ceil(xs * t.inv_dk) - 1;
+    idx = max(0, min(idx, t.n - 2));
+    while (idx > 0 && t.ks[idx] >= xs) --idx;            // searchsorted(x[1:], xs): #entries of x[1:] below xs
+    while (idx < t.n - 2 && t.ks[idx + 1] < xs) ++idx;
+    const double dx = t.ks[idx + 1] - t.ks[idx];
+    const double u = (xs - t.ks[idx]) / dx, u2 = u * u, u3 = u2 * u;
+    const double v = (1.0 - 3.0 * u2 + 2.0 * u3) * t.y[idx] + (u - 2.0 * u2 + u3) * t.m[idx] * dx +
+                     (3.0 * u2 - 2.0 * u3) * t.y[idx + 1] + (-u2 + u3) * t.m[idx + 1] * dx;
+    return (kabs != 0.0) ? v - 4.0 * kPi * t.z / (kabs * kabs) : v;
+}
+
+// F^ = conj(b0 b1 b2 Q^) v~(|k|) / vol  (PME, ion_utils.py:275-286,118) -- or, with cart != nullptr, the exact
+// structure factor sum_i exp(-i k.r_i) (ion_utils.py:121-137)
+__global__ void ion_potential_spec_kernel(const cplx* __restrict__ Qk, cplx* __restrict__ out, KGeom kg,
+                                          const cplx* __restrict__ b0, const cplx* __restrict__ b1,
+                                          const cplx* __restrict__ b2, const double* __restrict__ cart, int nion,
+                                          RecpotTable tab, double inv_vol) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        int x, y, z;
+        spec_decode(kg.g, i, x, y, z);
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        cplx S;
+        if (cart) {
+            double sr = 0.0, si = 0.0;
+            for (int a = 0; a < nion; ++a) {
+                double sn, cs;
+                sincos(kx * cart[3 * a] + ky * cart[3 * a + 1] + kz * cart[3 * a + 2], &sn, &cs);
+                sr += cs;
+                si -= sn;
+            }
+            S = make_double2(sr, si);
+        } else {
+            const cplx b = cmul(cmul(b0[x], b1[y]), b2[z]);
+            S = cconj(cmul(b, Qk[i]));
+        }
+        const double f = recpot_value(tab, (k2 != 0.0) ? sqrt(k2) : 0.0) * inv_vol;
+        out[i] = make_double2(S.x * f, S.y * f);
+    }
+}
+
+__global__ void axpy_kernel(const double* __restrict__ x, double* __restrict__ y, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = accumulate ? y[i] + x[i] : x[i];
+}
+
+}  // namespace ofdft

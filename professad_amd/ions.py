@@ -1,0 +1,63 @@
+"""Ionic (external) potential from ion positions -- the step right before the energy path.
+
+`read_recpot` restates the reference's recpot parsing (src/professad/ion_utils.py:20-81: units, ion charge from the
+first two table entries, Coulomb tail added for interpolation); `ionic_potential` builds v_ext on the GPU through
+`ofdft_ionic_potential` (exact or particle-mesh-Ewald structure factor), species by species like
+System.__potential_from_ions (src/professad/system.py:183-194).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+# the recpot unit conversion uses its own constants in the reference (ion_utils.py:11-13)
+BOHR = 0.529177208607388
+HARTREE_TO_EV = 27.2113834279111
+POT_CONV = 1.0 / (BOHR * BOHR * BOHR * HARTREE_TO_EV)
+
+
+def recpot_table(raw, k_max):
+    """(ks, v, z) from the raw table in atomic units: uniform k grid, Coulomb tail 4 pi z / k^2 added for k > 0."""
+    raw = np.asarray(raw, dtype=np.float64)
+    ks, dk = np.linspace(0.0, float(k_max), raw.size, retstep=True)
+    z = round((raw[1] - raw[0]) * dk * dk / (-4 * math.pi))                     # ion_utils.py:66
+    v = raw.copy()
+    v[1:] += 4 * math.pi * z / (ks[1:] * ks[1:])                                # ion_utils.py:67
+    return ks, v, z
+
+
+def read_recpot(path):
+    """Parse a CASTEP-style .recpot file -> (ks, v, z) as `recpot_table` (ion_utils.py:49-73)."""
+    vals = []
+    with open(path, 'r') as f:
+        for line in f:
+            if 'END COMMENT' in line:
+                break
+        f.readline()                                  # the '3     5' line
+        k_max = float(f.readline()) * BOHR
+        for line in f:
+            parts = line.split()
+            if len(parts) == 3:
+                vals += parts
+    raw = np.asarray(vals, dtype=np.float64) * POT_CONV
+    return recpot_table(raw, k_max)
+
+
+def ionic_potential(engine, box_vecs, species, pme_order=None):
+    """v_ext on the engine's grid.  species: iterable of (frac_coords [n,3], (ks, v, z)) per ion type.
+    pme_order None -> exact O(N_ion N_k) structure factor; even int >= 2 -> particle-mesh Ewald."""
+    engine.set_cell(box_vecs)
+    out = torch.zeros(engine.shape, dtype=torch.double, device=engine.device)
+    dp = C.POINTER(C.c_double)
+    for i, (frac, (ks, v, z)) in enumerate(species):
+        frac = np.ascontiguousarray(np.asarray(torch.as_tensor(frac).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 3))
+        ks = np.ascontiguousarray(ks, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        if ks.shape != v.shape or ks.ndim != 1:
+            raise ValueError('table k and v must be 1-D arrays of equal length')
+        rc = engine.lib.ofdft_ionic_potential(engine._ctx, frac.ctypes.data_as(dp), frac.shape[0], ks.ctypes.data_as(dp),
+                                              v.ctypes.data_as(dp), ks.size, float(z), 0 if pme_order is None else int(pme_order),
+                                              C.c_void_p(out.data_ptr()), 1 if i else 0, engine._stream())
+        engine._check(rc, 'ofdft_ionic_potential')
+    return out

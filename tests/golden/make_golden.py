@@ -223,9 +223,10 @@ if __name__ == '__main__':
     ap.add_argument('--cfg1', action='store_true')
     ap.add_argument('--huge', action='store_true')
     ap.add_argument('--small', action='store_true')
+    ap.add_argument('--ions', action='store_true')
     a = ap.parse_args()
     torch.set_num_threads(8)
-    if a.small or not (a.big or a.cfg1 or a.huge):
+    if a.small or not (a.big or a.cfg1 or a.huge or a.ions):
         gen_wavevecs()
         for c in cases.PER_TERM_CASES:
             gen_terms(c)
@@ -237,3 +238,65 @@ if __name__ == '__main__':
         gen_cfg1()
     if a.huge:
         gen_big([256], 'huge_scalars.json', ['cfg3'])
+
+
+def gen_ions():
+    """Ionic potential fixtures (ion_utils.py:49-286, system.py:183-194): the parsed al.gga recpot table (data file of
+    the reference's tests), the reference's interpolation of it, exact and PME structure factors and v_ext."""
+    import professad.ion_utils as IU
+    from professad.crystal_tools import get_cell
+    os.chdir('/root/reference/tests')
+    path = 'potentials/al.gga.recpot'
+    # parsed table exactly as interpolate_recpot builds it (:62-73)
+    pot = []
+    with open(path) as f:
+        for line in f:
+            if 'END COMMENT' in line:
+                break
+        f.readline()
+        k_max = float(f.readline()) * IU.bohr
+        for line in f:
+            if len(line.split()) == 3:
+                pot += line.split()
+    pot = np.asarray(pot, dtype=np.float64) * IU.pot_conv_factor
+    out = {'recpot_raw': pot, 'recpot_kmax': np.float64(k_max), 'z': np.float64(IU.get_ion_charge(path))}
+    # case A: fcc-Al conventional cell, 32^3 (config 1) -- exact and PME orders 4, 10
+    box_a, frac = get_cell('fcc-c', vol_per_atom=16.8, coord_type='fractional')
+    box = box_a / 0.529177210903          # angstrom -> bohr as System does (system.py:27-33)
+    shape = (32, 32, 32)
+    kx, ky, kz, k2 = T.wavevecs(box, shape)
+    k = torch.zeros(k2.shape, dtype=DT)
+    k[k2 != 0] = torch.sqrt(k2[k2 != 0])
+    vk = IU.interpolate_recpot(path, k)
+    cart = frac @ box
+    out.update(a_box=box.numpy(), a_frac=frac.numpy(), a_vk=vk.numpy(),
+               a_S_exact=IU.structure_factor(box, shape, cart).numpy(),
+               a_v_exact=IU.lattice_sum(box, shape, cart, vk, None).numpy())
+    for order in (4, 10):
+        out['a_S_pme%d' % order] = IU.structure_factor_spline(box, shape, cart, order).resolve_conj().numpy()
+        out['a_v_pme%d' % order] = IU.lattice_sum(box, shape, cart, vk, order).numpy()
+    # case B: 7 random ions in a triclinic cell on a mixed grid (16, 20, 24), PME order 6 (non power-of-two axis)
+    rng = np.random.default_rng(99)
+    box_b = t(cases.make_cell(('tri', 1.0)))
+    frac_b = t(rng.random((7, 3)))
+    shape_b = (16, 20, 24)
+    kx, ky, kz, k2 = T.wavevecs(box_b, shape_b)
+    kb = torch.zeros(k2.shape, dtype=DT)
+    kb[k2 != 0] = torch.sqrt(k2[k2 != 0])
+    vkb = IU.interpolate_recpot(path, kb)
+    cart_b = frac_b @ box_b
+    out.update(b_box=box_b.numpy(), b_frac=frac_b.numpy(), b_vk=vkb.numpy(),
+               b_S_exact=IU.structure_factor(box_b, shape_b, cart_b).numpy(),
+               b_S_pme6=IU.structure_factor_spline(box_b, shape_b, cart_b, 6).resolve_conj().numpy(),
+               b_v_exact=IU.lattice_sum(box_b, shape_b, cart_b, vkb, None).numpy(),
+               b_v_pme6=IU.lattice_sum(box_b, shape_b, cart_b, vkb, 6).numpy())
+    x = torch.linspace(0.0, 0.999, 7, dtype=DT)
+    out['bspline_x'] = x.numpy()
+    for order in (2, 3, 6, 10):
+        out['bspline_%d' % order] = IU.cardinal_b_spline_values(x, order).numpy()
+    np.savez_compressed(os.path.join(HERE, 'ions.npz'), **out)
+    print('ions.npz', {k: v.shape for k, v in out.items() if hasattr(v, 'shape') and v.ndim > 0})
+
+
+if '--ions' in sys.argv:
+    gen_ions()

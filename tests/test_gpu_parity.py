@@ -296,3 +296,30 @@ def test_density_optimisation_reaches_reference_ground_state():
     # first outer iteration (before the chaotic amplification sets in) matches the reference's log to all digits shown
     assert abs(res['history'][0][1] - 68.191536) < 1e-6 and abs(res['history'][0][3] - 0.593563) < 1e-6
     eng.close()
+
+
+def test_ionic_potential_matches_reference_golden():
+    """v_ext from ion positions (exact and PME structure factors) against the reference's lattice_sum outputs."""
+    from professad_amd.ions import ionic_potential, recpot_table
+    g = load('ions.npz')
+    tab = recpot_table(g['recpot_raw'], float(g['recpot_kmax']))
+    assert tab[2] == 3
+    for tag, shape, orders in (('a', (32, 32, 32), (None, 4, 10)), ('b', (16, 20, 24), (None, 6))):
+        eng = Engine(shape, DEV)
+        for o in orders:
+            v = ionic_potential(eng, g[tag + '_box'], [(g[tag + '_frac'], tab)], pme_order=o).cpu().numpy()
+            ref = g[tag + '_v_exact'] if o is None else g['%s_v_pme%d' % (tag, o)]
+            assert relerr(v, ref) < 1e-11, (tag, o, relerr(v, ref))
+        # two "species" (the ion list split in two) accumulate to the same potential
+        fr = g[tag + '_frac']
+        v2 = ionic_potential(eng, g[tag + '_box'], [(fr[:2], tab), (fr[2:], tab)], pme_order=orders[-1]).cpu().numpy()
+        assert relerr(v2, g['%s_v_pme%d' % (tag, orders[-1])]) < 1e-11
+        with pytest.raises(RuntimeError):
+            ionic_potential(eng, g[tag + '_box'], [(fr, tab)], pme_order=3)
+        eng.close()
+    # config 1 end to end: ions -> v_ext equals the potential the reference's System used
+    c1 = load('cfg1_fccAl_32.npz')
+    eng = Engine((32, 32, 32), DEV)
+    v = ionic_potential(eng, c1['box'], [(g['a_frac'], tab)]).cpu().numpy()
+    assert relerr(v, c1['vext']) < 1e-10
+    eng.close()

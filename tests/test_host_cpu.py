@@ -63,3 +63,26 @@ def test_reference_protocol_names():
     assert F.NativeTerms(['wt', 'pz']).__qualname__ == 'NativeTerms'
     with pytest.raises(KeyError):
         F.NativeTerms(['nope'])
+
+
+def test_recpot_reader(tmp_path):
+    """The recpot parser on a synthetic file in the reference's format (ion_utils.py:20-81)."""
+    import numpy as np
+    from professad_amd.ions import BOHR, POT_CONV, read_recpot
+    z, n = 3, 30
+    kmax_file = 8.0
+    ks = np.linspace(0.0, kmax_file * BOHR, n)
+    dk = ks[1] - ks[0]
+    v = np.empty(n)
+    v[1:] = -4 * np.pi * z / ks[1:] ** 2 * np.exp(-ks[1:] ** 2 / 4)
+    v[0] = v[1] + 4 * np.pi * z / dk ** 2          # makes (v1 - v0) dk^2 / (-4 pi) = z exactly
+    p = tmp_path / 'x.recpot'
+    with open(p, 'w') as f:
+        f.write('START COMMENT\nsynthetic\nEND COMMENT\n3     5\n%.10f\n' % kmax_file)
+        raw = v / POT_CONV
+        for i in range(0, n, 3):
+            f.write(' '.join('%.16e' % x for x in raw[i:i + 3]) + '\n')
+        f.write('1000\n')
+    k2, v2, z2 = read_recpot(str(p))
+    assert z2 == z and np.allclose(k2, ks, rtol=1e-12)
+    assert np.allclose(v2[1:], v[1:] + 4 * np.pi * z / ks[1:] ** 2, rtol=1e-10) and abs(v2[0] - v[0]) < 1e-8 * abs(v[0])

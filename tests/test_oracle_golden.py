@@ -84,3 +84,24 @@ def test_fused_configs_and_closure(case):
             Ec, g = rp.closure(torch.as_tensor(box), torch.as_tensor(chi), n_elec, [table[n] for n in names])
             assert abs(float(Ec) - float(gold['Ec_' + cfg])) <= 1e-13 * max(1.0, abs(float(Ec)))
             assert relerr(g.numpy(), gold['g_' + cfg]) < 1e-12
+
+
+def test_ionic_potential_oracle():
+    from oracle import ions as oi
+    g = load('ions.npz')
+    raw, kmax = g['recpot_raw'], float(g['recpot_kmax'])
+    assert oi.recpot_table(raw, kmax)[2] == int(g['z']) == 3
+    for order in (2, 3, 6, 10):
+        assert relerr(oi.cardinal_b_spline(g['bspline_x'], order), g['bspline_%d' % order]) < 1e-14
+    for tag, shape, orders in (('a', (32, 32, 32), (4, 10)), ('b', (16, 20, 24), (6,))):
+        box, frac = g[tag + '_box'], g[tag + '_frac']
+        k2 = cf.recip(box, shape)[3]
+        assert relerr(oi.recpot_on_grid(raw, kmax, np.sqrt(k2)), g[tag + '_vk']) < 1e-13
+        assert relerr(oi.structure_factor_exact(box, shape, frac), g[tag + '_S_exact']) < 1e-12
+        assert relerr(oi.ionic_potential(box, shape, frac, raw, kmax, None), g[tag + '_v_exact']) < 1e-12
+        for o in orders:
+            assert relerr(oi.structure_factor_pme(shape, frac, o), g['%s_S_pme%d' % (tag, o)]) < 1e-11
+            assert relerr(oi.ionic_potential(box, shape, frac, raw, kmax, o), g['%s_v_pme%d' % (tag, o)]) < 1e-11
+    # the config-1 fixture's v_ext is this potential (reference System, exact structure factor)
+    c1 = load('cfg1_fccAl_32.npz')
+    assert relerr(oi.ionic_potential(c1['box'], (32, 32, 32), g['a_frac'], raw, kmax, None), c1['vext']) < 1e-10
