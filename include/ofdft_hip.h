@@ -138,6 +138,13 @@ int  ofdft_ionic_potential(ofdft_ctx* ctx, const double* frac_coords_host, int n
                            const double* table_v_host, int ntable, double z_ion, int pme_order, void* vext_dev,
                            int accumulate, void* stream);
 
+/* Ion-electron forces of one species for a given density: F_a = -d/dR_a int n v_ext (Ha/bohr, [nions][3] on the host),
+ * with the same structure-factor options as ofdft_ionic_potential.  Stands behind the IonElectron part of
+ * System.__compute_forces (system.py:913-923), which the reference obtains by autograd through the potential build. */
+int  ofdft_ion_electron_forces(ofdft_ctx* ctx, const void* den_dev, const double* frac_coords_host, int nions,
+                               const double* table_k_host, const double* table_v_host, int ntable, double z_ion,
+                               int pme_order, double* forces_host, void* stream);
+
 /* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (power-of-two grids: fused x passes and z
  * passes that keep every real-space intermediate on chip), 1 = force the unfused pipeline (separate forward,
  * multiply, inverse and pointwise passes; the only one for other grids), 2 = fused x passes only. */

@@ -105,3 +105,58 @@ def ionic_potential(box, shape, frac, raw, k_max, order=None):
     S = structure_factor_exact(box, shape, frac) if order is None else structure_factor_pme(shape, frac, order)
     vol = abs(np.linalg.det(box))
     return np.fft.irfftn(S * vk, s=shape, axes=(0, 1, 2), norm='forward') / vol
+
+
+def half_weights(shape):
+    """multiplicity of each rfftn half-spectrum coefficient in a full-spectrum sum of a real field's products"""
+    nzc = shape[2] // 2 + 1
+    w = np.full(nzc, 2.0)
+    w[0] = 1.0
+    if shape[2] % 2 == 0:
+        w[-1] = 1.0
+    return w
+
+
+def ion_electron_forces(box, shape, frac, den, raw, k_max, order=None):
+    """F_a = -d/dR_a [dV sum_r n v_ext]: what autograd through lattice_sum + IonElectron yields in
+    System.__compute_forces (system.py:913-923), restated analytically.  -> [n_ion, 3] Ha/bohr"""
+    kx, ky, kz, k2 = recip(box, shape)
+    vk = recpot_on_grid(raw, k_max, np.sqrt(k2))
+    vol = abs(np.linalg.det(box))
+    dV = vol / np.prod(shape)
+    nk = np.fft.rfftn(den)
+    F = np.zeros((frac.shape[0], 3))
+    if order is None:
+        w = half_weights(shape)[None, None, :]
+        cart = frac @ box
+        for a in range(frac.shape[0]):
+            ph = np.exp(-1j * (kx * cart[a, 0] + ky * cart[a, 1] + kz * cart[a, 2]))
+            core = w * vk * (1j * ph * np.conj(nk))
+            for j, kj in enumerate((kx, ky, kz)):
+                F[a, j] = dV / vol * np.sum((kj * core).real)
+        return F
+    N = np.array(shape)
+    b = (spline_b(N[0], nk.shape[0], order)[:, None, None] * spline_b(N[1], nk.shape[1], order)[None, :, None]
+         * spline_b(N[2], nk.shape[2], order)[None, None, :])
+    theta = np.fft.irfftn(vk * np.conj(b * nk), s=shape, axes=(0, 1, 2), norm='forward') / vol
+    f = frac - np.floor(frac)
+    f = f - np.floor(f)
+    u = f * N
+    fl = np.floor(u).astype(np.int64)
+    inv = np.linalg.inv(box)
+    for a in range(frac.shape[0]):
+        Ms, Ds, ls = [], [], []
+        for d in range(3):
+            x = u[a, d] - fl[a, d]
+            M = cardinal_b_spline(x, order)
+            P = cardinal_b_spline(x, order - 1) if order > 2 else np.array([1.0])
+            P = np.concatenate([[0.0], P, [0.0]])
+            Ms.append(M)
+            Ds.append(P[1:] - P[:-1])          # d/dx M_n(x+i) = M_{n-1}(x+i) - M_{n-1}(x+i-1)
+            ls.append(np.mod(np.arange(order) - fl[a, d], N[d]))
+        th = theta[np.ix_(ls[0], ls[1], ls[2])]
+        G = np.array([np.einsum('ijk,i,j,k->', th, Ds[0], Ms[1], Ms[2]),
+                      np.einsum('ijk,i,j,k->', th, Ms[0], Ds[1], Ms[2]),
+                      np.einsum('ijk,i,j,k->', th, Ms[0], Ms[1], Ds[2])])
+        F[a] = -dV * inv @ (N * G)
+    return F

@@ -1660,70 +1660,67 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
 }
 
 // ------------------------------------------------------------------------------ ionic potential
-int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, const double* tab_k, const double* tab_v,
-                          int ntab, double z_ion, int pme_order, void* vext_dev, int accumulate, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!c || !frac_host || !tab_k || !tab_v || !vext_dev) return OFDFT_EINVAL;
+struct IonPrep {
+    std::vector<double> frac, cart, slopes;
+    std::vector<cplx> hb;
+    double *d_frac = nullptr, *d_cart = nullptr;
+    cplx *d_b0 = nullptr, *d_b1 = nullptr, *d_b2 = nullptr;
+    RecpotTable tab{};
+};
+
+// shared host-side preparation of the ionic-potential entry points: wrapped fractional coordinates, Cartesian
+// coordinates, Hermite slopes, PME b factors; uploads everything on `st` (caller syncs before `p` dies)
+static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int nions, const double* tab_k,
+                       const double* tab_v, int ntab, double z_ion, int pme_order, hipStream_t st) {
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_ionic_potential: single-GPU contexts only");
+    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ionic-potential entry points: single-GPU contexts only");
     if (nions < 1 || ntab < 2) return fail(c, OFDFT_EINVAL, "need at least one ion and two table points");
     if (pme_order != 0 && (pme_order < 2 || pme_order > kMaxPmeOrder || (pme_order & 1)))
         return fail(c, OFDFT_EINVAL, "Requires even order n >= 2 (<= %d)", kMaxPmeOrder);       // ion_utils.py:116
     HIP_TRY(c, hipSetDevice(c->device));
-    // ---- host-side small tables: fractional coordinates in [0,1), Hermite slopes, spline b factors
-    std::vector<double> frac(3 * (size_t)nions), cart(3 * (size_t)nions);
+    p.frac.resize(3 * (size_t)nions);
+    p.cart.resize(3 * (size_t)nions);
     for (int a = 0; a < nions; ++a) {
         for (int d = 0; d < 3; ++d) {
             double f = frac_host[3 * a + d];
             f -= std::floor(f);
             f -= std::floor(f);                                                      // ion_utils.py:241-242
-            frac[3 * a + d] = f;
+            p.frac[3 * a + d] = f;
         }
-        for (int d = 0; d < 3; ++d)     // cart = frac @ box (the un-wrapped coordinates, as the reference's exact sum uses)
-            cart[3 * a + d] = frac_host[3 * a] * c->box[d] + frac_host[3 * a + 1] * c->box[3 + d] +
-                              frac_host[3 * a + 2] * c->box[6 + d];
+        for (int d = 0; d < 3; ++d)     // cart = frac @ box (un-wrapped, as the reference's exact sum uses)
+            p.cart[3 * a + d] = frac_host[3 * a] * c->box[d] + frac_host[3 * a + 1] * c->box[3 + d] +
+                                frac_host[3 * a + 2] * c->box[6 + d];
     }
-    std::vector<double> slopes(ntab);
+    p.slopes.resize(ntab);
     {
         std::vector<double> m(ntab - 1);
         for (int i = 0; i + 1 < ntab; ++i) m[i] = (tab_v[i + 1] - tab_v[i]) / (tab_k[i + 1] - tab_k[i]);
-        slopes[0] = m[0];
-        for (int i = 1; i + 1 < ntab; ++i) slopes[i] = (m[i] + m[i - 1]) / 2;
-        slopes[ntab - 1] = m[ntab - 2];
+        p.slopes[0] = m[0];
+        for (int i = 1; i + 1 < ntab; ++i) p.slopes[i] = (m[i] + m[i - 1]) / 2;
+        p.slopes[ntab - 1] = m[ntab - 2];
     }
-    double *d_frac, *d_cart, *d_k, *d_y, *d_m;
-    if (int rc = get_ws(c, "i:frac", sizeof(double) * frac.size(), (void**)&d_frac)) return rc;
-    if (int rc = get_ws(c, "i:cart", sizeof(double) * cart.size(), (void**)&d_cart)) return rc;
+    double *d_k, *d_y, *d_m;
+    if (int rc = get_ws(c, "i:frac", sizeof(double) * p.frac.size(), (void**)&p.d_frac)) return rc;
+    if (int rc = get_ws(c, "i:cart", sizeof(double) * p.cart.size(), (void**)&p.d_cart)) return rc;
     if (int rc = get_ws(c, "i:k", sizeof(double) * ntab, (void**)&d_k)) return rc;
     if (int rc = get_ws(c, "i:y", sizeof(double) * ntab, (void**)&d_y)) return rc;
     if (int rc = get_ws(c, "i:m", sizeof(double) * ntab, (void**)&d_m)) return rc;
-    HIP_TRY(c, hipMemcpyAsync(d_frac, frac.data(), sizeof(double) * frac.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * cart.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(p.d_frac, p.frac.data(), sizeof(double) * p.frac.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(p.d_cart, p.cart.data(), sizeof(double) * p.cart.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(d_k, tab_k, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(d_y, tab_v, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_m, slopes.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, st));
-    RecpotTable tab{d_k, d_y, d_m, ntab, z_ion, 1.0 / (tab_k[1] - tab_k[0])};
-    cplx *sQ, *sF;
-    double* tmp;
-    if (int rc = spec_ws(c, "i:F", &sF)) return rc;
-    if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
-    const int sp_grid = grid_for(c->g.total);
-    std::vector<cplx> hb;
-    if (pme_order == 0) {
-        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)nullptr, sF, c->kg,
-                     (const cplx*)nullptr, (const cplx*)nullptr, (const cplx*)nullptr, (const double*)d_cart, nions, tab,
-                     1.0 / c->vol);
-    } else {
+    HIP_TRY(c, hipMemcpyAsync(d_m, p.slopes.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, st));
+    p.tab = RecpotTable{d_k, d_y, d_m, ntab, z_ion, 1.0 / (tab_k[1] - tab_k[0])};
+    if (pme_order != 0) {
         // b(m) = exp(2 pi i m (n-1)/N) / sum_i M_n(i) exp(2 pi i m (i-1)/N)        ion_utils.py:207-215
         std::vector<double> M(pme_order, 0.0);
-        M[0] = 0.0;
         M[1] = 1.0;
         for (int n = 3; n <= pme_order; ++n) {
-            for (int i = n - 1; i >= 1; --i) M[i] = ((0.0 + i) * M[i] + (n - 0.0 - i) * M[i - 1]) / (n - 1);
+            for (int i = n - 1; i >= 1; --i) M[i] = (i * M[i] + (double)(n - i) * M[i - 1]) / (n - 1);
             M[0] = 0.0;
         }
         const int cnt[3] = {c->n0, c->n1, c->g.nzc}, Ns[3] = {c->n0, c->n1, c->n2};
-        hb.resize((size_t)cnt[0] + cnt[1] + cnt[2]);
+        p.hb.resize((size_t)cnt[0] + cnt[1] + cnt[2]);
         size_t off = 0;
         for (int d = 0; d < 3; ++d) {
             for (int m = 0; m < cnt[d]; ++m) {
@@ -1735,26 +1732,116 @@ int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, cons
                 }
                 const double ph = 2.0 * kPi * m * (pme_order - 1.0) / Ns[d];
                 const double nr = std::cos(ph), ni = std::sin(ph), den = br * br + bi * bi;
-                hb[off + m] = make_double2((nr * br + ni * bi) / den, (ni * br - nr * bi) / den);
+                p.hb[off + m] = make_double2((nr * br + ni * bi) / den, (ni * br - nr * bi) / den);
             }
             off += cnt[d];
         }
         cplx* d_b;
-        if (int rc = get_ws(c, "i:b", sizeof(cplx) * hb.size(), (void**)&d_b)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(d_b, hb.data(), sizeof(cplx) * hb.size(), hipMemcpyHostToDevice, st));
+        if (int rc = get_ws(c, "i:b", sizeof(cplx) * p.hb.size(), (void**)&d_b)) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d_b, p.hb.data(), sizeof(cplx) * p.hb.size(), hipMemcpyHostToDevice, st));
+        p.d_b0 = d_b;
+        p.d_b1 = d_b + cnt[0];
+        p.d_b2 = d_b + cnt[0] + cnt[1];
+    }
+    return 0;
+}
+
+int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, const double* tab_k, const double* tab_v,
+                          int ntab, double z_ion, int pme_order, void* vext_dev, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !frac_host || !tab_k || !tab_v || !vext_dev) return OFDFT_EINVAL;
+    IonPrep p;
+    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
+    cplx *sQ, *sF;
+    double* tmp;
+    if (int rc = spec_ws(c, "i:F", &sF)) return rc;
+    if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
+    const int sp_grid = grid_for(c->g.total);
+    if (pme_order == 0) {
+        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)nullptr, sF, c->kg,
+                     (const cplx*)nullptr, (const cplx*)nullptr, (const cplx*)nullptr, (const double*)p.d_cart, nions, p.tab,
+                     1.0 / c->vol);
+    } else {
         if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
         HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
-        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)d_frac, nions, pme_order,
-                     tmp, c->n0, c->n1, c->n2);
+        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
+                     pme_order, tmp, c->n0, c->n1, c->n2);
         if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
         OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)sQ, sF, c->kg,
-                     (const cplx*)d_b, (const cplx*)(d_b + cnt[0]), (const cplx*)(d_b + cnt[0] + cnt[1]),
-                     (const double*)nullptr, nions, tab, 1.0 / c->vol);
+                     (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, (const double*)nullptr, nions, p.tab,
+                     1.0 / c->vol);
     }
     if (int rc = irfftn_internal(c, sF, tmp, 1.0, st)) return rc;              // norm='forward': no 1/N  (ion_utils.py:118)
     OFDFT_LAUNCH(c, st, "axpy", axpy_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)tmp, (double*)vext_dev,
                  c->npts, accumulate);
-    HIP_TRY(c, hipStreamSynchronize(st));      // host vectors above must outlive the async copies
+    HIP_TRY(c, hipStreamSynchronize(st));      // `p` (host staging) must outlive the async copies
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+// F_a = -dU/dR_a, U = int n v_ext for one species (the ion-electron part of System.forces, system.py:913-923)
+int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* frac_host, int nions, const double* tab_k,
+                              const double* tab_v, int ntab, double z_ion, int pme_order, double* forces_host,
+                              void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !den_dev || !frac_host || !tab_k || !tab_v || !forces_host) return OFDFT_EINVAL;
+    IonPrep p;
+    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
+    cplx *sN, *sT;
+    if (int rc = spec_ws(c, "i:Q", &sN)) return rc;
+    if (int rc = rfftn_internal(c, (const double*)den_dev, sN, st)) return rc;
+    const double pref = c->dV / c->vol;
+    if (pme_order == 0) {
+        const int kb = grid_for(c->g.total, kRedThreads, 64);
+        double* d_part;
+        std::vector<double> h((size_t)nions * kb * 3);
+        if (int rc = get_ws(c, "i:fpart", sizeof(double) * h.size(), (void**)&d_part)) return rc;
+        OFDFT_LAUNCH(c, st, "ion_force", ion_force_exact_kernel, dim3(kb, nions), dim3(kRedThreads), 0, (const cplx*)sN, c->kg,
+                     (const double*)p.d_cart, p.tab, d_part);
+        HIP_TRY(c, hipMemcpyAsync(h.data(), d_part, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int a = 0; a < nions; ++a)
+            for (int s3 = 0; s3 < 3; ++s3) {
+                long double t = 0.0L;
+                for (int b = 0; b < kb; ++b) t += h[((size_t)a * kb + b) * 3 + s3];
+                forces_host[3 * a + s3] = pref * (double)t;
+            }
+    } else {
+        double *theta, *d_G;
+        std::vector<double> G(3 * (size_t)nions);
+        if (int rc = spec_ws(c, "i:F", &sT)) return rc;
+        if (int rc = real_ws(c, "i:tmp", &theta)) return rc;
+        if (int rc = get_ws(c, "i:G", sizeof(double) * G.size(), (void**)&d_G)) return rc;
+        OFDFT_LAUNCH(c, st, "pme_theta", pme_theta_spec_kernel, dim3(grid_for(c->g.total)), dim3(256), 0, (const cplx*)sN, sT,
+                     c->kg, (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, p.tab, 1.0 / c->vol);
+        if (int rc = irfftn_internal(c, sT, theta, 1.0, st)) return rc;
+        OFDFT_LAUNCH(c, st, "pme_gather", pme_gather_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
+                     pme_order, (const double*)theta, c->n0, c->n1, c->n2, d_G);
+        HIP_TRY(c, hipMemcpyAsync(G.data(), d_G, sizeof(double) * G.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        // dU/dR_j = dV sum_d G_d N_d d(frac_d)/d(cart_j),  frac = cart @ inv(box)  ->  d frac_d / d cart_j = inv(box)[j][d]
+        const double* a9 = c->box;
+        const double det = a9[0] * (a9[4] * a9[8] - a9[5] * a9[7]) - a9[1] * (a9[3] * a9[8] - a9[5] * a9[6]) +
+                           a9[2] * (a9[3] * a9[7] - a9[4] * a9[6]);
+        double inv[9];
+        inv[0] = (a9[4] * a9[8] - a9[5] * a9[7]) / det;
+        inv[1] = (a9[2] * a9[7] - a9[1] * a9[8]) / det;
+        inv[2] = (a9[1] * a9[5] - a9[2] * a9[4]) / det;
+        inv[3] = (a9[5] * a9[6] - a9[3] * a9[8]) / det;
+        inv[4] = (a9[0] * a9[8] - a9[2] * a9[6]) / det;
+        inv[5] = (a9[2] * a9[3] - a9[0] * a9[5]) / det;
+        inv[6] = (a9[3] * a9[7] - a9[4] * a9[6]) / det;
+        inv[7] = (a9[1] * a9[6] - a9[0] * a9[7]) / det;
+        inv[8] = (a9[0] * a9[4] - a9[1] * a9[3]) / det;
+        const int Ns[3] = {c->n0, c->n1, c->n2};
+        for (int a = 0; a < nions; ++a)
+            for (int j = 0; j < 3; ++j) {
+                double t = 0.0;
+                for (int d = 0; d < 3; ++d) t += inv[3 * j + d] * Ns[d] * G[3 * a + d];
+                forces_host[3 * a + j] = -c->dV * t;
+            }
+    }
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
     return OFDFT_OK;

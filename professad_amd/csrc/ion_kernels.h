@@ -104,3 +104,119 @@ __global__ void axpy_kernel(const double* __restrict__ x, double* __restrict__ y
 }
 
 }  // namespace ofdft
+
+namespace ofdft {
+
+// Exact-structure-factor ion-electron forces: F_a = (dV/vol) sum_k w_k v~(k) k (cos(k.R) Im n^ + sin(k.R) Re n^)
+// (= -d/dR_a of dV sum_r n v_ext; reference system.py:913-923 by autograd).  grid = (k chunks, ions).
+__global__ __launch_bounds__(kRedThreads) void ion_force_exact_kernel(const cplx* __restrict__ nk, KGeom kg,
+                                                                      const double* __restrict__ cart, RecpotTable tab,
+                                                                      double* __restrict__ partial) {
+    const int a = blockIdx.y;
+    const double rx = cart[3 * a], ry = cart[3 * a + 1], rz = cart[3 * a + 2];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        int x, y, z;
+        spec_decode(kg.g, i, x, y, z);
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        if (k2 == 0.0) continue;
+        const double w = (z == 0 || ((kg.g.n2 & 1) == 0 && z == kg.g.n2 / 2)) ? 1.0 : 2.0;
+        double sn, cs;
+        sincos(kx * rx + ky * ry + kz * rz, &sn, &cs);
+        const cplx n = nk[i];
+        const double f = w * recpot_value(tab, sqrt(k2)) * (cs * n.y + sn * n.x);
+        acc[0] += kx * f;
+        acc[1] += ky * f;
+        acc[2] += kz * f;
+    }
+    // partial[(a * gridDim.x + blockIdx.x) * 3 + c]
+    __shared__ double red[kRedThreads / 64][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        double v = acc[s];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[s] = v;
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int s = 0; s < 3; ++s) red[threadIdx.x >> 6][s] = acc[s];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int s = 0; s < 3; ++s) {
+            double t = 0.0;
+            for (int w = 0; w < kRedThreads / 64; ++w) t += red[w][s];
+            partial[((long long)a * gridDim.x + blockIdx.x) * 3 + s] = t;
+        }
+}
+
+// theta^ = v~(k) conj(b(k) n^(k)) / vol  (the adjoint of the PME potential build applied to the density)
+__global__ void pme_theta_spec_kernel(const cplx* __restrict__ nk, cplx* __restrict__ out, KGeom kg,
+                                      const cplx* __restrict__ b0, const cplx* __restrict__ b1,
+                                      const cplx* __restrict__ b2, RecpotTable tab, double inv_vol) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        int x, y, z;
+        spec_decode(kg.g, i, x, y, z);
+        double kx, ky, kz, k2;
+        kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+        const cplx b = cmul(cmul(b0[x], b1[y]), b2[z]);
+        const cplx s = cconj(cmul(b, nk[i]));
+        const double f = recpot_value(tab, (k2 != 0.0) ? sqrt(k2) : 0.0) * inv_vol;
+        out[i] = make_double2(s.x * f, s.y * f);
+    }
+}
+
+// G[a][d] = sum over the ion's B-spline stencil of theta(l) * d/du_d (M0 M1 M2); one workgroup per ion
+__global__ __launch_bounds__(256) void pme_gather_kernel(const double* __restrict__ frac, int nion, int order,
+                                                         const double* __restrict__ theta, int n0, int n1, int n2,
+                                                         double* __restrict__ G) {
+    __shared__ double M[3][kMaxPmeOrder], D[3][kMaxPmeOrder];
+    __shared__ int L[3][kMaxPmeOrder];
+    __shared__ double red[4][3];
+    const int a = blockIdx.x;
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        const int N = d == 0 ? n0 : (d == 1 ? n1 : n2);
+        const double u = frac[3 * a + d] * N;
+        const long long fl = (long long)floor(u);
+        const double x = u - (double)fl;
+        double P[kMaxPmeOrder];
+        if (order > 2) {
+            bspline_values(x, order - 1, P);
+        } else {
+            P[0] = 1.0;              // M_1 = indicator of [0,1): M_1(x) = 1, M_1(x+1) = 0
+        }
+        bspline_values(x, order, M[d]);
+        for (int i = 0; i < order; ++i) {
+            const double hi = (i < order - 1) ? P[i] : 0.0, lo = (i > 0) ? P[i - 1] : 0.0;
+            D[d][i] = hi - lo;       // d/dx M_n(x+i) = M_{n-1}(x+i) - M_{n-1}(x+i-1)
+            long long l = (i - fl) % N;
+            if (l < 0) l += N;
+            L[d][i] = (int)l;
+        }
+    }
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int tot = order * order * order;
+    for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+        const int i2 = t % order, i1 = (t / order) % order, i0 = t / (order * order);
+        const double th = theta[((long long)L[0][i0] * n1 + L[1][i1]) * n2 + L[2][i2]];
+        acc[0] += th * D[0][i0] * M[1][i1] * M[2][i2];
+        acc[1] += th * M[0][i0] * D[1][i1] * M[2][i2];
+        acc[2] += th * M[0][i0] * M[1][i1] * D[2][i2];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        double v = acc[s];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        acc[s] = v;
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int s = 0; s < 3; ++s) red[threadIdx.x >> 6][s] = acc[s];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int s = 0; s < 3; ++s) G[3 * a + s] = red[0][s] + red[1][s] + red[2][s] + red[3][s];
+}
+
+}  // namespace ofdft

@@ -61,3 +61,24 @@ def ionic_potential(engine, box_vecs, species, pme_order=None):
                                               C.c_void_p(out.data_ptr()), 1 if i else 0, engine._stream())
         engine._check(rc, 'ofdft_ionic_potential')
     return out
+
+
+def ion_electron_forces(engine, box_vecs, den, species, pme_order=None):
+    """Forces F = -dU/dR of U = int n v_ext on every ion (Ha/bohr), species by species -> list of [n,3] arrays
+    (the IonElectron part of System.forces(), system.py:913-923)."""
+    engine.set_cell(box_vecs)
+    den = engine._grid_tensor(den, 'den')
+    dp = C.POINTER(C.c_double)
+    out = []
+    for frac, (ks, v, z) in species:
+        frac = np.ascontiguousarray(np.asarray(torch.as_tensor(frac).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 3))
+        ks = np.ascontiguousarray(ks, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        f = np.zeros_like(frac)
+        rc = engine.lib.ofdft_ion_electron_forces(engine._ctx, C.c_void_p(den.data_ptr()), frac.ctypes.data_as(dp), frac.shape[0],
+                                                  ks.ctypes.data_as(dp), v.ctypes.data_as(dp), ks.size, float(z),
+                                                  0 if pme_order is None else int(pme_order), f.ctypes.data_as(dp),
+                                                  engine._stream())
+        engine._check(rc, 'ofdft_ion_electron_forces')
+        out.append(f)
+    return out

@@ -290,6 +290,17 @@ def gen_ions():
                b_S_pme6=IU.structure_factor_spline(box_b, shape_b, cart_b, 6).resolve_conj().numpy(),
                b_v_exact=IU.lattice_sum(box_b, shape_b, cart_b, vkb, None).numpy(),
                b_v_pme6=IU.lattice_sum(box_b, shape_b, cart_b, vkb, 6).numpy())
+    # ion-electron forces F = -dU/dR by autograd through the potential build (system.py:913-923), fixed density
+    den_b = t(cases.synth.smooth_density(shape_b, seed=7, n0=0.05, amp=0.5))
+    den_a = t(cases.synth.smooth_density(shape, seed=8, n0=0.03, amp=0.5))
+    for tag, bx, shp, fr, vkk, dn, orders in (('a', box, shape, frac, vk, den_a, (None, 10)),
+                                             ('b', box_b, shape_b, frac_b, vkb, den_b, (None, 6))):
+        for order in orders:
+            cart_g = (fr @ bx).clone().requires_grad_()
+            U = F.IonElectron(bx, dn, IU.lattice_sum(bx, shp, cart_g, vkk, order))
+            out['%s_force_%s' % (tag, 'exact' if order is None else 'pme%d' % order)] = \
+                (-torch.autograd.grad(U, cart_g)[0]).numpy()
+            out['%s_U_%s' % (tag, 'exact' if order is None else 'pme%d' % order)] = np.float64(U.item())
     x = torch.linspace(0.0, 0.999, 7, dtype=DT)
     out['bspline_x'] = x.numpy()
     for order in (2, 3, 6, 10):

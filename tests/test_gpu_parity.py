@@ -323,3 +323,41 @@ def test_ionic_potential_matches_reference_golden():
     v = ionic_potential(eng, c1['box'], [(g['a_frac'], tab)]).cpu().numpy()
     assert relerr(v, c1['vext']) < 1e-10
     eng.close()
+
+
+def test_ion_electron_forces_match_reference_golden():
+    """-dU/dR on every ion (exact and PME) against the reference's autograd forces; plus a finite-difference check
+    of the forces against the engine's own ionic potential at a size the goldens do not cover."""
+    from professad_amd.ions import ion_electron_forces, ionic_potential, recpot_table
+    g = load('ions.npz')
+    tab = recpot_table(g['recpot_raw'], float(g['recpot_kmax']))
+    for tag, shape, order, dk in (('a', (32, 32, 32), 10, dict(seed=8, n0=0.03, amp=0.5)),
+                                  ('b', (16, 20, 24), 6, dict(seed=7, n0=0.05, amp=0.5))):
+        eng = Engine(shape, DEV)
+        den = torch.as_tensor(synth.smooth_density(shape, **dk), device=DEV)
+        for o in (None, order):
+            F = ion_electron_forces(eng, g[tag + '_box'], den, [(g[tag + '_frac'], tab)], pme_order=o)[0]
+            ref = g[tag + '_force_exact'] if o is None else g['%s_force_pme%d' % (tag, o)]
+            assert np.abs(F - ref).max() < 1e-12, (tag, o, np.abs(F - ref).max())
+        eng.close()
+    # 64^3, triclinic: central finite differences of U = dV sum n v_ext[R]
+    shape = (64, 64, 64)
+    box = synth.triclinic_cell(1.0)
+    frac = np.array([[0.03, 0.11, 0.52], [0.48, 0.57, 0.02], [0.71, 0.33, 0.80]])
+    den = torch.as_tensor(synth.smooth_density(shape, seed=3, n0=0.03, amp=0.4), device=DEV)
+    eng = Engine(shape, DEV)
+    dV = abs(np.linalg.det(box)) / np.prod(shape)
+    inv = np.linalg.inv(box)
+    for o in (None, 8):
+        F = ion_electron_forces(eng, box, den, [(frac, tab)], pme_order=o)[0]
+        h = 1e-4
+        for a, j in ((0, 0), (1, 2), (2, 1)):
+            U = []
+            for sgn in (+1, -1):
+                cart = frac @ box
+                cart[a, j] += sgn * h
+                v = ionic_potential(eng, box, [(cart @ inv, tab)], pme_order=o)
+                U.append(float((v * den).sum()) * dV)
+            fd = -(U[0] - U[1]) / (2 * h)
+            assert abs(fd - F[a, j]) < 2e-7 * max(1.0, abs(fd)), (o, a, j, fd, F[a, j])
+    eng.close()

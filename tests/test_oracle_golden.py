@@ -105,3 +105,18 @@ def test_ionic_potential_oracle():
     # the config-1 fixture's v_ext is this potential (reference System, exact structure factor)
     c1 = load('cfg1_fccAl_32.npz')
     assert relerr(oi.ionic_potential(c1['box'], (32, 32, 32), g['a_frac'], raw, kmax, None), c1['vext']) < 1e-10
+
+
+def test_ion_electron_forces_oracle():
+    """analytic force restatement against the reference's autograd forces (exact and PME structure factors)"""
+    from oracle import ions as oi
+    from professad_amd import synth
+    g = load('ions.npz')
+    raw, kmax = g['recpot_raw'], float(g['recpot_kmax'])
+    for tag, shape, order, dk in (('a', (32, 32, 32), 10, dict(seed=8, n0=0.03, amp=0.5)),
+                                  ('b', (16, 20, 24), 6, dict(seed=7, n0=0.05, amp=0.5))):
+        den = synth.smooth_density(shape, **dk)
+        for o in (None, order):
+            F = oi.ion_electron_forces(g[tag + '_box'], shape, g[tag + '_frac'], den, raw, kmax, o)
+            ref = g[tag + '_force_exact'] if o is None else g['%s_force_pme%d' % (tag, o)]
+            assert np.abs(F - ref).max() < 1e-13, (tag, o)
