@@ -32,7 +32,7 @@ struct ofdft_ctx {
     SpecGeom g{};      // spectrum geometry of the z and y passes (x-slab: n0 local, n1 global)
     SpecGeom gx{};     // spectrum geometry of the x pass (y-slab: n0 global, n1 local); == g on one GPU
     KGeom kg{};        // k-vectors in the x-pass geometry
-    SlabGeom sg{};
+    XchgGeom xg{};     // exchange-buffer layout of the slab-decomposed path (rec / chunk filled per stage)
     long long npts = 0;      // local points
     long long npts_g = 0;    // global points (normalisation, dV)
     bool fast = false, cell_set = false, force_unfused = false;
@@ -246,6 +246,38 @@ int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
 }
 
+// y pass of `narr` x-slab spectra straight into (forward) / out of (inverse) an all-to-all buffer
+template <int LEN, bool INV>
+int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    LineMap main, rem;
+    pass_maps(c, 1, main, rem);
+    XchgGeom xg = c->xg;
+    xg.rec = narr * xg.arr_sz;
+    xg.chunk = xg.nxl * xg.rec;
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, INV ? "ypass_recv" : "ypass_send", (ypass_xchg_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB),
+                 Cfg::LDS, arrs, buf, xg, main, rem, mb, c->g.main_count, tw);
+    return 0;
+}
+template <bool INV>
+int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st) {
+    const int narr = (int)list.size();
+    if (narr == 0) return 0;
+    if (narr > 16) return fail(c, OFDFT_EINVAL, "too many spectra in one exchange (%d)", narr);
+    ArrList arrs{};
+    for (int a = 0; a < narr; ++a) arrs.p[a] = list[a];
+#define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st);
+    switch (c->n1) {
+        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
+        OFDFT_CASE(1024)
+    }
+#undef OFDFT_CASE
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
+}
+
 template <int M>
 int launch_zfwd_t(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
     cplx *twM, *twN;
@@ -380,33 +412,48 @@ int inv_yz(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) 
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
+// where the x pass finds its spectra: {} = y-slab arrays in the block-8 layout (one GPU); otherwise the exchange
+// buffers of the slab-decomposed path (x-major records, see XchgGeom): element strides along x of the inputs, the
+// outputs and the k-point tables
+struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; };
+
 template <int LEN, int NIN, int NOUT, class Mix>
-int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
+int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
     using Cfg = XfCfg<LEN, G, NOUT>;
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     LineMap main, rem;
-    pass_maps(c, 0, main, rem);
+    SpecGeom gk = c->gx;
+    if (lay.se_in) {
+        const int nyl = c->xg.nyl;
+        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
+        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
+        if (main.nlines == 0) main.d = 1;
+        if (rem.nlines == 0) rem.d = 1;
+        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
+    } else {
+        pass_maps(c, 0, main, rem);
+    }
     main.lf = rem.lf = Cfg::LPW;
     const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
     OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
-                 c->gx, tw, mix);
+                 gk, tw, mix, XfStride{lay.se_out, lay.tse});
     return 0;
 }
 
 // forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
 template <int NIN, int NOUT, class Mix>
-int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm) {
+int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{}) {
     switch (c->n0g) {
-        case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 64: return launch_xfused_t<64, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 128: return launch_xfused_t<128, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, st, nm);
-        case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, st, nm);
+        case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 64: return launch_xfused_t<64, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 128: return launch_xfused_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
     }
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
 }
@@ -517,7 +564,8 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     K1 = w0 + 1;
     K2 = w0 + 2;
     K3 = w0 + 3;
-    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s);
+    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s,
+                 TabMap{c->nranks > 1 ? 1 : 0, c->xg.nyl, c->g.nzm, c->xg.arr_sz});
     c->wgc_key_nel = nel_rounded;
     c->wgc_valid = true;
     return 0;
@@ -996,11 +1044,14 @@ namespace {
 
 ZRun& zrun(ofdft_ctx* c);
 
+int dist_buffers(ofdft_ctx* c, cplx** send, cplx** recv);
+
 int zstage1(ofdft_ctx* c, hipStream_t st) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    const bool dx = c->nranks > 1;
     r.has_h = mask & OFDFT_HARTREE;
     r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
     r.has_vw = mask & OFDFT_VW;
@@ -1026,8 +1077,8 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
             HIP_TRY(c, hipEventRecord(c->ev_a, st));
             HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
         }
-        if (r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
-        if (r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
+        if (!dx && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+        if (!dx && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
         if (r.s_n) r.xlist.push_back(r.s_n);
         if (r.s_s) r.xlist.push_back(r.s_s);
     }
@@ -1046,7 +1097,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
         if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
         for (cplx* sp : {r.s_b, r.s_a}) {
             if (!sp) continue;
-            if ((rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
+            if (!dx && (rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
             r.xlist.push_back(sp);
         }
         r.za.wt_alpha = al;
@@ -1075,13 +1126,18 @@ int zstage1(ofdft_ctx* c, hipStream_t st) {
             HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
         }
         for (int i = 0; i < 6; ++i) {
-            if ((rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
+            if (!dx && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
             r.xlist.push_back(r.sw[i]);
         }
         r.za.wgc_alpha = al;
         r.za.wgc_beta = be;
         r.za.nref = nref;
         r.za.wgc_sum_53 = pa.sum53;
+    }
+    if (dx) {        // every y-forward in one launch, written in the exchange layout
+        cplx *send, *recv;
+        if ((rc = dist_buffers(c, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<false>(c, r.xlist, send, st))) return rc;
     }
     r.stage = 1;
     return 0;
@@ -1091,45 +1147,63 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
     ZRun& r = zrun(c);
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    // several ranks: the inputs sit in the receive buffer (slot = position in stage 1's list) and the outputs are
+    // written to the send buffer in the order they are listed here
+    const bool dx = c->nranks > 1;
+    const std::vector<cplx*> in_list = r.xlist;
     r.xlist.clear();
+    cplx *send = nullptr, *recv = nullptr;
+    XfLayout lay{};
+    if (dx) {
+        if ((rc = dist_buffers(c, &send, &recv))) return rc;
+        const int nout = (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0) + (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) +
+                         (r.has_wgc ? 6 : 0);
+        lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
+    }
+    auto in_of = [&](cplx* arr) -> cplx* {
+        if (!dx) return arr;
+        for (size_t i = 0; i < in_list.size(); ++i)
+            if (in_list[i] == arr) return recv + (long long)i * c->xg.arr_sz;
+        return nullptr;
+    };
+    auto out_of = [&](cplx* arr) -> cplx* {       // also records the array as crossing the next boundary
+        r.xlist.push_back(arr);
+        return dx ? send + (long long)(r.xlist.size() - 1) * c->xg.arr_sz : arr;
+    };
     if (r.s_n) {
         XfIo io{};
-        io.in[0] = r.s_n;
+        io.in[0] = in_of(r.s_n);
         int no = 0;
         if (r.has_h) {
             if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
-            io.out[no++] = r.s_vh;
-            r.xlist.push_back(r.s_vh);
+            io.out[no++] = out_of(r.s_vh);
         }
         if (r.has_g) {
             const char* gn[3] = {"zgx", "zgy", "zgz"};
             for (int k = 0; k < 3; ++k) {
                 if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
-                io.out[no++] = r.s_g[k];
-                r.xlist.push_back(r.s_g[k]);
+                io.out[no++] = out_of(r.s_g[k]);
             }
         }
-        if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n");
-        else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n");
-        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n");
+        if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
+        else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
+        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
         if (rc) return rc;
     }
     if (r.s_s) {
         XfIo io{};
-        io.in[0] = r.s_s;
-        io.out[0] = r.s_s;
-        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap"))) return rc;
-        r.xlist.push_back(r.s_s);
+        io.in[0] = in_of(r.s_s);
+        io.out[0] = out_of(r.s_s);
+        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap", lay))) return rc;
     }
     if (r.has_wt) {
         const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
         for (cplx* sp : {r.s_b, r.s_a}) {
             if (!sp) continue;
             XfIo io{};
-            io.in[0] = sp;
-            io.out[0] = sp;
-            if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind"))) return rc;
-            r.xlist.push_back(sp);
+            io.in[0] = in_of(sp);
+            io.out[0] = out_of(sp);
+            if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind", lay))) return rc;
         }
     }
     if (r.has_wgc) {
@@ -1137,12 +1211,11 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
         for (int half = 0; half < 2; ++half) {
             XfIo io{};
             for (int i = 0; i < 3; ++i) {
-                io.in[i] = r.sw[3 * half + i];
-                io.out[i] = r.sw[3 * half + i];
+                io.in[i] = in_of(r.sw[3 * half + i]);
+                io.out[i] = out_of(r.sw[3 * half + i]);
             }
-            if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc"))) return rc;
+            if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
         }
-        for (int i = 0; i < 6; ++i) r.xlist.push_back(r.sw[i]);
     }
     r.stage = 2;
     return 0;
@@ -1153,10 +1226,16 @@ int zstage3(ofdft_ctx* c, hipStream_t st) {
     int rc;
     // y-inverse of everything that came back from the x passes (each completes one c2r except grad n)
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    const bool dx = c->nranks > 1;
+    cplx *send = nullptr, *recv = nullptr;
+    if (dx) {        // one launch: every y-inverse, read from the exchange layout
+        if ((rc = dist_buffers(c, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<true>(c, r.xlist, recv, st))) return rc;
+    }
     for (cplx* sp : r.xlist) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
-        if ((rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) return rc;
+        if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) return rc;
         if (sp != r.s_g[0] && sp != r.s_g[1] && sp != r.s_g[2]) c->fft_count++;
     }
     r.xlist.clear();
@@ -1180,9 +1259,10 @@ int zstage3(ofdft_ctx* c, hipStream_t st) {
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
                      c->d_reduced + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
-            if ((rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
+            if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             r.xlist.push_back(r.s_g[k]);
         }
+        if (dx && (rc = ypass_xchg<false>(c, r.xlist, send, st))) return rc;
     }
     r.stage = 3;
     return 0;
@@ -1193,9 +1273,17 @@ int zstage4(ofdft_ctx* c, hipStream_t st) {
     r.xlist.clear();
     if (r.has_g) {
         XfIo dio{};
+        XfLayout lay{};
         for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
         dio.out[0] = r.s_n;      // n^ is no longer needed
-        if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div")) return rc;
+        if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0
+            cplx *send, *recv;
+            if (int rc = dist_buffers(c, &send, &recv)) return rc;
+            for (int k = 0; k < 3; ++k) dio.in[k] = recv + k * c->xg.arr_sz;
+            dio.out[0] = send;
+            lay = XfLayout{3 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+        }
+        if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div", lay)) return rc;
         r.xlist.push_back(r.s_n);
     }
     r.stage = 4;
@@ -1207,7 +1295,13 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     ZRun& r = zrun(c);
     int rc;
     if (r.has_g) {
-        if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) return rc;
+        if (c->nranks > 1) {
+            cplx *send, *recv;
+            if ((rc = dist_buffers(c, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
+        } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
+            return rc;
+        }
         c->fft_count++;
         r.za.div = r.s_n;
         r.za.dfdn = r.dfdn;
@@ -1260,33 +1354,13 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     return 0;
 }
 
-// ---- slab transpose helpers (multi-GPU): pack the stage's arrays for the all-to-all / unpack what came back
-int dist_buffers(ofdft_ctx* c, size_t narr, cplx** send, cplx** recv) {
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
+// ---- all-to-all buffers of the slab-decomposed path: room for the largest stage (13 spectra: Hartree, grad n,
+// vW, two Wang-Teter and six WGC99 results leaving stage 2); both directions reuse the same pair
+constexpr int kMaxXchgArrays = 13;
+int dist_buffers(ofdft_ctx* c, cplx** send, cplx** recv) {
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * kMaxXchgArrays;
     if (int rc = get_ws(c, "x:send", bytes, (void**)send)) return rc;
     return get_ws(c, "x:recv", bytes, (void**)recv);
-}
-int dist_pack(ofdft_ctx* c, int dir, hipStream_t st) {
-    ZRun& r = zrun(c);
-    cplx *send, *recv;
-    const int narr = (int)r.xlist.size();
-    if (narr == 0) return 0;
-    if (int rc = dist_buffers(c, 11, &send, &recv)) return rc;
-    for (int a = 0; a < narr; ++a)
-        OFDFT_LAUNCH(c, st, "slab_pack", slab_copy_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, r.xlist[a], send,
-                     c->sg, narr, a, dir);
-    return 0;
-}
-int dist_unpack(ofdft_ctx* c, int dir, hipStream_t st) {
-    ZRun& r = zrun(c);
-    cplx *send, *recv;
-    const int narr = (int)r.xlist.size();
-    if (narr == 0) return 0;
-    if (int rc = dist_buffers(c, 11, &send, &recv)) return rc;
-    for (int a = 0; a < narr; ++a)
-        OFDFT_LAUNCH(c, st, "slab_unpack", slab_copy_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, r.xlist[a], recv,
-                     c->sg, narr, a, dir);
-    return 0;
 }
 
 ZRun& zrun(ofdft_ctx* c) {
@@ -1355,9 +1429,10 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
         delete c;
         return fail(nullptr, OFDFT_EINVAL, "the slab-decomposed path needs power-of-two extents (n2 <= 1024)");
     }
-    c->sg.nxl = n0; c->sg.nyl = c->gx.n1; c->sg.nranks = nranks; c->sg.n0g = n0g; c->sg.n1g = n1g;
-    c->sg.nzm = g.nzm; c->sg.nrem = g.nzc - g.nzm;
-    c->sg.chunk = (long long)g.nzc * n0 * c->gx.n1;
+    c->xg.nxl = n0; c->xg.nyl = c->gx.n1; c->xg.nb = g.nzm / 8; c->xg.nrem = g.nzc - g.nzm;
+    c->xg.log_nyl = 0;
+    while ((1 << c->xg.log_nyl) < c->xg.nyl) c->xg.log_nyl++;
+    c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
     const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
@@ -1593,7 +1668,8 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     return OFDFT_OK;
 }
 
-// Runs stage `stage` (1..4): un-packs the previous exchange, does the stage's local work, packs its outputs.
+// Runs stage `stage` (1..4): its kernels read the previous exchange's receive buffer and write the send buffer
+// directly (exchange layout, see XchgGeom); there are no pack / un-pack copies.
 // On return *bytes_per_peer is the all-to-all message size (0: nothing to exchange) and the buffers to use.
 int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* bytes_per_peer, void** sendbuf,
                      void** recvbuf) {
@@ -1603,8 +1679,6 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* 
     ZRun& r = zrun(c);
     if (stage != r.stage + 1 || stage < 1 || stage > 4) return fail(c, OFDFT_ESTATE, "stage %d out of order", stage);
     int rc;
-    if (c->nranks > 1 && stage > 1)
-        if ((rc = dist_unpack(c, (stage % 2 == 0) ? 1 : 3, st))) return rc;
     switch (stage) {
         case 1: rc = zstage1(c, st); break;
         case 2: rc = zstage2(c, st); break;
@@ -1615,10 +1689,9 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* 
     *bytes_per_peer = 0;
     *sendbuf = *recvbuf = nullptr;
     if (c->nranks > 1 && !r.xlist.empty()) {
-        if ((rc = dist_pack(c, (stage % 2 == 1) ? 0 : 2, st))) return rc;
         cplx *send, *recv;
-        if ((rc = dist_buffers(c, 11, &send, &recv))) return rc;
-        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->sg.chunk * r.xlist.size());
+        if ((rc = dist_buffers(c, &send, &recv))) return rc;
+        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist.size());
         *sendbuf = send;
         *recvbuf = recv;
     }
@@ -1626,7 +1699,7 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* 
     return OFDFT_OK;
 }
 
-// Stage 5: un-pack the last exchange, combine; local_sums[11] = 9 combine scalars + PBE x, c (to be summed
+// Stage 5: y-inverse of the last exchange, combine; local_sums[11] = 9 combine scalars + PBE x, c (to be summed
 // over ranks by the caller, then turned into energies by ofdft_dist_energies).
 int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -1635,8 +1708,6 @@ int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     ZRun& r = zrun(c);
     if (r.stage != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4");
     int rc;
-    if (c->nranks > 1)
-        if ((rc = dist_unpack(c, 3, st))) return rc;
     if ((rc = zstage5(c, local_sums, st))) return rc;
     return end_call(c, st);
 }

@@ -108,6 +108,89 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(cplx* __restri
 }
 
 // ----------------------------------------------------------------------------------------------
+// y pass of the slab-decomposed path, writing / reading the all-to-all buffers directly (no pack / un-pack copies).
+// Exchange layout (the same for both directions, so the fused x pass can work in place on what it received):
+//   buffer = [peer][xl][array][ main: (b, yl, kin) | planes: (plane, yl) ]      xl: x inside a rank's x-slab
+// i.e. per (peer, xl) one record of `narr` arrays of arr_sz = nb*nyl*8 + nrem*nyl elements.  On the y-slab rank
+// (peer-major == x-major) this is a regular [x][array][...] array whose x lines have stride `rec`; on the x-slab
+// rank a y line is piecewise: y = peer*nyl + yl.
+struct XchgGeom {
+    int nxl, nyl, log_nyl, nb, nrem;
+    long long arr_sz;      // elements of one array in one x-plane record
+    long long rec;         // narr * arr_sz
+    long long chunk;       // nxl * rec: elements per peer
+};
+struct ArrList { cplx* p[16]; };
+
+template <int LEN, bool INV>
+__global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList arrs, cplx* __restrict__ buf, XchgGeom xg,
+                                                                       LineMap m_main, LineMap m_rem, int main_blocks,
+                                                                       long long rem_offset,
+                                                                       const cplx* __restrict__ tw) {
+    constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int a = blockIdx.y;
+    const bool in_rem = (int)blockIdx.x >= main_blocks;
+    const LineMap m = in_rem ? m_rem : m_main;
+    cplx* data = arrs.p[a] + (in_rem ? rem_offset : 0);
+    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    const int l_lo = tid % m.lf;
+    const int j = (tid / m.lf) % P;
+    const int l = (tid / (m.lf * P)) * m.lf + l_lo;
+    const long long L0 = (long long)bid * LPW;
+    const long long L = L0 + l;
+    const bool valid = L < m.nlines;
+    const long long b0 = uniform64(line_base(m, L0));
+    cplx* ub = data + b0;
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const long long qstep = uniform64((long long)P * m.se);
+    // buffer side: line part (per lane) and element part (y = j + P*q -> peer, yl)
+    long long lb;
+    int es;
+    if (!in_rem) {               // L = (b*nxl + xl)*8 + kin
+        const long long r = L >> 3;
+        const int kin = (int)(L & 7), xl = (int)(r % xg.nxl);
+        const long long b = r / xg.nxl;
+        lb = xl * xg.rec + a * xg.arr_sz + ((b << xg.log_nyl) << 3) + kin;
+        es = 8;
+    } else {                     // L = plane*nxl + xl
+        const int xl = (int)(L % xg.nxl);
+        const long long plane = L / xg.nxl;
+        lb = xl * xg.rec + a * xg.arr_sz + (((long long)xg.nb << xg.log_nyl) << 3) + (plane << xg.log_nyl);
+        es = 1;
+    }
+    const int ymask = xg.nyl - 1;
+    cplx v[E];
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            if (INV) {
+                const int e = j + P * q;
+                v[q] = buf[lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es];
+            } else {
+                v[q] = buf_load_c(ub + q * qstep, voff);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+    }
+    line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            if (INV) {
+                buf_store_c(ub + q * qstep, voff, v[q]);
+            } else {
+                const int e = j + P * q;
+                buf[lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es] = v[q];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // z pass, forward r2c: real rows [nrows][N2] -> half spectrum.  M = N2/2.
 template <int M> struct ZCfg {
     static constexpr int P = Plan<M>::P;
@@ -457,9 +540,14 @@ __device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E]
 #ifndef OFDFT_XF_MINWAVES
 #define OFDFT_XF_MINWAVES 1
 #endif
+// strides of the output arrays and of k-point tables along the line when they differ from the inputs' (0: the same).
+// Used by the slab-decomposed path, where inputs and outputs live in exchange buffers with different record sizes.
+struct XfStride { long long se_out, tse; };
+
 template <int LEN, int NIN, int NOUT, class Mix>
 __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB), OFDFT_XF_MINWAVES) void xfused_kernel(
-    XfIo io, LineMap m_main, LineMap m_rem, int main_blocks, SpecGeom g, const cplx* __restrict__ tw, Mix mix) {
+    XfIo io, LineMap m_main, LineMap m_rem, int main_blocks, SpecGeom g, const cplx* __restrict__ tw, Mix mix,
+    XfStride xs) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
     using Cfg = XfCfg<LEN, G, NOUT>;
     constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = LineBuf<LEN>::STRIDE;
@@ -497,6 +585,10 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     const long long b0 = uniform64(region + line_base(m, L0));                 // wave-uniform
     const unsigned voff = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * m.se) * 16) : 0u;
     const long long qstep = uniform64((long long)P * m.se);
+    const long long se_o = xs.se_out ? xs.se_out : m.se, se_t = xs.tse ? xs.tse : m.se;
+    const unsigned voff_o = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * se_o) * 16) : 0u;
+    const unsigned tloff = valid ? (unsigned)(base - line_base(m, L0) + (long long)j * se_t) : 0u;
+    const long long qstep_o = uniform64((long long)P * se_o), tqstep = uniform64((long long)P * se_t);
     cplx v[E];
     if (valid && grp < NIN) {
         // the group index is wave-uniform only when a group is a whole number of waves; select the pointer
@@ -514,7 +606,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     cplx o[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) o[q] = make_double2(0.0, 0.0);
-    XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, qstep, voff >> 4};
+    XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, tqstep, tloff};
     // ---- mix in two halves of the k-points (x < LEN/2, then the rest): the line buffer holds the real parts of a
     // half at [0, LEN/2) and the imaginary parts at [LEN/2, LEN)
     static_assert(E % 2 == 0, "points per thread must be even");
@@ -538,7 +630,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     if (valid && grp < NOUT) {
         cplx* ub = xf_pick(io.out, grp) + b0;
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c(ub + q * qstep, voff, o[q]);
+        for (int q = 0; q < E; ++q) buf_store_c(ub + q * qstep_o, voff_o, o[q]);
     }
 }
 

@@ -201,11 +201,22 @@ struct WgcSeries {
     int nt;
 };
 
+// where the k-point tables live when the x pass works on exchange buffers (slab-decomposed path): x-major records
+// [x][ main (b, yl, kin) | planes (plane, yl) ] of arr_sz elements, the one-array form of the exchange layout
+struct TabMap { int on, nyl, nzm; long long arr_sz; };
+
 __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ K1o, double* __restrict__ K2o,
-                                 double* __restrict__ K3o, KGeom kg, WgcSeries s) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+                                 double* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
+    for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < kg.g.total; ii += (long long)gridDim.x * blockDim.x) {
         double kx, ky, kz, k2;
-        kvec(kg, i, kx, ky, kz, k2);
+        kvec(kg, ii, kx, ky, kz, k2);
+        long long i = ii;
+        if (tm.on) {
+            int x, y, z;
+            spec_decode(kg.g, ii, x, y, z);
+            i = x * tm.arr_sz + (z < tm.nzm ? (((long long)(z >> 3) * tm.nyl + y) * 8 + (z & 7))
+                                            : ((long long)tm.nzm * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y));
+        }
         const double eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
         if (eta != 0.0) {
@@ -331,54 +342,6 @@ struct MixWgc {
         return (O + I == 0) ? pr.x : ((O + I == 1) ? pr.y : ((O == 1) ? pr.y : pr.x));
     }
 };
-
-// ---- slab transpose (multi-GPU): x-slab spectrum [b][xl][y][8] (+ planes [xl][y]) <-> y-slab [b][x][yl][8].
-// The exchange buffer is [peer][array][chunk], chunk = the (xl, yl) sub-block in block-8 order:
-//   main (b, xl, yl, kin) -> ((b*nxl + xl)*nyl + yl)*8 + kin ;  planes (p, xl, yl) -> main_chunk + (p*nxl + xl)*nyl + yl
-struct SlabGeom {
-    int nxl, nyl, nranks;      // local x extent in x-slab form, local y extent in y-slab form
-    int n0g, n1g, nzm, nrem;   // global extents, blocked kz count, remainder planes
-    long long chunk;           // elements per (peer, array)
-};
-// dir 0: x-slab array -> send buffer (peer = y / nyl);   dir 1: recv buffer -> y-slab array (peer = x / nxl)
-// dir 2: y-slab array -> send buffer (peer = x / nxl);   dir 3: recv buffer -> x-slab array (peer = y / nyl)
-__global__ void slab_copy_kernel(cplx* __restrict__ arr, cplx* __restrict__ buf, SlabGeom sg, int narr, int a, int dir) {
-    const long long total = (long long)(sg.nzm + sg.nrem) * sg.nxl * sg.nyl * sg.nranks;   // local elements
-    const long long main_chunk = (long long)sg.nzm * sg.nxl * sg.nyl;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        // enumerate (peer, chunk offset): i = peer*chunk + off
-        const int peer = (int)(i / sg.chunk);
-        const long long off = i % sg.chunk;
-        int b, xl, yl, kin;
-        bool in_main = off < main_chunk;
-        if (in_main) {
-            kin = (int)(off & 7);
-            const long long r = off >> 3;
-            yl = (int)(r % sg.nyl);
-            xl = (int)((r / sg.nyl) % sg.nxl);
-            b = (int)(r / ((long long)sg.nyl * sg.nxl));
-        } else {
-            const long long r = off - main_chunk;
-            kin = 0;
-            yl = (int)(r % sg.nyl);
-            xl = (int)((r / sg.nyl) % sg.nxl);
-            b = (int)(r / ((long long)sg.nyl * sg.nxl));      // plane index
-        }
-        cplx* pb = buf + ((long long)peer * narr + a) * sg.chunk + off;
-        long long ai;
-        if (dir == 0 || dir == 3) {           // x-slab array: [b][xl][y][8], y = peer*nyl + yl, rows = nxl*n1g
-            const long long rows = (long long)sg.nxl * sg.n1g;
-            const long long row = (long long)xl * sg.n1g + (long long)peer * sg.nyl + yl;
-            ai = in_main ? ((long long)b * rows + row) * 8 + kin : (long long)sg.nzm * rows + (long long)b * rows + row;
-        } else {                              // y-slab array: [b][x][yl][8], x = peer*nxl + xl, rows = n0g*nyl
-            const long long rows = (long long)sg.n0g * sg.nyl;
-            const long long row = ((long long)peer * sg.nxl + xl) * sg.nyl + yl;
-            ai = in_main ? ((long long)b * rows + row) * 8 + kin : (long long)sg.nzm * rows + (long long)b * rows + row;
-        }
-        if (dir == 0 || dir == 2) *pb = arr[ai];
-        else arr[ai] = *pb;
-    }
-}
 
 // ---- XC pointwise math -------------------------------------------------------------------------
 // PW92 eps_c(rs) and d eps_c / d rs (functionals.py:1524-1530; tests/tools_for_tests.py:136-144)
