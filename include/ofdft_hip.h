@@ -109,18 +109,21 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
 /* ---- slab-decomposed evaluation over several GPUs (one process per GPU) --------------------
  * Rank r of P owns the real-space x-slab [n0/P][n1][n2].  The evaluation is cut at the four points where the
  * spectra change between the x-slab geometry (z, y passes) and the y-slab geometry (x pass); at each one the
- * engine packs the arrays, the HOST does one equal-split all-to-all (RCCL through torch.distributed) from
- * sendbuf to recvbuf, and the next call un-packs.  Sequence per evaluation:
+ * engine's kernels leave the spectra in sendbuf in the exchange layout, the HOST does one equal-split all-to-all
+ * (RCCL through torch.distributed) from sendbuf to recvbuf, and the next stage's kernels read recvbuf directly.
+ * The work is two independent chains (0: density / Hartree / vW / PBE, 1: nonlocal KEDF) with their own buffers, so
+ * one chain's all-to-all can be in flight while the other chain computes.  Sequence per evaluation:
  *     ofdft_dist_sumsq (closure form only) -> all-reduce -> c = N_e / (mean chi^2 vol)
- *     ofdft_dist_begin; for stage in 1..4: ofdft_dist_stage + all_to_all(bytes_per_peer);
- *     ofdft_dist_finish -> all-reduce of 11 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
+ *     ofdft_dist_begin; for stage in 1..4, for chain in 0..1: [wait for the chain's previous all-to-all]
+ *         ofdft_dist_stage(stage, chain) + all_to_all(bytes_per_peer)  (asynchronous if the transport allows);
+ *     [wait for both] ofdft_dist_finish -> all-reduce of 11 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
  * With nranks == 1 the same calls work and every bytes_per_peer is 0.  These stand behind the same reference
  * interfaces as ofdft_energy_potential / ofdft_energy_grad_chi (system.py:830-838, functional_tools.py:9-31). */
 int  ofdft_create_dist(ofdft_ctx** out, int n0_global, int n1_global, int n2, int dtype, int device_id, int nranks, int rank);
 int  ofdft_dist_sumsq(ofdft_ctx* ctx, const void* x_local_dev, int square, double* local_sum_host, void* stream);
 int  ofdft_dist_begin(ofdft_ctx* ctx, const void* src_local_dev, int from_chi, double cscale, double n_electrons_global,
                       const void* vext_local_dev, void* v_out_local_dev, void* stream);
-int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
+int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
                       void** recvbuf_dev);
 int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[11]*/, void* stream);
 int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[11]*/, double* E_terms_host, double* vn_integral);

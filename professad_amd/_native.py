@@ -84,7 +84,7 @@ def load():
     lib.ofdft_dist_sumsq.restype = ip
     lib.ofdft_dist_begin.argtypes = [vp, vp, ip, C.c_double, C.c_double, vp, vp, vp]
     lib.ofdft_dist_begin.restype = ip
-    lib.ofdft_dist_stage.argtypes = [vp, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
+    lib.ofdft_dist_stage.argtypes = [vp, ip, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
     lib.ofdft_dist_stage.restype = ip
     lib.ofdft_dist_finish.argtypes = [vp, dp, vp]
     lib.ofdft_dist_finish.restype = ip

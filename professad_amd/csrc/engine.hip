@@ -1030,8 +1030,12 @@ struct ZRun {
     cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* dfdn = nullptr;
     double wt_pref = 0.0, wt_kf = 1.0;
-    std::vector<cplx*> xlist;      // arrays that cross the next geometry boundary
-    int stage = 0;
+    // The evaluation is two independent chains that meet only in the combine kernel:
+    //   chain 0: density spectrum -> Hartree, grad n -> PBE -> divergence;  sqrt(n) -> Laplacian (vW)
+    //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
+    // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
+    std::vector<cplx*> xlist[2];
+    int stage[2] = {0, 0};
     int combine_blocks = 0, pbe_blocks = 0;
     hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
     hipStream_t sc = nullptr;      // second side stream: vW chain and the second half of the WGC99 chain
@@ -1044,120 +1048,133 @@ namespace {
 
 ZRun& zrun(ofdft_ctx* c);
 
-int dist_buffers(ofdft_ctx* c, cplx** send, cplx** recv);
+// ---- all-to-all buffers of the slab-decomposed path, one pair per chain (both directions reuse the pair):
+// chain 0 carries at most 5 spectra (Hartree, grad n, vW leaving stage 2), chain 1 at most 8 (2 Wang-Teter + 6 WGC99)
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * (chain == 0 ? 5 : 8);
+    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
+    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
+}
 
-int zstage1(ofdft_ctx* c, hipStream_t st) {
+// Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.
+int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     const bool dx = c->nranks > 1;
-    r.has_h = mask & OFDFT_HARTREE;
-    r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
-    r.has_vw = mask & OFDFT_VW;
-    r.has_wt = mask & OFDFT_WT_NL;
-    r.has_wgc = mask & OFDFT_WGC99_NL;
-    r.xlist.clear();
-    r.za = ZCombineArgs{};
-    r.za.ds = r.ds;
-    r.za.vext = r.vext;
-    r.za.v_out = r.v_out;
-    r.za.mask = mask;
-    r.za.inv_n = 1.0 / (double)c->npts_g;
-    r.pbe_sums[0] = r.pbe_sums[1] = 0.0;
-    r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
-    if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
-    if (r.has_h || r.has_g)
-        if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
-    if (r.has_vw)
-        if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
-    if (r.s_n || r.s_s) {
-        if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) return rc;
-        if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
-            HIP_TRY(c, hipEventRecord(c->ev_a, st));
-            HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
+    std::vector<cplx*>& xl = r.xlist[chain];
+    xl.clear();
+    if (chain == 0) {
+        r.has_h = mask & OFDFT_HARTREE;
+        r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
+        r.has_vw = mask & OFDFT_VW;
+        r.has_wt = mask & OFDFT_WT_NL;
+        r.has_wgc = mask & OFDFT_WGC99_NL;
+        r.za = ZCombineArgs{};
+        r.za.ds = r.ds;
+        r.za.vext = r.vext;
+        r.za.v_out = r.v_out;
+        r.za.mask = mask;
+        r.za.inv_n = 1.0 / (double)c->npts_g;
+        r.pbe_sums[0] = r.pbe_sums[1] = 0.0;
+        r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
+        if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+        if (r.has_h || r.has_g)
+            if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
+        if (r.has_vw)
+            if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
+        if (r.s_n || r.s_s) {
+            if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) return rc;
+            if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
+                HIP_TRY(c, hipEventRecord(c->ev_a, st));
+                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
+            }
+            if (!dx && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+            if (!dx && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
+            if (r.s_n) xl.push_back(r.s_n);
+            if (r.s_s) xl.push_back(r.s_s);
         }
-        if (!dx && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
-        if (!dx && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
-        if (r.s_n) r.xlist.push_back(r.s_n);
-        if (r.s_s) r.xlist.push_back(r.s_s);
+    } else {
+        if (r.has_wt) {
+            const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+            const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
+            r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
+            r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+            if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
+            if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
+            PowersArgs pa{};
+            pa.out[0] = r.s_b;
+            pa.out[3] = r.s_a;
+            pa.e0 = be;
+            pa.e1 = al;
+            if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
+            for (cplx* sp : {r.s_b, r.s_a}) {
+                if (!sp) continue;
+                if (!dx && (rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
+                xl.push_back(sp);
+            }
+            r.za.wt_alpha = al;
+            r.za.wt_beta = be;
+            r.za.wt_nbar_pa = std::pow(nbar, al);
+            r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+        }
+        if (r.has_wgc) {
+            const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+            const long long nel_r = std::llround(r.nel);                         // functionals.py:952
+            double nref;
+            if ((rc = ensure_wgc_tables(c, nel_r, sb, &nref))) return rc;
+            const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
+            PowersArgs pa{};
+            for (int i = 0; i < 6; ++i) {
+                if ((rc = spec_ws(c, wn[i], &r.sw[i]))) return rc;
+                pa.out[i] = r.sw[i];
+            }
+            pa.e0 = be;
+            pa.e1 = al;
+            pa.nref = nref;
+            pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+            if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
+            if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
+                HIP_TRY(c, hipEventRecord(c->ev_b, sb));
+                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
+            }
+            for (int i = 0; i < 6; ++i) {
+                if (!dx && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
+                xl.push_back(r.sw[i]);
+            }
+            r.za.wgc_alpha = al;
+            r.za.wgc_beta = be;
+            r.za.nref = nref;
+            r.za.wgc_sum_53 = pa.sum53;
+        }
     }
-    if (r.has_wt) {
-        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-        const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
-        r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-        if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
-        if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
-        PowersArgs pa{};
-        pa.out[0] = r.s_b;
-        pa.out[3] = r.s_a;
-        pa.e0 = be;
-        pa.e1 = al;
-        if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
-        for (cplx* sp : {r.s_b, r.s_a}) {
-            if (!sp) continue;
-            if (!dx && (rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
-            r.xlist.push_back(sp);
-        }
-        r.za.wt_alpha = al;
-        r.za.wt_beta = be;
-        r.za.wt_nbar_pa = std::pow(nbar, al);
-        r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
-    }
-    if (r.has_wgc) {
-        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
-        const long long nel_r = std::llround(r.nel);                         // functionals.py:952
-        double nref;
-        if ((rc = ensure_wgc_tables(c, nel_r, sb, &nref))) return rc;
-        const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
-        PowersArgs pa{};
-        for (int i = 0; i < 6; ++i) {
-            if ((rc = spec_ws(c, wn[i], &r.sw[i]))) return rc;
-            pa.out[i] = r.sw[i];
-        }
-        pa.e0 = be;
-        pa.e1 = al;
-        pa.nref = nref;
-        pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
-        if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
-        if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
-            HIP_TRY(c, hipEventRecord(c->ev_b, sb));
-            HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
-        }
-        for (int i = 0; i < 6; ++i) {
-            if (!dx && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
-            r.xlist.push_back(r.sw[i]);
-        }
-        r.za.wgc_alpha = al;
-        r.za.wgc_beta = be;
-        r.za.nref = nref;
-        r.za.wgc_sum_53 = pa.sum53;
-    }
-    if (dx) {        // every y-forward in one launch, written in the exchange layout
+    if (dx && !xl.empty()) {        // the chain's y-forwards in one launch, written in the exchange layout
         cplx *send, *recv;
-        if ((rc = dist_buffers(c, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<false>(c, r.xlist, send, st))) return rc;
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
     }
-    r.stage = 1;
+    r.stage[chain] = 1;
     return 0;
 }
 
-int zstage2(ofdft_ctx* c, hipStream_t st) {
+// Stage 2: the fused x passes (forward x, k-space mixing, inverse x).
+int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
     ZRun& r = zrun(c);
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
-    // several ranks: the inputs sit in the receive buffer (slot = position in stage 1's list) and the outputs are
-    // written to the send buffer in the order they are listed here
+    // several ranks: the inputs sit in the chain's receive buffer (slot = position in stage 1's list) and the
+    // outputs are written to its send buffer in the order they are listed here
     const bool dx = c->nranks > 1;
-    const std::vector<cplx*> in_list = r.xlist;
-    r.xlist.clear();
+    std::vector<cplx*>& xl = r.xlist[chain];
+    const std::vector<cplx*> in_list = xl;
+    xl.clear();
     cplx *send = nullptr, *recv = nullptr;
     XfLayout lay{};
     if (dx) {
-        if ((rc = dist_buffers(c, &send, &recv))) return rc;
-        const int nout = (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0) + (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) +
-                         (r.has_wgc ? 6 : 0);
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0)
+                                    : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
         lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
     }
     auto in_of = [&](cplx* arr) -> cplx* {
@@ -1167,89 +1184,98 @@ int zstage2(ofdft_ctx* c, hipStream_t st) {
         return nullptr;
     };
     auto out_of = [&](cplx* arr) -> cplx* {       // also records the array as crossing the next boundary
-        r.xlist.push_back(arr);
-        return dx ? send + (long long)(r.xlist.size() - 1) * c->xg.arr_sz : arr;
+        xl.push_back(arr);
+        return dx ? send + (long long)(xl.size() - 1) * c->xg.arr_sz : arr;
     };
-    if (r.s_n) {
-        XfIo io{};
-        io.in[0] = in_of(r.s_n);
-        int no = 0;
-        if (r.has_h) {
-            if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
-            io.out[no++] = out_of(r.s_vh);
+    if (chain == 0) {
+        if (r.s_n) {
+            XfIo io{};
+            io.in[0] = in_of(r.s_n);
+            int no = 0;
+            if (r.has_h) {
+                if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
+                io.out[no++] = out_of(r.s_vh);
+            }
+            if (r.has_g) {
+                const char* gn[3] = {"zgx", "zgy", "zgz"};
+                for (int k = 0; k < 3; ++k) {
+                    if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
+                    io.out[no++] = out_of(r.s_g[k]);
+                }
+            }
+            if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
+            else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
+            else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
+            if (rc) return rc;
         }
-        if (r.has_g) {
-            const char* gn[3] = {"zgx", "zgy", "zgz"};
-            for (int k = 0; k < 3; ++k) {
-                if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
-                io.out[no++] = out_of(r.s_g[k]);
+        if (r.s_s) {
+            XfIo io{};
+            io.in[0] = in_of(r.s_s);
+            io.out[0] = out_of(r.s_s);
+            if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap", lay))) return rc;
+        }
+    } else {
+        if (r.has_wt) {
+            const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
+            for (cplx* sp : {r.s_b, r.s_a}) {
+                if (!sp) continue;
+                XfIo io{};
+                io.in[0] = in_of(sp);
+                io.out[0] = out_of(sp);
+                if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind", lay))) return rc;
             }
         }
-        if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
-        else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
-        else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
-        if (rc) return rc;
-    }
-    if (r.s_s) {
-        XfIo io{};
-        io.in[0] = in_of(r.s_s);
-        io.out[0] = out_of(r.s_s);
-        if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap", lay))) return rc;
-    }
-    if (r.has_wt) {
-        const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
-        for (cplx* sp : {r.s_b, r.s_a}) {
-            if (!sp) continue;
-            XfIo io{};
-            io.in[0] = in_of(sp);
-            io.out[0] = out_of(sp);
-            if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind", lay))) return rc;
-        }
-    }
-    if (r.has_wgc) {
-        const MixWgc mix{(double*)c->ws["t:wgc"].p};
-        for (int half = 0; half < 2; ++half) {
-            XfIo io{};
-            for (int i = 0; i < 3; ++i) {
-                io.in[i] = in_of(r.sw[3 * half + i]);
-                io.out[i] = out_of(r.sw[3 * half + i]);
+        if (r.has_wgc) {
+            const MixWgc mix{(double*)c->ws["t:wgc"].p};
+            for (int half = 0; half < 2; ++half) {
+                XfIo io{};
+                for (int i = 0; i < 3; ++i) {
+                    io.in[i] = in_of(r.sw[3 * half + i]);
+                    io.out[i] = out_of(r.sw[3 * half + i]);
+                }
+                if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
             }
-            if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
         }
     }
-    r.stage = 2;
+    r.stage[chain] = 2;
     return 0;
 }
 
-int zstage3(ofdft_ctx* c, hipStream_t st) {
+// Stage 3: y-inverse of what came back from the x passes (each completes one c2r except grad n); chain 0 then runs
+// the PBE mid stage on chip and starts the three r2c of the flux.
+int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     ZRun& r = zrun(c);
     int rc;
-    // y-inverse of everything that came back from the x passes (each completes one c2r except grad n)
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     const bool dx = c->nranks > 1;
+    std::vector<cplx*>& xl = r.xlist[chain];
     cplx *send = nullptr, *recv = nullptr;
-    if (dx) {        // one launch: every y-inverse, read from the exchange layout
-        if ((rc = dist_buffers(c, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<true>(c, r.xlist, recv, st))) return rc;
+    if (dx && !xl.empty()) {        // one launch: the chain's y-inverses, read from the exchange layout
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<true>(c, xl, recv, st))) return rc;
     }
-    for (cplx* sp : r.xlist) {
+    for (cplx* sp : xl) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
         if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) return rc;
         if (sp != r.s_g[0] && sp != r.s_g[1] && sp != r.s_g[2]) c->fft_count++;
     }
-    r.xlist.clear();
+    xl.clear();
+    if (chain == 1) {
+        if (r.has_wt) {
+            r.za.conv_b = r.s_b;
+            r.za.conv_a = r.s_a;
+        }
+        if (r.has_wgc)
+            for (int i = 0; i < 3; ++i) {
+                r.za.u[i] = r.sw[i];
+                r.za.gw[i] = r.sw[3 + i];
+            }
+        r.stage[1] = 3;
+        return 0;
+    }
     if (r.has_h) r.za.vh = r.s_vh;
     if (r.s_s) r.za.lap = r.s_s;
-    if (r.has_wt) {
-        r.za.conv_b = r.s_b;
-        r.za.conv_a = r.s_a;
-    }
-    if (r.has_wgc)
-        for (int i = 0; i < 3; ++i) {
-            r.za.u[i] = r.sw[i];
-            r.za.gw[i] = r.sw[3 + i];
-        }
     if (r.has_g) {
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
         if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
@@ -1260,33 +1286,37 @@ int zstage3(ofdft_ctx* c, hipStream_t st) {
                      c->d_reduced + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
             if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
-            r.xlist.push_back(r.s_g[k]);
+            xl.push_back(r.s_g[k]);
         }
-        if (dx && (rc = ypass_xchg<false>(c, r.xlist, send, st))) return rc;
+        if (dx) {
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+        }
     }
-    r.stage = 3;
+    r.stage[0] = 3;
     return 0;
 }
 
-int zstage4(ofdft_ctx* c, hipStream_t st) {
+// Stage 4: fused x pass of the divergence (chain 0 only).
+int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
     ZRun& r = zrun(c);
-    r.xlist.clear();
-    if (r.has_g) {
+    r.xlist[chain].clear();
+    if (chain == 0 && r.has_g) {
         XfIo dio{};
         XfLayout lay{};
         for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
         dio.out[0] = r.s_n;      // n^ is no longer needed
         if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0
             cplx *send, *recv;
-            if (int rc = dist_buffers(c, &send, &recv)) return rc;
+            if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
             for (int k = 0; k < 3; ++k) dio.in[k] = recv + k * c->xg.arr_sz;
             dio.out[0] = send;
             lay = XfLayout{3 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
         }
         if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div", lay)) return rc;
-        r.xlist.push_back(r.s_n);
+        r.xlist[0].push_back(r.s_n);
     }
-    r.stage = 4;
+    r.stage[chain] = 4;
     return 0;
 }
 
@@ -1297,7 +1327,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     if (r.has_g) {
         if (c->nranks > 1) {
             cplx *send, *recv;
-            if ((rc = dist_buffers(c, &send, &recv))) return rc;
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
             if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
         } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
             return rc;
@@ -1306,7 +1336,8 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
         r.za.div = r.s_n;
         r.za.dfdn = r.dfdn;
     }
-    r.xlist.clear();
+    r.xlist[0].clear();
+    r.xlist[1].clear();
     if (r.forked) {       // the combine needs both chains
         HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1320,7 +1351,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     HIP_TRY(c, hipStreamSynchronize(st));
     for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
     if (!r.has_g) sums[kCombineScalars] = sums[kCombineScalars + 1] = 0.0;
-    r.stage = 5;
+    r.stage[0] = r.stage[1] = 5;
     return 0;
 }
 
@@ -1333,8 +1364,8 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     r.v_out = v_out;
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     int rc;
-    // two independent chains meet only in the combine kernel: {Hartree, vW, PBE} and the nonlocal KEDF.  Forking
-    // the second onto its own stream lets its latency-bound fused kernels overlap the other's bandwidth-bound passes.
+    // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
+    // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.
     r.forked = c->use_side_stream && c->side_stream && c->side_stream2 && (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) &&
                (c->mask & (OFDFT_HARTREE | OFDFT_VW | OFDFT_PBE_X | OFDFT_PBE_C));
     if (r.forked) {
@@ -1344,23 +1375,17 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
         HIP_TRY(c, hipStreamWaitEvent(r.sb, c->ev_fork, 0));
         HIP_TRY(c, hipStreamWaitEvent(r.sc, c->ev_fork, 0));
     }
-    if ((rc = zstage1(c, st))) return rc;
-    if ((rc = zstage2(c, st))) return rc;
-    if ((rc = zstage3(c, st))) return rc;
-    if ((rc = zstage4(c, st))) return rc;
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage1(c, st, chain))) return rc;
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage2(c, st, chain))) return rc;
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage3(c, st, chain))) return rc;
+    if ((rc = zstage4(c, st, 0))) return rc;
     double sums[kCombineScalars + 2];
     if ((rc = zstage5(c, sums, st))) return rc;
     energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
     return 0;
-}
-
-// ---- all-to-all buffers of the slab-decomposed path: room for the largest stage (13 spectra: Hartree, grad n,
-// vW, two Wang-Teter and six WGC99 results leaving stage 2); both directions reuse the same pair
-constexpr int kMaxXchgArrays = 13;
-int dist_buffers(ofdft_ctx* c, cplx** send, cplx** recv) {
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * kMaxXchgArrays;
-    if (int rc = get_ws(c, "x:send", bytes, (void**)send)) return rc;
-    return get_ws(c, "x:recv", bytes, (void**)recv);
 }
 
 ZRun& zrun(ofdft_ctx* c) {
@@ -1662,36 +1687,40 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.nel = nel_global;
     r.vext = (const double*)vext_local;
     r.v_out = (double*)v_out_local;
-    r.stage = 0;
+    r.stage[0] = r.stage[1] = 0;
     r.forked = false;
-    r.xlist.clear();
+    r.xlist[0].clear();
+    r.xlist[1].clear();
     return OFDFT_OK;
 }
 
-// Runs stage `stage` (1..4): its kernels read the previous exchange's receive buffer and write the send buffer
-// directly (exchange layout, see XchgGeom); there are no pack / un-pack copies.
-// On return *bytes_per_peer is the all-to-all message size (0: nothing to exchange) and the buffers to use.
-int ofdft_dist_stage(ofdft_ctx* c, int stage, void* stream, unsigned long long* bytes_per_peer, void** sendbuf,
+// Runs stage `stage` (1..4) of chain `chain` (0: density / Hartree / vW / PBE; 1: nonlocal KEDF).  Its kernels read
+// the chain's receive buffer of the previous exchange and write its send buffer directly (exchange layout, see
+// XchgGeom); there are no pack / un-pack copies.  On return *bytes_per_peer is the all-to-all message size (0:
+// nothing to exchange) and the buffers to use.  The chains are independent until ofdft_dist_finish, so the host
+// can keep one chain's all-to-all in flight while the other chain computes.
+int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf,
                      void** recvbuf) {
     hipStream_t st = (hipStream_t)stream;
-    if (!c || !bytes_per_peer || !sendbuf || !recvbuf) return OFDFT_EINVAL;
+    if (!c || !bytes_per_peer || !sendbuf || !recvbuf || chain < 0 || chain > 1) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     ZRun& r = zrun(c);
-    if (stage != r.stage + 1 || stage < 1 || stage > 4) return fail(c, OFDFT_ESTATE, "stage %d out of order", stage);
+    if (stage != r.stage[chain] + 1 || stage < 1 || stage > 4 || (chain == 1 && r.stage[0] < 1))
+        return fail(c, OFDFT_ESTATE, "stage %d of chain %d out of order", stage, chain);
     int rc;
     switch (stage) {
-        case 1: rc = zstage1(c, st); break;
-        case 2: rc = zstage2(c, st); break;
-        case 3: rc = zstage3(c, st); break;
-        default: rc = zstage4(c, st); break;
+        case 1: rc = zstage1(c, st, chain); break;
+        case 2: rc = zstage2(c, st, chain); break;
+        case 3: rc = zstage3(c, st, chain); break;
+        default: rc = zstage4(c, st, chain); break;
     }
     if (rc) return rc;
     *bytes_per_peer = 0;
     *sendbuf = *recvbuf = nullptr;
-    if (c->nranks > 1 && !r.xlist.empty()) {
+    if (c->nranks > 1 && !r.xlist[chain].empty()) {
         cplx *send, *recv;
-        if ((rc = dist_buffers(c, &send, &recv))) return rc;
-        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist.size());
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist[chain].size());
         *sendbuf = send;
         *recvbuf = recv;
     }
@@ -1706,7 +1735,7 @@ int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     if (!c || !local_sums) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     ZRun& r = zrun(c);
-    if (r.stage != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4");
+    if (r.stage[0] != 4 || r.stage[1] != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4 of both chains");
     int rc;
     if ((rc = zstage5(c, local_sums, st))) return rc;
     return end_call(c, st);

@@ -3,10 +3,12 @@
 Rank r of P owns the real-space x-slab ``[n0/P, n1, n2]`` of chi / n / v_ext and gets back its slab of the
 potential / gradient.  The engine (C ABI ``ofdft_dist_*``) does all local work -- z and y passes on x-slabs,
 fused x passes on y-slabs, pack / un-pack of the exchange buffers -- and this module only sequences the
-stages and performs the collectives through ``torch.distributed``: four equal-split all-to-alls (the FFT
-transposes, every array of a stage in ONE message per peer) and two small all-reduces per evaluation.  With
-the ``nccl`` backend (= RCCL) the all-to-all runs device-to-device over xGMI; with ``gloo`` the buffers are
-staged through the host (used for tests, including two ranks sharing one GPU).
+stages and performs the collectives through ``torch.distributed``: equal-split all-to-alls (the FFT transposes,
+every array of a stage and chain in ONE message per peer) and two small all-reduces per evaluation.  The work is
+two independent chains (density / Hartree / vW / PBE and the nonlocal KEDF) with separate exchange buffers: with
+the ``nccl`` backend (= RCCL) the all-to-alls are asynchronous, device-to-device over xGMI, and one chain's
+exchange is in flight while the other chain's kernels run; with ``gloo`` the buffers are staged through the host
+(used for tests, including several ranks sharing one GPU).
 
 The orchestration (`run_closure`, `run_potential`) is written against a tiny "stages" interface so that the
 CPU-only test-suite can drive it with a numpy double under gloo; the product implementation of that
@@ -71,12 +73,13 @@ class Comm:
         return t.cpu().numpy()
 
     def all_to_all(self, send_t, recv_t):
-        """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo)"""
+        """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo).
+        Returns None when complete on return, else a work handle whose .wait() orders the current stream after it."""
         if not self.active:
             recv_t.copy_(send_t)
-            return
+            return None
         if self.backend == 'nccl':
-            dist.all_to_all_single(recv_t, send_t, group=self.group)
+            return dist.all_to_all_single(recv_t, send_t, group=self.group, async_op=True)
         else:
             # gloo has no all-to-all: host-staged pairwise exchange (test / fallback transport only)
             hs = send_t.cpu()
@@ -93,6 +96,7 @@ class Comm:
             for r in reqs:
                 r.wait()
             recv_t.copy_(hr)
+            return None
 
 
 class _RawDeviceBuffer:
@@ -123,11 +127,11 @@ class HipStages(Engine):
                                               C.c_void_p(v_out.data_ptr() if v_out is not None else 0), self._stream()),
                     'ofdft_dist_begin')
 
-    def stage(self, k):
+    def stage(self, k, chain):
         """-> None or (send, recv) flat uint8 device tensors of nranks * bytes_per_peer bytes"""
         nbytes, sp, rp = C.c_ulonglong(0), C.c_void_p(0), C.c_void_p(0)
-        self._check(self.lib.ofdft_dist_stage(self._ctx, int(k), self._stream(), C.byref(nbytes), C.byref(sp), C.byref(rp)),
-                    'ofdft_dist_stage')
+        self._check(self.lib.ofdft_dist_stage(self._ctx, int(k), int(chain), self._stream(), C.byref(nbytes), C.byref(sp),
+                                              C.byref(rp)), 'ofdft_dist_stage')
         if nbytes.value == 0:
             return None
         tot = nbytes.value * self.plan.nranks
@@ -159,10 +163,20 @@ class HipStages(Engine):
 
 
 def _run_stages(stages, comm):
+    """Stage / chain sequencing: a chain's stage k+1 waits only for that chain's exchange, so (with an asynchronous
+    transport) the other chain's kernels run while it is in flight."""
+    pending = [None, None]
     for k in (1, 2, 3, 4):
-        ex = stages.stage(k)
-        if ex is not None:
-            comm.all_to_all(ex[0], ex[1])
+        for chain in (0, 1):
+            if pending[chain] is not None:
+                pending[chain].wait()
+                pending[chain] = None
+            ex = stages.stage(k, chain)
+            if ex is not None:
+                pending[chain] = comm.all_to_all(ex[0], ex[1])
+    for w in pending:
+        if w is not None:
+            w.wait()
     local = stages.finish()
     return comm.all_reduce_sum(local, getattr(stages, 'device', 'cpu'))
 

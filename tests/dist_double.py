@@ -41,7 +41,9 @@ class NumpyStages:
     def _bytes(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
 
-    def stage(self, k):
+    def stage(self, k, chain):
+        if chain == 1:       # the double has no nonlocal-KEDF chain
+            return None
         p = self.plan
         assert k == self.k + 1
         self.k = k

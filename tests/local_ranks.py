@@ -43,13 +43,14 @@ class LocalRanks:
     def _stages(self):
         P = self.P
         for k in (1, 2, 3, 4):
-            ex = [self._timed(r, s.stage, k) for r, s in enumerate(self.st)]
-            if ex[0] is None:
-                continue
-            for r in range(P):
-                rc = ex[r][1].chunk(P)
-                for p in range(P):
-                    rc[p].copy_(ex[p][0].chunk(P)[r])
+            for chain in (0, 1):
+                ex = [self._timed(r, s.stage, k, chain) for r, s in enumerate(self.st)]
+                if ex[0] is None:
+                    continue
+                for r in range(P):
+                    rc = ex[r][1].chunk(P)
+                    for p in range(P):
+                        rc[p].copy_(ex[p][0].chunk(P)[r])
         return sum(self._timed(r, s.finish) for r, s in enumerate(self.st))
 
     def closure(self, chi, n_elec, vext):
