@@ -117,6 +117,10 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
  *     ofdft_dist_begin; for stage in 1..4, for chain in 0..1: [wait for the chain's previous all-to-all]
  *         ofdft_dist_stage(stage, chain) + all_to_all(bytes_per_peer)  (asynchronous if the transport allows);
  *     [wait for both] ofdft_dist_finish -> all-reduce of 11 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
+ * Device-resident scalars (no host round trip before the final sums): pass local_sum_host = NULL to
+ * ofdft_dist_sumsq, all-reduce scalars[11] in place (ofdft_dist_scalars), call ofdft_dist_begin with from_chi = 2
+ * (the closure scale is then formed on the device), ofdft_dist_finish with local_sums_host = NULL, all-reduce
+ * scalars[0..10] in place and copy them to the host once; ofdft_dist_chi_grad with cscale = 0 uses the device scale.
  * With nranks == 1 the same calls work and every bytes_per_peer is 0.  These stand behind the same reference
  * interfaces as ofdft_energy_potential / ofdft_energy_grad_chi (system.py:830-838, functional_tools.py:9-31). */
 int  ofdft_create_dist(ofdft_ctx** out, int n0_global, int n1_global, int n2, int dtype, int device_id, int nranks, int rank);
@@ -125,7 +129,8 @@ int  ofdft_dist_begin(ofdft_ctx* ctx, const void* src_local_dev, int from_chi, d
                       const void* vext_local_dev, void* v_out_local_dev, void* stream);
 int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
                       void** recvbuf_dev);
-int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[11]*/, void* stream);
+int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[11] or NULL*/, void* stream);
+int  ofdft_dist_scalars(ofdft_ctx* ctx, void** scalars_dev /* 12 doubles owned by the context */);
 int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[11]*/, double* E_terms_host, double* vn_integral);
 int  ofdft_dist_chi_grad(ofdft_ctx* ctx, const void* chi_local_dev, const void* v_local_dev, void* grad_local_dev,
                          double cscale, double mu, void* stream);

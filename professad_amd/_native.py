@@ -27,7 +27,7 @@ Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1,
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
-           'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish',
+           'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
            'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
@@ -86,6 +86,8 @@ def load():
     lib.ofdft_dist_begin.restype = ip
     lib.ofdft_dist_stage.argtypes = [vp, ip, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
     lib.ofdft_dist_stage.restype = ip
+    lib.ofdft_dist_scalars.argtypes = [vp, C.POINTER(vp)]
+    lib.ofdft_dist_scalars.restype = ip
     lib.ofdft_dist_finish.argtypes = [vp, dp, vp]
     lib.ofdft_dist_finish.restype = ip
     lib.ofdft_dist_energies.argtypes = [vp, dp, dp, dp]

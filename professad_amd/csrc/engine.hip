@@ -1347,11 +1347,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) return rc;
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
+    if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, 2 * sizeof(double), st));
+    r.stage[0] = r.stage[1] = 5;
+    if (!sums) return 0;          // the caller reduces the device-resident sums (c->d_reduced) itself
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
-    if (!r.has_g) sums[kCombineScalars] = sums[kCombineScalars + 1] = 0.0;
-    r.stage[0] = r.stage[1] = 5;
     return 0;
 }
 
@@ -1670,9 +1671,27 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
 // ------------------------------------------------------------------------------ slab-decomposed (multi-GPU) API
 int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* local_sum, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!c || !x_local || !local_sum) return OFDFT_EINVAL;
+    if (!c || !x_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    return device_sum(c, (const double*)x_local, square != 0, local_sum, st);
+    if (local_sum) return device_sum(c, (const double*)x_local, square != 0, local_sum, st);
+    // device-resident form: the local sum goes to scalars[11] (ofdft_dist_scalars), no host synchronisation
+    const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+    if (square)
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
+                     c->d_partial);
+    else
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
+                     c->d_partial);
+    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
+                 c->d_reduced + 11);
+    HIP_TRY(c, hipGetLastError());
+    return OFDFT_OK;
+}
+
+int ofdft_dist_scalars(ofdft_ctx* c, void** scalars_dev) {
+    if (!c || !scalars_dev) return OFDFT_EINVAL;
+    *scalars_dev = c->d_reduced;
+    return OFDFT_OK;
 }
 
 int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double cscale, double nel_global,
@@ -1683,7 +1702,13 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
     ZRun& r = zrun(c);
-    r.ds = DenSrc{(const double*)src_local, cscale, from_chi, nullptr};
+    if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[11]; it never visits the host
+        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + 11, c->d_scal, nel_global,
+                     c->vol / (double)c->npts_g);
+        r.ds = DenSrc{(const double*)src_local, 0.0, 1, c->d_scal};
+    } else {
+        r.ds = DenSrc{(const double*)src_local, cscale, from_chi, nullptr};
+    }
     r.nel = nel_global;
     r.vext = (const double*)vext_local;
     r.v_out = (double*)v_out_local;
@@ -1732,12 +1757,16 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
 // over ranks by the caller, then turned into energies by ofdft_dist_energies).
 int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!c || !local_sums) return OFDFT_EINVAL;
+    if (!c) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     ZRun& r = zrun(c);
     if (r.stage[0] != 4 || r.stage[1] != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4 of both chains");
     int rc;
     if ((rc = zstage5(c, local_sums, st))) return rc;
+    if (!local_sums) {        // device-resident form: scalars[0..10] hold the local sums, nothing waits here
+        HIP_TRY(c, hipGetLastError());
+        return OFDFT_OK;
+    }
     return end_call(c, st);
 }
 
@@ -1754,7 +1783,8 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
     if (!c || !chi_local || !v_local || !grad_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi_local,
-                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV, (const double*)nullptr, 0.0, mu);
+                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV,
+                 cscale > 0.0 ? (const double*)nullptr : (const double*)c->d_scal, 2.0 * c->dV, mu);
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }

@@ -72,6 +72,17 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
+    def all_reduce_dev(self, t):
+        """in-place sum over ranks of a small fp64 DEVICE tensor; no host synchronisation under nccl"""
+        if not self.active:
+            return
+        if self.backend == 'nccl':
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+
     def all_to_all(self, send_t, recv_t):
         """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo).
         Returns None when complete on return, else a work handle whose .wait() orders the current stream after it."""
@@ -102,8 +113,8 @@ class Comm:
 class _RawDeviceBuffer:
     """Zero-copy view of engine-owned device memory for torch (``__cuda_array_interface__``)."""
 
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(ptr), False), 'version': 2}
+    def __init__(self, ptr, count, typestr='|u1'):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
 
 
 class HipStages(Engine):
@@ -112,17 +123,25 @@ class HipStages(Engine):
     def __init__(self, shape, device, nranks=1, rank=0):
         self.plan = SlabPlan(shape, nranks, rank)
         super().__init__(shape, device, nranks=nranks, rank=rank)
+        p = C.c_void_p(0)
+        self._check(self.lib.ofdft_dist_scalars(self._ctx, C.byref(p)), 'ofdft_dist_scalars')
+        # 12 device-resident doubles owned by the context: [0..10] local sums of an evaluation, [11] sum chi^2
+        self.device_scalars = torch.as_tensor(_RawDeviceBuffer(p.value, 12, '<f8'), device=self.device)
+        self._xbuf = {}
 
-    def sumsq(self, x, square=True):
+    def sumsq(self, x, square=True, on_device=False):
+        """local sum of x^2 (or x): returned as a float, or left in device_scalars[11] without a host sync"""
         x = self._grid_tensor(x, 'x')
         out = C.c_double(0.0)
-        self._check(self.lib.ofdft_dist_sumsq(self._ctx, C.c_void_p(x.data_ptr()), 1 if square else 0, C.byref(out),
-                                              self._stream()), 'ofdft_dist_sumsq')
-        return out.value
+        self._check(self.lib.ofdft_dist_sumsq(self._ctx, C.c_void_p(x.data_ptr()), 1 if square else 0,
+                                              None if on_device else C.byref(out), self._stream()), 'ofdft_dist_sumsq')
+        return None if on_device else out.value
 
     def begin(self, src, from_chi, cscale, nel, vext, v_out):
+        """from_chi: False = src is the density, True = chi with the host scale `cscale`, 2 = chi with the scale formed
+        on the device from the all-reduced device_scalars[11]"""
         self._keep = (src, vext, v_out)          # keep the tensors alive for the duration of the evaluation
-        self._check(self.lib.ofdft_dist_begin(self._ctx, C.c_void_p(src.data_ptr()), 1 if from_chi else 0, float(cscale),
+        self._check(self.lib.ofdft_dist_begin(self._ctx, C.c_void_p(src.data_ptr()), int(from_chi), float(cscale),
                                               float(nel), C.c_void_p(vext.data_ptr() if vext is not None else 0),
                                               C.c_void_p(v_out.data_ptr() if v_out is not None else 0), self._stream()),
                     'ofdft_dist_begin')
@@ -135,11 +154,18 @@ class HipStages(Engine):
         if nbytes.value == 0:
             return None
         tot = nbytes.value * self.plan.nranks
-        send = torch.as_tensor(_RawDeviceBuffer(sp.value, tot), device=self.device)
-        recv = torch.as_tensor(_RawDeviceBuffer(rp.value, tot), device=self.device)
-        return send, recv
+        key = (sp.value, rp.value, tot)
+        ex = self._xbuf.get(key)
+        if ex is None:           # the engine reuses its buffers: wrap each (pointer, size) once
+            ex = self._xbuf[key] = (torch.as_tensor(_RawDeviceBuffer(sp.value, tot), device=self.device),
+                                    torch.as_tensor(_RawDeviceBuffer(rp.value, tot), device=self.device))
+        return ex
 
-    def finish(self):
+    def finish(self, on_device=False):
+        """the 11 local sums: as a numpy vector, or left in device_scalars[0:11] without a host sync"""
+        if on_device:
+            self._check(self.lib.ofdft_dist_finish(self._ctx, None, self._stream()), 'ofdft_dist_finish')
+            return None
         sums = (C.c_double * NSUMS)()
         self._check(self.lib.ofdft_dist_finish(self._ctx, sums, self._stream()), 'ofdft_dist_finish')
         return np.array(list(sums), dtype=np.float64)
@@ -162,7 +188,7 @@ class HipStages(Engine):
         torch.cuda.current_stream(self.device).synchronize()
 
 
-def _run_stages(stages, comm):
+def _run_exchanges(stages, comm):
     """Stage / chain sequencing: a chain's stage k+1 waits only for that chain's exchange, so (with an asynchronous
     transport) the other chain's kernels run while it is in flight."""
     pending = [None, None]
@@ -177,12 +203,30 @@ def _run_stages(stages, comm):
     for w in pending:
         if w is not None:
             w.wait()
+
+
+def _run_stages(stages, comm):
+    _run_exchanges(stages, comm)
     local = stages.finish()
     return comm.all_reduce_sum(local, getattr(stages, 'device', 'cpu'))
 
 
 def run_closure(stages, comm, chi, n_elec, vext, vol, npts_global, new_like):
     """The optimize_density closure (system.py:830-838) over slabs -> (E_terms, mu, grad slab)."""
+    sc = getattr(stages, 'device_scalars', None)
+    if sc is not None:
+        # device-resident scalars: sum chi^2 and the closure scale never visit the host; the only host
+        # synchronisation of the evaluation is the copy of the 11 all-reduced sums
+        stages.sumsq(chi, True, on_device=True)
+        comm.all_reduce_dev(sc[11:12])
+        v = new_like(chi)
+        stages.begin(chi, 2, 0.0, n_elec, vext, v)
+        _run_exchanges(stages, comm)
+        stages.finish(on_device=True)
+        comm.all_reduce_dev(sc[0:NSUMS])
+        E_terms, vn = stages.energies(sc[0:NSUMS].cpu().numpy())
+        mu = vn / n_elec                                    # system.py:851
+        return E_terms, mu, stages.chi_grad(chi, v, 0.0, mu)
     s2 = comm.all_reduce_sum(np.array([stages.sumsq(chi, True)]), getattr(stages, 'device', 'cpu'))[0]
     ntilde = s2 / npts_global * vol                     # system.py:833
     cscale = n_elec / ntilde                            # system.py:834

@@ -41,6 +41,17 @@ def main():
     torch.cuda.synchronize()
     single = (time.perf_counter() - t0) / reps
     eng.close()
+    from professad_amd.distributed import DistEngine
+    de = DistEngine(shape, dev).set_cell(box).set_terms(names)      # one rank: the staged host protocol without exchange
+    for _ in range(2):
+        de.energy_grad_chi(chi, n_elec, vext)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        de.energy_grad_chi(chi, n_elec, vext)
+    torch.cuda.synchronize()
+    staged1 = (time.perf_counter() - t0) / reps
+    de.close()
     loc = LocalRanks(shape, dev, P).set_cell(box).set_terms(names)
     loc.closure(chi, n_elec, vext)
     loc.compute_s = [0.0] * P
@@ -53,7 +64,7 @@ def main():
     print('rank-0 kernels (ms per eval, launches per eval):', prof, file=sys.stderr)
     loc.close()
     err = float((g - gr).abs().max() / gr.abs().max())
-    print(json.dumps({'grid': n, 'ranks': P, 'single_gpu_ms': round(single * 1e3, 3),
+    print(json.dumps({'grid': n, 'ranks': P, 'single_gpu_ms': round(single * 1e3, 3), 'staged_protocol_1rank_ms': round(staged1 * 1e3, 3),
                       'local_compute_ms_per_rank_max': round(max(per_rank) * 1e3, 3),
                       'local_compute_ms_per_rank_mean': round(float(np.mean(per_rank)) * 1e3, 3),
                       'exchange_MB_per_rank_per_eval': round(23 * 16 * (n * n * (n // 2 + 1)) / P * (P - 1) / P / 1e6, 1),
