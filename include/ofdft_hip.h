@@ -153,6 +153,29 @@ int  ofdft_ion_electron_forces(ofdft_ctx* ctx, const void* den_dev, const double
                                const double* table_k_host, const double* table_v_host, int ntable, double z_ion,
                                int pme_order, double* forces_host, void* stream);
 
+/* ---- limited-memory BFGS building blocks (the consumer of the closure) ----------------
+ * The reference's fixed-step optimiser (_optimizers/lbfgs/lbfgsnew.py:594-663) forms y = g - g_prev and s = t d, keeps
+ * the pair if y.s > 1e-10 |s|^2, and gets the direction from the two-loop recursion: 2m dependent dot / axpy pairs over
+ * full-grid vectors.  Here the history lives on the device and each inner iteration is two sweeps:
+ *   ofdft_lbfgs_dots    forms the candidate pair from g, the previous gradient and the previous step, and returns every
+ *                       inner product the recursion needs: for each stored pair j (oldest first) (s.S_j, y.S_j, g.S_j), then
+ *                       (s.Y_j, y.Y_j, g.Y_j) for each j, then s.s, s.y, y.y, g.s, g.y, g.g, |g|_1  ->  6*npairs + 7 numbers
+ *                       (LOCAL sums: all-reduce them over ranks when the vectors are slabs);
+ *   ofdft_lbfgs_commit  stores (push = 1) or discards the candidate pair (the caller applies the curvature test);
+ *   ofdft_lbfgs_update  d = coef_g g + sum_j coef_s[j] S_j + coef_y[j] Y_j over the stored pairs (oldest first, the
+ *                       just-committed pair last), x += t d in place, g_prev = g; returns the local sum |t d|_1.
+ * The recursion itself runs on the coefficients (professad_amd/optimize.py), so the result is the same direction as
+ * the reference's up to round-off. */
+typedef struct ofdft_lbfgs ofdft_lbfgs;
+int  ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history /* 1..8 */, int device_id);
+void ofdft_lbfgs_destroy(ofdft_lbfgs* h);
+const char* ofdft_lbfgs_last_error(const ofdft_lbfgs* h);
+int  ofdft_lbfgs_reset(ofdft_lbfgs* h);
+int  ofdft_lbfgs_dots(ofdft_lbfgs* h, const void* g_dev, double* dots_host /* [6*8+7] */, int* npairs, void* stream);
+int  ofdft_lbfgs_commit(ofdft_lbfgs* h, int push);
+int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef_y, double coef_g, double t, void* x_dev,
+                        const void* g_dev, double* abs_step_sum_host, void* stream);
+
 /* Tuning / validation switches.  OFDFT_OPT_PIPELINE: 0 = automatic (power-of-two grids: fused x passes and z
  * passes that keep every real-space intermediate on chip), 1 = force the unfused pipeline (separate forward,
  * multiply, inverse and pointwise passes; the only one for other grids), 2 = fused x passes only. */

@@ -2025,3 +2025,5 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
 }
 
 }  // extern "C"
+
+#include "lbfgs_abi.h"

@@ -1,0 +1,203 @@
+// C ABI of the device-side limited-memory BFGS building blocks (see lbfgs_kernels.h and include/ofdft_hip.h).
+// Included once, at the end of engine.hip (one translation unit: the kernels in the headers are not inline).
+#pragma once
+#include <new>
+
+#include "lbfgs_kernels.h"
+
+struct ofdft_lbfgs {
+    long long n = 0;
+    int hist = 0, device = 0;
+    int count = 0;                 // stored pairs
+    int order[kLbfgsMaxHist + 1];  // physical slot of the logical pair j (oldest first); order[count] = free slot
+    double* S[kLbfgsMaxHist + 1] = {nullptr};
+    double* Y[kLbfgsMaxHist + 1] = {nullptr};
+    double *d = nullptr, *g_prev = nullptr;
+    double *d_partial = nullptr, *d_out = nullptr, *h_out = nullptr;
+    bool have_prev = false;        // a step (d, t) and the gradient before it exist
+    bool pending = false;          // a candidate pair sits in the free slot
+    double t_prev = 0.0;
+    char err[256] = "";
+};
+
+namespace {
+
+int lfail(ofdft_lbfgs* o, int code, const char* msg) {
+    if (o) std::snprintf(o->err, sizeof(o->err), "%s", msg);
+    return code;
+}
+#define L_TRY(o, expr)                                                     \
+    do {                                                                   \
+        hipError_t e_ = (expr);                                            \
+        if (e_ != hipSuccess) return lfail(o, OFDFT_EHIP, hipGetErrorString(e_)); \
+    } while (0)
+
+LbfgsVecs logical(const ofdft_lbfgs* o, int count) {
+    LbfgsVecs v{};
+    for (int j = 0; j < count; ++j) {
+        v.S[j] = o->S[o->order[j]];
+        v.Y[j] = o->Y[o->order[j]];
+    }
+    return v;
+}
+
+template <int K>
+void launch_dots(ofdft_lbfgs* o, const LbfgsVecs& v, const double* g, int blocks, hipStream_t st) {
+    const int slot = o->order[o->count];
+    hipLaunchKernelGGL((lbfgs_dots_kernel<K>), dim3(blocks), dim3(kRedThreads), 0, st, v, g, o->g_prev, o->d, o->t_prev,
+                       o->have_prev ? 1 : 0, o->S[slot], o->Y[slot], o->n, o->d_partial);
+}
+template <int K>
+void launch_update(ofdft_lbfgs* o, const LbfgsVecs& v, const LbfgsCoef& c, const double* g, double t, double* x, int blocks,
+                   hipStream_t st) {
+    hipLaunchKernelGGL((lbfgs_update_kernel<K>), dim3(blocks), dim3(kRedThreads), 0, st, v, c, g, t, o->d, x, o->g_prev, o->n,
+                       o->d_partial);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history, int device_id) {
+    if (!out || n_local < 1 || history < 1 || history > kLbfgsMaxHist) return OFDFT_EINVAL;
+    *out = nullptr;
+    ofdft_lbfgs* o = new (std::nothrow) ofdft_lbfgs();
+    if (!o) return OFDFT_ENOMEM;
+    o->n = n_local;
+    o->hist = history;
+    o->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    const size_t vb = sizeof(double) * (size_t)n_local;
+    for (int i = 0; i <= history && e == hipSuccess; ++i) {
+        e = hipMalloc((void**)&o->S[i], vb);
+        if (e == hipSuccess) e = hipMalloc((void**)&o->Y[i], vb);
+        o->order[i] = i;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&o->g_prev, vb);
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d_partial, sizeof(double) * kRedBlocks * lbfgs_nscal(kLbfgsMaxHist));
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d_out, sizeof(double) * lbfgs_nscal(kLbfgsMaxHist));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&o->h_out, sizeof(double) * lbfgs_nscal(kLbfgsMaxHist));
+    if (e != hipSuccess) {
+        ofdft_lbfgs_destroy(o);
+        return e == hipErrorOutOfMemory ? OFDFT_ENOMEM : OFDFT_EHIP;
+    }
+    *out = o;
+    return OFDFT_OK;
+}
+
+void ofdft_lbfgs_destroy(ofdft_lbfgs* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    for (int i = 0; i <= kLbfgsMaxHist; ++i) {
+        if (o->S[i]) (void)hipFree(o->S[i]);
+        if (o->Y[i]) (void)hipFree(o->Y[i]);
+    }
+    if (o->d) (void)hipFree(o->d);
+    if (o->g_prev) (void)hipFree(o->g_prev);
+    if (o->d_partial) (void)hipFree(o->d_partial);
+    if (o->d_out) (void)hipFree(o->d_out);
+    if (o->h_out) (void)hipHostFree(o->h_out);
+    delete o;
+}
+
+const char* ofdft_lbfgs_last_error(const ofdft_lbfgs* o) { return o ? o->err : "null handle"; }
+
+int ofdft_lbfgs_dots(ofdft_lbfgs* o, const void* g_dev, double* dots_host, int* npairs, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!o || !g_dev || !dots_host || !npairs) return OFDFT_EINVAL;
+    L_TRY(o, hipSetDevice(o->device));
+    const int K = o->count;
+    const int ns = lbfgs_nscal(K);
+    const LbfgsVecs v = logical(o, K);
+    long long want = (o->n / 2 + kRedThreads) / kRedThreads;
+    const int blocks = (int)(want < 1 ? 1 : (want > kRedBlocks ? kRedBlocks : want));
+    const double* g = (const double*)g_dev;
+    switch (K) {
+        case 0: launch_dots<0>(o, v, g, blocks, st); break;
+        case 1: launch_dots<1>(o, v, g, blocks, st); break;
+        case 2: launch_dots<2>(o, v, g, blocks, st); break;
+        case 3: launch_dots<3>(o, v, g, blocks, st); break;
+        case 4: launch_dots<4>(o, v, g, blocks, st); break;
+        case 5: launch_dots<5>(o, v, g, blocks, st); break;
+        case 6: launch_dots<6>(o, v, g, blocks, st); break;
+        case 7: launch_dots<7>(o, v, g, blocks, st); break;
+        default: launch_dots<8>(o, v, g, blocks, st); break;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ns), dim3(kRedThreads), 0, st, (const double*)o->d_partial, blocks, ns,
+                       o->d_out);
+    L_TRY(o, hipMemcpyAsync(o->h_out, o->d_out, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+    L_TRY(o, hipStreamSynchronize(st));
+    L_TRY(o, hipGetLastError());
+    std::memcpy(dots_host, o->h_out, sizeof(double) * ns);
+    *npairs = K;
+    o->pending = o->have_prev;
+    return OFDFT_OK;
+}
+
+int ofdft_lbfgs_commit(ofdft_lbfgs* o, int push) {
+    if (!o) return OFDFT_EINVAL;
+    if (push && !o->pending) return lfail(o, OFDFT_ESTATE, "no candidate pair to store (call ofdft_lbfgs_dots after a step)");
+    if (push) {
+        if (o->count == o->hist) {          // drop the oldest: its slot becomes the free one
+            const int freed = o->order[0];
+            for (int j = 0; j < o->hist; ++j) o->order[j] = o->order[j + 1];
+            o->order[o->hist] = freed;
+        } else {
+            o->count++;
+        }
+    }
+    o->pending = false;
+    return OFDFT_OK;
+}
+
+int ofdft_lbfgs_update(ofdft_lbfgs* o, const double* coef_s, const double* coef_y, double coef_g, double t, void* x_dev,
+                       const void* g_dev, double* abs_step_sum, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!o || !x_dev || !g_dev || !abs_step_sum || (o->count > 0 && (!coef_s || !coef_y))) return OFDFT_EINVAL;
+    if (o->pending) return lfail(o, OFDFT_ESTATE, "ofdft_lbfgs_commit must follow ofdft_lbfgs_dots");
+    L_TRY(o, hipSetDevice(o->device));
+    const int K = o->count;
+    const LbfgsVecs v = logical(o, K);
+    LbfgsCoef c{};
+    for (int j = 0; j < K; ++j) {
+        c.cs[j] = coef_s[j];
+        c.cy[j] = coef_y[j];
+    }
+    c.cg = coef_g;
+    long long want = (o->n / 2 + kRedThreads) / kRedThreads;
+    const int blocks = (int)(want < 1 ? 1 : (want > kRedBlocks ? kRedBlocks : want));
+    const double* g = (const double*)g_dev;
+    double* x = (double*)x_dev;
+    switch (K) {
+        case 0: launch_update<0>(o, v, c, g, t, x, blocks, st); break;
+        case 1: launch_update<1>(o, v, c, g, t, x, blocks, st); break;
+        case 2: launch_update<2>(o, v, c, g, t, x, blocks, st); break;
+        case 3: launch_update<3>(o, v, c, g, t, x, blocks, st); break;
+        case 4: launch_update<4>(o, v, c, g, t, x, blocks, st); break;
+        case 5: launch_update<5>(o, v, c, g, t, x, blocks, st); break;
+        case 6: launch_update<6>(o, v, c, g, t, x, blocks, st); break;
+        case 7: launch_update<7>(o, v, c, g, t, x, blocks, st); break;
+        default: launch_update<8>(o, v, c, g, t, x, blocks, st); break;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, st, (const double*)o->d_partial, blocks, 1,
+                       o->d_out);
+    L_TRY(o, hipMemcpyAsync(o->h_out, o->d_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    L_TRY(o, hipStreamSynchronize(st));
+    L_TRY(o, hipGetLastError());
+    *abs_step_sum = o->h_out[0];
+    o->have_prev = true;
+    o->t_prev = t;
+    return OFDFT_OK;
+}
+
+int ofdft_lbfgs_reset(ofdft_lbfgs* o) {
+    if (!o) return OFDFT_EINVAL;
+    o->count = 0;
+    o->have_prev = false;
+    o->pending = false;
+    for (int i = 0; i <= kLbfgsMaxHist; ++i) o->order[i] = i;
+    return OFDFT_OK;
+}
+
+}  // extern "C"

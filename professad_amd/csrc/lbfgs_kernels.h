@@ -1,0 +1,128 @@
+// Limited-memory BFGS on the device in "vector-free" form: per inner iteration ONE multi-dot sweep over the history
+// (all inner products the two-loop recursion needs) and ONE multi-axpy sweep (direction, parameter update, gradient
+// copy), instead of the 2m dependent dot / axpy pairs of the textbook recursion.  The recursion itself then runs on
+// the (2m+1)-dimensional coefficient vector on the host (professad_amd/optimize.py), which on several GPUs needs
+// only one small all-reduce per iteration.  Semantics follow the reference's fixed-step optimiser
+// (src/professad/_optimizers/lbfgs/lbfgsnew.py:594-663: y = g - g_prev, s = t d, curvature test, two-loop, H_diag).
+#pragma once
+#include "pointwise_kernels.h"
+
+namespace ofdft {
+
+constexpr int kLbfgsMaxHist = 8;
+
+struct LbfgsVecs {
+    const double* S[kLbfgsMaxHist];   // stored steps, oldest first
+    const double* Y[kLbfgsMaxHist];   // stored gradient differences
+};
+struct LbfgsCoef {
+    double cs[kLbfgsMaxHist], cy[kLbfgsMaxHist], cg;
+};
+
+// number of scalars the sweep produces for K stored pairs:
+//   for j < K: (s.S_j, y.S_j, g.S_j), then (s.Y_j, y.Y_j, g.Y_j); tail: s.s, s.y, y.y, g.s, g.y, g.g, |g|_1
+__host__ __device__ constexpr int lbfgs_nscal(int K) { return 6 * K + 7; }
+
+// Sweep 1: forms the candidate pair y = g - g_prev, s = t d (written to s_new / y_new; zeros when there is no
+// previous step) and accumulates every inner product of {s, y, g} with the stored vectors and with each other.
+template <int K>
+__global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, const double* __restrict__ g,
+                                                                 const double* __restrict__ g_prev,
+                                                                 const double* __restrict__ d, double t, int have_prev,
+                                                                 double* __restrict__ s_new, double* __restrict__ y_new,
+                                                                 long long n, double* __restrict__ partial) {
+    constexpr int NS = lbfgs_nscal(K);
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+    const long long n2 = n >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2 + (n & 1); i += (long long)gridDim.x * blockDim.x) {
+        const bool tail = i == n2;          // odd length: the last element alone
+        double2 gi, si = make_double2(0.0, 0.0), yi = make_double2(0.0, 0.0);
+        if (!tail) gi = reinterpret_cast<const double2*>(g)[i];
+        else gi = make_double2(g[n - 1], 0.0);
+        if (have_prev) {
+            double2 gp, di;
+            if (!tail) {
+                gp = reinterpret_cast<const double2*>(g_prev)[i];
+                di = reinterpret_cast<const double2*>(d)[i];
+            } else {
+                gp = make_double2(g_prev[n - 1], 0.0);
+                di = make_double2(d[n - 1], 0.0);
+            }
+            yi = make_double2(gi.x - gp.x, gi.y - gp.y);
+            si = make_double2(t * di.x, t * di.y);
+            if (!tail) {
+                reinterpret_cast<double2*>(s_new)[i] = si;
+                reinterpret_cast<double2*>(y_new)[i] = yi;
+            } else {
+                s_new[n - 1] = si.x;
+                y_new[n - 1] = yi.x;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            double2 a, b;
+            if (!tail) {
+                a = reinterpret_cast<const double2*>(v.S[j])[i];
+                b = reinterpret_cast<const double2*>(v.Y[j])[i];
+            } else {
+                a = make_double2(v.S[j][n - 1], 0.0);
+                b = make_double2(v.Y[j][n - 1], 0.0);
+            }
+            acc[3 * j + 0] += si.x * a.x + si.y * a.y;
+            acc[3 * j + 1] += yi.x * a.x + yi.y * a.y;
+            acc[3 * j + 2] += gi.x * a.x + gi.y * a.y;
+            acc[3 * K + 3 * j + 0] += si.x * b.x + si.y * b.y;
+            acc[3 * K + 3 * j + 1] += yi.x * b.x + yi.y * b.y;
+            acc[3 * K + 3 * j + 2] += gi.x * b.x + gi.y * b.y;
+        }
+        acc[6 * K + 0] += si.x * si.x + si.y * si.y;
+        acc[6 * K + 1] += si.x * yi.x + si.y * yi.y;
+        acc[6 * K + 2] += yi.x * yi.x + yi.y * yi.y;
+        acc[6 * K + 3] += gi.x * si.x + gi.y * si.y;
+        acc[6 * K + 4] += gi.x * yi.x + gi.y * yi.y;
+        acc[6 * K + 5] += gi.x * gi.x + gi.y * gi.y;
+        acc[6 * K + 6] += fabs(gi.x) + fabs(gi.y);
+    }
+    block_reduce_store<NS>(acc, partial);
+}
+
+// Sweep 2: d = cg g + sum_j cs_j S_j + cy_j Y_j;  x += t d;  g_prev = g;  partial sums of |t d|.
+template <int K>
+__global__ __launch_bounds__(kRedThreads) void lbfgs_update_kernel(LbfgsVecs v, LbfgsCoef c, const double* __restrict__ g,
+                                                                   double t, double* __restrict__ d, double* __restrict__ x,
+                                                                   double* __restrict__ g_prev, long long n,
+                                                                   double* __restrict__ partial) {
+    double acc[1] = {0.0};
+    const long long n2 = n >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const double2 gi = reinterpret_cast<const double2*>(g)[i];
+        double2 di = make_double2(c.cg * gi.x, c.cg * gi.y);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double2 a = reinterpret_cast<const double2*>(v.S[j])[i], b = reinterpret_cast<const double2*>(v.Y[j])[i];
+            di.x += c.cs[j] * a.x + c.cy[j] * b.x;
+            di.y += c.cs[j] * a.y + c.cy[j] * b.y;
+        }
+        double2 xi = reinterpret_cast<double2*>(x)[i];
+        xi.x += t * di.x;
+        xi.y += t * di.y;
+        reinterpret_cast<double2*>(d)[i] = di;
+        reinterpret_cast<double2*>(x)[i] = xi;
+        reinterpret_cast<double2*>(g_prev)[i] = gi;
+        acc[0] += fabs(t * di.x) + fabs(t * di.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long i = n - 1;
+        double di = c.cg * g[i];
+        for (int j = 0; j < K; ++j) di += c.cs[j] * v.S[j][i] + c.cy[j] * v.Y[j][i];
+        d[i] = di;
+        x[i] += t * di;
+        g_prev[i] = g[i];
+        acc[0] += fabs(t * di);
+    }
+    block_reduce_store<1>(acc, partial);
+}
+
+}  // namespace ofdft

@@ -10,9 +10,17 @@ differences in eV against `ntol`, convergence only counted after the 5th outer i
 y.s > 1e-10 |s|^2 curvature test and gamma = y.s / y.y scaling, reference semantics
 _optimizers/lbfgs/lbfgsnew.py:512-769) that keeps the (s, y) history as two [m, N] device matrices so the
 two-loop dot products and updates are batched tensor ops on the GPU.
+
+`VectorFreeLBFGS` is the same algorithm arranged for the GPU: the history lives behind the
+`ofdft_lbfgs_*` C ABI and every inner iteration is ONE multi-dot sweep (all inner products of {s, y, g} with the
+stored pairs) plus ONE multi-axpy sweep (direction, chi update, gradient copy) -- about 40 grid-sized reads/writes
+instead of the ~135 of the op-by-op form -- while the two-loop recursion itself runs here on the (2m+1) coefficients
+of the direction in the basis {S_j, Y_j, g}.  On several ranks the sweep's local sums need one small all-reduce.
 """
+import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 EV_PER_HA = 4.3597447222071e-18 / 1.602176634e-19      # system.py:27-33
@@ -114,13 +122,195 @@ class FixedStepLBFGS:
         return loss0
 
 
+class HipLbfgsBackend:
+    """History and sweeps on the device (ofdft_lbfgs_* in libofdft_hip.so; no CPU fallback)."""
+
+    def __init__(self, n, history, device):
+        from . import _native as N
+        self.lib = N.load()
+        self.device = torch.device(device)
+        self._h = C.c_void_p(0)
+        rc = self.lib.ofdft_lbfgs_create(C.byref(self._h), int(n), int(history), self.device.index or 0)
+        if rc != 0:
+            raise RuntimeError('ofdft_lbfgs_create failed with code %d' % rc)
+        self._buf = (C.c_double * (6 * 8 + 7))()
+        self.n = int(n)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s: %s' % (what, self.lib.ofdft_lbfgs_last_error(self._h).decode()))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _vec(self, t, name):
+        if not (t.is_cuda and t.dtype == torch.double and t.is_contiguous() and t.numel() == self.n):
+            raise ValueError('%s must be a contiguous fp64 device tensor of %d elements' % (name, self.n))
+        return C.c_void_p(t.data_ptr())
+
+    def dots(self, g):
+        k = C.c_int(0)
+        self._check(self.lib.ofdft_lbfgs_dots(self._h, self._vec(g, 'g'), self._buf, C.byref(k), self._stream()), 'ofdft_lbfgs_dots')
+        return np.array(self._buf[:6 * k.value + 7], dtype=np.float64), k.value
+
+    def commit(self, push):
+        self._check(self.lib.ofdft_lbfgs_commit(self._h, 1 if push else 0), 'ofdft_lbfgs_commit')
+
+    def update(self, cs, cy, cg, t, x, g):
+        dp = C.POINTER(C.c_double)
+        cs = np.ascontiguousarray(cs, dtype=np.float64)
+        cy = np.ascontiguousarray(cy, dtype=np.float64)
+        out = C.c_double(0.0)
+        self._check(self.lib.ofdft_lbfgs_update(self._h, cs.ctypes.data_as(dp), cy.ctypes.data_as(dp), float(cg), float(t),
+                                                self._vec(x, 'x'), self._vec(g, 'g'), C.byref(out), self._stream()),
+                    'ofdft_lbfgs_update')
+        return out.value
+
+    def reset(self):
+        self._check(self.lib.ofdft_lbfgs_reset(self._h), 'ofdft_lbfgs_reset')
+
+    def close(self):
+        if self._h:
+            self.lib.ofdft_lbfgs_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VectorFreeLBFGS:
+    """FixedStepLBFGS with the vectors behind a backend (`dots`, `commit`, `update`) and the recursion on coefficients.
+
+    Gram blocks kept on the host for the stored pairs (oldest first): SS[i,j] = S_i.S_j, SY[i,j] = S_i.Y_j,
+    YY[i,j] = Y_i.Y_j.  `all_reduce(vec) -> vec` sums the sweeps' local scalars over ranks (None on one GPU)."""
+
+    def __init__(self, x, backend, lr=0.1, history_size=8, max_iter=6, tolerance_grad=1e-5, tolerance_change=1e-9,
+                 all_reduce=None):
+        self.x, self.b = x, backend
+        self.lr, self.m, self.max_iter = float(lr), int(history_size), int(max_iter)
+        self.max_eval = self.max_iter * 5 // 4       # lbfgsnew.py:69-70
+        self.tol_g, self.tol_c = tolerance_grad, tolerance_change
+        self.all_reduce = all_reduce
+        self.SS = np.zeros((0, 0))
+        self.SY = np.zeros((0, 0))
+        self.YY = np.zeros((0, 0))
+        self.gamma = 1.0
+        self.total_iter = 0
+        self.func_evals = 0
+        self.info = None
+
+    # ---- sweep 1: everything the iteration needs to know about the new gradient
+    def _analyse(self, g):
+        vals, k = self.b.dots(g.view(-1))
+        if self.all_reduce is not None:
+            vals = self.all_reduce(vals)
+        v = vals[:6 * k].reshape(2, k, 3)        # [S|Y][j][s,y,g]
+        tail = vals[6 * k:]
+        self.info = dict(k=k, sS=v[0, :, 0], yS=v[0, :, 1], gS=v[0, :, 2], sY=v[1, :, 0], yY=v[1, :, 1], gY=v[1, :, 2],
+                         ss=tail[0], sy=tail[1], yy=tail[2], gs=tail[3], gy=tail[4], gg=tail[5], g1=tail[6])
+        return self.info
+
+    def _push(self, f):
+        """append the candidate pair's row / column to the Gram blocks (dropping the oldest pair when full)"""
+        k = f['k']
+        sS, yS, sY, yY, gS, gY = f['sS'], f['yS'], f['sY'], f['yY'], f['gS'], f['gY']
+        SS, SY, YY = self.SS, self.SY, self.YY
+        if k == self.m:
+            SS, SY, YY = SS[1:, 1:], SY[1:, 1:], YY[1:, 1:]
+            sS, yS, sY, yY, gS, gY = sS[1:], yS[1:], sY[1:], yY[1:], gS[1:], gY[1:]
+            k -= 1
+        n = k + 1
+        nSS, nSY, nYY = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n))
+        nSS[:k, :k], nSY[:k, :k], nYY[:k, :k] = SS, SY, YY
+        nSS[k, :k] = nSS[:k, k] = sS
+        nSS[k, k] = f['ss']
+        nYY[k, :k] = nYY[:k, k] = yY
+        nYY[k, k] = f['yy']
+        nSY[k, :k] = sY              # s_new . Y_j
+        nSY[:k, k] = yS              # S_j . y_new
+        nSY[k, k] = f['sy']
+        self.SS, self.SY, self.YY = nSS, nSY, nYY
+        return np.append(gS, f['gs']), np.append(gY, f['gy'])
+
+    def _coefficients(self, gS, gY, gg):
+        """two-loop recursion (lbfgsnew.py:649-663) on the coefficients of the direction in {S_j, Y_j, g}"""
+        k = self.SS.shape[0]
+        dS, dY, dg = np.zeros(k), np.zeros(k), -1.0
+        rho = 1.0 / np.diag(self.SY) if k else np.zeros(0)
+        al = np.zeros(k)
+        for i in range(k - 1, -1, -1):
+            al[i] = (dS @ self.SS[:, i] + dY @ self.SY[i, :] + dg * gS[i]) * rho[i]
+            dY[i] -= al[i]
+        dS *= self.gamma
+        dY *= self.gamma
+        dg *= self.gamma
+        for i in range(k):
+            be = (dS @ self.SY[:, i] + dY @ self.YY[:, i] + dg * gY[i]) * rho[i]
+            dS[i] += al[i] - be
+        gtd = dS @ gS + dY @ gY + dg * gg
+        return dS, dY, dg, gtd
+
+    def step(self, closure):
+        """Same contract as FixedStepLBFGS.step."""
+        loss0, g = closure()
+        loss = loss0
+        evals = 1
+        self.func_evals += 1
+        f = self._analyse(g)
+        g1 = f['g1']
+        if g1 <= self.tol_g:
+            return loss0
+        n_iter = 0
+        while n_iter < self.max_iter and not math.isnan(f['gg']):
+            n_iter += 1
+            self.total_iter += 1
+            if self.total_iter == 1:
+                self.b.commit(False)
+                self.SS = self.SY = self.YY = np.zeros((0, 0))
+                self.gamma = 1.0
+                gS, gY = np.zeros(0), np.zeros(0)
+            else:
+                push = f['sy'] > 1e-10 * f['ss']                      # lbfgsnew.py:622 (sn*sn = s.s)
+                self.b.commit(push)
+                if push:
+                    gS, gY = self._push(f)
+                    self.gamma = f['sy'] / f['yy']
+                else:
+                    gS, gY = f['gS'], f['gY']
+            cs, cy, cg, gtd = self._coefficients(gS, gY, f['gg'])
+            prev_loss = loss
+            t = min(1.0, 1.0 / g1) * self.lr if self.total_iter == 1 else self.lr
+            abs_step = self.b.update(cs, cy, cg, t, self.x.view(-1), g.view(-1))       # x += t d, g_prev = g
+            if self.all_reduce is not None:
+                abs_step = float(self.all_reduce(np.array([abs_step]))[0])
+            if n_iter != self.max_iter:
+                loss, g = closure()
+                f = self._analyse(g)
+                g1 = f['g1']
+                evals += 1
+                self.func_evals += 1
+                if math.isnan(g1):
+                    break
+            if n_iter == self.max_iter or evals >= self.max_eval:
+                break
+            if g1 <= self.tol_g or gtd > -self.tol_c:
+                break
+            if abs_step <= self.tol_c or abs(loss - prev_loss) < self.tol_c:
+                break
+        return loss0
+
+
 def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_cond_count=3, n_step_size=0.1,
-                     n_maxiter=1000, conv_target='dE', verbose=False, volume=None):
+                     n_maxiter=1000, conv_target='dE', verbose=False, volume=None, optimizer='fused'):
     """Minimise E[n = N_e chi^2 / int chi^2] with the engine's terms.  Returns a dict with the converged density,
     chi, energy [Ha], iteration count and the convergence history.
 
     engine: an `Engine` (cell and terms already set); `volume` = cell volume (needed when chi0 is None to start from
-    the uniform density, as System.optimize_density does after System.__init__)."""
+    the uniform density, as System.optimize_density does after System.__init__).  `optimizer`: 'fused' (HIP sweeps,
+    `VectorFreeLBFGS`) or 'torch' (`FixedStepLBFGS` on torch tensors)."""
     shape, dev = engine.shape, engine.device
     if chi0 is None:
         if volume is None:
@@ -135,7 +325,12 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         state.update(E=sum(E_terms.values()), mu=mu, g=g, E_terms=E_terms)
         return state['E'], g
 
-    opt = FixedStepLBFGS(chi, lr=n_step_size, history_size=8, max_iter=6)
+    if optimizer == 'fused':        # device-resident history, two sweeps per inner iteration
+        opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev), lr=n_step_size, history_size=8, max_iter=6)
+    elif optimizer == 'torch':      # op-by-op form on torch tensors
+        opt = FixedStepLBFGS(chi, lr=n_step_size, history_size=8, max_iter=6)
+    else:
+        raise ValueError("optimizer must be 'fused' or 'torch'")
     E_prev = closure()[0] * EV_PER_HA
     history, conv = [], 0
     dV = None

@@ -279,7 +279,8 @@ def test_all_pipelines_agree(shape):
     eng.close()
 
 
-def test_density_optimisation_reaches_reference_ground_state():
+@pytest.mark.parametrize('optimizer', ['fused', 'torch'])
+def test_density_optimisation_reaches_reference_ground_state(optimizer):
     """Config 1 end to end (reference tests/test_den_opt.py path): from the uniform density the native closure +
     the from-scratch fixed-step L-BFGS reach the state the reference's System.optimize_density converged to
     (fixture made by running the reference: E = 2.40469334875 Ha in 17 outer iterations).  The fixed-step L-BFGS
@@ -289,7 +290,7 @@ def test_density_optimisation_reaches_reference_ground_state():
     d = np.load(os.path.join(GOLDEN, 'cfg1_fccAl_32.npz'))
     box, vext, den_ref, n_elec = d['box'], d['vext'], d['den'], float(d['n_elec'])
     eng = Engine((32, 32, 32), DEV).set_cell(dev(box)).set_terms(F.NativeTerms(_CFG_TERMS['cfg1']).names)
-    res = optimize_density(eng, n_elec, dev(vext), volume=abs(np.linalg.det(box)))
+    res = optimize_density(eng, n_elec, dev(vext), volume=abs(np.linalg.det(box)), optimizer=optimizer)
     assert res['converged'] and abs(res['iterations'] - 17) <= 3
     assert abs(res['E_Ha'] - float(d['E_Ha'])) < 2e-8
     assert relerr(res['den'].cpu().numpy(), den_ref) < 1e-4
@@ -361,3 +362,35 @@ def test_ion_electron_forces_match_reference_golden():
             fd = -(U[0] - U[1]) / (2 * h)
             assert abs(fd - F[a, j]) < 2e-7 * max(1.0, abs(fd)), (o, a, j, fd, F[a, j])
     eng.close()
+
+
+@pytest.mark.parametrize('n', [4096, 1001, 262147])
+def test_lbfgs_sweeps_match_numpy_double(n):
+    """ofdft_lbfgs_dots / _commit / _update against the numpy statement of their contract: a scripted sequence with
+    pushes, a rejected pair and history wrap-around; even and odd vector lengths"""
+    from lbfgs_double import NumpyLbfgsBackend
+    from professad_amd.optimize import HipLbfgsBackend
+    rng = np.random.default_rng(n)
+    hip, ref = HipLbfgsBackend(n, 8, DEV), NumpyLbfgsBackend(n, 8)
+    x = rng.standard_normal(n)
+    xd = dev(x.copy())
+    for it in range(12):
+        g = rng.standard_normal(n) * (1.0 + it)
+        gd = dev(g)
+        va, ka = hip.dots(gd)
+        vb, kb = ref.dots(g)
+        assert ka == kb and va.shape == vb.shape
+        assert np.abs(va - vb).max() <= 1e-12 * max(1.0, np.abs(vb).max()), (it, np.abs(va - vb).max())
+        push = it > 0 and it != 5          # iteration 5: the candidate is discarded
+        hip.commit(push)
+        ref.commit(push)
+        k = len(ref.S)
+        cs, cy, cg, t = rng.standard_normal(k), rng.standard_normal(k), -0.7, 0.1 + 0.01 * it
+        sa = hip.update(cs, cy, cg, t, xd, gd)
+        sb = ref.update(cs, cy, cg, t, x, g)
+        assert abs(sa - sb) <= 1e-12 * max(1.0, abs(sb))
+        assert np.abs(xd.cpu().numpy() - x).max() <= 1e-13 * max(1.0, np.abs(x).max())
+    with pytest.raises(RuntimeError):       # protocol errors are reported, not ignored
+        hip.dots(gd)
+        hip.update(cs, cy, cg, t, xd, gd)
+    hip.close()

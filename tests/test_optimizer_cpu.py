@@ -33,3 +33,78 @@ def test_lbfgs_reproduces_reference_log_with_oracle_closure():
     for w in want:
         opt.step(closure)
         assert abs(last['E'] * EV_PER_HA - w) < 2e-6
+
+
+def _test_problem(n=400, seed=3):
+    """a smooth non-quadratic test function with an ill-conditioned quadratic part"""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n)) / math.sqrt(n)
+    H = torch.as_tensor(A @ A.T + np.diag(np.linspace(0.05, 3.0, n)))
+    b = torch.as_tensor(rng.standard_normal(n))
+
+    def make(x):
+        def closure():
+            xx = x.detach().clone().requires_grad_(True)
+            f = 0.5 * xx @ (H @ xx) - b @ xx + 0.05 * (xx ** 4).sum()
+            f.backward()
+            return float(f.detach()), xx.grad.detach()
+        return closure
+    return make
+
+
+def test_vector_free_lbfgs_equals_two_loop_form():
+    """the coefficient-space recursion + sweeps (numpy double of the HIP backend) walk the same path as the
+    op-by-op two-loop form, including history wrap-around, rejected pairs and the step's break conditions"""
+    from lbfgs_double import NumpyLbfgsBackend
+    from professad_amd.optimize import VectorFreeLBFGS
+    n = 400
+    make = _test_problem(n)
+    xa = torch.full((n,), 0.3, dtype=torch.double)
+    xb = xa.clone()
+    a = FixedStepLBFGS(xa, lr=0.1, history_size=8, max_iter=6)
+    b = VectorFreeLBFGS(xb, NumpyLbfgsBackend(n, 8), lr=0.1, history_size=8, max_iter=6)
+    ca, cb = make(xa), make(xb)
+    for it in range(12):          # 12 outer steps = up to 72 inner iterations: the 8-pair history wraps several times
+        la, lb = a.step(ca), b.step(cb)
+        assert abs(la - lb) <= 1e-9 * max(1.0, abs(la)), (it, la, lb)
+        assert float((xa - xb).abs().max()) <= 1e-8 * float(xa.abs().max()), it
+    assert a.func_evals == b.func_evals and a.total_iter == b.total_iter
+
+
+def test_vector_free_lbfgs_sharded_sums():
+    """two 'ranks' each holding half of the vector, local sums added by the all_reduce hook: same path"""
+    from lbfgs_double import NumpyLbfgsBackend
+    from professad_amd.optimize import VectorFreeLBFGS
+    n = 400
+    make = _test_problem(n)
+    xa = torch.full((n,), 0.3, dtype=torch.double)
+    xb = xa.clone()
+    a = VectorFreeLBFGS(xa, NumpyLbfgsBackend(n, 8), lr=0.1, history_size=8, max_iter=6)
+
+    class Halves:
+        """backend over two shards; returns rank 0's local sums, the hook adds rank 1's"""
+        def __init__(self):
+            self.h = [NumpyLbfgsBackend(n // 2, 8), NumpyLbfgsBackend(n // 2, 8)]
+            self.other = None
+
+        def dots(self, g):
+            v0, k = self.h[0].dots(g[:n // 2])
+            self.other, _ = self.h[1].dots(g[n // 2:])
+            return v0, k
+
+        def commit(self, push):
+            for h in self.h:
+                h.commit(push)
+
+        def update(self, cs, cy, cg, t, x, g):
+            s0 = self.h[0].update(cs, cy, cg, t, x[:n // 2], g[:n // 2])
+            self.other = np.array([self.h[1].update(cs, cy, cg, t, x[n // 2:], g[n // 2:])])
+            return s0
+
+    hb = Halves()
+    b = VectorFreeLBFGS(xb, hb, lr=0.1, history_size=8, max_iter=6, all_reduce=lambda v: v + hb.other)
+    ca, cb = make(xa), make(xb)
+    for it in range(6):
+        la, lb = a.step(ca), b.step(cb)
+        assert abs(la - lb) <= 1e-10 * max(1.0, abs(la))
+    assert float((xa - xb).abs().max()) <= 1e-9 * float(xa.abs().max())
