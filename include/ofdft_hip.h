@@ -153,6 +153,18 @@ int  ofdft_ion_electron_forces(ofdft_ctx* ctx, const void* den_dev, const double
                                const double* table_k_host, const double* table_v_host, int ntable, double z_ion,
                                int pme_order, double* forces_host, void* stream);
 
+/* ---- stress -----------------------------------------------------------------------------
+ * sigma_ij = (1/Omega) dE/d eps_ij at fixed electron number, per term: what get_stress (functional_tools.py:73-101)
+ * and System.__compute_stress (system.py:925-935) obtain by autograd through every FFT.  Closed forms of the
+ * reference's own analytic tests (tests/tools_for_tests.py:212-307, 367-472) for Hartree, TF, Wang-Teter, LDA, PBE; the
+ * exact discrete forms for vW, the density-dependent WGC99 kernel and the ion-electron term are derived in
+ * oracle/stress.py.  sigma_terms_host[OFDFT_NTERMS][9]: row-major symmetric 3x3 per term bit, Ha/bohr^3; the
+ * ion-electron entry stays zero (it needs the ions: ofdft_ion_electron_stress, same arguments as the forces). */
+int  ofdft_stress(ofdft_ctx* ctx, const void* den_dev, double* sigma_terms_host, void* stream);
+int  ofdft_ion_electron_stress(ofdft_ctx* ctx, const void* den_dev, const double* frac_coords_host, int nions,
+                               const double* table_k_host, const double* table_v_host, int ntable, double z_ion,
+                               int pme_order, double* sigma_host /*[9]*/, void* stream);
+
 /* ---- limited-memory BFGS building blocks (the consumer of the closure) ----------------
  * The reference's fixed-step optimiser (_optimizers/lbfgs/lbfgsnew.py:594-663) forms y = g - g_prev and s = t d, keeps
  * the pair if y.s > 1e-10 |s|^2, and gets the direction from the two-loop recursion: 2m dependent dot / axpy pairs over

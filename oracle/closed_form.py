@@ -76,8 +76,9 @@ def wgc_coeffs(nt=100):
     return A, B
 
 
-def wgc_kernel(eta, alpha=WGC_ALPHA, beta=WGC_BETA, gamma=2.7, nt=100):
-    """w, w', w'' at the given eta values (functionals.py:845-939), Horner form."""
+def wgc_kernel(eta, alpha=WGC_ALPHA, beta=WGC_BETA, gamma=2.7, nt=100, third=False):
+    """w, w', w'' at the given eta values (functionals.py:845-939), Horner form; with third=True also the third
+    derivative (needed by the stress of the density-dependent kernel, oracle/stress.py)."""
     eta = np.asarray(eta, dtype=np.float64)
     u = 3 * (alpha + beta) - gamma / 2
     v = u * u - 36 * alpha * beta
@@ -134,7 +135,22 @@ def wgc_kernel(eta, alpha=WGC_ALPHA, beta=WGC_BETA, gamma=2.7, nt=100):
     w0 = np.where(nz, H0 + P0, 0.0)
     w1 = np.where(nz, H1 + P1, 0.0)
     w2 = np.where(nz, H2 + P2, 0.0)
-    return w0, w1, w2
+    if not third:
+        return w0, w1, w2
+    if v > 0:
+        x_, y_ = u + math.sqrt(v), u - math.sqrt(v)
+        H3 = C1 * x_ * (x_ - 1) * (x_ - 2) * e ** (x_ - 3) + C2 * y_ * (y_ - 1) * (y_ - 2) * e ** (y_ - 3)
+    elif v == 0:
+        raise NotImplementedError('third derivative for the degenerate case v == 0')
+    else:       # H = Re[(C1 - i C2) eta^z], z = u + i sqrt(-v)
+        z = complex(u, math.sqrt(-v))
+        H3 = ((C1 - 1j * C2) * (z * (z - 1) * (z - 2)) * e ** (z - 3)).real
+    c3_ = np.where(inner[..., None], 2 * i * (2 * i - 1) * (2 * i - 2) * cb, -2 * i * (2 * i + 1) * (2 * i + 2) * ca)
+    P3 = np.zeros(eta.shape)
+    for j in range(nt - 1, -1, -1):
+        P3 = P3 * x + c3_[..., j]
+    P3 = P3 / (e * e * e)
+    return w0, w1, w2, np.where(nz, H3 + P3, 0.0)
 
 
 # ----------------------------------------------------------------------------- per-term closed forms

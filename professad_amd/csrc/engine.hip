@@ -11,6 +11,7 @@
 
 #include "../../include/ofdft_hip.h"
 #include "ion_kernels.h"
+#include "stress_kernels.h"
 #include "zpass.h"
 
 using namespace ofdft;
@@ -514,12 +515,12 @@ void wgc_series_coeffs(int nt, std::vector<double>& A, std::vector<double>& B) {
     for (int i = 2; i < nt; ++i) B[i] = b[i];
 }
 
-int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out) {
+// series constants of the WGC99 kernel for n_ref = kappa round(N_e) / vol (functionals.py:845-939); uploads the
+// coefficient arrays
+int wgc_series_setup(ofdft_ctx* c, long long nel_rounded, hipStream_t st, WgcSeries* out) {
     const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
     const double ga = c->params[OFDFT_P_WGC_GAMMA], ka = c->params[OFDFT_P_WGC_KAPPA];
     const double nref = ka * ((double)nel_rounded / c->vol);
-    *nref_out = nref;
-    if (c->wgc_valid && c->wgc_key_nel == nel_rounded) return 0;
     const int nt = 100;
     const double u = 3.0 * (al + be) - ga / 2.0, v = u * u - 36.0 * al * be;
     std::vector<double> A, B, coef(2 * nt);
@@ -558,6 +559,16 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     HIP_TRY(c, hipStreamSynchronize(st));   // coef is a stack-backed vector
     s.ca = c->d_wgc_coef;
     s.cb = c->d_wgc_coef + nt;
+    *out = s;
+    return 0;
+}
+
+int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out) {
+    const double nref = c->params[OFDFT_P_WGC_KAPPA] * ((double)nel_rounded / c->vol);
+    *nref_out = nref;
+    if (c->wgc_valid && c->wgc_key_nel == nel_rounded) return 0;
+    WgcSeries s{};
+    if (int rc = wgc_series_setup(c, nel_rounded, st, &s)) return rc;
     double *w0, *K1, *K2, *K3;
     const size_t tb = sizeof(double) * (size_t)c->g.total;
     if (int rc = get_ws(c, "t:wgc", 4 * tb, (void**)&w0)) return rc;      // interleaved (w0,K1,K2,K3) per k-point
@@ -1972,6 +1983,183 @@ int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* f
                 forces_host[3 * a + j] = -c->dV * t;
             }
     }
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+// ------------------------------------------------------------------------------ stress
+namespace {
+
+void sym_store(double* out9, const double* c6, double diag) {
+    out9[0] = c6[0] + diag; out9[4] = c6[1] + diag; out9[8] = c6[2] + diag;
+    out9[1] = out9[3] = c6[3];
+    out9[2] = out9[6] = c6[4];
+    out9[5] = out9[7] = c6[5];
+}
+
+}  // namespace
+
+// Per-term stress tensors for the active terms, sigma_terms_host[OFDFT_NTERMS][9] (row-major 3x3, Ha/bohr^3); the
+// ion-electron entry stays zero (its potential depends on the ions: ofdft_ion_electron_stress).
+int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = begin_call(c, st)) return rc;
+    if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_stress: single-GPU contexts only");
+    const double* den = (const double*)den_dev;
+    const unsigned mask = c->mask;
+    const long long npts = c->npts;
+    const double invN = 1.0 / (double)npts, invN2 = invN * invN;
+    for (int i = 0; i < OFDFT_NTERMS * 9; ++i) sig[i] = 0.0;
+    const int sp_blocks = grid_for(c->g.total, kRedThreads, kRedBlocks), pw_grid = grid_for(npts / 2 + 1);
+    double s7[kStressSpecScalars];
+    double nsum;
+    if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
+    const double nbar = nsum * invN;                    // N_e / vol, un-rounded (functionals.py:634)
+    cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
+    double *gx = nullptr, *gy = nullptr, *gz = nullptr;
+    if (int rc = spec_ws(c, "s0", &s0)) return rc;
+    if (int rc = spec_ws(c, "s1", &s1)) return rc;
+    if (mask & (OFDFT_HARTREE | OFDFT_PBE_X | OFDFT_PBE_C)) {
+        if (int rc = rfftn_internal(c, den, s0, st)) return rc;
+        if (mask & OFDFT_HARTREE) {
+            OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HARTREE>), dim3(sp_blocks), dim3(kRedThreads), 0,
+                         (const cplx*)s0, (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
+            if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+            sym_store(sig + 9 * 1, s7, -0.5 * s7[6]);                 // -E_H / vol on the diagonal
+        }
+        if (mask & (OFDFT_PBE_X | OFDFT_PBE_C)) {
+            if (int rc = spec_ws(c, "s2", &s2)) return rc;
+            if (int rc = spec_ws(c, "s3", &s3)) return rc;
+            if (int rc = real_ws(c, "gx", &gx)) return rc;
+            if (int rc = real_ws(c, "gy", &gy)) return rc;
+            if (int rc = real_ws(c, "gz", &gz)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(grid_for(c->g.total)), dim3(256), 0, s0, s1, s2, s3, c->kg);
+            if (int rc = irfftn_internal(c, s1, gx, invN, st)) return rc;
+            if (int rc = irfftn_internal(c, s2, gy, invN, st)) return rc;
+            if (int rc = irfftn_internal(c, s3, gz, invN, st)) return rc;
+        }
+    }
+    if (mask & (OFDFT_TF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | OFDFT_PBE_X | OFDFT_PBE_C)) {
+        const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
+        double r[kStressRealScalars];
+        OFDFT_LAUNCH(c, st, "stress_real", stress_real_kernel, dim3(blocks), dim3(kRedThreads), 0, den, (const double*)gx,
+                     (const double*)gy, (const double*)gz, npts, mask, c->d_partial);
+        if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
+        const double zero6[6] = {0, 0, 0, 0, 0, 0};
+        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
+        if (mask & OFDFT_TF) sym_store(sig + 9 * 2, zero6, -2.0 / 3.0 * ctf * r[0] * invN);      // tools_for_tests.py:241-243
+        if (mask & OFDFT_LDA_X) sym_store(sig + 9 * 6, zero6, r[1] * invN);                    // :367-370
+        int nc = 0;
+        for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
+        for (int b = 7; b <= 9; ++b)
+            if ((mask >> b) & 1) sym_store(sig + 9 * b, zero6, r[2] * invN / nc);
+        for (int which = 0; which < 2; ++which) {                                              // :393-472
+            if (!(mask & (which == 0 ? OFDFT_PBE_X : OFDFT_PBE_C))) continue;
+            const double* o = r + (which == 0 ? 3 : 11);
+            double c6[6];
+            for (int k = 0; k < 6; ++k) c6[k] = -2.0 * o[k] * invN;
+            for (int k = 0; k < 3; ++k) c6[k] += -2.0 * o[6] * invN;
+            sym_store(sig + 9 * (10 + which), c6, o[7] * invN);
+        }
+    }
+    if (mask & OFDFT_VW) {
+        double* tmp;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
+        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
+        OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_VW>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)s0,
+                     (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
+        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        sym_store(sig + 9 * 3, s7, 0.0);
+    }
+    if (mask & OFDFT_WT_NL) {
+        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
+        const double pref = ctf * 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        double* tmp;
+        if (int rc = real_ws(c, "t0", &tmp)) return rc;
+        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
+        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
+        cplx* sa = s0;
+        if (al != be) {
+            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
+            if (int rc = rfftn_internal(c, tmp, s1, st)) return rc;
+            sa = s1;
+        }
+        OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_WT>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)sa,
+                     (const cplx*)s0, c->kg, invN2, 1.0 / (2.0 * kf), c->d_partial);
+        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        double c6[6];
+        for (int k = 0; k < 6; ++k) c6[k] = pref * s7[k];
+        sym_store(sig + 9 * 4, c6, -2.0 / 3.0 * pref * s7[6]);                                  // -2/3 T_NL / vol
+    }
+    if (mask & OFDFT_WGC99_NL) {
+        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+        const long long nel_r = std::llround(nsum * c->dV);                                      // functionals.py:952
+        WgcSeries ser{};
+        if (int rc = wgc_series_setup(c, nel_r, st, &ser)) return rc;
+        if (ser.v == 0.0) return fail(c, OFDFT_EINVAL, "WGC99 stress: degenerate kernel parameters (v = 0) not supported");
+        const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
+        WgcSpectra sp{};
+        double* t[3];
+        if (int rc = real_ws(c, "t0", &t[0])) return rc;
+        if (int rc = real_ws(c, "t1", &t[1])) return rc;
+        if (int rc = real_ws(c, "t2", &t[2])) return rc;
+        for (int pass = 0; pass < 2; ++pass) {
+            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t[0], t[1], t[2], npts,
+                         pass == 0 ? be : al, ser.nref);
+            for (int k = 0; k < 3; ++k) {
+                cplx* w;
+                if (int rc = spec_ws(c, wn[3 * pass + k], &w)) return rc;
+                if (int rc = rfftn_internal(c, t[k], w, st)) return rc;
+                sp.s[3 * pass + k] = w;
+            }
+        }
+        OFDFT_LAUNCH(c, st, "stress_wgc", stress_wgc_kernel, dim3(sp_blocks), dim3(kRedThreads), 0, sp, c->kg, ser, invN2,
+                     c->d_partial);
+        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
+        double c6[6];
+        for (int k = 0; k < 6; ++k) c6[k] = ctf * s7[k];
+        sym_store(sig + 9 * 5, c6, -2.0 / 3.0 * ctf * s7[6]);
+    }
+    return end_call(c, st);
+}
+
+// Ion-electron stress of one species for a given density, the potential being rebuilt from the ions at fixed fractional
+// coordinates (what System.__compute_stress differentiates, system.py:925-935).  sigma_host[9], row-major.
+int ofdft_ion_electron_stress(ofdft_ctx* c, const void* den_dev, const double* frac_host, int nions, const double* tab_k,
+                              const double* tab_v, int ntab, double z_ion, int pme_order, double* sigma_host, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !den_dev || !frac_host || !tab_k || !tab_v || !sigma_host) return OFDFT_EINVAL;
+    IonPrep p;
+    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
+    cplx *sN, *sQ = nullptr;
+    if (int rc = spec_ws(c, "i:F", &sN)) return rc;
+    if (int rc = rfftn_internal(c, (const double*)den_dev, sN, st)) return rc;
+    if (pme_order != 0) {
+        double* tmp;
+        if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
+        if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
+        HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
+        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
+                     pme_order, tmp, c->n0, c->n1, c->n2);
+        if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
+    }
+    const int blocks = grid_for(c->g.total, kRedThreads, kRedBlocks);
+    OFDFT_LAUNCH(c, st, "stress_ion", stress_ion_kernel, dim3(blocks), dim3(kRedThreads), 0, (const cplx*)sN, (const cplx*)sQ,
+                 c->kg, (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2,
+                 pme_order == 0 ? (const double*)p.d_cart : (const double*)nullptr, nions, p.tab, c->d_partial);
+    double s7[kStressSpecScalars];
+    if (int rc = fetch_partials(c, blocks, kStressSpecScalars, s7, st)) return rc;
+    const double invN = 1.0 / (double)c->npts;
+    double c6[6];
+    for (int k = 0; k < 6; ++k) c6[k] = -s7[k] * invN / c->vol;
+    sym_store(sigma_host, c6, -s7[6] * invN / c->vol);
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
     return OFDFT_OK;

@@ -11,7 +11,7 @@ namespace ofdft {
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
 constexpr int kRedThreads = 256;
-constexpr int kMaxScalars = 12;    // scalars reduced by one kernel
+constexpr int kMaxScalars = 20;    // scalars reduced by one kernel (19: the real-space stress sums)
 
 // ---- block reduction of NS scalars; thread 0 writes partial[blockIdx.x * NS + s]
 template <int NS>
@@ -205,6 +205,68 @@ struct WgcSeries {
 // [x][ main (b, yl, kin) | planes (plane, yl) ] of arr_sz elements, the one-array form of the exchange layout
 struct TabMap { int on, nyl, nzm; long long arr_sz; };
 
+// w, w', w'' (and w''' when THIRD) of the WGC99 kernel at eta != 0, before the prefactor (functionals.py:845-939):
+// homogeneous solution + particular series by Horner in eta^2 (inside) or eta^-2 (outside)
+template <bool THIRD>
+__device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, double& w0, double& w1, double& w2, double& w3) {
+    const bool inner = eta <= 1.0;
+    const bool on = (s.u >= 0.0) ? inner : !inner;
+    const double C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
+    const double le = log(eta);
+    double H0, H1, H2, H3 = 0.0;
+    if (s.v > 0.0) {
+        const double rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
+        const double px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
+        H0 = (C1 * px + C2 * py) * eta * eta;
+        H1 = (C1 * x * px + C2 * y * py) * eta;
+        H2 = C1 * x * (x - 1.0) * px + C2 * y * (y - 1.0) * py;
+        if (THIRD) H3 = (C1 * x * (x - 1.0) * (x - 2.0) * px + C2 * y * (y - 1.0) * (y - 2.0) * py) / eta;
+    } else if (s.v == 0.0) {
+        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        H0 = pu * (C2 * le + C1);
+        H1 = C2 * pu1 * (1.0 + s.u * le) + C1 * s.u * pu1;
+        H2 = C2 * ((s.u - 1.0) * pu2 * (1.0 + s.u * le) + pu2) + C1 * s.u * (s.u - 1.0) * pu2;
+        // third derivative of eta^u (C2 ln eta + C1)
+        if (THIRD) {
+            const double a3 = s.u * (s.u - 1.0) * (s.u - 2.0), b3 = 3.0 * s.u * s.u - 6.0 * s.u + 2.0;
+            H3 = pu2 / eta * (C2 * (a3 * le + b3) + C1 * a3);
+        }
+    } else {
+        const double rv = sqrt(-s.v);
+        const double tc = cos(rv * le), ts = sin(rv * le);
+        const double p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
+        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        H0 = pu * (C1 * tc + C2 * ts);
+        H1 = pu1 * (C1 * p + C2 * q);
+        H2 = pu2 * ((s.u - 1.0) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q));
+        if (THIRD) {      // H = Re[(C1 - i C2) eta^z], z = u + i rv:  H''' = Re[(C1 - i C2) z (z-1) (z-2) eta^(z-3)]
+            const double zr = s.u, zi = rv;
+            double ar = zr * (zr - 1.0) - zi * zi, ai = zi * (2.0 * zr - 1.0);           // z (z-1)
+            const double br = ar * (zr - 2.0) - ai * zi, bi = ar * zi + ai * (zr - 2.0);  // ... (z-2)
+            const double dr = C1 * br + C2 * bi, di = C1 * bi - C2 * br;                  // (C1 - i C2) * that
+            H3 = pu2 / eta * (dr * tc - di * ts);
+        }
+    }
+    const double x = inner ? eta * eta : 1.0 / (eta * eta);
+    double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
+    for (int t = s.nt - 1; t >= 0; --t) {
+        const double ti = 2.0 * t;
+        const double c = inner ? s.cb[t] : s.ca[t];
+        const double d1 = inner ? ti * c : -ti * c;
+        const double d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
+        P0 = P0 * x + c;
+        P1 = P1 * x + d1;
+        P2 = P2 * x + d2;
+        if (THIRD) P3 = P3 * x + (inner ? ti * (ti - 1.0) * (ti - 2.0) * c : -ti * (ti + 1.0) * (ti + 2.0) * c);
+    }
+    P1 /= eta;
+    P2 /= eta * eta;
+    w0 = H0 + P0;
+    w1 = H1 + P1;
+    w2 = H2 + P2;
+    w3 = THIRD ? H3 + P3 / (eta * eta * eta) : 0.0;
+}
+
 __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ K1o, double* __restrict__ K2o,
                                  double* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
     for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < kg.g.total; ii += (long long)gridDim.x * blockDim.x) {
@@ -218,51 +280,8 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
                                             : ((long long)tm.nzm * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y));
         }
         const double eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-        if (eta != 0.0) {
-            const bool inner = eta <= 1.0;
-            const bool on = (s.u >= 0.0) ? inner : !inner;
-            const double C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
-            const double le = log(eta);
-            double H0, H1, H2;
-            if (s.v > 0.0) {
-                const double rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
-                const double px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
-                H0 = (C1 * px + C2 * py) * eta * eta;
-                H1 = (C1 * x * px + C2 * y * py) * eta;
-                H2 = C1 * x * (x - 1.0) * px + C2 * y * (y - 1.0) * py;
-            } else if (s.v == 0.0) {
-                const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
-                H0 = pu * (C2 * le + C1);
-                H1 = C2 * pu1 * (1.0 + s.u * le) + C1 * s.u * pu1;
-                H2 = C2 * ((s.u - 1.0) * pu2 * (1.0 + s.u * le) + pu2) + C1 * s.u * (s.u - 1.0) * pu2;
-            } else {
-                const double rv = sqrt(-s.v);
-                const double tc = cos(rv * le), ts = sin(rv * le);
-                const double p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
-                const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
-                H0 = pu * (C1 * tc + C2 * ts);
-                H1 = pu1 * (C1 * p + C2 * q);
-                H2 = pu2 * ((s.u - 1.0) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q));
-            }
-            // particular solution: Horner in eta^2 (inside) or eta^-2 (outside)
-            const double x = inner ? eta * eta : 1.0 / (eta * eta);
-            double P0 = 0.0, P1 = 0.0, P2 = 0.0;
-            for (int t = s.nt - 1; t >= 0; --t) {
-                const double ti = 2.0 * t;
-                const double c = inner ? s.cb[t] : s.ca[t];
-                const double d1 = inner ? ti * c : -ti * c;
-                const double d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
-                P0 = P0 * x + c;
-                P1 = P1 * x + d1;
-                P2 = P2 * x + d2;
-            }
-            P1 /= eta;
-            P2 /= eta * eta;
-            w0 = H0 + P0;
-            w1 = H1 + P1;
-            w2 = H2 + P2;
-        }
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;
+        if (eta != 0.0) wgc_series<false>(eta, s, w0, w1, w2, w3);
         w0 *= s.pref;
         w1 *= s.pref;
         w2 *= s.pref;

@@ -148,6 +148,15 @@ class Engine:
         self._check(self.lib.ofdft_set_option(self._ctx, int(option), float(value)), 'ofdft_set_option')
         return self
 
+    def stress(self, den):
+        """per-term stress tensors {term name: 3x3 numpy array, Ha/bohr^3} for the active terms at fixed electron number
+        (get_stress semantics, functional_tools.py:73-101); the ion-electron entry is zero (see ions.ion_electron_stress)"""
+        den = self._grid_tensor(den, 'den')
+        buf = (C.c_double * (N.NTERMS * 9))()
+        self._check(self.lib.ofdft_stress(self._ctx, C.c_void_p(den.data_ptr()), buf, self._stream()), 'ofdft_stress')
+        a = np.array(list(buf), dtype=np.float64).reshape(N.NTERMS, 3, 3)
+        return {nm: a[i] for i, nm in enumerate(N.TERM_ORDER)}
+
     def set_profiling(self, on):
         self._check(self.lib.ofdft_set_profiling(self._ctx, 1 if on else 0), 'ofdft_set_profiling')
 

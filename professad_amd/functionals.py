@@ -11,7 +11,8 @@ handed to professad's ``System`` unchanged, and ``get_functional_derivative(box_
 (functional_tools.py:9-31) works on them.  ``NativeTerms`` fuses several terms into one engine call
 (shared spectra; System only sums its terms, system.py:771).
 
-Gradients w.r.t. ``box_vecs`` (stress) are not produced natively: asking for them raises.
+Gradients w.r.t. ``box_vecs`` come from the engine's analytic per-term stress (ofdft_stress), so the reference's
+``get_stress(box_vecs, den, f)`` (functional_tools.py:73-101) works on these terms too.
 """
 import numpy as np
 import torch
@@ -23,22 +24,37 @@ _S5 = np.sqrt(5.0)
 
 
 class _NativeEnergy(torch.autograd.Function):
-    """forward: C-ABI call (energy + dE/dn); backward: gE * dE/dn * dV  (functional_tools.py:31)."""
+    """forward: C-ABI call (energy + dE/dn); backward: gE * dE/dn * dV  (functional_tools.py:31).
+
+    When ``box_vecs.requires_grad`` (the reference's get_stress / System.stress differentiate the energy with respect
+    to the lattice vectors, functional_tools.py:94-99) the engine's analytic stress supplies the PARTIAL derivative at
+    fixed density grid values: with sigma the stress at fixed electron number (density ~ 1/volume),
+        dE/dB |_n = B^-T (vol * sigma + (int v n) * 1),
+    because the density path -- which torch differentiates itself through ``den * vol.detach() / vol`` -- contributes
+    -(int v n) B^-T.  For IonElectron (fixed v_ext array) sigma = 0 and the formula reduces to E B^-T; the dependence
+    of v_ext on the cell is differentiated by whoever built v_ext."""
 
     @staticmethod
     def forward(ctx, box_vecs, den, v_ext, term_names, params):
-        if box_vecs.requires_grad:
-            raise NotImplementedError('native terms do not provide dE/d(box_vecs) (stress); '
-                                      'use the reference torch terms for System.stress()')
         eng = engine_for(den.shape, den.device)
         eng.set_cell(box_vecs)
         eng.set_terms(term_names, dict(params))
-        need_v = den.requires_grad
+        need_box = box_vecs.requires_grad
+        need_v = den.requires_grad or need_box
         E_terms, v = eng.energy_potential(den, v_ext, want_potential=need_v)
-        dV = float(torch.abs(torch.linalg.det(box_vecs.detach().double().cpu()))) / den.numel()
+        box = box_vecs.detach().double().cpu()
+        vol = float(torch.abs(torch.linalg.det(box)))
+        dV = vol / den.numel()
         ctx.dV = dV
         ctx.has_vext = v_ext is not None
-        ctx.save_for_backward(v if need_v else None, den.detach() if (v_ext is not None and v_ext.requires_grad) else None)
+        ctx.g_box = None
+        if need_box:
+            sig = sum(eng.stress(den).values())                              # total over the active terms (3x3)
+            vn = float((v * den.detach()).sum()) * dV
+            g = torch.linalg.inv(box).T @ torch.as_tensor(vol * sig + vn * np.eye(3))
+            ctx.g_box = g.to(box_vecs.device)
+        ctx.save_for_backward(v if den.requires_grad else None,
+                              den.detach() if (v_ext is not None and v_ext.requires_grad) else None)
         ctx.E_terms = E_terms
         return torch.tensor(sum(E_terms.values()), dtype=torch.double, device=den.device)
 
@@ -47,7 +63,8 @@ class _NativeEnergy(torch.autograd.Function):
         v, den = ctx.saved_tensors
         g_den = gE * v * ctx.dV if v is not None else None
         g_vext = gE * den * ctx.dV if den is not None else None       # d/dv_ext of mean(n v) vol
-        return None, g_den, g_vext, None, None
+        g_box = gE.to(ctx.g_box.device) * ctx.g_box if ctx.g_box is not None else None
+        return g_box, g_den, g_vext, None, None
 
 
 def _evaluate(box_vecs, den, names, params=(), v_ext=None):

@@ -82,3 +82,24 @@ def ion_electron_forces(engine, box_vecs, den, species, pme_order=None):
         engine._check(rc, 'ofdft_ion_electron_forces')
         out.append(f)
     return out
+
+
+def ion_electron_stress(engine, box_vecs, den, species, pme_order=None):
+    """Ion-electron stress (3x3, Ha/bohr^3) with the potential rebuilt from the ions at fixed fractional coordinates
+    (the IonElectron part of System.stress(), system.py:925-935), summed over species."""
+    engine.set_cell(box_vecs)
+    den = engine._grid_tensor(den, 'den')
+    dp = C.POINTER(C.c_double)
+    total = np.zeros((3, 3))
+    for frac, (ks, v, z) in species:
+        frac = np.ascontiguousarray(np.asarray(torch.as_tensor(frac).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 3))
+        ks = np.ascontiguousarray(ks, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        s = np.zeros(9)
+        rc = engine.lib.ofdft_ion_electron_stress(engine._ctx, C.c_void_p(den.data_ptr()), frac.ctypes.data_as(dp), frac.shape[0],
+                                                  ks.ctypes.data_as(dp), v.ctypes.data_as(dp), ks.size, float(z),
+                                                  0 if pme_order is None else int(pme_order), s.ctypes.data_as(dp),
+                                                  engine._stream())
+        engine._check(rc, 'ofdft_ion_electron_stress')
+        total += s.reshape(3, 3)
+    return total

@@ -224,9 +224,10 @@ if __name__ == '__main__':
     ap.add_argument('--huge', action='store_true')
     ap.add_argument('--small', action='store_true')
     ap.add_argument('--ions', action='store_true')
+    ap.add_argument('--stress', action='store_true')
     a = ap.parse_args()
     torch.set_num_threads(8)
-    if a.small or not (a.big or a.cfg1 or a.huge or a.ions):
+    if a.small or not (a.big or a.cfg1 or a.huge or a.ions or a.stress):
         gen_wavevecs()
         for c in cases.PER_TERM_CASES:
             gen_terms(c)
@@ -311,3 +312,42 @@ def gen_ions():
 
 if '--ions' in sys.argv:
     gen_ions()
+
+
+STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99']
+
+
+def gen_stress():
+    """Per-term stress tensors by the reference's own get_stress (autograd w.r.t. the lattice vectors with the density
+    scaled as 1/volume, functional_tools.py:73-101) and the ion-electron stress with the potential rebuilt from the ions
+    at fixed fractional coordinates (as System.__compute_stress does, system.py:925-935)."""
+    import professad.ion_utils as IU
+    out = {}
+    for case in ('g16r', 'gmix', 'g18t'):
+        box, den, vext, chi, n_elec = cases.make_inputs(case)
+        terms, _ = reference_terms(t(vext))
+        for nm in STRESS_TERMS:
+            out['%s_%s' % (case, nm)] = T.get_stress(t(box), t(den), terms[nm]).detach().numpy()
+        print('stress', case)
+    os.chdir('/root/reference/tests')
+    path = 'potentials/al.gga.recpot'
+    g = np.load(os.path.join(HERE, 'ions.npz'))
+    dens = {'a': cases.synth.smooth_density((32, 32, 32), seed=8, n0=0.03, amp=0.5),
+            'b': cases.synth.smooth_density((16, 20, 24), seed=7, n0=0.05, amp=0.5)}
+    for tag, shape, orders in (('a', (32, 32, 32), (None, 10)), ('b', (16, 20, 24), (None, 6))):
+        frac = t(g[tag + '_frac'])
+        for order in orders:
+            def fun(bv, dn):
+                kx, ky, kz, k2 = T.wavevecs(bv, shape)
+                k = torch.zeros(k2.shape, dtype=DT)
+                k[k2 != 0] = torch.sqrt(k2[k2 != 0])
+                vk = IU.interpolate_recpot(path, k)
+                return F.IonElectron(bv, dn, IU.lattice_sum(bv, shape, torch.matmul(frac, bv), vk, order))
+            sig = T.get_stress(t(g[tag + '_box']), t(dens[tag]), fun).detach().numpy()
+            out['%s_ion_electron_%s' % (tag, 'exact' if order is None else 'pme%d' % order)] = sig
+    np.savez_compressed(os.path.join(HERE, 'stress.npz'), **out)
+    print('stress.npz')
+
+
+if __name__ == '__main__' and '--stress' in sys.argv:
+    gen_stress()

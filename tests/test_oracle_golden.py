@@ -120,3 +120,29 @@ def test_ion_electron_forces_oracle():
             F = oi.ion_electron_forces(g[tag + '_box'], shape, g[tag + '_frac'], den, raw, kmax, o)
             ref = g[tag + '_force_exact'] if o is None else g['%s_force_pme%d' % (tag, o)]
             assert np.abs(F - ref).max() < 1e-13, (tag, o)
+
+
+def test_stress_oracle():
+    """closed-form / derived stress restatements against the reference's get_stress (autograd) outputs"""
+    from oracle import stress as st
+    from professad_amd import synth
+    g = load('stress.npz')
+    for case in ('g16r', 'gmix', 'g18t'):
+        box, den, vext, chi, n_elec = cases.make_inputs(case)
+        got = {'hartree': st.hartree(box, den), 'tf': st.tf(box, den), 'vw': st.vw(box, den), 'wt_nl': st.wt_nl(box, den),
+               'lda_x': st.lda(box, den, 'lda_x'), 'pz_c': st.lda(box, den, 'pz_c'), 'pw_c': st.lda(box, den, 'pw_c'),
+               'chachiyo_c': st.lda(box, den, 'chachiyo_c'), 'pbe_x': st.pbe(box, den, True, False),
+               'pbe_c': st.pbe(box, den, False, True),
+               'wgc99': st.tf(box, den) + st.vw(box, den) + st.wgc99_nl(box, den)}
+        for k, v in got.items():
+            ref = g['%s_%s' % (case, k)]
+            assert np.abs(v - ref).max() <= 1e-11 * np.abs(ref).max(), (case, k)
+    ions = load('ions.npz')
+    raw, kmax = ions['recpot_raw'], float(ions['recpot_kmax'])
+    for tag, shape, order, dk in (('a', (32, 32, 32), 10, dict(seed=8, n0=0.03, amp=0.5)),
+                                  ('b', (16, 20, 24), 6, dict(seed=7, n0=0.05, amp=0.5))):
+        den = synth.smooth_density(shape, **dk)
+        for o in (None, order):
+            s = st.ion_electron(ions[tag + '_box'], den, ions[tag + '_frac'], raw, kmax, o)
+            ref = g['%s_ion_electron_%s' % (tag, 'exact' if o is None else 'pme%d' % o)]
+            assert np.abs(s - ref).max() <= 1e-12 * np.abs(ref).max(), (tag, o)
