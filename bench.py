@@ -197,11 +197,19 @@ def main():
     roofline = None
     kernels = {k: {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof,
                    'share': round(v[0] / tot_ms, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    pmc = None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_r01.json')
+    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3':     # counters were collected on this workload
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
     if dom:
         avg_ms = prof[dom][0] / prof[dom][1]
         ach = kernel_alg_bytes(dom, n) / (avg_ms * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(ach / HBM_PEAK_GBS, 4),
+                    'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
+                                if pmc and dom in pmc.get('kernels', {}) else None),
+                    'traffic_source': ('profiles/pmc_traffic_r01.json: ' + pmc['source']) if pmc else None,
                     'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n),
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg)
@@ -215,7 +223,7 @@ def main():
                    if a.cfg == 'cfg3' else '%d^3 grid, fp64, IonElectron+Hartree+WT(+TF+vW)+PZ-LDA closure' % n,
                    'grid': [n, n, n], 'terms': names, 'density': src,
                    'parallelism': 'single GPU' if world == 1 else
-                   'x-slab decomposition over %d GPUs, 4 RCCL all-to-all transposes + 2 all-reduces per evaluation' % world},
+                   'x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world},
         'roofline': roofline,
         'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
                           'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'ffts_executed': n_fft,

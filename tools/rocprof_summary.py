@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output into a small markdown table for profiles/.
 
-usage: rocprof_summary.py <stats_dir> [<fetch_dir> <write_dir>] > profiles/NAME.md
+usage: rocprof_summary.py <stats_dir> [<fetch_dir> <write_dir>] [--json OUT.json] > profiles/NAME.md
+
+--json also writes the per-kernel-class figures (engine profiling class names, e.g. cpass_y) that bench.py reads
+for `roofline.traffic`.
 
 Per (kernel, grid size): launches, average duration from --kernel-trace, and -- when the two PMC passes are
 given -- HBM traffic per launch: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
@@ -41,7 +44,25 @@ def load_counter(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+CLASSES = [('cpass_kernel', 'cpass_y'), ('MixWgc', 'xfused_wgc'), ('MixDiv', 'xfused_div'), ('MixDensity', 'xfused_n'),
+           ('MixScale<1>', 'xfused_lap'), ('MixScale<2>', 'xfused_lind'), ('zi_combine_kernel', 'zi_combine'),
+           ('zpbe_kernel', 'zpbe'), ('zf_powers_kernel', 'zf_powers'), ('zf_density_kernel', 'zf_density'),
+           ('chi_grad_kernel', 'chi_grad'), ('sum_kernel', 'sum')]
+
+
+def klass(name):
+    for key, c in CLASSES:
+        if key in name:
+            return c
+    return None
+
+
 def main():
+    json_out = None
+    if '--json' in sys.argv:
+        i = sys.argv.index('--json')
+        json_out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     stats = sys.argv[1]
     fetch = load_counter(sys.argv[2], 'FETCH_SIZE') if len(sys.argv) > 3 else {}
     write = load_counter(sys.argv[3], 'WRITE_SIZE') if len(sys.argv) > 3 else {}
@@ -51,8 +72,16 @@ def main():
     tot = sum(sum(v) for v in agg.values())
     print('| kernel | grid | launches | avg us | share | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | traffic GB/s |')
     print('|---|---|---|---|---|---|---|---|')
+    per_class = defaultdict(lambda: [0, 0.0, 0.0, 0.0])       # launches, ns, read MB, write MB (launch-weighted sums)
     for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         avg = sum(v) / len(v)
+        c = klass(name)
+        if c and fetch.get((name, grid)) is not None and write.get((name, grid)) is not None:
+            pc = per_class[c]
+            pc[0] += len(v)
+            pc[1] += sum(v)
+            pc[2] += len(v) * 2 * fetch[(name, grid)] * 1024 / 1e6
+            pc[3] += len(v) * write[(name, grid)] * 1024 / 1e6
         rd = fetch.get((name, grid))
         wr = write.get((name, grid))
         rd_mb = 2 * rd * 1024 / 1e6 if rd is not None else None
@@ -62,6 +91,18 @@ def main():
             name, grid, len(v), avg / 1e3, 100.0 * sum(v) / tot,
             '%.1f' % rd_mb if rd_mb is not None else '-', '%.1f' % wr_mb if wr_mb is not None else '-',
             '%.0f' % gbs if gbs is not None else '-'))
+
+
+    if json_out:
+        import json
+        out = {'source': 'rocprofv3 --kernel-trace (durations) and two --pmc passes (FETCH_SIZE, WRITE_SIZE) of '
+                         '`OFDFT_SIDE_STREAM=0 python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline`; '
+                         'reads = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM section), '
+                         'writes = WRITE_SIZE KiB; per launch',
+               'kernels': {c: {'launches': v[0], 'avg_us': round(v[1] / v[0] / 1e3, 2), 'read_MB': round(v[2] / v[0], 1),
+                               'write_MB': round(v[3] / v[0], 1)} for c, v in per_class.items()}}
+        with open(json_out, 'w') as fh:
+            json.dump(out, fh, indent=1)
 
 
 if __name__ == '__main__':
