@@ -993,7 +993,8 @@ int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipS
     case M_:                                                                                                      \
         *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                          \
         OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256), \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), a, c->g, twM, twN, c->d_partial);                           \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS + sizeof(double) * 256 * kCombineScalars), a, c->g, twM, twN,  \
+                     c->d_partial);                                                                               \
         return 0;
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X

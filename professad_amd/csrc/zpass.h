@@ -329,9 +329,12 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const ZLane<M, E> z(g, lds);
     const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
-    double acc[kCombineScalars];
+    // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
+    // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
+    // a thread only reads what it wrote).  The final reduction order is unchanged.
+    double* park = lds + ZW<M, E>::LDS / sizeof(double) + threadIdx.x;
 #pragma unroll
-    for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
+    for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
 #pragma unroll
@@ -342,39 +345,45 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
     const double sc = a.inv_n;
     if (a.mask & 2u) {                                   // Hartree  functionals.py:72
         z_load_inverse<M, E>(w, z, a.vh, g, twM, twN);
+        double e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-            acc[1] += 0.5 * (n[q].x * x0 + n[q].y * x1);
+            e += 0.5 * (n[q].x * x0 + n[q].y * x1);
             vacc[q].x += x0;
             vacc[q].y += x1;
         }
+        park[1 * 256] = e;
     }
     if (a.mask & 8u) {                                   // vW  functionals.py:245; tools_for_tests.py:23-26
         z_load_inverse<M, E>(w, z, a.lap, g, twM, twN);
+        double e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const double x0 = w[q].x * sc, x1 = w[q].y * sc;
             const double s0 = n[q].x != 0.0 ? sqrt(n[q].x) : 0.0, s1 = n[q].y != 0.0 ? sqrt(n[q].y) : 0.0;
-            acc[3] += -0.5 * (s0 * x0 + s1 * x1);
+            e += -0.5 * (s0 * x0 + s1 * x1);
             if (n[q].x != 0.0) vacc[q].x += -0.5 * x0 / s0;
             if (n[q].y != 0.0) vacc[q].y += -0.5 * x1 / s1;
         }
+        park[3 * 256] = e;
     }
     if (a.mask & 16u) {                                  // WT family  functionals.py:650-651; tools_for_tests.py:29-39
         z_load_inverse<M, E>(w, z, a.conv_b, g, twM, twN);
         cplx pa1[E];
+        double e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             __builtin_amdgcn_sched_barrier(0);
             const double x0 = w[q].x * sc, x1 = w[q].y * sc;
             pa1[q] = a.wt_is_56 ? make_double2(1.0 / sqrt(cbrt(n[q].x)), 1.0 / sqrt(cbrt(n[q].y)))
                                 : make_double2(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
-            acc[4] += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
+            e += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
             const double f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
             vacc[q].x += ctf * f * pa1[q].x * x0;
             vacc[q].y += ctf * f * pa1[q].y * x1;
         }
+        park[4 * 256] = e;
         if (a.conv_a) {
             z_load_inverse<M, E>(w, z, a.conv_a, g, twM, twN);
 #pragma unroll
@@ -386,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
     }
     if (a.mask & 32u) {                                  // WGC99  SURVEY §8a-8 closed form
         cplx t1[E], t2[E];
+        double e = 0.0;
         z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
 #pragma unroll
         for (int q = 0; q < E; ++q) t1[q] = make_double2(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
@@ -411,11 +421,12 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
             const double pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
             const double pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
             const double pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
-            acc[5] += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
+            e += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
             vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
             vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
             t2[q] = make_double2(pb0, pb1);
         }
+        park[5 * 256] = e;
         z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
 #pragma unroll
         for (int q = 0; q < E; ++q) t1[q] = make_double2(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
@@ -449,13 +460,18 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
     if (a.mask & 1u) {
         cplx ve[E];
         z_load_real<M, E>(ve, z, a.vext);
+        double e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            acc[0] += n[q].x * ve[q].x + n[q].y * ve[q].y;
+            e += n[q].x * ve[q].x + n[q].y * ve[q].y;
             vacc[q].x += ve[q].x;
             vacc[q].y += ve[q].y;
         }
+        park[0] = e;
     }
+    double acc[kCombineScalars];
+#pragma unroll
+    for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
@@ -474,6 +490,11 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
         }
         acc[8] += vacc[q].x * n[q].x + vacc[q].y * n[q].y;
     }
+    acc[0] = park[0];
+    acc[1] = park[1 * 256];
+    acc[3] = park[3 * 256];
+    acc[4] = park[4 * 256];
+    acc[5] = park[5 * 256];
     if (!z.valid) {
 #pragma unroll
         for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
