@@ -165,6 +165,14 @@ int  ofdft_ion_electron_stress(ofdft_ctx* ctx, const void* den_dev, const double
                                const double* table_k_host, const double* table_v_host, int ntable, double z_ion,
                                int pme_order, double* sigma_host /*[9]*/, void* stream);
 
+/* Ion-ion interaction: the real-space damped pair sum in a neutralising background of
+ * ion_interaction_sum (ion_utils.py:293-333) with System.__ion_ion_interaction's parameters (system.py:733-754);
+ * Rc <= 0 selects its default Rd = 2 h_max, Rc = 3 Rd^2 / h_max.  The pair list (torch-nl's neighbour list in the
+ * reference) is every (i, j, lattice shift) with 0 < r <= Rc.  forces_host [nions][3] = -dE/dR and stress_host [9] =
+ * (1/vol) dE/d eps are what autograd gives the reference (system.py:913-935); either may be NULL. */
+int  ofdft_ion_ion(ofdft_ctx* ctx, const double* frac_coords_host, const double* charges_host, int nions, double Rc,
+                   double* E_host, double* forces_host, double* stress_host, void* stream);
+
 /* ---- limited-memory BFGS building blocks (the consumer of the closure) ----------------
  * The reference's fixed-step optimiser (_optimizers/lbfgs/lbfgsnew.py:594-663) forms y = g - g_prev and s = t d, keeps
  * the pair if y.s > 1e-10 |s|^2, and gets the direction from the two-loop recursion: 2m dependent dot / axpy pairs over

@@ -28,7 +28,7 @@ Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1,
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
            'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
-           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_dots',
+           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_dots',
            'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
@@ -103,6 +103,8 @@ def load():
     lib.ofdft_stress.restype = ip
     lib.ofdft_ion_electron_stress.argtypes = [vp, vp, dp, ip, dp, dp, ip, C.c_double, ip, dp, vp]
     lib.ofdft_ion_electron_stress.restype = ip
+    lib.ofdft_ion_ion.argtypes = [vp, dp, dp, ip, C.c_double, dp, dp, dp, vp]
+    lib.ofdft_ion_ion.restype = ip
     lib.ofdft_lbfgs_create.argtypes = [C.POINTER(vp), C.c_longlong, ip, ip]
     lib.ofdft_lbfgs_create.restype = ip
     lib.ofdft_lbfgs_destroy.argtypes = [vp]

@@ -1,6 +1,7 @@
 // C-ABI implementation of the OFDFT energy/gradient engine (include/ofdft_hip.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2162,6 +2163,101 @@ int ofdft_ion_electron_stress(ofdft_ctx* c, const void* den_dev, const double* f
     for (int k = 0; k < 6; ++k) c6[k] = -s7[k] * invN / c->vol;
     sym_store(sigma_host, c6, -s7[6] * invN / c->vol);
     HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return OFDFT_OK;
+}
+
+// Ion-ion interaction energy, forces and stress (ion_utils.py:293-333 with the parameter heuristics of
+// System.__ion_ion_interaction, system.py:733-754; forces / stress = what autograd yields, system.py:913-935).
+// Rc <= 0 selects the reference's default (Rd = 2 h_max, Rc = 3 Rd^2 / h_max); forces_host [nions][3] and
+// stress_host [9] may be NULL.
+int ofdft_ion_ion(ofdft_ctx* c, const double* frac_host, const double* charges_host, int nions, double Rc, double* E_host,
+                  double* forces_host, double* stress_host, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !frac_host || !charges_host || !E_host || nions < 1) return OFDFT_EINVAL;
+    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double* B = c->box;
+    // interplanar spacings h_d = 1 / |row d of inv(B^T)| = vol / |cross of the other two lattice vectors|
+    double h[3];
+    for (int d = 0; d < 3; ++d) {
+        const double* u = B + 3 * ((d + 1) % 3);
+        const double* v = B + 3 * ((d + 2) % 3);
+        const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+        h[d] = c->vol / std::sqrt(cx * cx + cy * cy + cz * cz);
+    }
+    const double h_max = std::max(h[0], std::max(h[1], h[2]));
+    double Rd;
+    if (Rc <= 0.0) {
+        Rd = 2.0 * h_max;
+        Rc = 3.0 * Rd * Rd / h_max;
+    } else {
+        Rd = std::sqrt(h_max * Rc / 3.0);
+    }
+    IonIonGeom g{};
+    std::memcpy(g.box, B, sizeof(g.box));
+    g.Rc = Rc;
+    g.Rd = Rd;
+    std::vector<double> cart(3 * (size_t)nions);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int a = 0; a < nions; ++a)
+        for (int d = 0; d < 3; ++d) {
+            cart[3 * a + d] = frac_host[3 * a] * B[d] + frac_host[3 * a + 1] * B[3 + d] + frac_host[3 * a + 2] * B[6 + d];
+            lo[d] = std::min(lo[d], frac_host[3 * a + d]);
+            hi[d] = std::max(hi[d], frac_host[3 * a + d]);
+        }
+    long long nshift = 1;
+    for (int d = 0; d < 3; ++d) {
+        g.nmax[d] = (int)std::ceil(Rc / h[d] + (hi[d] - lo[d]));
+        nshift *= 2 * g.nmax[d] + 1;
+    }
+    const long long total = nshift * nions;
+    const int chunks = (int)std::min<long long>(256, (total + kRedThreads * 8 - 1) / (kRedThreads * 8));
+    double *d_cart, *d_z, *d_part;
+    const size_t np = (size_t)nions * chunks * kIonIonScalars;
+    if (int rc = get_ws(c, "ii:cart", sizeof(double) * cart.size(), (void**)&d_cart)) return rc;
+    if (int rc = get_ws(c, "ii:z", sizeof(double) * nions, (void**)&d_z)) return rc;
+    if (int rc = get_ws(c, "ii:part", sizeof(double) * np, (void**)&d_part)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * cart.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_z, charges_host, sizeof(double) * nions, hipMemcpyHostToDevice, st));
+    OFDFT_LAUNCH(c, st, "ion_ion", ion_ion_kernel, dim3(chunks, nions), dim3(kRedThreads), 0, (const double*)d_cart,
+                 (const double*)d_z, nions, g, d_part);
+    std::vector<double> hp(np);
+    HIP_TRY(c, hipMemcpyAsync(hp.data(), d_part, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    double ztot = 0.0;
+    for (int a = 0; a < nions; ++a) ztot += charges_host[a];
+    const double rho = ztot / c->vol, spi = std::sqrt(kPi);
+    long double E = 0.0L, sig6[6] = {0, 0, 0, 0, 0, 0}, corr = 0.0L;
+    for (int a = 0; a < nions; ++a) {
+        long double s[kIonIonScalars];
+        for (int k = 0; k < kIonIonScalars; ++k) {
+            s[k] = 0.0L;
+            for (int b = 0; b < chunks; ++b) s[k] += hp[((size_t)a * chunks + b) * kIonIonScalars + k];
+        }
+        const double Z = charges_host[a];
+        const double Q = Z + (double)s[1];
+        const double aux = 0.75 / kPi * Q / rho;
+        const double Ra = std::cbrt(aux);
+        const double ex = std::exp(-Ra * Ra / (Rd * Rd)), er = std::erf(Ra / Rd);
+        E += 0.5L * s[0] - kPi * Z * rho * Ra * Ra + kPi * Z * rho * (Ra * Ra - 0.5 * Rd * Rd) * er + spi * Z * rho * Ra * Rd * ex -
+             Z * Z / spi / Rd;
+        if (forces_host)
+            for (int d = 0; d < 3; ++d) forces_host[3 * a + d] = (double)s[2 + d];
+        for (int k = 0; k < 6; ++k) sig6[k] += 0.5L * s[5 + k];
+        const double e_rho = -kPi * Z * Ra * Ra + kPi * Z * (Ra * Ra - 0.5 * Rd * Rd) * er + spi * Z * Ra * Rd * ex;
+        const double dE_dRa = -2.0 * kPi * Z * rho * Ra + 2.0 * kPi * Z * rho * Ra * er +
+                              kPi * Z * rho * (Ra * Ra - 0.5 * Rd * Rd) * 2.0 / (spi * Rd) * ex +
+                              spi * Z * rho * Rd * ex * (1.0 - 2.0 * Ra * Ra / (Rd * Rd));
+        corr += -rho * e_rho + dE_dRa * Ra / 3.0;
+    }
+    *E_host = (double)E;
+    if (stress_host) {
+        double c6[6];
+        for (int k = 0; k < 6; ++k) c6[k] = (double)sig6[k] / c->vol;
+        sym_store(stress_host, c6, (double)corr / c->vol);
+    }
     if (c->profiling) prof_collect(c);
     return OFDFT_OK;
 }

@@ -220,3 +220,58 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(const double* __restric
 }
 
 }  // namespace ofdft
+
+namespace ofdft {
+
+// Ion-ion real-space damped pair sum (ion_utils.py:293-333).  grid = (chunks, ions): block (c, i) scans its share of
+// the (j, lattice shift) combinations and accumulates for ion i:
+//   [0] sum Z_i Z_j erfc(r/Rd)/r   [1] sum Z_j (neighbour charge)   [2..4] sum f'(r) d / r   [5..10] sum f'(r) d_a d_b / r
+// over 0 < r = |R_j + shift - R_i| <= Rc (xx, yy, zz, xy, xz, yz);  f(r) = Z_i Z_j erfc(r/Rd)/r.
+constexpr int kIonIonScalars = 11;
+struct IonIonGeom {
+    double box[9];       // rows = lattice vectors
+    int nmax[3];         // shifts -nmax..nmax per axis
+    double Rc, Rd;
+};
+__global__ __launch_bounds__(kRedThreads) void ion_ion_kernel(const double* __restrict__ cart, const double* __restrict__ Z,
+                                                              int nion, IonIonGeom g, double* __restrict__ partial) {
+    const int i = blockIdx.y;
+    const double xi = cart[3 * i], yi = cart[3 * i + 1], zi = cart[3 * i + 2], Zi = Z[i];
+    const int w0 = 2 * g.nmax[0] + 1, w1 = 2 * g.nmax[1] + 1, w2 = 2 * g.nmax[2] + 1;
+    const long long total = (long long)nion * w0 * w1 * w2;
+    const double inv_rd = 1.0 / g.Rd, two_over = 2.0 / (sqrt(kPi) * g.Rd);
+    double acc[kIonIonScalars];
+#pragma unroll
+    for (int s = 0; s < kIonIonScalars; ++s) acc[s] = 0.0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(t % nion);
+        long long u = t / nion;
+        const int s2 = (int)(u % w2) - g.nmax[2];
+        u /= w2;
+        const int s1 = (int)(u % w1) - g.nmax[1];
+        const int s0 = (int)(u / w1) - g.nmax[0];
+        const double dx = cart[3 * j] + s0 * g.box[0] + s1 * g.box[3] + s2 * g.box[6] - xi;
+        const double dy = cart[3 * j + 1] + s0 * g.box[1] + s1 * g.box[4] + s2 * g.box[7] - yi;
+        const double dz = cart[3 * j + 2] + s0 * g.box[2] + s1 * g.box[5] + s2 * g.box[8] - zi;
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 > 1e-24 && r2 <= g.Rc * g.Rc) {
+            const double r = sqrt(r2), ir = 1.0 / r, zz = Zi * Z[j];
+            const double ec = erfc(r * inv_rd) * ir;
+            acc[0] += zz * ec;
+            acc[1] += Z[j];
+            const double fpr = zz * (-two_over * exp(-r2 * inv_rd * inv_rd) * ir - ec * ir) * ir;     // f'(r) / r
+            acc[2] += fpr * dx;
+            acc[3] += fpr * dy;
+            acc[4] += fpr * dz;
+            acc[5] += fpr * dx * dx;
+            acc[6] += fpr * dy * dy;
+            acc[7] += fpr * dz * dz;
+            acc[8] += fpr * dx * dy;
+            acc[9] += fpr * dx * dz;
+            acc[10] += fpr * dy * dz;
+        }
+    }
+    block_reduce_store<kIonIonScalars>(acc, partial + (long long)i * gridDim.x * kIonIonScalars);
+}
+
+}  // namespace ofdft

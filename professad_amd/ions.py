@@ -103,3 +103,22 @@ def ion_electron_stress(engine, box_vecs, den, species, pme_order=None):
         engine._check(rc, 'ofdft_ion_electron_stress')
         total += s.reshape(3, 3)
     return total
+
+
+def ion_ion(engine, box_vecs, frac, charges, Rc=None):
+    """Ion-ion energy [Ha], forces [n,3] (Ha/bohr) and stress [3,3] (Ha/bohr^3): ion_interaction_sum with System's
+    parameter heuristics (ion_utils.py:293-333, system.py:733-754) and its autograd derivatives (system.py:913-935)."""
+    engine.set_cell(box_vecs)
+    dp = C.POINTER(C.c_double)
+    frac = np.ascontiguousarray(np.asarray(torch.as_tensor(frac).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 3))
+    z = np.ascontiguousarray(np.asarray(charges, dtype=np.float64).reshape(-1))
+    if z.size != frac.shape[0]:
+        raise ValueError('one charge per ion')
+    E = C.c_double(0.0)
+    F = np.zeros_like(frac)
+    S = np.zeros(9)
+    rc = engine.lib.ofdft_ion_ion(engine._ctx, frac.ctypes.data_as(dp), z.ctypes.data_as(dp), frac.shape[0],
+                                  float(Rc) if Rc else 0.0, C.byref(E), F.ctypes.data_as(dp), S.ctypes.data_as(dp),
+                                  engine._stream())
+    engine._check(rc, 'ofdft_ion_ion')
+    return E.value, F, S.reshape(3, 3)

@@ -452,3 +452,36 @@ def test_get_stress_protocol_on_native_terms():
                    (F.NativeTerms(['pbe']), g['gmix_pbe_x'] + g['gmix_pbe_c'])):
         s = get_stress(f)
         assert np.abs(s - ref).max() <= 2e-10 * np.abs(ref).max()
+
+
+def test_ion_ion_known_answers_forces_and_stress():
+    """ofdft_ion_ion against the reference's known-answer energies (tests/test_ion_utils.py:12-147 data), and its forces /
+    stress against the oracle's analytic forms (themselves checked by finite differences in the CPU suite)"""
+    import json
+    from oracle import ionion as ii
+    from professad_amd.ions import ion_ion
+    doc = json.load(open(os.path.join(GOLDEN, 'ion_ion_known_answers.json')))
+    eng = Engine((16, 16, 16), DEV)
+    E = {}
+    for c in doc['cases']:
+        box = np.array(c['box'], dtype=np.float64)
+        frac = np.array(c['frac'], dtype=np.float64) if c['frac'] is not None else np.array(c['cart'], dtype=np.float64) @ np.linalg.inv(box)
+        z = np.array(c['charges'], dtype=np.float64)
+        E[c['name']], F, S = ion_ion(eng, box, frac, z, Rc=12 * c['h_max'])
+        if c['expected'] is not None:
+            assert abs(E[c['name']] - c['expected']) / len(z) < 1e-10, (c['name'], E[c['name']])
+        if c['name'] in ('Si', 'SiO2'):
+            Rc = 12 * c['h_max']
+            Rd = float(np.sqrt((1.0 / np.sqrt(np.sum(np.linalg.inv(box.T) ** 2, axis=1))).max() * Rc / 3))
+            Fo, So = ii.forces_stress(box, frac @ box, z, Rc, Rd)
+            assert np.abs(F - Fo).max() < 1e-11 and np.abs(S - So).max() < 1e-12, c['name']
+    assert abs(4 * E['NaCl_fcc'] - E['NaCl_two'] - doc['madelung']) < 1e-10
+    # the reference's default parameters (Rc = None) on its FD-stress cell
+    box = np.array([[6.5, -0.13, 0.25], [-0.33, 7.21, 0.24], [0.55, 0.04, 6.78]])
+    frac = np.array([[0, 0, 0], [0.35, 0.65, 0.45]])
+    Ed, Fd, Sd = ion_ion(eng, box, frac, [1.0, 1.0])
+    Rc, Rd = ii.heuristics(box)
+    Fo, So = ii.forces_stress(box, frac @ box, np.array([1.0, 1.0]), Rc, Rd)
+    assert abs(Ed - ii.energy(box, frac @ box, np.array([1.0, 1.0]), Rc, Rd)) < 1e-11
+    assert np.abs(Fd - Fo).max() < 1e-11 and np.abs(Sd - So).max() < 1e-12
+    eng.close()

@@ -146,3 +146,50 @@ def test_stress_oracle():
             s = st.ion_electron(ions[tag + '_box'], den, ions[tag + '_frac'], raw, kmax, o)
             ref = g['%s_ion_electron_%s' % (tag, 'exact' if o is None else 'pme%d' % o)]
             assert np.abs(s - ref).max() <= 1e-12 * np.abs(ref).max(), (tag, o)
+
+
+def _ion_ion_cases():
+    import json
+    doc = json.load(open(os.path.join(GOLDEN, 'ion_ion_known_answers.json')))
+    out = {}
+    for c in doc['cases']:
+        box = np.array(c['box'], dtype=np.float64)
+        cart = np.array(c['cart'], dtype=np.float64) if c['cart'] is not None else np.array(c['frac'], dtype=np.float64) @ box
+        out[c['name']] = (box, cart, np.array(c['charges'], dtype=np.float64), c['h_max'], c['expected'])
+    return out, doc['madelung']
+
+
+def test_ion_ion_oracle_known_answers_and_derivatives():
+    """energies against the reference's own known-answer values; forces / stress formulas against finite differences of
+    that energy (fixed Rc, Rd: the quantities autograd holds constant)"""
+    from oracle import ionion as ii
+    cs, madelung = _ion_ion_cases()
+    E = {}
+    for name in ('Al', 'Si', 'SiO2', 'NaCl_fcc', 'NaCl_two'):
+        box, cart, z, h, want = cs[name]
+        E[name] = ii.energy(box, cart, z, 12 * h, 2 * h)
+        if want is not None:
+            assert abs(E[name] - want) / len(z) < 1e-10, name
+    assert abs(4 * E['NaCl_fcc'] - E['NaCl_two'] - madelung) < 1e-10
+    # derivatives on a small low-symmetry case (the reference's FD-stress cell, tests/test_ion_utils.py:151-155)
+    box = np.array([[6.5, -0.13, 0.25], [-0.33, 7.21, 0.24], [0.55, 0.04, 6.78]])
+    frac = np.array([[0, 0, 0], [0.35, 0.65, 0.45]])
+    z = np.array([1.0, 1.0])
+    Rc, Rd = ii.heuristics(box)
+    Rc *= 0.5                                            # keep the CPU test short; still converged to ~1e-9
+    F, sig = ii.forces_stress(box, frac @ box, z, Rc, Rd)
+    h = 1e-5
+    for a, d in ((0, 0), (1, 2)):
+        cp, cm = (frac @ box).copy(), (frac @ box).copy()
+        cp[a, d] += h
+        cm[a, d] -= h
+        fd = -(ii.energy(box, cp, z, Rc, Rd) - ii.energy(box, cm, z, Rc, Rd)) / (2 * h)
+        assert abs(fd - F[a, d]) < 1e-8
+    vol = abs(np.linalg.det(box))
+    for i, j in ((0, 0), (1, 2)):
+        eps = np.zeros((3, 3))
+        eps[i, j] += 0.5 * h
+        eps[j, i] += 0.5 * h
+        bp, bm = box + box @ eps, box - box @ eps
+        fd = (ii.energy(bp, frac @ bp, z, Rc, Rd) - ii.energy(bm, frac @ bm, z, Rc, Rd)) / (2 * h * vol)
+        assert abs(fd - sig[i, j]) < 1e-8, (i, j, fd, sig[i, j])
