@@ -152,6 +152,10 @@ def main():
     vext = torch.as_tensor(vext_h, dtype=torch.double, device=device)
     if os.environ.get('OFDFT_SIDE_STREAM') == '0':       # A/B switch: everything on one stream
         raw.set_option(1, 0)
+    if os.environ.get('OFDFT_XCHUNKS'):                  # A/B switch: x-chunked z / y stages
+        raw.set_option(2, int(os.environ['OFDFT_XCHUNKS']))
+    if os.environ.get('OFDFT_XCHUNK_MASK'):
+        raw.set_option(3, int(os.environ['OFDFT_XCHUNK_MASK']))
 
     def step():
         return eng.energy_grad_chi(chi, n_elec, vext)

@@ -63,6 +63,8 @@ struct ofdft_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
+    int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
+    int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
     // optional per-kernel-class profiling (HIP events around every launch)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -204,12 +206,13 @@ void prof_collect(ofdft_ctx* c) {
 
 // ---------------------------------------------------------------------------------- FFT drivers
 template <int LEN, bool INV>
-int launch_cpass_t(ofdft_ctx* c, cplx* data, const LineMap& main, const LineMap& rem, hipStream_t st, const char* nm) {
+int launch_cpass_t(ofdft_ctx* c, const ArrList& arrs, int narr, const LineMap& main, const LineMap& rem, hipStream_t st,
+                   const char* nm) {
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     using Cfg = PassCfg<LEN>;
     const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, data, main, rem, mb,
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, main, rem, mb,
                  c->g.main_count, tw);
     return 0;
 }
@@ -230,16 +233,26 @@ void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
     if (rem.nlines == 0) { rem.d = 1; rem.lf = 1; }
 }
 
+// line pass over `narr` spectra in ONE launch; cx > 0 restricts a y pass to the x planes [x0, x0 + cx)
 template <bool INV>
-int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
+int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0) {
     LineMap main, rem;
     pass_maps(c, axis, main, rem);
+    if (cx > 0 && axis == 1) {
+        main.gc = rem.gc = cx;
+        main.gn = rem.gn = c->g.n0;
+        main.g0 = rem.g0 = x0;
+        main.nlines = (c->g.nzm / 8) * cx * 8;
+        rem.nlines = (c->g.nzc - c->g.nzm) * cx;
+    }
+    ArrList arrs{};
+    for (int a = 0; a < narr; ++a) arrs.p[a] = specs[a];
     const int len = axis == 0 ? c->n0g : c->n1;
     const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
 #define OFDFT_CASE(L)                                                   \
     case L:                                                             \
         if (axis == 0) main.lf = rem.lf = PassCfg<L>::LPW;              \
-        return launch_cpass_t<L, INV>(c, spec, main, rem, st, nm);
+        return launch_cpass_t<L, INV>(c, arrs, narr, main, rem, st, nm);
     switch (len) {
         OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
         OFDFT_CASE(1024)
@@ -248,6 +261,10 @@ int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
 }
 
+template <bool INV>
+int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
+    return fast_axis_pass_multi<INV>(c, axis, &spec, 1, st);
+}
 // y pass of `narr` x-slab spectra straight into (forward) / out of (inverse) an all-to-all buffer
 template <int LEN, bool INV>
 int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st) {
@@ -941,62 +958,81 @@ int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
 }
 template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nrows + ZW<M, E>::RPB - 1) / ZW<M, E>::RPB); }
 
-int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st) {
+// The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
+// [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
+int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
+                      int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
-    c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
+    if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
+    SpecGeom gz = c->g;
 #define X(M_)                                                                                                       \
-    case M_:                                                                                                        \
-        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(z_blocks<M_, 8>(c)), dim3(256),          \
-                     (ZW<M_, 8>::LDS), ds, out_n, out_s, c->g, twM, twN);                                           \
-        return 0;
+    case M_: {                                                                                                      \
+        const int nb = z_blocks<M_, 8>(c) / nchunks;                                                                \
+        gz.blk0 = chunk * nb;                                                                                       \
+        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(nb), dim3(256), (ZW<M_, 8>::LDS), ds,    \
+                     out_n, out_s, gz, twM, twN);                                                                   \
+        return 0;                                                                                                   \
+    }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
-int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st) {
+int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
-    for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
+    if (chunk == 0)
+        for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
+    SpecGeom gz = c->g;
 #define X(M_)                                                                                                      \
-    case M_:                                                                                                       \
-        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>),                                \
-                     dim3(z_blocks<M_, ZPick<M_, EZ>::E>(c)), dim3(256), (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, c->g,  \
-                     twM, twN);                                                                                    \
-        return 0;
+    case M_: {                                                                                                     \
+        const int nb = z_blocks<M_, ZPick<M_, EZ>::E>(c) / nchunks;                                                \
+        gz.blk0 = chunk * nb;                                                                                      \
+        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),           \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, gz, twM, twN);                                       \
+        return 0;                                                                                                  \
+    }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
 int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n, int do_x,
-                int do_c, int* blocks_out, hipStream_t st) {
+                int do_c, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
-    c->fft_count += 6;    // three c2r finished + three r2c started on chip
+    if (chunk == 0) c->fft_count += 6;    // three c2r finished + three r2c started on chip
+    SpecGeom gq = c->g;
 #define X(M_)                                                                                                   \
-    case M_:                                                                                                    \
+    case M_: {                                                                                                  \
         *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
-        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256),          \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, do_x, do_c, c->g, twM, twN,  \
+        const int nb = *blocks_out / nchunks;                                                                   \
+        gq.blk0 = chunk * nb;                                                                                   \
+        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),                   \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, do_x, do_c, gq, twM, twN,    \
                      c->d_partial);                                                                             \
-        return 0;
+        return 0;                                                                                               \
+    }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
-int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st) {
+int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
+    SpecGeom gq = c->g;
 #define X(M_)                                                                                                     \
-    case M_:                                                                                                      \
+    case M_: {                                                                                                    \
         *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                          \
-        OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256), \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS + sizeof(double) * 256 * kCombineScalars), a, c->g, twM, twN,  \
+        const int nb = *blocks_out / nchunks;                                                                     \
+        gq.blk0 = chunk * nb;                                                                                     \
+        OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),         \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS + sizeof(double) * 256 * kCombineScalars), a, gq, twM, twN,    \
                      c->d_partial);                                                                               \
-        return 0;
+        return 0;                                                                                                 \
+    }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X
     return fail(c, OFDFT_EINVAL, "bad n2");
@@ -1048,6 +1084,7 @@ struct ZRun {
     //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
+    std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
     int combine_blocks = 0, pbe_blocks = 0;
     hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
@@ -1063,6 +1100,19 @@ ZRun& zrun(ofdft_ctx* c);
 
 // ---- all-to-all buffers of the slab-decomposed path, one pair per chain (both directions reuse the pair):
 // chain 0 carries at most 5 spectra (Hartree, grad n, vW leaving stage 2), chain 1 at most 8 (2 Wang-Teter + 6 WGC99)
+// x chunks for a loop whose working set is `narr` spectra: the option value is the count for six spectra; more
+// spectra -> proportionally more chunks, so that a chunk's working set stays the same share of the Infinity Cache.
+// Every chunk must be whole workgroups of every z kernel (at most 256 rows each) -> powers of two that divide n0.
+int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
+    if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which)) return 1;
+    // automatic: about 100 MB of spectra per chunk (measured best at 256^3: 8 chunks for the six WGC99 spectra)
+    int want = c->xchunks > 1 ? (c->xchunks * narr + 5) / 6
+                              : (int)std::min<double>(64.0, (double)narr * sizeof(cplx) * (double)c->g.total / 100e6);
+    int n = 1;
+    while (n * 2 <= want && c->n0 % (n * 2) == 0 && ((long long)(c->n0 / (n * 2)) * c->n1) % 256 == 0) n *= 2;
+    return n;
+}
+
 int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
     const size_t bytes = sizeof(cplx) * (size_t)c->g.total * (chain == 0 ? 5 : 8);
     if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
@@ -1098,13 +1148,25 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
         if (r.has_vw)
             if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
         if (r.s_n || r.s_s) {
-            if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) return rc;
+            cplx* both[2];
+            int nb = 0;
+            if (r.s_n) both[nb++] = r.s_n;
+            if (r.s_s) both[nb++] = r.s_s;
+            const int nch = chunks_for(c, nb, 1);
+            if (nch > 1) {        // x-chunked: a chunk's spectra are y-transformed while still in the Infinity Cache
+                for (int ch = 0; ch < nch; ++ch) {
+                    if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st, ch, nch))) return rc;
+                    if ((rc = fast_axis_pass_multi<false>(c, 1, both, nb, st, ch * (c->n0 / nch), c->n0 / nch))) return rc;
+                }
+            } else if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) {
+                return rc;
+            }
             if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
                 HIP_TRY(c, hipEventRecord(c->ev_a, st));
                 HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
             }
-            if (!dx && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
-            if (!dx && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
+            if (!dx && nch == 1 && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+            if (!dx && nch == 1 && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
             if (r.s_n) xl.push_back(r.s_n);
             if (r.s_s) xl.push_back(r.s_s);
         }
@@ -1147,13 +1209,22 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             pa.e1 = al;
             pa.nref = nref;
             pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
-            if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
+            // x-chunked form: each chunk's six spectra (6 x C / nchunks) are y-transformed while still in the Infinity Cache
+            const int nch = chunks_for(c, 6, 2);
+            if (nch > 1) {
+                for (int ch = 0; ch < nch; ++ch) {
+                    if ((rc = launch_zf_powers(c, r.ds, pa, sb, ch, nch))) return rc;
+                    if ((rc = fast_axis_pass_multi<false>(c, 1, r.sw, 6, sb, ch * (c->n0 / nch), c->n0 / nch))) return rc;
+                }
+            } else if ((rc = launch_zf_powers(c, r.ds, pa, sb))) {
+                return rc;
+            }
             if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
                 HIP_TRY(c, hipEventRecord(c->ev_b, sb));
                 HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
             }
             for (int i = 0; i < 6; ++i) {
-                if (!dx && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
+                if (!dx && nch == 1 && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
                 xl.push_back(r.sw[i]);
             }
             r.za.wgc_alpha = al;
@@ -1267,11 +1338,19 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
         if ((rc = ypass_xchg<true>(c, xl, recv, st))) return rc;
     }
+    // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
+    // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
+    const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = chunks_for(c, 6, 4) > 1;
     for (cplx* sp : xl) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
-        if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) return rc;
-        if (sp != r.s_g[0] && sp != r.s_g[1] && sp != r.s_g[2]) c->fft_count++;
+        const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2];
+        if (is_g ? pbe_chunked : chunked) {
+            if (!is_g) r.deferred.push_back(sp);
+        } else if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) {
+            return rc;
+        }
+        if (!is_g) c->fft_count++;
     }
     xl.clear();
     if (chain == 1) {
@@ -1291,14 +1370,20 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     if (r.s_s) r.za.lap = r.s_s;
     if (r.has_g) {
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
-        if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
-                              (c->mask & OFDFT_PBE_C) ? 1 : 0, &r.pbe_blocks, st)))
-            return rc;
+        const int nch = chunks_for(c, 6, 4);       // 3 spectra in, 3 out, the density and df/dn rows
+        for (int ch = 0; ch < nch; ++ch) {
+            const int x0 = ch * (c->n0 / nch), cx = c->n0 / nch;
+            if (pbe_chunked && (rc = fast_axis_pass_multi<true>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
+            if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
+                                  (c->mask & OFDFT_PBE_C) ? 1 : 0, &r.pbe_blocks, st, ch, nch)))
+                return rc;
+            if (pbe_chunked && (rc = fast_axis_pass_multi<false>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
+        }
         // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
                      c->d_reduced + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
-            if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
+            if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             xl.push_back(r.s_g[k]);
         }
         if (dx) {
@@ -1337,11 +1422,14 @@ int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
 int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     ZRun& r = zrun(c);
     int rc;
+    const bool chunked = chunks_for(c, 6, 8) > 1;
     if (r.has_g) {
         if (c->nranks > 1) {
             cplx *send, *recv;
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
             if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
+        } else if (chunked) {
+            r.deferred.push_back(r.s_n);
         } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
             return rc;
         }
@@ -1357,7 +1445,18 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
         HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
     }
-    if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) return rc;
+    if (chunked) {        // y-inverse of a chunk of every result spectrum, then the combine kernel on the same x planes
+        const int narr = (int)r.deferred.size();
+        const int nch = chunks_for(c, narr + 2, 8);       // + the real rows (chi, v_ext, df/dn, v) the kernel touches
+        for (int ch = 0; ch < nch; ++ch) {
+            if (narr && (rc = fast_axis_pass_multi<true>(c, 1, r.deferred.data(), narr, st, ch * (c->n0 / nch), c->n0 / nch)))
+                return rc;
+            if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st, ch, nch))) return rc;
+        }
+        r.deferred.clear();
+    } else if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) {
+        return rc;
+    }
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
     if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, 2 * sizeof(double), st));
@@ -1376,6 +1475,7 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     r.nel = nel;
     r.vext = vext;
     r.v_out = v_out;
+    r.deferred.clear();
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     int rc;
     // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
@@ -1726,6 +1826,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.vext = (const double*)vext_local;
     r.v_out = (double*)v_out_local;
     r.stage[0] = r.stage[1] = 0;
+    r.deferred.clear();
     r.forked = false;
     r.xlist[0].clear();
     r.xlist[1].clear();
@@ -2271,6 +2372,13 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             return OFDFT_OK;
         case OFDFT_OPT_SIDE_STREAM:
             c->use_side_stream = value != 0.0;
+            return OFDFT_OK;
+        case OFDFT_OPT_XCHUNKS:
+            if (value < 0.0 || value > 64.0) return fail(c, OFDFT_EINVAL, "x chunks must be 0 (automatic) or 1..64");
+            c->xchunks = (int)value;
+            return OFDFT_OK;
+        case OFDFT_OPT_XCHUNK_MASK:
+            c->xchunk_mask = (int)value & 15;
             return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);

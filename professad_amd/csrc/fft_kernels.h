@@ -18,6 +18,7 @@ namespace ofdft {
 
 struct SpecGeom {
     int n0, n1, n2, nzc, nzm;
+    int blk0 = 0;          // first workgroup of a z-kernel launch that covers only a range of rows (x-chunked pipeline)
     long long nrows;       // n0*n1
     long long main_count;  // nzm*n0*n1
     long long total;       // nzc*n0*n1
@@ -55,6 +56,9 @@ struct LineMap {
     int sl;
     int nlines;
     int lf;  // lines that vary fastest over the lanes (memory-contiguous direction)
+    // optional restriction to a range of an outer index (x-chunked y passes): group G = L / d enumerates (b, xl) with
+    // xl < gc; it stands for group (G / gc) * gn + g0 + G % gc of the full array.  gc == 0: no remapping.
+    int gc = 0, gn = 0, g0 = 0;
 };
 
 template <int LEN> struct PassCfg {
@@ -67,13 +71,18 @@ template <int LEN> struct PassCfg {
 
 // uniform base of a tile (first line of the workgroup) and the per-lane byte offset of line L, element j
 __device__ __forceinline__ long long line_base(const LineMap& m, long long L) {
-    return (L / m.d) * m.sb + (L % m.d) * (long long)m.sl;
+    long long grp = L / m.d;
+    if (m.gc) grp = (grp / m.gc) * m.gn + m.g0 + grp % m.gc;
+    return grp * m.sb + (L % m.d) * (long long)m.sl;
 }
 
+struct ArrList { cplx* p[16]; };
+
 template <int LEN, bool INV>
-__global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(cplx* __restrict__ data, LineMap m_main, LineMap m_rem,
+__global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, LineMap m_main, LineMap m_rem,
                                                                    int main_blocks, long long rem_offset,
                                                                    const cplx* __restrict__ tw) {
+    cplx* data = arrs.p[blockIdx.y];          // one launch may cover several spectra (grid.y)
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -120,8 +129,6 @@ struct XchgGeom {
     long long rec;         // narr * arr_sz
     long long chunk;       // nxl * rec: elements per peer
 };
-struct ArrList { cplx* p[16]; };
-
 template <int LEN, bool INV>
 __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList arrs, cplx* __restrict__ buf, XchgGeom xg,
                                                                        LineMap m_main, LineMap m_rem, int main_blocks,

@@ -42,7 +42,7 @@ template <int M, int E> struct ZLane {
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         j = lane % W::P;
         rw = lane / W::P;
-        row_u = uniform64((long long)blockIdx.x * W::RPB + (long long)wave * W::RPWV);
+        row_u = uniform64((long long)(blockIdx.x + g.blk0) * W::RPB + (long long)wave * W::RPWV);
         row = row_u + rw;
         valid = row < g.nrows;
         mine = lds + (wave * W::RPWV + rw) * W::RS;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restric
     z_forward_store<M, E>(a, z, gx, g, twM, twN);
     z_forward_store<M, E>(b, z, gy, g, twM, twN);
     z_forward_store<M, E>(c, z, gz, g, twM, twN);
-    block_reduce_store<2>(acc, partial);
+    block_reduce_store<2>(acc, partial + (long long)g.blk0 * 2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
         for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
     }
     if (a.v_out) z_store_real<M, E>(vacc, z, a.v_out);
-    block_reduce_store<kCombineScalars>(acc, partial);
+    block_reduce_store<kCombineScalars>(acc, partial + (long long)g.blk0 * kCombineScalars);
 }
 
 }  // namespace ofdft

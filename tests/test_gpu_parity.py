@@ -276,6 +276,18 @@ def test_all_pipelines_agree(shape):
             assert relerr(res[mode][4], res[1][4]) < 1e-12, (cfg, mode)
             assert abs(res[mode][3] - res[1][3]) < 1e-12 * max(1.0, abs(res[1][3]))
             assert res[mode][5] == res[1][5]          # same number of 3-D FFTs
+        # x-chunked form of the z-fused pipeline (Infinity-Cache reuse): same kernels on x ranges, same reduction order
+        eng.set_option(0, 0)
+        eng.set_option(3, 15)                          # every stage pair chunked
+        for nch in (1, 2, 8):
+            eng.set_option(2, nch)
+            E, v = eng.energy_potential(dev(den), dev(vext))
+            Ec, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+            assert all(E[k] == res[0][0][k] and Ec[k] == res[0][2][k] for k in E), (cfg, nch)
+            assert np.array_equal(v.cpu().numpy(), res[0][1]) and np.array_equal(g.cpu().numpy(), res[0][4]), (cfg, nch)
+            assert mu == res[0][3] and eng.query(0) == res[0][5]
+        eng.set_option(2, 0)
+        eng.set_option(3, 2)
     eng.close()
 
 
