@@ -154,6 +154,8 @@ def main():
         raw.set_option(1, 0)
     if os.environ.get('OFDFT_XCHUNKS'):                  # A/B switch: x-chunked z / y stages
         raw.set_option(2, int(os.environ['OFDFT_XCHUNKS']))
+    if os.environ.get('OFDFT_SPLIT_COMBINE'):
+        raw.set_option(4, int(os.environ['OFDFT_SPLIT_COMBINE']))
     if os.environ.get('OFDFT_XCHUNK_MASK'):
         raw.set_option(3, int(os.environ['OFDFT_XCHUNK_MASK']))
 

@@ -63,6 +63,7 @@ struct ofdft_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
+    bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
     int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
     int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
     // optional per-kernel-class profiling (HIP events around every launch)
@@ -1023,14 +1024,36 @@ int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipS
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
     SpecGeom gq = c->g;
+    const size_t park = sizeof(double) * 256 * kCombineScalars;
 #define X(M_)                                                                                                     \
     case M_: {                                                                                                    \
-        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                          \
+        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
+        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
         const int nb = *blocks_out / nchunks;                                                                     \
         gq.blk0 = chunk * nb;                                                                                     \
-        OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),         \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS + sizeof(double) * 256 * kCombineScalars), a, gq, twM, twN,    \
-                     c->d_partial);                                                                               \
+        if (a.v_part)                                                                                             \
+            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, false>), dim3(nb), dim3(256),          \
+                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
+        else                                                                                                      \
+            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, true>), dim3(nb), dim3(256),           \
+                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
+        return 0;                                                                                                 \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+// split form: the WGC99 part of the combine on the nonlocal chain's stream -> v_part rows + one energy partial per block
+int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, double* v_part, double* partial, int* blocks_out, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+#define X(M_)                                                                                                     \
+    case M_: {                                                                                                    \
+        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
+        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
+        OFDFT_LAUNCH(c, st, "zi_wgc", (zi_wgc_kernel<M_, W::E>), dim3(*blocks_out), dim3(256), (W::LDS), a, v_part, \
+                     c->g, twM, twN, partial);                                                                    \
         return 0;                                                                                                 \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
@@ -1084,6 +1107,7 @@ struct ZRun {
     //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
+    bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
     int combine_blocks = 0, pbe_blocks = 0;
@@ -1363,6 +1387,21 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
                 r.za.u[i] = r.sw[i];
                 r.za.gw[i] = r.sw[3 + i];
             }
+        r.wgc_split = false;
+        if (r.has_wgc && r.forked && !chunked && c->split_combine && c->nranks == 1) {
+            // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
+            double *vp, *part2;
+            int blocks = 0;
+            if ((rc = real_ws(c, "vpart", &vp))) return rc;
+            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_b, sc));
+            HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
+            if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
+            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const double*)part2, blocks, 1,
+                         c->d_scal + 2);
+            r.za.v_part = vp;
+            r.wgc_split = true;
+        }
         r.stage[1] = 3;
         return 0;
     }
@@ -1463,8 +1502,11 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     r.stage[0] = r.stage[1] = 5;
     if (!sums) return 0;          // the caller reduces the device-resident sums (c->d_reduced) itself
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
+    if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
+        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kCombineScalars + 2, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
+    if (r.wgc_split) sums[5] += c->h_partial[kCombineScalars + 2];
     return 0;
 }
 
@@ -2376,6 +2418,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
         case OFDFT_OPT_XCHUNKS:
             if (value < 0.0 || value > 64.0) return fail(c, OFDFT_EINVAL, "x chunks must be 0 (automatic) or 1..64");
             c->xchunks = (int)value;
+            return OFDFT_OK;
+        case OFDFT_OPT_SPLIT_COMBINE:
+            c->split_combine = value != 0.0;
             return OFDFT_OK;
         case OFDFT_OPT_XCHUNK_MASK:
             c->xchunk_mask = (int)value & 15;

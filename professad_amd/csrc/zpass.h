@@ -316,6 +316,7 @@ struct ZCombineArgs {
     const cplx* gw[3];
     const cplx* div;
     double* v_out;
+    const double* v_part;     // split form: the WGC99 potential computed by zi_wgc_kernel (then u / gw are not read here)
     unsigned mask;
     double inv_n;
     double wt_alpha, wt_beta, wt_nbar_pa;
@@ -323,7 +324,65 @@ struct ZCombineArgs {
     int wt_is_56, wgc_sum_53;
 };
 
+// WGC99 nonlocal part of one row (SURVEY §8a-8 closed form): adds the potential to vacc, returns the thread's energy sum
 template <int M, int E>
+__device__ __forceinline__ double wgc_row_section(const cplx (&n)[E], cplx (&vacc)[E], cplx (&w)[E], const ZLane<M, E>& z,
+                                                  const ZCombineArgs& a, const SpecGeom& g, const cplx* __restrict__ twM,
+                                                  const cplx* __restrict__ twN, double sc, double ctf) {
+    cplx t1[E], t2[E];
+    double e = 0.0;
+    z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) t1[q] = make_double2(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
+    z_load_inverse<M, E>(w, z, a.u[1], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+        t1[q].x += (n[q].x - a.nref) * x0;
+        t1[q].y += (n[q].y - a.nref) * x1;
+        t2[q] = make_double2(x0, x1);                                                            // S_1 = u1 + ...
+    }
+    z_load_inverse<M, E>(w, z, a.u[2], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        __builtin_amdgcn_sched_barrier(0);      // one point pair at a time: pow_pos() is register-hungry
+        const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+        const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+        t1[q].x += 0.5 * h0 * h0 * x0;
+        t1[q].y += 0.5 * h1 * h1 * x1;
+        t2[q].x += h0 * x0;
+        t2[q].y += h1 * x1;
+        // fold: e_NL = ctf n^alpha S_e ; v += ctf n^(alpha-1) (alpha S_e + n S_1); keep n^(beta-1) in t2
+        const double pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
+        const double pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
+        const double pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
+        e += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
+        vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
+        vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
+        t2[q] = make_double2(pb0, pb1);
+    }
+    z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) t1[q] = make_double2(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
+    z_load_inverse<M, E>(w, z, a.gw[1], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        t1[q].x += (a.wgc_beta * (n[q].x - a.nref) + n[q].x) * w[q].x * sc;
+        t1[q].y += (a.wgc_beta * (n[q].y - a.nref) + n[q].y) * w[q].y * sc;
+    }
+    z_load_inverse<M, E>(w, z, a.gw[2], g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+        t1[q].x += (0.5 * a.wgc_beta * h0 * h0 + n[q].x * h0) * w[q].x * sc;
+        t1[q].y += (0.5 * a.wgc_beta * h1 * h1 + n[q].y * h1) * w[q].y * sc;
+        vacc[q].x += ctf * t2[q].x * t1[q].x;
+        vacc[q].y += ctf * t2[q].y * t1[q].y;
+    }
+    return e;
+}
+
+template <int M, int E, bool WGC_INLINE>
 __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
                                                          const cplx* __restrict__ twN, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -393,57 +452,16 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
             }
         }
     }
-    if (a.mask & 32u) {                                  // WGC99  SURVEY §8a-8 closed form
-        cplx t1[E], t2[E];
-        double e = 0.0;
-        z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
+    if (a.mask & 32u) {                                  // WGC99
+        if (WGC_INLINE) {
+            park[5 * 256] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, sc, ctf);
+        } else {                                         // computed by zi_wgc_kernel on the nonlocal chain's stream
+            z_load_real<M, E>(w, z, a.v_part);
 #pragma unroll
-        for (int q = 0; q < E; ++q) t1[q] = make_double2(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
-        z_load_inverse<M, E>(w, z, a.u[1], g, twM, twN);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-            t1[q].x += (n[q].x - a.nref) * x0;
-            t1[q].y += (n[q].y - a.nref) * x1;
-            t2[q] = make_double2(x0, x1);                                                            // S_1 = u1 + ...
-        }
-        z_load_inverse<M, E>(w, z, a.u[2], g, twM, twN);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            __builtin_amdgcn_sched_barrier(0);      // one point pair at a time: pow_pos() is register-hungry
-            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-            const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
-            t1[q].x += 0.5 * h0 * h0 * x0;
-            t1[q].y += 0.5 * h1 * h1 * x1;
-            t2[q].x += h0 * x0;
-            t2[q].y += h1 * x1;
-            // fold: e_NL = ctf n^alpha S_e ; v += ctf n^(alpha-1) (alpha S_e + n S_1); keep n^(beta-1) in t2
-            const double pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
-            const double pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
-            const double pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
-            e += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
-            vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
-            vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
-            t2[q] = make_double2(pb0, pb1);
-        }
-        park[5 * 256] = e;
-        z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
-#pragma unroll
-        for (int q = 0; q < E; ++q) t1[q] = make_double2(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
-        z_load_inverse<M, E>(w, z, a.gw[1], g, twM, twN);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            t1[q].x += (a.wgc_beta * (n[q].x - a.nref) + n[q].x) * w[q].x * sc;
-            t1[q].y += (a.wgc_beta * (n[q].y - a.nref) + n[q].y) * w[q].y * sc;
-        }
-        z_load_inverse<M, E>(w, z, a.gw[2], g, twM, twN);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
-            t1[q].x += (0.5 * a.wgc_beta * h0 * h0 + n[q].x * h0) * w[q].x * sc;
-            t1[q].y += (0.5 * a.wgc_beta * h1 * h1 + n[q].y * h1) * w[q].y * sc;
-            vacc[q].x += ctf * t2[q].x * t1[q].x;
-            vacc[q].y += ctf * t2[q].y * t1[q].y;
+            for (int q = 0; q < E; ++q) {
+                vacc[q].x += w[q].x;
+                vacc[q].y += w[q].y;
+            }
         }
     }
     if (a.mask & (3u << 10)) {                           // PBE: v += df/dn - 2 div  (tools_for_tests.py:168-170)
@@ -501,6 +519,29 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
     }
     if (a.v_out) z_store_real<M, E>(vacc, z, a.v_out);
     block_reduce_store<kCombineScalars>(acc, partial + (long long)g.blk0 * kCombineScalars);
+}
+
+// The WGC99 part of the combine on its own (split form): chi|n row + the six result spectra -> v_part rows and the
+// energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
+template <int M, int E>
+__global__ __launch_bounds__(256, 2) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
+                                                       const cplx* __restrict__ twM, const cplx* __restrict__ twN,
+                                                       double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    cplx n[E], vacc[E], w[E];
+    z_load_real<M, E>(n, z, a.ds.src);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        n[q] = z.valid ? make_double2(a.ds(n[q].x), a.ds(n[q].y)) : make_double2(1.0, 1.0);
+        vacc[q] = make_double2(0.0, 0.0);
+    }
+    double acc[1];
+    acc[0] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, a.inv_n, ctf);
+    if (!z.valid) acc[0] = 0.0;
+    z_store_real<M, E>(vacc, z, v_part);
+    block_reduce_store<1>(acc, partial + (long long)g.blk0);
 }
 
 }  // namespace ofdft

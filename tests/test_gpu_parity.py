@@ -278,6 +278,14 @@ def test_all_pipelines_agree(shape):
             assert res[mode][5] == res[1][5]          # same number of 3-D FFTs
         # x-chunked form of the z-fused pipeline (Infinity-Cache reuse): same kernels on x ranges, same reduction order
         eng.set_option(0, 0)
+        # the split combine (WGC99 part as its own kernel on the side stream) adds the same numbers in another order
+        eng.set_option(4, 0)
+        E0, v0 = eng.energy_potential(dev(den), dev(vext))
+        Ec0, mu0, g0 = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+        for k in E0:
+            assert abs(E0[k] - res[0][0][k]) <= 1e-13 * max(1.0, abs(E0[k])) and abs(Ec0[k] - res[0][2][k]) <= 1e-13 * max(1.0, abs(Ec0[k]))
+        assert relerr(v0.cpu().numpy(), res[0][1]) < 1e-13 and relerr(g0.cpu().numpy(), res[0][4]) < 1e-13
+        res[0] = (E0, v0.cpu().numpy(), Ec0, mu0, g0.cpu().numpy(), eng.query(0))
         eng.set_option(3, 15)                          # every stage pair chunked
         for nch in (1, 2, 8):
             eng.set_option(2, nch)
@@ -288,6 +296,7 @@ def test_all_pipelines_agree(shape):
             assert mu == res[0][3] and eng.query(0) == res[0][5]
         eng.set_option(2, 0)
         eng.set_option(3, 2)
+        eng.set_option(4, 1)
     eng.close()
 
 
