@@ -74,6 +74,14 @@ __device__ __forceinline__ cplx buf_load_c(const cplx* ubase, unsigned voff_byte
 __device__ __forceinline__ void buf_store_c(cplx* ubase, unsigned voff_bytes, cplx v) {
     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, 0);
 }
+// streaming variants (aux bit 1 = nt): data that is touched once per pass and not re-read before it leaves the caches
+template <int AUX> __device__ __forceinline__ cplx buf_load_c_aux(const cplx* ubase, unsigned voff_bytes) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+    return *reinterpret_cast<cplx*>(&t);
+}
+template <int AUX> __device__ __forceinline__ void buf_store_c_aux(cplx* ubase, unsigned voff_bytes, cplx v) {
+    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+}
 __device__ __forceinline__ double buf_load_d(const double* ubase, unsigned voff_bytes) {
     u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(ubase), (int)voff_bytes, 0, 0);
     return *reinterpret_cast<double*>(&t);

@@ -56,7 +56,7 @@ __device__ __forceinline__ void z_load_real(cplx (&v)[E], const ZLane<M, E>& z, 
     const cplx* ub = reinterpret_cast<const cplx*>(a + z.row_u * W::N2);
     const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c(ub + q * W::P, voff) : make_double2(0.0, 0.0);
+    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c_aux<OFDFT_ZR_LD_AUX>(ub + q * W::P, voff) : make_double2(0.0, 0.0);
 }
 template <int M, int E>
 __device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, E>& z, double* __restrict__ a) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, 
     const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
     if (z.valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c(ub + q * W::P, voff, v[q]);
+        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_ZR_ST_AUX>(ub + q * W::P, voff, v[q]);
     }
 }
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
         const cplx ev = make_double2(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
         const cplx od = make_double2(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
         const cplx X = cadd(ev, cmul(twN[k], od));
-        if (z.valid) buf_store_c(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
+        if (z.valid) buf_store_c_aux<OFDFT_ZS_ST_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
     });
     if (z.j == 0 && z.valid) {
         const double c0i = z.mine[0];
@@ -131,7 +131,7 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
     const unsigned voff = z_spec_voff<M, E>(z, g);
     static_for<E>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        v[q] = z.valid ? buf_load_c(spec + z_spec_ubase<M, E, q>(z, g), voff) : make_double2(0.0, 0.0);
+        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : make_double2(0.0, 0.0);
     });
     const double nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
     double xr_m[E];
