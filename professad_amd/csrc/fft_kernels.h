@@ -92,7 +92,7 @@ struct ArrList { cplx* p[16]; };
 #define OFDFT_XF_LD_AUX 0
 #endif
 #ifndef OFDFT_XF_ST_AUX
-#define OFDFT_XF_ST_AUX 0
+#define OFDFT_XF_ST_AUX 2     // fused x pass: nt stores (-8 % on the WGC99 kernel); nt LOADS cost +14 % (partner half-lines in L2)
 #endif
 #ifndef OFDFT_ZS_LD_AUX
 #define OFDFT_ZS_LD_AUX 0
