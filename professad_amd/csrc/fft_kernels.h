@@ -203,7 +203,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
         for (int q = 0; q < E; ++q) {
             if (INV) {
                 const int e = j + P * q;
-                v[q] = buf[lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es];
+                v[q] = nt_load_c(buf + lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es);
             } else {
                 v[q] = buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + q * qstep, voff);
             }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
                 buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + q * qstep, voff, v[q]);
             } else {
                 const int e = j + P * q;
-                buf[lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es] = v[q];
+                nt_store_c(buf + lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es, v[q]);
             }
         }
     }
@@ -666,7 +666,11 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     if (valid && grp < NOUT) {
         cplx* ub = xf_pick(io.out, grp) + b0;
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_XF_ST_AUX>(ub + q * qstep_o, voff_o, o[q]);
+        for (int q = 0; q < E; ++q) {
+            // nt stores pay in the block-8 layout (one GPU); in the exchange layout (x stride = a whole record) they cost 16 %
+            if (xs.se_out) buf_store_c(ub + q * qstep_o, voff_o, o[q]);
+            else buf_store_c_aux<OFDFT_XF_ST_AUX>(ub + q * qstep_o, voff_o, o[q]);
+        }
     }
 }
 

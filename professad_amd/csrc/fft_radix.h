@@ -74,6 +74,18 @@ __device__ __forceinline__ cplx buf_load_c(const cplx* ubase, unsigned voff_byte
 __device__ __forceinline__ void buf_store_c(cplx* ubase, unsigned voff_bytes, cplx v) {
     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, 0);
 }
+// plain-pointer nontemporal accesses (per-lane 64-bit addresses: the exchange-buffer side of the slab-decomposed y pass)
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx nt_load_c(const cplx* p) {
+    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
+    return make_double2(t.x, t.y);
+}
+__device__ __forceinline__ void nt_store_c(cplx* p, cplx v) {
+    dbl2_t t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(p));
+}
 // streaming variants (aux bit 1 = nt): data that is touched once per pass and not re-read before it leaves the caches
 template <int AUX> __device__ __forceinline__ cplx buf_load_c_aux(const cplx* ubase, unsigned voff_bytes) {
     u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, AUX);

@@ -14,6 +14,7 @@ The orchestration (`run_closure`, `run_potential`) is written against a tiny "st
 CPU-only test-suite can drive it with a numpy double under gloo; the product implementation of that
 interface is `HipStages` (ctypes -> libofdft_hip.so), which has no CPU fallback.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -190,19 +191,34 @@ class HipStages(Engine):
 
 def _run_exchanges(stages, comm):
     """Stage / chain sequencing: a chain's stage k+1 waits only for that chain's exchange, so (with an asynchronous
-    transport) the other chain's kernels run while it is in flight."""
+    transport) the other chain's kernels run while it is in flight.  On a GPU the nonlocal-KEDF chain is issued on its
+    own stream: its kernels and exchanges then neither wait for nor delay the other chain's (the engine enqueues on
+    whatever stream is current, and so does the collective)."""
+    dev = getattr(stages, 'device', None)
+    on_gpu = isinstance(dev, torch.device) and dev.type == 'cuda'
+    side = None
+    if on_gpu:
+        side = getattr(stages, '_side_stream', None)
+        if side is None:
+            side = stages._side_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))          # everything ofdft_dist_begin enqueued
     pending = [None, None]
     for k in (1, 2, 3, 4):
         for chain in (0, 1):
-            if pending[chain] is not None:
-                pending[chain].wait()
-                pending[chain] = None
-            ex = stages.stage(k, chain)
-            if ex is not None:
-                pending[chain] = comm.all_to_all(ex[0], ex[1])
-    for w in pending:
+            ctx = torch.cuda.stream(side) if (side is not None and chain == 1) else contextlib.nullcontext()
+            with ctx:
+                if pending[chain] is not None:
+                    pending[chain].wait()
+                    pending[chain] = None
+                ex = stages.stage(k, chain)
+                if ex is not None:
+                    pending[chain] = comm.all_to_all(ex[0], ex[1])
+    for chain, w in enumerate(pending):
         if w is not None:
-            w.wait()
+            with (torch.cuda.stream(side) if (side is not None and chain == 1) else contextlib.nullcontext()):
+                w.wait()
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)           # the combine needs both chains
 
 
 def _run_stages(stages, comm):
