@@ -1388,14 +1388,16 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
                 r.za.gw[i] = r.sw[3 + i];
             }
         r.wgc_split = false;
-        if (r.has_wgc && r.forked && !chunked && c->split_combine && c->nranks == 1) {
+        if (r.has_wgc && !chunked && c->split_combine) {
             // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
             double *vp, *part2;
             int blocks = 0;
             if ((rc = real_ws(c, "vpart", &vp))) return rc;
             if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_b, sc));
-            HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
+            if (r.forked) {
+                HIP_TRY(c, hipEventRecord(c->ev_b, sc));
+                HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
+            }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
             OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const double*)part2, blocks, 1,
                          c->d_scal + 2);
@@ -1500,7 +1502,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
                  r.combine_blocks, kCombineScalars, c->d_reduced);
     if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, 2 * sizeof(double), st));
     r.stage[0] = r.stage[1] = 5;
-    if (!sums) return 0;          // the caller reduces the device-resident sums (c->d_reduced) itself
+    if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
+        if (r.wgc_split)          // fold in the energy sum of the split WGC99 kernel
+            OFDFT_LAUNCH(c, st, "reduce", axpy_kernel, dim3(1), dim3(64), 0, (const double*)(c->d_scal + 2), c->d_reduced + 5,
+                         (long long)1, 1);
+        return 0;
+    }
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
     if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
         HIP_TRY(c, hipMemcpyAsync(c->h_partial + kCombineScalars + 2, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
