@@ -44,15 +44,12 @@ def algorithmic_bytes(n, cfg):
 
 
 def kernel_alg_bytes(name, n):
-    """Algorithmic bytes moved by ONE launch of a kernel class (what it must read + write once)."""
+    """Algorithmic bytes of ONE spectrum pass of a kernel class (what it must read + write once).  A launch may cover
+    several spectra or only an x range of them (batched / x-chunked y passes), so rooflines are formed per evaluation:
+    passes x bytes / time of the class."""
     R = 8.0 * n ** 3
     Cc = 16.0 * n * n * (n // 2 + 1)
-    Cmain = 16.0 * n * n * (n // 2)
-    Cnyq = Cc - Cmain
-    table = {
-        'cpass_x': 2 * Cmain, 'cpass_y': 2 * Cmain, 'cpass_x_nyq': 2 * Cnyq, 'cpass_y_nyq': 2 * Cnyq,
-        'zfwd': R + Cc, 'zinv': R + Cc,
-    }
+    table = {'cpass_x': 2 * Cc, 'cpass_y': 2 * Cc, 'zfwd': R + Cc, 'zinv': R + Cc}
     return table.get(name)
 
 
@@ -209,14 +206,19 @@ def main():
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if dom:
-        avg_ms = prof[dom][0] / prof[dom][1]
-        ach = kernel_alg_bytes(dom, n) / (avg_ms * 1e-3) / 1e9
+        # per evaluation: every 3-D FFT has one y pass (n_fft spectrum passes), whatever the launch granularity
+        passes = n_fft if dom == 'cpass_y' else prof[dom][1] / nprof
+        launches = prof[dom][1] / nprof
+        class_ms = prof[dom][0] / nprof
+        avg_ms = class_ms / launches
+        ach = kernel_alg_bytes(dom, n) * passes / (class_ms * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
                                 if pmc and dom in pmc.get('kernels', {}) else None),
+                    'launches_per_eval': launches, 'spectrum_passes_per_eval': passes,
                     'traffic_source': ('profiles/pmc_traffic_r01.json: ' + pmc['source']) if pmc else None,
-                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n),
+                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n) * passes / launches,
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg)
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU

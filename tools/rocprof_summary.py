@@ -30,7 +30,11 @@ def load_trace(d):
     for f in glob.glob(os.path.join(d, '**', '*_kernel_trace.csv'), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                rows.append((short(r['Kernel_Name']), int(r.get('Grid_Size') or r['Grid_Size_X']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+                if r.get('Grid_Size'):
+                    grid = int(r['Grid_Size'])
+                else:       # kernel-trace CSV: per-dimension sizes; the counter CSV has the product
+                    grid = int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y') or 1) * int(r.get('Grid_Size_Z') or 1)
+                rows.append((short(r['Kernel_Name']), grid, int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
     return rows
 
 
