@@ -116,17 +116,18 @@ def test_fused_configs_and_closure_match_reference_golden(case):
         assert relerr(g.cpu().numpy(), gold['g_' + cfg]) < V_RTOL
 
 
-def test_big_scalars_match_reference_golden():
+@pytest.mark.parametrize('fname', ['big_scalars.json', 'huge_scalars.json'])
+def test_big_scalars_match_reference_golden(fname):
+    """64^3 / 128^3 (big) and the full 256^3 bench size (huge): energy and statistics / probes of dE/dn of the fused
+    configurations against the reference itself run at that size"""
     import json
-    path = os.path.join(GOLDEN, 'big_scalars.json')
+    path = os.path.join(GOLDEN, fname)
     if not os.path.exists(path):
-        pytest.skip('big_scalars.json not generated')
+        pytest.skip(fname + ' not generated')
     big = json.load(open(path))
     for key, rec in big.items():
         cfg, n = key.split('_')
         n = int(n)
-        if n > 128:
-            continue
         shape = (n, n, n)
         box = synth.cubic_cell(n)
         den = synth.random_density(shape, seed=1234)
