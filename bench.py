@@ -125,10 +125,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    # rehearsal switches for a one-GPU box (never set by the driver): OFDFT_BENCH_BACKEND=gloo stages the exchange
+    # through the host, OFDFT_BENCH_SHARE_GPU=1 puts every rank on cuda:0
+    backend = os.environ.get('OFDFT_BENCH_BACKEND', 'nccl')
+    if os.environ.get('OFDFT_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
@@ -195,6 +203,10 @@ def main():
     raw.set_profiling(False)
     if os.environ.get('OFDFT_SIDE_STREAM') != '0':
         raw.set_option(1, 1)
+    if world > 1 and ('ypass_send' in prof or 'ypass_recv' in prof):
+        # slab-decomposed path: the y passes read / write the exchange buffers; one class for the roofline
+        ys = [prof.pop(k) for k in ('ypass_send', 'ypass_recv') if k in prof]
+        prof['cpass_y'] = (sum(v[0] for v in ys), sum(v[1] for v in ys))
     tot_ms = sum(v[0] for v in prof.values()) or 1.0
     dom = max((k for k in prof if kernel_alg_bytes(k, n)), key=lambda k: prof[k][0], default=None)
     roofline = None
@@ -211,14 +223,14 @@ def main():
         launches = prof[dom][1] / nprof
         class_ms = prof[dom][0] / nprof
         avg_ms = class_ms / launches
-        ach = kernel_alg_bytes(dom, n) * passes / (class_ms * 1e-3) / 1e9
+        ach = kernel_alg_bytes(dom, n) / world * passes / (class_ms * 1e-3) / 1e9      # per GPU: a rank holds 1/world of a spectrum
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
                                 if pmc and dom in pmc.get('kernels', {}) else None),
                     'launches_per_eval': launches, 'spectrum_passes_per_eval': passes,
                     'traffic_source': ('profiles/pmc_traffic_r01.json: ' + pmc['source']) if pmc else None,
-                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n) * passes / launches,
+                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n) / world * passes / launches,
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg)
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU

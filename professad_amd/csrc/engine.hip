@@ -1928,6 +1928,10 @@ int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     if ((rc = zstage5(c, local_sums, st))) return rc;
     if (!local_sums) {        // device-resident form: scalars[0..10] hold the local sums, nothing waits here
         HIP_TRY(c, hipGetLastError());
+        if (c->profiling) {   // profiling pass only: the event times are read back, which needs the stream drained
+            HIP_TRY(c, hipStreamSynchronize(st));
+            prof_collect(c);
+        }
         return OFDFT_OK;
     }
     return end_call(c, st);
