@@ -64,7 +64,10 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_CHACHIYO_C    (1u << 9)   /* functionals.py:1533-1537                              */
 #define OFDFT_PBE_X         (1u << 10)  /* functionals.py:1597-1603                              */
 #define OFDFT_PBE_C         (1u << 11)  /* functionals.py:1606-1618                              */
-#define OFDFT_NTERMS        12
+#define OFDFT_GGA_K         (1u << 12)  /* Pauli part of a GGA kinetic functional, int tau_TF F(s): LuoKarasievTrickey
+                                           functionals.py:309-333 (F = 1/cosh(1.3 s)) or PauliGaussian :336-403 with
+                                           beta = lambda = sigma = 0 (F = exp(-mu s^2)); the vW part is OFDFT_VW */
+#define OFDFT_NTERMS        13
 
 /* params[] slots for ofdft_set_terms (missing trailing slots keep their defaults) */
 #define OFDFT_P_WT_ALPHA    0   /* default 5/6 */
@@ -73,7 +76,9 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_P_WGC_BETA    3   /* default (5-sqrt5)/6 */
 #define OFDFT_P_WGC_GAMMA   4   /* default 2.7 */
 #define OFDFT_P_WGC_KAPPA   5   /* default 1.0 */
-#define OFDFT_NPARAMS       6
+#define OFDFT_P_GGAK_KIND   6   /* 0 = LKT (default), 1 = Pauli-Gaussian exp(-mu s^2) */
+#define OFDFT_P_GGAK_MU     7   /* default 40/27 (PGS); 1.0 = PG1 */
+#define OFDFT_NPARAMS       8
 
 /* ofdft_query selectors */
 #define OFDFT_Q_FFT_COUNT        0  /* 3-D FFTs executed by the last energy call              */
@@ -116,11 +121,11 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
  *     ofdft_dist_sumsq (closure form only) -> all-reduce -> c = N_e / (mean chi^2 vol)
  *     ofdft_dist_begin; for stage in 1..4, for chain in 0..1: [wait for the chain's previous all-to-all]
  *         ofdft_dist_stage(stage, chain) + all_to_all(bytes_per_peer)  (asynchronous if the transport allows);
- *     [wait for both] ofdft_dist_finish -> all-reduce of 11 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
+ *     [wait for both] ofdft_dist_finish -> all-reduce of 12 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
  * Device-resident scalars (no host round trip before the final sums): pass local_sum_host = NULL to
- * ofdft_dist_sumsq, all-reduce scalars[11] in place (ofdft_dist_scalars), call ofdft_dist_begin with from_chi = 2
+ * ofdft_dist_sumsq, all-reduce scalars[15] in place (ofdft_dist_scalars), call ofdft_dist_begin with from_chi = 2
  * (the closure scale is then formed on the device), ofdft_dist_finish with local_sums_host = NULL, all-reduce
- * scalars[0..10] in place and copy them to the host once; ofdft_dist_chi_grad with cscale = 0 uses the device scale.
+ * scalars[0..11] in place and copy them to the host once; ofdft_dist_chi_grad with cscale = 0 uses the device scale.
  * With nranks == 1 the same calls work and every bytes_per_peer is 0.  These stand behind the same reference
  * interfaces as ofdft_energy_potential / ofdft_energy_grad_chi (system.py:830-838, functional_tools.py:9-31). */
 int  ofdft_create_dist(ofdft_ctx** out, int n0_global, int n1_global, int n2, int dtype, int device_id, int nranks, int rank);
@@ -129,9 +134,9 @@ int  ofdft_dist_begin(ofdft_ctx* ctx, const void* src_local_dev, int from_chi, d
                       const void* vext_local_dev, void* v_out_local_dev, void* stream);
 int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
                       void** recvbuf_dev);
-int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[11] or NULL*/, void* stream);
-int  ofdft_dist_scalars(ofdft_ctx* ctx, void** scalars_dev /* 12 doubles owned by the context */);
-int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[11]*/, double* E_terms_host, double* vn_integral);
+int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[12] or NULL*/, void* stream);
+int  ofdft_dist_scalars(ofdft_ctx* ctx, void** scalars_dev /* 16 doubles owned by the context */);
+int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[12]*/, double* E_terms_host, double* vn_integral);
 int  ofdft_dist_chi_grad(ofdft_ctx* ctx, const void* chi_local_dev, const void* v_local_dev, void* grad_local_dev,
                          double cscale, double mu, void* stream);
 

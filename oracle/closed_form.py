@@ -351,6 +351,34 @@ class Evaluator:
         v = dfdn - 2 * self._divergence([dfdg * c for c in grad])
         return g.integral(f), v
 
+    def ggak_pointwise(self, n, gn2, kind='lkt', mu=40 / 27):
+        """Pauli part of a GGA kinetic functional, f = tau_TF F(s): LKT F = 1/cosh(1.3 s) (functionals.py:309-333, s
+        clamped at 100) or Pauli-Gaussian F = exp(-mu s^2) (:336-403 with beta = lambda = sigma = 0)
+        -> f, df/dn, df/d|grad n|^2"""
+        cs = 0.25 * (3 * PI * PI) ** (-2 / 3)
+        s2 = cs * gn2 / n ** (8 / 3)
+        tau = C_TF * n ** (5 / 3)
+        if kind == 'lkt':
+            a = 1.3
+            s = np.minimum(np.sqrt(s2), 100.0)
+            F = 1 / np.cosh(a * s)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                dF = np.where(s > 1e-8, -a * np.tanh(a * s) * F / (2 * np.where(s > 0, s, 1.0)), -0.5 * a * a)
+            dF = np.where(s < 100.0, dF, 0.0)
+        else:
+            F = np.exp(-mu * s2)
+            dF = -mu * F
+        return tau * F, (5 / 3) * tau / n * F + tau * dF * (-(8 / 3) * s2 / n), tau * dF * cs / n ** (8 / 3)
+
+    def ggak(self, n, kind='lkt', mu=40 / 27, nk=None):
+        g = self.g
+        nk = g.fwd(n) if nk is None else nk
+        grad = self._gradient(nk)
+        gn2 = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
+        f, dfdn, dfdg = self.ggak_pointwise(n, gn2, kind, mu)
+        v = dfdn - 2 * self._divergence([dfdg * c for c in grad])
+        return g.integral(f), v
+
     # -- dispatcher over golden-case names
     def term(self, name, n, vext=None):
         s5 = math.sqrt(5)
@@ -372,6 +400,10 @@ class Evaluator:
             return self.pbe(n, do_x=False)
         if name == 'pbe':
             return self.pbe(n)
+        if name in ('lkt', 'pg1', 'pgs'):                  # vW + Pauli GGA part (functionals.py:309-403)
+            E1, v1 = self.vw(n)
+            E2, v2 = self.ggak(n, 'lkt') if name == 'lkt' else self.ggak(n, 'pg', 1.0 if name == 'pg1' else 40 / 27)
+            return E1 + E2, v1 + v2
         raise KeyError(name)
 
     def terms(self, names, n, vext=None):

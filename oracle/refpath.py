@@ -352,6 +352,27 @@ def pbe(box, den):
 
 
 # ----------------------------------------------------------------------------- drivers
+def lkt(box, den):
+    """functionals.py:309-333"""
+    kx, ky, kz, _ = recip_grid(box, den.shape)
+    gdg = grad_sq(kx, ky, kz, den)
+    ag = torch.zeros(den.shape, dtype=torch.double, device=den.device)
+    ag[gdg != 0] = torch.sqrt(gdg[gdg != 0])                          # functional_tools.py:246-249
+    s = 0.5 * (3 * PI * PI) ** (-1 / 3) * ag / den.pow(4 / 3)
+    tf_ked = 0.3 * (3 * PI * PI) ** (2 / 3) * den.pow(5 / 3)
+    return weizsaecker(box, den) + torch.mean(tf_ked / torch.cosh(1.3 * s.clamp(max=100))) * _vol(box)
+
+
+def pauli_gaussian(mu):
+    """functionals.py:336-403 with beta = lambda = sigma = 0"""
+    def f(box, den):
+        kx, ky, kz, _ = recip_grid(box, den.shape)
+        s2 = 0.25 * (3 * PI * PI) ** (-2 / 3) * grad_sq(kx, ky, kz, den) / den.pow(8 / 3)
+        tf_ked = 0.3 * (3 * PI * PI) ** (2 / 3) * den.pow(5 / 3)
+        return weizsaecker(box, den) + torch.mean(tf_ked * torch.exp(-abs(mu) * s2)) * _vol(box)
+    return f
+
+
 def term_table(vext=None):
     """name -> callable(box, den), same keys as tests/golden/cases.py."""
     return {
@@ -362,6 +383,7 @@ def term_table(vext=None):
         'wgc99': Wgc99(),
         'lda_x': lda_exchange, 'pz_c': pz_correlation, 'pw_c': pw_correlation,
         'chachiyo_c': chachiyo_correlation, 'pbe_x': pbe_exchange, 'pbe_c': pbe_correlation,
+        'lkt': lkt, 'pg1': pauli_gaussian(1.0), 'pgs': pauli_gaussian(40 / 27),
     }
 
 

@@ -80,6 +80,15 @@ struct ofdft_ctx {
 
 namespace {
 
+constexpr unsigned kGgaAny = OFDFT_PBE_X | OFDFT_PBE_C | OFDFT_GGA_K;   // terms served by the gradient / divergence machinery
+constexpr int kNSums = kCombineScalars + kPbeScalars;                  // local sums of an evaluation (12)
+constexpr int kSumsqSlot = 15;                                         // d_reduced slot of sum chi^2 (closure form)
+
+GgaSel gga_sel(const ofdft_ctx* c) {
+    return GgaSel{(c->mask & OFDFT_PBE_X) ? 1 : 0, (c->mask & OFDFT_PBE_C) ? 1 : 0, (c->mask & OFDFT_GGA_K) ? 1 : 0,
+                  (int)c->params[OFDFT_P_GGAK_KIND], c->params[OFDFT_P_GGAK_MU]};
+}
+
 int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -636,6 +645,7 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
     }
     if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
     if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
     *vn_int = sums[8] * dV;
     return 0;
 }
@@ -664,12 +674,12 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
     ca.v_out = v_out;
     ca.npts = npts;
     ca.mask = mask;
-    double pbe_sums[2] = {0.0, 0.0};
+    double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
 
     cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
     if (int rc = spec_ws(c, "s0", &s0)) return rc;
 
-    if (mask & (OFDFT_HARTREE | OFDFT_PBE_X | OFDFT_PBE_C)) {
+    if (mask & (OFDFT_HARTREE | kGgaAny)) {
         if (int rc = rfftn_internal(c, den, s0, st)) return rc;             // n^ (shared)
         if (int rc = spec_ws(c, "s1", &s1)) return rc;
         if (mask & OFDFT_HARTREE) {
@@ -679,7 +689,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = irfftn_internal(c, s1, vh, inv_n, st)) return rc;
             ca.vh = vh;
         }
-        if (mask & (OFDFT_PBE_X | OFDFT_PBE_C)) {
+        if (mask & kGgaAny) {
             double *gx, *gy, *gz, *dfdn, *dv;
             if (int rc = spec_ws(c, "s2", &s2)) return rc;
             if (int rc = spec_ws(c, "s3", &s3)) return rc;
@@ -694,8 +704,8 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
             const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
             OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
-                               (mask & OFDFT_PBE_X) ? 1 : 0, (mask & OFDFT_PBE_C) ? 1 : 0, c->d_partial);
-            if (int rc = fetch_partials(c, blocks, 2, pbe_sums, st)) return rc;
+                               gga_sel(c), c->d_partial);
+            if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
             if (int rc = rfftn_internal(c, gx, s1, st)) return rc;
             if (int rc = rfftn_internal(c, gy, s2, st)) return rc;
             if (int rc = rfftn_internal(c, gz, s3, st)) return rc;
@@ -804,12 +814,12 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
     ca.v_out = v_out;
     ca.npts = npts;
     ca.mask = mask;
-    double pbe_sums[2] = {0.0, 0.0};
+    double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx* s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const char* sn[5] = {"s0", "s1", "s2", "s3", "s4"};
     if (int rc = spec_ws(c, sn[0], &s[0])) return rc;
 
-    const bool has_h = mask & OFDFT_HARTREE, has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
+    const bool has_h = mask & OFDFT_HARTREE, has_g = mask & kGgaAny;
     if (has_h || has_g) {
         if (int rc = fwd_zy(c, den, s[0], st)) return rc;
         XfIo io{};
@@ -845,8 +855,8 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
                 if ((rc = inv_yz(c, s[2 + k], gr[k], inv_n, st))) return rc;
             const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
             OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gr[0], gr[1], gr[2], dfdn, npts,
-                         (mask & OFDFT_PBE_X) ? 1 : 0, (mask & OFDFT_PBE_C) ? 1 : 0, c->d_partial);
-            if ((rc = fetch_partials(c, blocks, 2, pbe_sums, st))) return rc;
+                         gga_sel(c), c->d_partial);
+            if ((rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st))) return rc;
             for (int k = 0; k < 3; ++k)
                 if ((rc = fwd_zy(c, gr[k], s[2 + k], st))) return rc;
             XfIo dio{};
@@ -999,8 +1009,8 @@ int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipSt
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
-int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n, int do_x,
-                int do_c, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
+int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n,
+                int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
     if (chunk == 0) c->fft_count += 6;    // three c2r finished + three r2c started on chip
@@ -1011,7 +1021,7 @@ int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, do
         const int nb = *blocks_out / nchunks;                                                                   \
         gq.blk0 = chunk * nb;                                                                                   \
         OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),                   \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, do_x, do_c, gq, twM, twN,    \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, gga_sel(c), gq, twM, twN,   \
                      c->d_partial);                                                                             \
         return 0;                                                                                               \
     }
@@ -1077,6 +1087,7 @@ void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pb
         if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
     if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
     if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
     *vn_int = sums[8] * dV;
 }
 
@@ -1096,7 +1107,7 @@ struct ZRun {
     const double* vext = nullptr;
     double* v_out = nullptr;
     ZCombineArgs za{};
-    double pbe_sums[2] = {0.0, 0.0};
+    double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
     bool has_h = false, has_g = false, has_vw = false, has_wt = false, has_wgc = false;
     cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
     cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1154,7 +1165,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
     xl.clear();
     if (chain == 0) {
         r.has_h = mask & OFDFT_HARTREE;
-        r.has_g = mask & (OFDFT_PBE_X | OFDFT_PBE_C);
+        r.has_g = mask & kGgaAny;
         r.has_vw = mask & OFDFT_VW;
         r.has_wt = mask & OFDFT_WT_NL;
         r.has_wgc = mask & OFDFT_WGC99_NL;
@@ -1164,7 +1175,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
         r.za.v_out = r.v_out;
         r.za.mask = mask;
         r.za.inv_n = 1.0 / (double)c->npts_g;
-        r.pbe_sums[0] = r.pbe_sums[1] = 0.0;
+        r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
         r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
         if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
         if (r.has_h || r.has_g)
@@ -1415,14 +1426,13 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         for (int ch = 0; ch < nch; ++ch) {
             const int x0 = ch * (c->n0 / nch), cx = c->n0 / nch;
             if (pbe_chunked && (rc = fast_axis_pass_multi<true>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
-            if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, (c->mask & OFDFT_PBE_X) ? 1 : 0,
-                                  (c->mask & OFDFT_PBE_C) ? 1 : 0, &r.pbe_blocks, st, ch, nch)))
+            if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, &r.pbe_blocks, st, ch, nch)))
                 return rc;
             if (pbe_chunked && (rc = fast_axis_pass_multi<false>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
         }
         // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks, 2,
-                     c->d_reduced + kCombineScalars);
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
+                     kPbeScalars, c->d_reduced + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
             if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             xl.push_back(r.s_g[k]);
@@ -1500,7 +1510,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     }
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
-    if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, 2 * sizeof(double), st));
+    if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
     r.stage[0] = r.stage[1] = 5;
     if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
         if (r.wgc_split)          // fold in the energy sum of the split WGC99 kernel
@@ -1508,12 +1518,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
                          (long long)1, 1);
         return 0;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kCombineScalars + 2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
     if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
-        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kCombineScalars + 2, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kNSums, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    for (int i = 0; i < kCombineScalars + 2; ++i) sums[i] = c->h_partial[i];
-    if (r.wgc_split) sums[5] += c->h_partial[kCombineScalars + 2];
+    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+    if (r.wgc_split) sums[5] += c->h_partial[kNSums];
     return 0;
 }
 
@@ -1530,7 +1540,7 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
     // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.
     r.forked = c->use_side_stream && c->side_stream && c->side_stream2 && (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) &&
-               (c->mask & (OFDFT_HARTREE | OFDFT_VW | OFDFT_PBE_X | OFDFT_PBE_C));
+               (c->mask & (OFDFT_HARTREE | OFDFT_VW | kGgaAny));
     if (r.forked) {
         r.sb = c->side_stream;
         r.sc = c->side_stream2;
@@ -1545,7 +1555,7 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* v
     for (int chain = 0; chain < 2; ++chain)
         if ((rc = zstage3(c, st, chain))) return rc;
     if ((rc = zstage4(c, st, 0))) return rc;
-    double sums[kCombineScalars + 2];
+    double sums[kNSums];
     if ((rc = zstage5(c, sums, st))) return rc;
     energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
     return 0;
@@ -1622,7 +1632,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     while ((1 << c->xg.log_nyl) < c->xg.nyl) c->xg.log_nyl++;
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
-    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0};
+    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0, 0.0, 40.0 / 27.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     hipError_t e = hipSetDevice(device_id);
     // partial-sum rows: the pointwise kernels use <= kRedBlocks blocks, the z kernels one block per row group
@@ -1722,7 +1732,7 @@ int ofdft_set_terms(ofdft_ctx* c, uint32_t mask, const double* params, int npara
     if (mask == 0 || (mask >> OFDFT_NTERMS)) return fail(c, OFDFT_EINVAL, "bad term mask 0x%x", mask);
     if (nparams < 0 || nparams > OFDFT_NPARAMS || (nparams > 0 && !params)) return fail(c, OFDFT_EINVAL, "bad params");
     for (int i = 0; i < nparams; ++i) {
-        if (i >= OFDFT_P_WGC_ALPHA && c->params[i] != params[i]) c->wgc_valid = false;
+        if (i >= OFDFT_P_WGC_ALPHA && i <= OFDFT_P_WGC_KAPPA && c->params[i] != params[i]) c->wgc_valid = false;
         c->params[i] = params[i];
     }
     c->mask = mask;
@@ -1768,8 +1778,8 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
         OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)chi, c->npts,
                      c->d_partial);
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
-                     c->d_reduced + 11);
-        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + 11, c->d_scal, n_electrons,
+                     c->d_reduced + kSumsqSlot);
+        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, n_electrons,
                      c->vol / (double)c->npts);
         const DenSrc ds{(const double*)chi, 0.0, 1, c->d_scal};
         double vn;
@@ -1836,7 +1846,7 @@ int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* loca
     if (!c || !x_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     if (local_sum) return device_sum(c, (const double*)x_local, square != 0, local_sum, st);
-    // device-resident form: the local sum goes to scalars[11] (ofdft_dist_scalars), no host synchronisation
+    // device-resident form: the local sum goes to scalars[15] (ofdft_dist_scalars), no host synchronisation
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     if (square)
         OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
@@ -1845,7 +1855,7 @@ int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* loca
         OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
                      c->d_partial);
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
-                 c->d_reduced + 11);
+                 c->d_reduced + kSumsqSlot);
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
@@ -1864,8 +1874,8 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
     ZRun& r = zrun(c);
-    if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[11]; it never visits the host
-        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + 11, c->d_scal, nel_global,
+    if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[15]; it never visits the host
+        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel_global,
                      c->vol / (double)c->npts_g);
         r.ds = DenSrc{(const double*)src_local, 0.0, 1, c->d_scal};
     } else {
@@ -1916,7 +1926,7 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
     return OFDFT_OK;
 }
 
-// Stage 5: y-inverse of the last exchange, combine; local_sums[11] = 9 combine scalars + PBE x, c (to be summed
+// Stage 5: y-inverse of the last exchange, combine; local_sums[12] = 9 combine scalars + GGA sums (PBE x, c, kinetic) (to be summed
 // over ranks by the caller, then turned into energies by ofdft_dist_energies).
 int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -2178,7 +2188,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     double *gx = nullptr, *gy = nullptr, *gz = nullptr;
     if (int rc = spec_ws(c, "s0", &s0)) return rc;
     if (int rc = spec_ws(c, "s1", &s1)) return rc;
-    if (mask & (OFDFT_HARTREE | OFDFT_PBE_X | OFDFT_PBE_C)) {
+    if (mask & (OFDFT_HARTREE | kGgaAny)) {
         if (int rc = rfftn_internal(c, den, s0, st)) return rc;
         if (mask & OFDFT_HARTREE) {
             OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HARTREE>), dim3(sp_blocks), dim3(kRedThreads), 0,
@@ -2186,7 +2196,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
             sym_store(sig + 9 * 1, s7, -0.5 * s7[6]);                 // -E_H / vol on the diagonal
         }
-        if (mask & (OFDFT_PBE_X | OFDFT_PBE_C)) {
+        if (mask & kGgaAny) {
             if (int rc = spec_ws(c, "s2", &s2)) return rc;
             if (int rc = spec_ws(c, "s3", &s3)) return rc;
             if (int rc = real_ws(c, "gx", &gx)) return rc;
@@ -2198,11 +2208,11 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             if (int rc = irfftn_internal(c, s3, gz, invN, st)) return rc;
         }
     }
-    if (mask & (OFDFT_TF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | OFDFT_PBE_X | OFDFT_PBE_C)) {
+    if (mask & (OFDFT_TF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | kGgaAny)) {
         const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
         double r[kStressRealScalars];
         OFDFT_LAUNCH(c, st, "stress_real", stress_real_kernel, dim3(blocks), dim3(kRedThreads), 0, den, (const double*)gx,
-                     (const double*)gy, (const double*)gz, npts, mask, c->d_partial);
+                     (const double*)gy, (const double*)gz, npts, mask, gga_sel(c), c->d_partial);
         if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
         const double zero6[6] = {0, 0, 0, 0, 0, 0};
         const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
@@ -2212,9 +2222,9 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
         for (int b = 7; b <= 9; ++b)
             if ((mask >> b) & 1) sym_store(sig + 9 * b, zero6, r[2] * invN / nc);
-        for (int which = 0; which < 2; ++which) {                                              // :393-472
-            if (!(mask & (which == 0 ? OFDFT_PBE_X : OFDFT_PBE_C))) continue;
-            const double* o = r + (which == 0 ? 3 : 11);
+        for (int which = 0; which < 3; ++which) {                                              // :393-472 (same form for the kinetic GGA)
+            if (!(mask & (which == 0 ? OFDFT_PBE_X : (which == 1 ? OFDFT_PBE_C : OFDFT_GGA_K)))) continue;
+            const double* o = r + 3 + 8 * which;
             double c6[6];
             for (int k = 0; k < 6; ++k) c6[k] = -2.0 * o[k] * invN;
             for (int k = 0; k < 3; ++k) c6[k] += -2.0 * o[6] * invN;

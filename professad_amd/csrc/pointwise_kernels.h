@@ -11,7 +11,7 @@ namespace ofdft {
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
 constexpr int kRedThreads = 256;
-constexpr int kMaxScalars = 20;    // scalars reduced by one kernel (19: the real-space stress sums)
+constexpr int kMaxScalars = 28;    // scalars reduced by one kernel (27: the real-space stress sums)
 
 // ---- block reduction of NS scalars; thread 0 writes partial[blockIdx.x * NS + s]
 template <int NS>
@@ -421,14 +421,40 @@ __device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
     return r;
 }
 
-struct PbePoint { double fx, fc, dfdn, dfdg; };
+struct PbePoint { double fx, fc, fk, dfdn, dfdg; };
+// which GGA pieces a pass evaluates: PBE exchange / correlation, and the Pauli part of a GGA kinetic functional
+// (kkind 0: LuoKarasievTrickey F = 1/cosh(1.3 s), functionals.py:309-333; 1: Pauli-Gaussian F = exp(-mu s^2), :336-403)
+struct GgaSel { int x, c, k, kkind; double kmu; };
+constexpr int kPbeScalars = 3;     // energy sums of a GGA pass: exchange, correlation, kinetic
 
 // PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
 // (fp64 division costs ~10x a multiply on gfx950, so every quotient below goes through a shared reciprocal)
-__device__ __forceinline__ PbePoint pbe_point(double n, double gn2, bool do_x, bool do_c) {
-    PbePoint r = {0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ PbePoint pbe_point(double n, double gn2, const GgaSel& sel) {
+    PbePoint r = {0.0, 0.0, 0.0, 0.0, 0.0};
     const double n13 = cbrt(n);
     const double inv_n = 1.0 / n;
+    const bool do_x = sel.x != 0, do_c = sel.c != 0;
+    if (sel.k) {
+        // f = tau_TF F(s^2), tau_TF = C_TF n^(5/3), s^2 = |grad n|^2 / (4 (3 pi^2)^(2/3) n^(8/3))  (functional_tools.py:230-268)
+        const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+        const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+        const double n83i = inv_n * inv_n * inv_n * n13;
+        const double s2 = cs * gn2 * n83i;
+        const double tau = ctf * n13 * n13 * n;
+        double F, dF;                       // F and dF / d(s^2)
+        if (sel.kkind == 0) {
+            const double a = 1.3, s = fmin(sqrt(s2), 100.0);                  // clamp as functionals.py:330
+            const double ch = cosh(a * s);
+            F = 1.0 / ch;
+            dF = (s > 1e-8 && s < 100.0) ? -a * tanh(a * s) * F / (2.0 * s) : (s < 100.0 ? -0.5 * a * a : 0.0);
+        } else {
+            F = exp(-sel.kmu * s2);
+            dF = -sel.kmu * F;
+        }
+        r.fk = tau * F;
+        r.dfdn += (5.0 / 3.0) * tau * inv_n * F + tau * dF * (-(8.0 / 3.0) * s2 * inv_n);
+        r.dfdg += tau * dF * cs * n83i;
+    }
     if (do_x) {
         const double kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
         const double cx = -0.75 * cbrt(3.0 / kPi);
@@ -477,18 +503,19 @@ __device__ __forceinline__ PbePoint pbe_point(double n, double gn2, bool do_x, b
 // PBE mid stage: grad n -> energy partials (x, c), df/dn, flux_j = df/dg * grad_j n (in place)
 __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restrict__ n, double* __restrict__ gx,
                                                           double* __restrict__ gy, double* __restrict__ gz,
-                                                          double* __restrict__ dfdn, long long npts, int do_x,
-                                                          int do_c, double* __restrict__ partial) {
-    double acc[2] = {0.0, 0.0};
+                                                          double* __restrict__ dfdn, long long npts, GgaSel sel,
+                                                          double* __restrict__ partial) {
+    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const double2 d = reinterpret_cast<const double2*>(n)[i];
         const double2 a = reinterpret_cast<double2*>(gx)[i], b = reinterpret_cast<double2*>(gy)[i],
                       c = reinterpret_cast<double2*>(gz)[i];
-        const PbePoint p0 = pbe_point(d.x, a.x * a.x + b.x * b.x + c.x * c.x, do_x != 0, do_c != 0);
-        const PbePoint p1 = pbe_point(d.y, a.y * a.y + b.y * b.y + c.y * c.y, do_x != 0, do_c != 0);
+        const PbePoint p0 = pbe_point(d.x, a.x * a.x + b.x * b.x + c.x * c.x, sel);
+        const PbePoint p1 = pbe_point(d.y, a.y * a.y + b.y * b.y + c.y * c.y, sel);
         acc[0] += p0.fx + p1.fx;
         acc[1] += p0.fc + p1.fc;
+        acc[2] += p0.fk + p1.fk;
         reinterpret_cast<double2*>(dfdn)[i] = make_double2(p0.dfdn, p1.dfdn);
         reinterpret_cast<double2*>(gx)[i] = make_double2(p0.dfdg * a.x, p1.dfdg * a.y);
         reinterpret_cast<double2*>(gy)[i] = make_double2(p0.dfdg * b.x, p1.dfdg * b.y);
@@ -497,15 +524,16 @@ __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restri
     if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long i = npts - 1;
         const double a = gx[i], b = gy[i], c = gz[i];
-        const PbePoint p = pbe_point(n[i], a * a + b * b + c * c, do_x != 0, do_c != 0);
+        const PbePoint p = pbe_point(n[i], a * a + b * b + c * c, sel);
         acc[0] += p.fx;
         acc[1] += p.fc;
+        acc[2] += p.fk;
         dfdn[i] = p.dfdn;
         gx[i] = p.dfdg * a;
         gy[i] = p.dfdg * b;
         gz[i] = p.dfdg * c;
     }
-    block_reduce_store<2>(acc, partial);
+    block_reduce_store<kPbeScalars>(acc, partial);
 }
 
 // ---- final combine: potential + all energy integrands -------------------------------------------
@@ -584,7 +612,7 @@ __device__ __forceinline__ double combine_point(const CombineArgs& a, const Comb
         acc[7] += x.ec;
         v += x.vx + x.vc;
     }
-    if (a.mask & (3u << 10)) v += p.dfdn - 2.0 * p.div;   // PBE  tools_for_tests.py:168-170
+    if (a.mask & (7u << 10)) v += p.dfdn - 2.0 * p.div;   // PBE / GGA kinetic  tools_for_tests.py:168-170
     acc[8] += v * n;
     return v;
 }

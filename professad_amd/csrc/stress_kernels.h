@@ -9,7 +9,7 @@
 namespace ofdft {
 
 constexpr int kStressSpecScalars = 7;
-constexpr int kStressRealScalars = 19;
+constexpr int kStressRealScalars = 27;
 
 __device__ __forceinline__ double half_weight(const SpecGeom& g, int z) {
     return (z == 0 || ((g.n2 & 1) == 0 && z == g.n2 / 2)) ? 1.0 : 2.0;
@@ -171,14 +171,16 @@ __global__ __launch_bounds__(kRedThreads) void stress_ion_kernel(const cplx* __r
 }
 
 // real-space sums: [0] n^(5/3); [1] LDA-x (e - v n); [2] LDA-c (e - v n); PBE-x: [3..8] d_i n d_j n df/dg, [9] |grad n|^2 df/dg,
-// [10] f - n df/dn; PBE-c: [11..16], [17], [18]   (tools_for_tests.py:241-243, 367-472)
+// [10] f - n df/dn; PBE-c: [11..16], [17], [18]; GGA kinetic (Pauli part): [19..24], [25], [26]
+// (tools_for_tests.py:241-243, 367-472; the kinetic GGA has the same form, :46-118)
 __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* __restrict__ n, const double* __restrict__ gx,
                                                                   const double* __restrict__ gy, const double* __restrict__ gz,
-                                                                  long long npts, unsigned mask, double* __restrict__ partial) {
+                                                                  long long npts, unsigned mask, GgaSel sel,
+                                                                  double* __restrict__ partial) {
     double acc[kStressRealScalars];
 #pragma unroll
     for (int i = 0; i < kStressRealScalars; ++i) acc[i] = 0.0;
-    const bool do_px = mask & OFDFT_PBE_X, do_pc = mask & OFDFT_PBE_C;
+    const bool do_px = mask & OFDFT_PBE_X, do_pc = mask & OFDFT_PBE_C, do_pk = mask & OFDFT_GGA_K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
         const double d = n[i];
         if (mask & OFDFT_TF) acc[0] += cbrt(d * d) * d;
@@ -187,13 +189,14 @@ __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* 
             acc[1] += r.ex - r.vx * d;
             acc[2] += r.ec - r.vc * d;
         }
-        if (do_px || do_pc) {
+        if (do_px || do_pc || do_pk) {
             const double a = gx[i], b = gy[i], c = gz[i];
             const double g2 = a * a + b * b + c * c;
-            for (int which = 0; which < 2; ++which) {
-                if (which == 0 ? !do_px : !do_pc) continue;
-                const PbePoint p = pbe_point(d, g2, which == 0, which == 1);
-                double* o = acc + (which == 0 ? 3 : 11);
+            for (int which = 0; which < 3; ++which) {
+                if (which == 0 ? !do_px : (which == 1 ? !do_pc : !do_pk)) continue;
+                const GgaSel one{which == 0, which == 1, which == 2, sel.kkind, sel.kmu};
+                const PbePoint p = pbe_point(d, g2, one);
+                double* o = acc + 3 + 8 * which;
                 o[0] += a * a * p.dfdg;
                 o[1] += b * b * p.dfdg;
                 o[2] += c * c * p.dfdg;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* 
                 o[4] += a * c * p.dfdg;
                 o[5] += b * c * p.dfdg;
                 o[6] += g2 * p.dfdg;
-                o[7] += (which == 0 ? p.fx : p.fc) - d * p.dfdn;
+                o[7] += (which == 0 ? p.fx : (which == 1 ? p.fc : p.fk)) - d * p.dfdn;
             }
         }
     }

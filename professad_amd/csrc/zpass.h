@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void zf_powers_kernel(DenSrc ds, PowersArgs
 template <int M, int E>
 __global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                                    cplx* __restrict__ gz, double* __restrict__ dfdn, double inv_n,
-                                                   int do_x, int do_c, SpecGeom g, const cplx* __restrict__ twM,
+                                                   GgaSel sel, SpecGeom g, const cplx* __restrict__ twM,
                                                    const cplx* __restrict__ twN, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const ZLane<M, E> z(g, lds);
@@ -276,20 +276,21 @@ __global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restric
     z_load_inverse<M, E>(b, z, gy, g, twM, twN);
     z_load_inverse<M, E>(c, z, gz, g, twM, twN);
     z_load_real<M, E>(n, z, ds.src);
-    double acc[2] = {0.0, 0.0};
+    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         const double ax = a[q].x * inv_n, bx = b[q].x * inv_n, cx = c[q].x * inv_n;
         const double ay = a[q].y * inv_n, by = b[q].y * inv_n, cy = c[q].y * inv_n;
-        PbePoint p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+        PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
         if (z.valid) {
-            p0 = pbe_point(ds(n[q].x), ax * ax + bx * bx + cx * cx, do_x != 0, do_c != 0);
-            p1 = pbe_point(ds(n[q].y), ay * ay + by * by + cy * cy, do_x != 0, do_c != 0);
+            p0 = pbe_point(ds(n[q].x), ax * ax + bx * bx + cx * cx, sel);
+            p1 = pbe_point(ds(n[q].y), ay * ay + by * by + cy * cy, sel);
         }
         acc[0] += p0.fx + p1.fx;
         acc[1] += p0.fc + p1.fc;
+        acc[2] += p0.fk + p1.fk;
         d[q] = make_double2(p0.dfdn, p1.dfdn);
         a[q] = make_double2(p0.dfdg * ax, p1.dfdg * ay);
         b[q] = make_double2(p0.dfdg * bx, p1.dfdg * by);
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restric
     z_forward_store<M, E>(a, z, gx, g, twM, twN);
     z_forward_store<M, E>(b, z, gy, g, twM, twN);
     z_forward_store<M, E>(c, z, gz, g, twM, twN);
-    block_reduce_store<2>(acc, partial + (long long)g.blk0 * 2);
+    block_reduce_store<kPbeScalars>(acc, partial + (long long)g.blk0 * kPbeScalars);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
             }
         }
     }
-    if (a.mask & (3u << 10)) {                           // PBE: v += df/dn - 2 div  (tools_for_tests.py:168-170)
+    if (a.mask & (7u << 10)) {                           // PBE / GGA kinetic: v += df/dn - 2 div  (tools_for_tests.py:168-170)
         z_load_inverse<M, E>(w, z, a.div, g, twM, twN);
         cplx d[E];
         z_load_real<M, E>(d, z, a.dfdn);

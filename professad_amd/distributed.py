@@ -24,7 +24,8 @@ import torch.distributed as dist
 from . import _native as N
 from .engine import Engine
 
-NSUMS = 11   # 9 combine scalars + PBE exchange, correlation
+NSUMS = 12   # 9 combine scalars + GGA sums (PBE exchange, correlation, kinetic GGA)
+SUMSQ_SLOT = 15   # slot of sum chi^2 in the context's device-resident scalar block (16 doubles)
 
 
 class SlabPlan:
@@ -126,12 +127,12 @@ class HipStages(Engine):
         super().__init__(shape, device, nranks=nranks, rank=rank)
         p = C.c_void_p(0)
         self._check(self.lib.ofdft_dist_scalars(self._ctx, C.byref(p)), 'ofdft_dist_scalars')
-        # 12 device-resident doubles owned by the context: [0..10] local sums of an evaluation, [11] sum chi^2
-        self.device_scalars = torch.as_tensor(_RawDeviceBuffer(p.value, 12, '<f8'), device=self.device)
+        # 16 device-resident doubles owned by the context: [0..11] local sums of an evaluation, [15] sum chi^2
+        self.device_scalars = torch.as_tensor(_RawDeviceBuffer(p.value, 16, '<f8'), device=self.device)
         self._xbuf = {}
 
     def sumsq(self, x, square=True, on_device=False):
-        """local sum of x^2 (or x): returned as a float, or left in device_scalars[11] without a host sync"""
+        """local sum of x^2 (or x): returned as a float, or left in device_scalars[15] without a host sync"""
         x = self._grid_tensor(x, 'x')
         out = C.c_double(0.0)
         self._check(self.lib.ofdft_dist_sumsq(self._ctx, C.c_void_p(x.data_ptr()), 1 if square else 0,
@@ -140,7 +141,7 @@ class HipStages(Engine):
 
     def begin(self, src, from_chi, cscale, nel, vext, v_out):
         """from_chi: False = src is the density, True = chi with the host scale `cscale`, 2 = chi with the scale formed
-        on the device from the all-reduced device_scalars[11]"""
+        on the device from the all-reduced device_scalars[15]"""
         self._keep = (src, vext, v_out)          # keep the tensors alive for the duration of the evaluation
         self._check(self.lib.ofdft_dist_begin(self._ctx, C.c_void_p(src.data_ptr()), int(from_chi), float(cscale),
                                               float(nel), C.c_void_p(vext.data_ptr() if vext is not None else 0),
@@ -163,7 +164,7 @@ class HipStages(Engine):
         return ex
 
     def finish(self, on_device=False):
-        """the 11 local sums: as a numpy vector, or left in device_scalars[0:11] without a host sync"""
+        """the 11 local sums: as a numpy vector, or left in device_scalars[0:12] without a host sync"""
         if on_device:
             self._check(self.lib.ofdft_dist_finish(self._ctx, None, self._stream()), 'ofdft_dist_finish')
             return None
@@ -234,7 +235,7 @@ def run_closure(stages, comm, chi, n_elec, vext, vol, npts_global, new_like):
         # device-resident scalars: sum chi^2 and the closure scale never visit the host; the only host
         # synchronisation of the evaluation is the copy of the 11 all-reduced sums
         stages.sumsq(chi, True, on_device=True)
-        comm.all_reduce_dev(sc[11:12])
+        comm.all_reduce_dev(sc[SUMSQ_SLOT:SUMSQ_SLOT + 1])
         v = new_like(chi)
         stages.begin(chi, 2, 0.0, n_elec, vext, v)
         _run_exchanges(stages, comm)

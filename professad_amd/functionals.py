@@ -82,7 +82,7 @@ class NativeTerms:
     ALIASES = {
         'wt': ('tf', 'vw', 'wt_nl'), 'wgc99': ('tf', 'vw', 'wgc99_nl'),
         'pz': ('lda_x', 'pz_c'), 'pw': ('lda_x', 'pw_c'), 'chachiyo': ('lda_x', 'chachiyo_c'),
-        'pbe': ('pbe_x', 'pbe_c'),
+        'pbe': ('pbe_x', 'pbe_c'), 'lkt': ('vw', 'gga_k'),
     }
 
     def __init__(self, names, **params):
@@ -237,3 +237,38 @@ def get_functional_derivative(box_vecs, den, functional):
     E = functional(box_vecs, den)
     (g,) = torch.autograd.grad(E, den)
     return g / (torch.abs(torch.linalg.det(box_vecs)) / den.numel())
+
+
+def LuoKarasievTrickey(box_vecs, den):
+    """functionals.py:309-333 (vW + int tau_TF / cosh(1.3 s))"""
+    return _evaluate(box_vecs, den, ('vw', 'gga_k'), (('ggak_kind', 0.0),))
+
+
+class PauliGaussian:
+    """functionals.py:336-403 for the members without the Laplacian-dependent terms (beta = lambda = sigma = 0:
+    PG1, PGS, any mu): vW + int tau_TF exp(-mu s^2).  The reference's DEFAULT parameters are PGSL0.25 (beta = 0.25),
+    whose q^2 term needs the reduced Laplacian: that member is not implemented natively and raises."""
+
+    def __init__(self, init_args=None):
+        self.mu, self.beta, self.lamb, self.sigma = (40 / 27, 0.25, 0.0, 0.0) if init_args is None else init_args
+        self.__name__ = self.__qualname__ = 'PauliGaussian'
+
+    def set_PG1(self):
+        self.mu, self.beta, self.lamb, self.sigma = 1.0, 0.0, 0.0, 0.0
+
+    def set_PGS(self):
+        self.mu, self.beta, self.lamb, self.sigma = 40 / 27, 0.0, 0.0, 0.0
+
+    def set_PGSL025(self):
+        self.mu, self.beta, self.lamb, self.sigma = 40 / 27, 0.25, 0.0, 0.0
+
+    def set_PGSLr(self):
+        self.mu, self.beta, self.lamb, self.sigma = 40 / 27, 0.25, 0.4, 0.2
+
+    def forward(self, box_vecs, den):
+        if self.beta or self.lamb or self.sigma:
+            raise NotImplementedError('native PauliGaussian covers beta = lambda = sigma = 0 (PG1, PGS); the Laplacian-'
+                                      'dependent members (PGSL0.25, PGSLr) need the reference torch term')
+        return _evaluate(box_vecs, den, ('vw', 'gga_k'), (('ggak_kind', 1.0), ('ggak_mu', abs(float(self.mu)))))
+
+    __call__ = forward

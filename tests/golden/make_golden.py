@@ -86,6 +86,9 @@ def reference_terms(vext_t):
         'chachiyo_c': F.chachiyo_correlation,
         'pbe_x': F.pbe_exchange,
         'pbe_c': F.pbe_correlation,
+        'lkt': F.LuoKarasievTrickey,
+        'pg1': F.PauliGaussian(init_args=(1.0, 0.0, 0.0, 0.0)),
+        'pgs': F.PauliGaussian(init_args=(40 / 27, 0.0, 0.0, 0.0)),
     }, wgc99
 
 
@@ -314,7 +317,7 @@ if '--ions' in sys.argv:
     gen_ions()
 
 
-STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99']
+STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99', 'lkt', 'pgs']
 
 
 def gen_stress():

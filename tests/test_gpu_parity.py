@@ -67,6 +67,7 @@ _REF_NAME = {
     'wgc99': F.WangGovindCarter99(), 'lda_x': F.lda_exchange, 'pz_c': F.perdew_zunger_correlation,
     'pw_c': F.perdew_wang_correlation, 'chachiyo_c': F.chachiyo_correlation,
     'pbe_x': F.pbe_exchange, 'pbe_c': F.pbe_correlation,
+    'lkt': F.LuoKarasievTrickey, 'pg1': F.PauliGaussian((1.0, 0.0, 0.0, 0.0)), 'pgs': F.PauliGaussian((40 / 27, 0.0, 0.0, 0.0)),
 }
 
 
@@ -420,7 +421,7 @@ def test_lbfgs_sweeps_match_numpy_double(n):
 
 _STRESS_BITS = {'hartree': ['hartree'], 'tf': ['tf'], 'vw': ['vw'], 'wt_nl': ['wt_nl'], 'lda_x': ['lda_x'], 'pz_c': ['pz_c'],
                 'pw_c': ['pw_c'], 'chachiyo_c': ['chachiyo_c'], 'pbe_x': ['pbe_x'], 'pbe_c': ['pbe_c'],
-                'wgc99': ['tf', 'vw', 'wgc99_nl']}
+                'wgc99': ['tf', 'vw', 'wgc99_nl'], 'lkt': ['vw', 'gga_k']}
 
 
 @pytest.mark.parametrize('case', ['g16r', 'gmix', 'g18t'])
@@ -430,8 +431,8 @@ def test_stress_matches_reference_get_stress(case):
     g = load('stress.npz')
     box, den, vext, chi, n_elec = cases.make_inputs(case)
     eng = Engine(den.shape, DEV).set_cell(dev(box))
-    for name, bits in _STRESS_BITS.items():
-        sig = eng.set_terms(bits).stress(dev(den))
+    for name, bits in list(_STRESS_BITS.items()) + [('pgs', ['vw', 'gga_k'])]:
+        sig = eng.set_terms(bits, {'ggak_kind': 1.0 if name == 'pgs' else 0.0}).stress(dev(den))
         tot = sum(sig[b] for b in bits)
         ref = g['%s_%s' % (case, name)]
         assert np.abs(tot - ref).max() <= 2e-10 * np.abs(ref).max(), (case, name, np.abs(tot - ref).max() / np.abs(ref).max())
@@ -507,3 +508,21 @@ def test_ion_ion_known_answers_forces_and_stress():
     assert abs(Ed - ii.energy(box, frac @ box, np.array([1.0, 1.0]), Rc, Rd)) < 1e-11
     assert np.abs(Fd - Fo).max() < 1e-11 and np.abs(Sd - So).max() < 1e-12
     eng.close()
+
+
+def test_pauli_gaussian_members_and_all_pipelines_for_gga_kinetic():
+    """the kinetic GGA through every engine pipeline, together with PBE (shared gradient / divergence); the Laplacian-
+    dependent Pauli-Gaussian members are refused"""
+    gold = load('terms_g16r.npz')
+    box, den, vext, chi, n_elec = cases.make_inputs('g16r')
+    eng = Engine(den.shape, DEV).set_cell(dev(box)).set_terms(['vw', 'gga_k', 'pbe_x', 'pbe_c'], {'ggak_kind': 0.0})
+    Eref = float(gold['E_lkt']) + float(gold['E_pbe_x']) + float(gold['E_pbe_c'])
+    vref = gold['v_lkt'] + gold['v_pbe_x'] + gold['v_pbe_c']
+    for mode in (0, 1, 2):
+        eng.set_option(0, mode)
+        E, v = eng.energy_potential(dev(den))
+        assert abs(sum(E.values()) - Eref) <= E_RTOL * abs(Eref), mode
+        assert relerr(v.cpu().numpy(), vref) < V_RTOL, mode
+    eng.close()
+    with pytest.raises(NotImplementedError):
+        F.PauliGaussian()(dev(box), dev(den))                     # default = PGSL0.25 (needs the reduced Laplacian)
