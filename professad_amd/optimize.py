@@ -308,10 +308,30 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     """Minimise E[n = N_e chi^2 / int chi^2] with the engine's terms.  Returns a dict with the converged density,
     chi, energy [Ha], iteration count and the convergence history.
 
-    engine: an `Engine` (cell and terms already set); `volume` = cell volume (needed when chi0 is None to start from
-    the uniform density, as System.optimize_density does after System.__init__).  `optimizer`: 'fused' (HIP sweeps,
-    `VectorFreeLBFGS`) or 'torch' (`FixedStepLBFGS` on torch tensors)."""
-    shape, dev = engine.shape, engine.device
+    engine: an `Engine` (cell and terms already set) or a `DistEngine` (slab-decomposed: chi / vext / the results are
+    this rank's x-slabs and every rank runs this function; the optimiser's scalars are all-reduced, so all ranks take
+    identical decisions); `volume` = cell volume (needed when chi0 is None to start from the uniform density, as
+    System.optimize_density does after System.__init__).  `optimizer`: 'fused' (HIP sweeps, `VectorFreeLBFGS`) or
+    'torch' (`FixedStepLBFGS` on torch tensors; single GPU only)."""
+    comm = getattr(engine, 'comm', None)                    # DistEngine
+    multi = comm is not None and comm.active
+    if comm is not None:
+        shape, dev = engine.plan.local_shape, engine.stages.device
+        npts_global = engine.npts_global
+    else:
+        shape, dev = engine.shape, engine.device
+        npts_global = int(np.prod(shape))
+
+    def gsum(x):                                            # sum over ranks of a python float
+        return float(comm.all_reduce_sum(np.array([x]), dev)[0]) if multi else x
+
+    def gmax(x):
+        if not multi:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.double, device=dev if comm.backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=comm.group)
+        return float(t[0])
     if chi0 is None:
         if volume is None:
             raise ValueError('volume is needed for the uniform start')
@@ -326,8 +346,10 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         return state['E'], g
 
     if optimizer == 'fused':        # device-resident history, two sweeps per inner iteration
-        opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev), lr=n_step_size, history_size=8, max_iter=6)
-    elif optimizer == 'torch':      # op-by-op form on torch tensors
+        hook = (lambda v: comm.all_reduce_sum(np.ascontiguousarray(v, dtype=np.float64), dev)) if multi else None
+        opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev), lr=n_step_size, history_size=8, max_iter=6,
+                              all_reduce=hook)
+    elif optimizer == 'torch' and not multi:      # op-by-op form on torch tensors
         opt = FixedStepLBFGS(chi, lr=n_step_size, history_size=8, max_iter=6)
     else:
         raise ValueError("optimizer must be 'fused' or 'torch'")
@@ -341,8 +363,8 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         dE = E - E_prev
         E_prev = E
         if dV is None and volume is not None:
-            dV = volume / chi.numel()
-        dEdchi = float(state['g'].abs().max()) / dV if dV else float('nan')
+            dV = volume / npts_global
+        dEdchi = gmax(float(state['g'].abs().max())) / dV if dV else float('nan')
         history.append((it, E, dE, dEdchi))
         if verbose:
             print('%5d %16.8f %12.4e %12.4e' % history[-1])
@@ -352,7 +374,7 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         if conv == n_conv_cond_count:
             break
     E_terms, mu, g = engine.energy_grad_chi(chi, n_elec, vext)
-    ntilde = float((chi * chi).mean()) * (volume if volume is not None else 1.0)
+    ntilde = gsum(float((chi * chi).sum())) / npts_global * (volume if volume is not None else 1.0)
     den = (n_elec / ntilde) * chi * chi if volume is not None else None
     return dict(chi=chi, den=den, E_Ha=sum(E_terms.values()), E_terms=E_terms, mu=mu, iterations=it,
                 converged=conv == n_conv_cond_count, history=history, func_evals=opt.func_evals)
