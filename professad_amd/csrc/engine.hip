@@ -959,632 +959,7 @@ int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_ter
 }
 
 
-// ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
-#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
-constexpr int EZ = 4;   // points per lane wanted by the register-hungry fused z kernels
-
-int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
-    if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;
-    return get_twiddle(c, c->n2, twN);
-}
-template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nrows + ZW<M, E>::RPB - 1) / ZW<M, E>::RPB); }
-
-// The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
-// [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
-int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
-                      int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
-    SpecGeom gz = c->g;
-#define X(M_)                                                                                                       \
-    case M_: {                                                                                                      \
-        const int nb = z_blocks<M_, 8>(c) / nchunks;                                                                \
-        gz.blk0 = chunk * nb;                                                                                       \
-        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(nb), dim3(256), (ZW<M_, 8>::LDS), ds,    \
-                     out_n, out_s, gz, twM, twN);                                                                   \
-        return 0;                                                                                                   \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0)
-        for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
-    SpecGeom gz = c->g;
-#define X(M_)                                                                                                      \
-    case M_: {                                                                                                     \
-        const int nb = z_blocks<M_, ZPick<M_, EZ>::E>(c) / nchunks;                                                \
-        gz.blk0 = chunk * nb;                                                                                      \
-        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),           \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, gz, twM, twN);                                       \
-        return 0;                                                                                                  \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n,
-                int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0) c->fft_count += 6;    // three c2r finished + three r2c started on chip
-    SpecGeom gq = c->g;
-#define X(M_)                                                                                                   \
-    case M_: {                                                                                                  \
-        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
-        const int nb = *blocks_out / nchunks;                                                                   \
-        gq.blk0 = chunk * nb;                                                                                   \
-        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),                   \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, gga_sel(c), gq, twM, twN,   \
-                     c->d_partial);                                                                             \
-        return 0;                                                                                               \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    SpecGeom gq = c->g;
-    const size_t park = sizeof(double) * 256 * kCombineScalars;
-#define X(M_)                                                                                                     \
-    case M_: {                                                                                                    \
-        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
-        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
-        const int nb = *blocks_out / nchunks;                                                                     \
-        gq.blk0 = chunk * nb;                                                                                     \
-        if (a.v_part)                                                                                             \
-            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, false>), dim3(nb), dim3(256),          \
-                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
-        else                                                                                                      \
-            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, true>), dim3(nb), dim3(256),           \
-                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
-        return 0;                                                                                                 \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-// split form: the WGC99 part of the combine on the nonlocal chain's stream -> v_part rows + one energy partial per block
-int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, double* v_part, double* partial, int* blocks_out, hipStream_t st) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-#define X(M_)                                                                                                     \
-    case M_: {                                                                                                    \
-        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
-        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
-        OFDFT_LAUNCH(c, st, "zi_wgc", (zi_wgc_kernel<M_, W::E>), dim3(*blocks_out), dim3(256), (W::LDS), a, v_part, \
-                     c->g, twM, twN, partial);                                                                    \
-        return 0;                                                                                                 \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pbe_sums, double* E_terms, double* vn_int) {
-    const unsigned mask = c->mask;
-    const double dV = c->dV;
-    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
-    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
-    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
-    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
-    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
-    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
-    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
-    int nc = 0;
-    for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
-    for (int b = 7; b <= 9; ++b)
-        if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
-    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
-    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
-    if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
-    *vn_int = sums[8] * dV;
-}
-
-// Pipeline with every real-space intermediate kept on chip: z kernels compute their inputs from chi|n on the
-// fly and consume the convolution results straight out of the inverse transform.  It is written as five
-// stages separated by the four points where the spectra change between the x-slab geometry (z, y passes) and
-// the x-pass geometry: on one GPU the two coincide and the stages simply run back to back; on several GPUs
-// each boundary is one all-to-all over the listed arrays (the host does the collective, see ofdft_dist_*).
-//   stage 1  z-forward (+pointwise pre-ops) and y-forward of every input spectrum          -> exchange
-//   stage 2  fused x passes (Hartree, gradient, Laplacian, Lindhard / WGC99 mixing)         -> exchange
-//   stage 3  y-inverse of the results; PBE mid stage on chip; y-forward of the flux          -> exchange
-//   stage 4  fused x pass of the divergence                                                  -> exchange
-//   stage 5  y-inverse of the divergence; combine kernel (potential + energy integrands)
-struct ZRun {
-    DenSrc ds{};
-    double nel = 0.0;
-    const double* vext = nullptr;
-    double* v_out = nullptr;
-    ZCombineArgs za{};
-    double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
-    bool has_h = false, has_g = false, has_vw = false, has_wt = false, has_wgc = false;
-    cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
-    cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double* dfdn = nullptr;
-    double wt_pref = 0.0, wt_kf = 1.0;
-    // The evaluation is two independent chains that meet only in the combine kernel:
-    //   chain 0: density spectrum -> Hartree, grad n -> PBE -> divergence;  sqrt(n) -> Laplacian (vW)
-    //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
-    // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
-    std::vector<cplx*> xlist[2];
-    bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
-    std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
-    int stage[2] = {0, 0};
-    int combine_blocks = 0, pbe_blocks = 0;
-    hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
-    hipStream_t sc = nullptr;      // second side stream: vW chain and the second half of the WGC99 chain
-    bool forked = false;
-};
-
-}  // namespace
-struct ofdft_zrun_holder { ZRun r; };
-namespace {
-
-ZRun& zrun(ofdft_ctx* c);
-
-// ---- all-to-all buffers of the slab-decomposed path, one pair per chain (both directions reuse the pair):
-// chain 0 carries at most 5 spectra (Hartree, grad n, vW leaving stage 2), chain 1 at most 8 (2 Wang-Teter + 6 WGC99)
-// x chunks for a loop whose working set is `narr` spectra: the option value is the count for six spectra; more
-// spectra -> proportionally more chunks, so that a chunk's working set stays the same share of the Infinity Cache.
-// Every chunk must be whole workgroups of every z kernel (at most 256 rows each) -> powers of two that divide n0.
-int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
-    if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which)) return 1;
-    // automatic: about 100 MB of spectra per chunk (measured best at 256^3: 8 chunks for the six WGC99 spectra)
-    int want = c->xchunks > 1 ? (c->xchunks * narr + 5) / 6
-                              : (int)std::min<double>(64.0, (double)narr * sizeof(cplx) * (double)c->g.total / 100e6);
-    int n = 1;
-    while (n * 2 <= want && c->n0 % (n * 2) == 0 && ((long long)(c->n0 / (n * 2)) * c->n1) % 256 == 0) n *= 2;
-    return n;
-}
-
-int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * (chain == 0 ? 5 : 8);
-    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
-    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
-}
-
-// Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.
-int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
-    ZRun& r = zrun(c);
-    const unsigned mask = c->mask;
-    int rc;
-    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
-    const bool dx = c->nranks > 1;
-    std::vector<cplx*>& xl = r.xlist[chain];
-    xl.clear();
-    if (chain == 0) {
-        r.has_h = mask & OFDFT_HARTREE;
-        r.has_g = mask & kGgaAny;
-        r.has_vw = mask & OFDFT_VW;
-        r.has_wt = mask & OFDFT_WT_NL;
-        r.has_wgc = mask & OFDFT_WGC99_NL;
-        r.za = ZCombineArgs{};
-        r.za.ds = r.ds;
-        r.za.vext = r.vext;
-        r.za.v_out = r.v_out;
-        r.za.mask = mask;
-        r.za.inv_n = 1.0 / (double)c->npts_g;
-        r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
-        r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
-        if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
-        if (r.has_h || r.has_g)
-            if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
-        if (r.has_vw)
-            if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
-        if (r.s_n || r.s_s) {
-            cplx* both[2];
-            int nb = 0;
-            if (r.s_n) both[nb++] = r.s_n;
-            if (r.s_s) both[nb++] = r.s_s;
-            const int nch = chunks_for(c, nb, 1);
-            if (nch > 1) {        // x-chunked: a chunk's spectra are y-transformed while still in the Infinity Cache
-                for (int ch = 0; ch < nch; ++ch) {
-                    if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st, ch, nch))) return rc;
-                    if ((rc = fast_axis_pass_multi<false>(c, 1, both, nb, st, ch * (c->n0 / nch), c->n0 / nch))) return rc;
-                }
-            } else if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) {
-                return rc;
-            }
-            if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
-                HIP_TRY(c, hipEventRecord(c->ev_a, st));
-                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
-            }
-            if (!dx && nch == 1 && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
-            if (!dx && nch == 1 && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
-            if (r.s_n) xl.push_back(r.s_n);
-            if (r.s_s) xl.push_back(r.s_s);
-        }
-    } else {
-        if (r.has_wt) {
-            const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-            const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
-            r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
-            r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-            if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
-            if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
-            PowersArgs pa{};
-            pa.out[0] = r.s_b;
-            pa.out[3] = r.s_a;
-            pa.e0 = be;
-            pa.e1 = al;
-            if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
-            for (cplx* sp : {r.s_b, r.s_a}) {
-                if (!sp) continue;
-                if (!dx && (rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
-                xl.push_back(sp);
-            }
-            r.za.wt_alpha = al;
-            r.za.wt_beta = be;
-            r.za.wt_nbar_pa = std::pow(nbar, al);
-            r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
-        }
-        if (r.has_wgc) {
-            const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
-            const long long nel_r = std::llround(r.nel);                         // functionals.py:952
-            double nref;
-            if ((rc = ensure_wgc_tables(c, nel_r, sb, &nref))) return rc;
-            const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
-            PowersArgs pa{};
-            for (int i = 0; i < 6; ++i) {
-                if ((rc = spec_ws(c, wn[i], &r.sw[i]))) return rc;
-                pa.out[i] = r.sw[i];
-            }
-            pa.e0 = be;
-            pa.e1 = al;
-            pa.nref = nref;
-            pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
-            // x-chunked form: each chunk's six spectra (6 x C / nchunks) are y-transformed while still in the Infinity Cache
-            const int nch = chunks_for(c, 6, 2);
-            if (nch > 1) {
-                for (int ch = 0; ch < nch; ++ch) {
-                    if ((rc = launch_zf_powers(c, r.ds, pa, sb, ch, nch))) return rc;
-                    if ((rc = fast_axis_pass_multi<false>(c, 1, r.sw, 6, sb, ch * (c->n0 / nch), c->n0 / nch))) return rc;
-                }
-            } else if ((rc = launch_zf_powers(c, r.ds, pa, sb))) {
-                return rc;
-            }
-            if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
-                HIP_TRY(c, hipEventRecord(c->ev_b, sb));
-                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
-            }
-            for (int i = 0; i < 6; ++i) {
-                if (!dx && nch == 1 && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
-                xl.push_back(r.sw[i]);
-            }
-            r.za.wgc_alpha = al;
-            r.za.wgc_beta = be;
-            r.za.nref = nref;
-            r.za.wgc_sum_53 = pa.sum53;
-        }
-    }
-    if (dx && !xl.empty()) {        // the chain's y-forwards in one launch, written in the exchange layout
-        cplx *send, *recv;
-        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
-    }
-    r.stage[chain] = 1;
-    return 0;
-}
-
-// Stage 2: the fused x passes (forward x, k-space mixing, inverse x).
-int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
-    ZRun& r = zrun(c);
-    int rc;
-    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
-    // several ranks: the inputs sit in the chain's receive buffer (slot = position in stage 1's list) and the
-    // outputs are written to its send buffer in the order they are listed here
-    const bool dx = c->nranks > 1;
-    std::vector<cplx*>& xl = r.xlist[chain];
-    const std::vector<cplx*> in_list = xl;
-    xl.clear();
-    cplx *send = nullptr, *recv = nullptr;
-    XfLayout lay{};
-    if (dx) {
-        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0)
-                                    : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
-        lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
-    }
-    auto in_of = [&](cplx* arr) -> cplx* {
-        if (!dx) return arr;
-        for (size_t i = 0; i < in_list.size(); ++i)
-            if (in_list[i] == arr) return recv + (long long)i * c->xg.arr_sz;
-        return nullptr;
-    };
-    auto out_of = [&](cplx* arr) -> cplx* {       // also records the array as crossing the next boundary
-        xl.push_back(arr);
-        return dx ? send + (long long)(xl.size() - 1) * c->xg.arr_sz : arr;
-    };
-    if (chain == 0) {
-        if (r.s_n) {
-            XfIo io{};
-            io.in[0] = in_of(r.s_n);
-            int no = 0;
-            if (r.has_h) {
-                if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
-                io.out[no++] = out_of(r.s_vh);
-            }
-            if (r.has_g) {
-                const char* gn[3] = {"zgx", "zgy", "zgz"};
-                for (int k = 0; k < 3; ++k) {
-                    if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
-                    io.out[no++] = out_of(r.s_g[k]);
-                }
-            }
-            if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
-            else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
-            else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
-            if (rc) return rc;
-        }
-        if (r.s_s) {
-            XfIo io{};
-            io.in[0] = in_of(r.s_s);
-            io.out[0] = out_of(r.s_s);
-            if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap", lay))) return rc;
-        }
-    } else {
-        if (r.has_wt) {
-            const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
-            for (cplx* sp : {r.s_b, r.s_a}) {
-                if (!sp) continue;
-                XfIo io{};
-                io.in[0] = in_of(sp);
-                io.out[0] = out_of(sp);
-                if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind", lay))) return rc;
-            }
-        }
-        if (r.has_wgc) {
-            const MixWgc mix{(double*)c->ws["t:wgc"].p};
-            for (int half = 0; half < 2; ++half) {
-                XfIo io{};
-                for (int i = 0; i < 3; ++i) {
-                    io.in[i] = in_of(r.sw[3 * half + i]);
-                    io.out[i] = out_of(r.sw[3 * half + i]);
-                }
-                if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
-            }
-        }
-    }
-    r.stage[chain] = 2;
-    return 0;
-}
-
-// Stage 3: y-inverse of what came back from the x passes (each completes one c2r except grad n); chain 0 then runs
-// the PBE mid stage on chip and starts the three r2c of the flux.
-int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
-    ZRun& r = zrun(c);
-    int rc;
-    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
-    const bool dx = c->nranks > 1;
-    std::vector<cplx*>& xl = r.xlist[chain];
-    cplx *send = nullptr, *recv = nullptr;
-    if (dx && !xl.empty()) {        // one launch: the chain's y-inverses, read from the exchange layout
-        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<true>(c, xl, recv, st))) return rc;
-    }
-    // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
-    // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
-    const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = chunks_for(c, 6, 4) > 1;
-    for (cplx* sp : xl) {
-        const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
-        const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
-        const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2];
-        if (is_g ? pbe_chunked : chunked) {
-            if (!is_g) r.deferred.push_back(sp);
-        } else if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) {
-            return rc;
-        }
-        if (!is_g) c->fft_count++;
-    }
-    xl.clear();
-    if (chain == 1) {
-        if (r.has_wt) {
-            r.za.conv_b = r.s_b;
-            r.za.conv_a = r.s_a;
-        }
-        if (r.has_wgc)
-            for (int i = 0; i < 3; ++i) {
-                r.za.u[i] = r.sw[i];
-                r.za.gw[i] = r.sw[3 + i];
-            }
-        r.wgc_split = false;
-        if (r.has_wgc && !chunked && c->split_combine) {
-            // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
-            double *vp, *part2;
-            int blocks = 0;
-            if ((rc = real_ws(c, "vpart", &vp))) return rc;
-            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
-            if (r.forked) {
-                HIP_TRY(c, hipEventRecord(c->ev_b, sc));
-                HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
-            }
-            if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
-            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const double*)part2, blocks, 1,
-                         c->d_scal + 2);
-            r.za.v_part = vp;
-            r.wgc_split = true;
-        }
-        r.stage[1] = 3;
-        return 0;
-    }
-    if (r.has_h) r.za.vh = r.s_vh;
-    if (r.s_s) r.za.lap = r.s_s;
-    if (r.has_g) {
-        if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
-        const int nch = chunks_for(c, 6, 4);       // 3 spectra in, 3 out, the density and df/dn rows
-        for (int ch = 0; ch < nch; ++ch) {
-            const int x0 = ch * (c->n0 / nch), cx = c->n0 / nch;
-            if (pbe_chunked && (rc = fast_axis_pass_multi<true>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
-            if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, &r.pbe_blocks, st, ch, nch)))
-                return rc;
-            if (pbe_chunked && (rc = fast_axis_pass_multi<false>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
-        }
-        // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
-                     kPbeScalars, c->d_reduced + kCombineScalars);
-        for (int k = 0; k < 3; ++k) {
-            if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
-            xl.push_back(r.s_g[k]);
-        }
-        if (dx) {
-            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
-        }
-    }
-    r.stage[0] = 3;
-    return 0;
-}
-
-// Stage 4: fused x pass of the divergence (chain 0 only).
-int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
-    ZRun& r = zrun(c);
-    r.xlist[chain].clear();
-    if (chain == 0 && r.has_g) {
-        XfIo dio{};
-        XfLayout lay{};
-        for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
-        dio.out[0] = r.s_n;      // n^ is no longer needed
-        if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0
-            cplx *send, *recv;
-            if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
-            for (int k = 0; k < 3; ++k) dio.in[k] = recv + k * c->xg.arr_sz;
-            dio.out[0] = send;
-            lay = XfLayout{3 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
-        }
-        if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div", lay)) return rc;
-        r.xlist[0].push_back(r.s_n);
-    }
-    r.stage[chain] = 4;
-    return 0;
-}
-
-// local sums: sums[0..8] combine scalars, sums[9..10] PBE x / c
-int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
-    ZRun& r = zrun(c);
-    int rc;
-    const bool chunked = chunks_for(c, 6, 8) > 1;
-    if (r.has_g) {
-        if (c->nranks > 1) {
-            cplx *send, *recv;
-            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
-        } else if (chunked) {
-            r.deferred.push_back(r.s_n);
-        } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
-            return rc;
-        }
-        c->fft_count++;
-        r.za.div = r.s_n;
-        r.za.dfdn = r.dfdn;
-    }
-    r.xlist[0].clear();
-    r.xlist[1].clear();
-    if (r.forked) {       // the combine needs both chains
-        HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
-    }
-    if (chunked) {        // y-inverse of a chunk of every result spectrum, then the combine kernel on the same x planes
-        const int narr = (int)r.deferred.size();
-        const int nch = chunks_for(c, narr + 2, 8);       // + the real rows (chi, v_ext, df/dn, v) the kernel touches
-        for (int ch = 0; ch < nch; ++ch) {
-            if (narr && (rc = fast_axis_pass_multi<true>(c, 1, r.deferred.data(), narr, st, ch * (c->n0 / nch), c->n0 / nch)))
-                return rc;
-            if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st, ch, nch))) return rc;
-        }
-        r.deferred.clear();
-    } else if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) {
-        return rc;
-    }
-    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
-                 r.combine_blocks, kCombineScalars, c->d_reduced);
-    if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
-    r.stage[0] = r.stage[1] = 5;
-    if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
-        if (r.wgc_split)          // fold in the energy sum of the split WGC99 kernel
-            OFDFT_LAUNCH(c, st, "reduce", axpy_kernel, dim3(1), dim3(64), 0, (const double*)(c->d_scal + 2), c->d_reduced + 5,
-                         (long long)1, 1);
-        return 0;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
-    if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
-        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kNSums, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
-    if (r.wgc_split) sums[5] += c->h_partial[kNSums];
-    return 0;
-}
-
-int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
-                     double* vn_int, hipStream_t st) {
-    ZRun& r = zrun(c);
-    r.ds = ds;
-    r.nel = nel;
-    r.vext = vext;
-    r.v_out = v_out;
-    r.deferred.clear();
-    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
-    int rc;
-    // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
-    // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.
-    r.forked = c->use_side_stream && c->side_stream && c->side_stream2 && (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) &&
-               (c->mask & (OFDFT_HARTREE | OFDFT_VW | kGgaAny));
-    if (r.forked) {
-        r.sb = c->side_stream;
-        r.sc = c->side_stream2;
-        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-        HIP_TRY(c, hipStreamWaitEvent(r.sb, c->ev_fork, 0));
-        HIP_TRY(c, hipStreamWaitEvent(r.sc, c->ev_fork, 0));
-    }
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage1(c, st, chain))) return rc;
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage2(c, st, chain))) return rc;
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage3(c, st, chain))) return rc;
-    if ((rc = zstage4(c, st, 0))) return rc;
-    double sums[kNSums];
-    if ((rc = zstage5(c, sums, st))) return rc;
-    energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
-    return 0;
-}
-
-ZRun& zrun(ofdft_ctx* c) {
-    if (!c->zr) c->zr = new ofdft_zrun_holder();
-    return c->zr->r;
-}
-
-int begin_call(ofdft_ctx* c, hipStream_t st) {
-    if (!c) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    c->fft_count = 0;
-    c->launch_count = 0;
-    HIP_TRY(c, hipEventRecord(c->ev0, st));
-    return 0;
-}
-int end_call(ofdft_ctx* c, hipStream_t st) {
-    HIP_TRY(c, hipEventRecord(c->ev1, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-    HIP_TRY(c, hipGetLastError());
-    if (c->profiling) prof_collect(c);
-    return 0;
-}
-
-}  // namespace
+#include "engine_zfused.inc.h"
 
 // ====================================================================================== C ABI
 extern "C" {
@@ -1966,465 +1341,7 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
     return OFDFT_OK;
 }
 
-// ------------------------------------------------------------------------------ ionic potential
-struct IonPrep {
-    std::vector<double> frac, cart, slopes;
-    std::vector<cplx> hb;
-    double *d_frac = nullptr, *d_cart = nullptr;
-    cplx *d_b0 = nullptr, *d_b1 = nullptr, *d_b2 = nullptr;
-    RecpotTable tab{};
-};
-
-// shared host-side preparation of the ionic-potential entry points: wrapped fractional coordinates, Cartesian
-// coordinates, Hermite slopes, PME b factors; uploads everything on `st` (caller syncs before `p` dies)
-static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int nions, const double* tab_k,
-                       const double* tab_v, int ntab, double z_ion, int pme_order, hipStream_t st) {
-    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ionic-potential entry points: single-GPU contexts only");
-    if (nions < 1 || ntab < 2) return fail(c, OFDFT_EINVAL, "need at least one ion and two table points");
-    if (pme_order != 0 && (pme_order < 2 || pme_order > kMaxPmeOrder || (pme_order & 1)))
-        return fail(c, OFDFT_EINVAL, "Requires even order n >= 2 (<= %d)", kMaxPmeOrder);       // ion_utils.py:116
-    HIP_TRY(c, hipSetDevice(c->device));
-    p.frac.resize(3 * (size_t)nions);
-    p.cart.resize(3 * (size_t)nions);
-    for (int a = 0; a < nions; ++a) {
-        for (int d = 0; d < 3; ++d) {
-            double f = frac_host[3 * a + d];
-            f -= std::floor(f);
-            f -= std::floor(f);                                                      // ion_utils.py:241-242
-            p.frac[3 * a + d] = f;
-        }
-        for (int d = 0; d < 3; ++d)     // cart = frac @ box (un-wrapped, as the reference's exact sum uses)
-            p.cart[3 * a + d] = frac_host[3 * a] * c->box[d] + frac_host[3 * a + 1] * c->box[3 + d] +
-                                frac_host[3 * a + 2] * c->box[6 + d];
-    }
-    p.slopes.resize(ntab);
-    {
-        std::vector<double> m(ntab - 1);
-        for (int i = 0; i + 1 < ntab; ++i) m[i] = (tab_v[i + 1] - tab_v[i]) / (tab_k[i + 1] - tab_k[i]);
-        p.slopes[0] = m[0];
-        for (int i = 1; i + 1 < ntab; ++i) p.slopes[i] = (m[i] + m[i - 1]) / 2;
-        p.slopes[ntab - 1] = m[ntab - 2];
-    }
-    double *d_k, *d_y, *d_m;
-    if (int rc = get_ws(c, "i:frac", sizeof(double) * p.frac.size(), (void**)&p.d_frac)) return rc;
-    if (int rc = get_ws(c, "i:cart", sizeof(double) * p.cart.size(), (void**)&p.d_cart)) return rc;
-    if (int rc = get_ws(c, "i:k", sizeof(double) * ntab, (void**)&d_k)) return rc;
-    if (int rc = get_ws(c, "i:y", sizeof(double) * ntab, (void**)&d_y)) return rc;
-    if (int rc = get_ws(c, "i:m", sizeof(double) * ntab, (void**)&d_m)) return rc;
-    HIP_TRY(c, hipMemcpyAsync(p.d_frac, p.frac.data(), sizeof(double) * p.frac.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(p.d_cart, p.cart.data(), sizeof(double) * p.cart.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_k, tab_k, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_y, tab_v, sizeof(double) * ntab, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_m, p.slopes.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, st));
-    p.tab = RecpotTable{d_k, d_y, d_m, ntab, z_ion, 1.0 / (tab_k[1] - tab_k[0])};
-    if (pme_order != 0) {
-        // b(m) = exp(2 pi i m (n-1)/N) / sum_i M_n(i) exp(2 pi i m (i-1)/N)        ion_utils.py:207-215
-        std::vector<double> M(pme_order, 0.0);
-        M[1] = 1.0;
-        for (int n = 3; n <= pme_order; ++n) {
-            for (int i = n - 1; i >= 1; --i) M[i] = (i * M[i] + (double)(n - i) * M[i - 1]) / (n - 1);
-            M[0] = 0.0;
-        }
-        const int cnt[3] = {c->n0, c->n1, c->g.nzc}, Ns[3] = {c->n0, c->n1, c->n2};
-        p.hb.resize((size_t)cnt[0] + cnt[1] + cnt[2]);
-        size_t off = 0;
-        for (int d = 0; d < 3; ++d) {
-            for (int m = 0; m < cnt[d]; ++m) {
-                double br = 0.0, bi = 0.0;
-                for (int i = 0; i < pme_order; ++i) {
-                    const double ph = 2.0 * kPi * m * (i - 1.0) / Ns[d];
-                    br += M[i] * std::cos(ph);
-                    bi += M[i] * std::sin(ph);
-                }
-                const double ph = 2.0 * kPi * m * (pme_order - 1.0) / Ns[d];
-                const double nr = std::cos(ph), ni = std::sin(ph), den = br * br + bi * bi;
-                p.hb[off + m] = make_double2((nr * br + ni * bi) / den, (ni * br - nr * bi) / den);
-            }
-            off += cnt[d];
-        }
-        cplx* d_b;
-        if (int rc = get_ws(c, "i:b", sizeof(cplx) * p.hb.size(), (void**)&d_b)) return rc;
-        HIP_TRY(c, hipMemcpyAsync(d_b, p.hb.data(), sizeof(cplx) * p.hb.size(), hipMemcpyHostToDevice, st));
-        p.d_b0 = d_b;
-        p.d_b1 = d_b + cnt[0];
-        p.d_b2 = d_b + cnt[0] + cnt[1];
-    }
-    return 0;
-}
-
-int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, const double* tab_k, const double* tab_v,
-                          int ntab, double z_ion, int pme_order, void* vext_dev, int accumulate, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!c || !frac_host || !tab_k || !tab_v || !vext_dev) return OFDFT_EINVAL;
-    IonPrep p;
-    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
-    cplx *sQ, *sF;
-    double* tmp;
-    if (int rc = spec_ws(c, "i:F", &sF)) return rc;
-    if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
-    const int sp_grid = grid_for(c->g.total);
-    if (pme_order == 0) {
-        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)nullptr, sF, c->kg,
-                     (const cplx*)nullptr, (const cplx*)nullptr, (const cplx*)nullptr, (const double*)p.d_cart, nions, p.tab,
-                     1.0 / c->vol);
-    } else {
-        if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
-        HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
-        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, tmp, c->n0, c->n1, c->n2);
-        if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
-        OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)sQ, sF, c->kg,
-                     (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, (const double*)nullptr, nions, p.tab,
-                     1.0 / c->vol);
-    }
-    if (int rc = irfftn_internal(c, sF, tmp, 1.0, st)) return rc;              // norm='forward': no 1/N  (ion_utils.py:118)
-    OFDFT_LAUNCH(c, st, "axpy", axpy_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)tmp, (double*)vext_dev,
-                 c->npts, accumulate);
-    HIP_TRY(c, hipStreamSynchronize(st));      // `p` (host staging) must outlive the async copies
-    HIP_TRY(c, hipGetLastError());
-    if (c->profiling) prof_collect(c);
-    return OFDFT_OK;
-}
-
-// F_a = -dU/dR_a, U = int n v_ext for one species (the ion-electron part of System.forces, system.py:913-923)
-int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* frac_host, int nions, const double* tab_k,
-                              const double* tab_v, int ntab, double z_ion, int pme_order, double* forces_host,
-                              void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!c || !den_dev || !frac_host || !tab_k || !tab_v || !forces_host) return OFDFT_EINVAL;
-    IonPrep p;
-    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
-    cplx *sN, *sT;
-    if (int rc = spec_ws(c, "i:Q", &sN)) return rc;
-    if (int rc = rfftn_internal(c, (const double*)den_dev, sN, st)) return rc;
-    const double pref = c->dV / c->vol;
-    if (pme_order == 0) {
-        const int kb = grid_for(c->g.total, kRedThreads, 64);
-        double* d_part;
-        std::vector<double> h((size_t)nions * kb * 3);
-        if (int rc = get_ws(c, "i:fpart", sizeof(double) * h.size(), (void**)&d_part)) return rc;
-        OFDFT_LAUNCH(c, st, "ion_force", ion_force_exact_kernel, dim3(kb, nions), dim3(kRedThreads), 0, (const cplx*)sN, c->kg,
-                     (const double*)p.d_cart, p.tab, d_part);
-        HIP_TRY(c, hipMemcpyAsync(h.data(), d_part, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        for (int a = 0; a < nions; ++a)
-            for (int s3 = 0; s3 < 3; ++s3) {
-                long double t = 0.0L;
-                for (int b = 0; b < kb; ++b) t += h[((size_t)a * kb + b) * 3 + s3];
-                forces_host[3 * a + s3] = pref * (double)t;
-            }
-    } else {
-        double *theta, *d_G;
-        std::vector<double> G(3 * (size_t)nions);
-        if (int rc = spec_ws(c, "i:F", &sT)) return rc;
-        if (int rc = real_ws(c, "i:tmp", &theta)) return rc;
-        if (int rc = get_ws(c, "i:G", sizeof(double) * G.size(), (void**)&d_G)) return rc;
-        OFDFT_LAUNCH(c, st, "pme_theta", pme_theta_spec_kernel, dim3(grid_for(c->g.total)), dim3(256), 0, (const cplx*)sN, sT,
-                     c->kg, (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, p.tab, 1.0 / c->vol);
-        if (int rc = irfftn_internal(c, sT, theta, 1.0, st)) return rc;
-        OFDFT_LAUNCH(c, st, "pme_gather", pme_gather_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, (const double*)theta, c->n0, c->n1, c->n2, d_G);
-        HIP_TRY(c, hipMemcpyAsync(G.data(), d_G, sizeof(double) * G.size(), hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        // dU/dR_j = dV sum_d G_d N_d d(frac_d)/d(cart_j),  frac = cart @ inv(box)  ->  d frac_d / d cart_j = inv(box)[j][d]
-        const double* a9 = c->box;
-        const double det = a9[0] * (a9[4] * a9[8] - a9[5] * a9[7]) - a9[1] * (a9[3] * a9[8] - a9[5] * a9[6]) +
-                           a9[2] * (a9[3] * a9[7] - a9[4] * a9[6]);
-        double inv[9];
-        inv[0] = (a9[4] * a9[8] - a9[5] * a9[7]) / det;
-        inv[1] = (a9[2] * a9[7] - a9[1] * a9[8]) / det;
-        inv[2] = (a9[1] * a9[5] - a9[2] * a9[4]) / det;
-        inv[3] = (a9[5] * a9[6] - a9[3] * a9[8]) / det;
-        inv[4] = (a9[0] * a9[8] - a9[2] * a9[6]) / det;
-        inv[5] = (a9[2] * a9[3] - a9[0] * a9[5]) / det;
-        inv[6] = (a9[3] * a9[7] - a9[4] * a9[6]) / det;
-        inv[7] = (a9[1] * a9[6] - a9[0] * a9[7]) / det;
-        inv[8] = (a9[0] * a9[4] - a9[1] * a9[3]) / det;
-        const int Ns[3] = {c->n0, c->n1, c->n2};
-        for (int a = 0; a < nions; ++a)
-            for (int j = 0; j < 3; ++j) {
-                double t = 0.0;
-                for (int d = 0; d < 3; ++d) t += inv[3 * j + d] * Ns[d] * G[3 * a + d];
-                forces_host[3 * a + j] = -c->dV * t;
-            }
-    }
-    HIP_TRY(c, hipGetLastError());
-    if (c->profiling) prof_collect(c);
-    return OFDFT_OK;
-}
-
-// ------------------------------------------------------------------------------ stress
-namespace {
-
-void sym_store(double* out9, const double* c6, double diag) {
-    out9[0] = c6[0] + diag; out9[4] = c6[1] + diag; out9[8] = c6[2] + diag;
-    out9[1] = out9[3] = c6[3];
-    out9[2] = out9[6] = c6[4];
-    out9[5] = out9[7] = c6[5];
-}
-
-}  // namespace
-
-// Per-term stress tensors for the active terms, sigma_terms_host[OFDFT_NTERMS][9] (row-major 3x3, Ha/bohr^3); the
-// ion-electron entry stays zero (its potential depends on the ions: ofdft_ion_electron_stress).
-int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = begin_call(c, st)) return rc;
-    if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
-    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
-    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_stress: single-GPU contexts only");
-    const double* den = (const double*)den_dev;
-    const unsigned mask = c->mask;
-    const long long npts = c->npts;
-    const double invN = 1.0 / (double)npts, invN2 = invN * invN;
-    for (int i = 0; i < OFDFT_NTERMS * 9; ++i) sig[i] = 0.0;
-    const int sp_blocks = grid_for(c->g.total, kRedThreads, kRedBlocks), pw_grid = grid_for(npts / 2 + 1);
-    double s7[kStressSpecScalars];
-    double nsum;
-    if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
-    const double nbar = nsum * invN;                    // N_e / vol, un-rounded (functionals.py:634)
-    cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
-    double *gx = nullptr, *gy = nullptr, *gz = nullptr;
-    if (int rc = spec_ws(c, "s0", &s0)) return rc;
-    if (int rc = spec_ws(c, "s1", &s1)) return rc;
-    if (mask & (OFDFT_HARTREE | kGgaAny)) {
-        if (int rc = rfftn_internal(c, den, s0, st)) return rc;
-        if (mask & OFDFT_HARTREE) {
-            OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HARTREE>), dim3(sp_blocks), dim3(kRedThreads), 0,
-                         (const cplx*)s0, (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
-            if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
-            sym_store(sig + 9 * 1, s7, -0.5 * s7[6]);                 // -E_H / vol on the diagonal
-        }
-        if (mask & kGgaAny) {
-            if (int rc = spec_ws(c, "s2", &s2)) return rc;
-            if (int rc = spec_ws(c, "s3", &s3)) return rc;
-            if (int rc = real_ws(c, "gx", &gx)) return rc;
-            if (int rc = real_ws(c, "gy", &gy)) return rc;
-            if (int rc = real_ws(c, "gz", &gz)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(grid_for(c->g.total)), dim3(256), 0, s0, s1, s2, s3, c->kg);
-            if (int rc = irfftn_internal(c, s1, gx, invN, st)) return rc;
-            if (int rc = irfftn_internal(c, s2, gy, invN, st)) return rc;
-            if (int rc = irfftn_internal(c, s3, gz, invN, st)) return rc;
-        }
-    }
-    if (mask & (OFDFT_TF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | kGgaAny)) {
-        const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
-        double r[kStressRealScalars];
-        OFDFT_LAUNCH(c, st, "stress_real", stress_real_kernel, dim3(blocks), dim3(kRedThreads), 0, den, (const double*)gx,
-                     (const double*)gy, (const double*)gz, npts, mask, gga_sel(c), c->d_partial);
-        if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
-        const double zero6[6] = {0, 0, 0, 0, 0, 0};
-        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
-        if (mask & OFDFT_TF) sym_store(sig + 9 * 2, zero6, -2.0 / 3.0 * ctf * r[0] * invN);      // tools_for_tests.py:241-243
-        if (mask & OFDFT_LDA_X) sym_store(sig + 9 * 6, zero6, r[1] * invN);                    // :367-370
-        int nc = 0;
-        for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
-        for (int b = 7; b <= 9; ++b)
-            if ((mask >> b) & 1) sym_store(sig + 9 * b, zero6, r[2] * invN / nc);
-        for (int which = 0; which < 3; ++which) {                                              // :393-472 (same form for the kinetic GGA)
-            if (!(mask & (which == 0 ? OFDFT_PBE_X : (which == 1 ? OFDFT_PBE_C : OFDFT_GGA_K)))) continue;
-            const double* o = r + 3 + 8 * which;
-            double c6[6];
-            for (int k = 0; k < 6; ++k) c6[k] = -2.0 * o[k] * invN;
-            for (int k = 0; k < 3; ++k) c6[k] += -2.0 * o[6] * invN;
-            sym_store(sig + 9 * (10 + which), c6, o[7] * invN);
-        }
-    }
-    if (mask & OFDFT_VW) {
-        double* tmp;
-        if (int rc = real_ws(c, "t0", &tmp)) return rc;
-        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
-        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
-        OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_VW>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)s0,
-                     (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
-        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
-        sym_store(sig + 9 * 3, s7, 0.0);
-    }
-    if (mask & OFDFT_WT_NL) {
-        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
-        const double pref = ctf * 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-        double* tmp;
-        if (int rc = real_ws(c, "t0", &tmp)) return rc;
-        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
-        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
-        cplx* sa = s0;
-        if (al != be) {
-            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
-            if (int rc = rfftn_internal(c, tmp, s1, st)) return rc;
-            sa = s1;
-        }
-        OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_WT>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)sa,
-                     (const cplx*)s0, c->kg, invN2, 1.0 / (2.0 * kf), c->d_partial);
-        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
-        double c6[6];
-        for (int k = 0; k < 6; ++k) c6[k] = pref * s7[k];
-        sym_store(sig + 9 * 4, c6, -2.0 / 3.0 * pref * s7[6]);                                  // -2/3 T_NL / vol
-    }
-    if (mask & OFDFT_WGC99_NL) {
-        const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
-        const long long nel_r = std::llround(nsum * c->dV);                                      // functionals.py:952
-        WgcSeries ser{};
-        if (int rc = wgc_series_setup(c, nel_r, st, &ser)) return rc;
-        if (ser.v == 0.0) return fail(c, OFDFT_EINVAL, "WGC99 stress: degenerate kernel parameters (v = 0) not supported");
-        const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
-        WgcSpectra sp{};
-        double* t[3];
-        if (int rc = real_ws(c, "t0", &t[0])) return rc;
-        if (int rc = real_ws(c, "t1", &t[1])) return rc;
-        if (int rc = real_ws(c, "t2", &t[2])) return rc;
-        for (int pass = 0; pass < 2; ++pass) {
-            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t[0], t[1], t[2], npts,
-                         pass == 0 ? be : al, ser.nref);
-            for (int k = 0; k < 3; ++k) {
-                cplx* w;
-                if (int rc = spec_ws(c, wn[3 * pass + k], &w)) return rc;
-                if (int rc = rfftn_internal(c, t[k], w, st)) return rc;
-                sp.s[3 * pass + k] = w;
-            }
-        }
-        OFDFT_LAUNCH(c, st, "stress_wgc", stress_wgc_kernel, dim3(sp_blocks), dim3(kRedThreads), 0, sp, c->kg, ser, invN2,
-                     c->d_partial);
-        if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
-        const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
-        double c6[6];
-        for (int k = 0; k < 6; ++k) c6[k] = ctf * s7[k];
-        sym_store(sig + 9 * 5, c6, -2.0 / 3.0 * ctf * s7[6]);
-    }
-    return end_call(c, st);
-}
-
-// Ion-electron stress of one species for a given density, the potential being rebuilt from the ions at fixed fractional
-// coordinates (what System.__compute_stress differentiates, system.py:925-935).  sigma_host[9], row-major.
-int ofdft_ion_electron_stress(ofdft_ctx* c, const void* den_dev, const double* frac_host, int nions, const double* tab_k,
-                              const double* tab_v, int ntab, double z_ion, int pme_order, double* sigma_host, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!c || !den_dev || !frac_host || !tab_k || !tab_v || !sigma_host) return OFDFT_EINVAL;
-    IonPrep p;
-    if (int rc = ion_prepare(c, p, frac_host, nions, tab_k, tab_v, ntab, z_ion, pme_order, st)) return rc;
-    cplx *sN, *sQ = nullptr;
-    if (int rc = spec_ws(c, "i:F", &sN)) return rc;
-    if (int rc = rfftn_internal(c, (const double*)den_dev, sN, st)) return rc;
-    if (pme_order != 0) {
-        double* tmp;
-        if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
-        if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
-        HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
-        OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, tmp, c->n0, c->n1, c->n2);
-        if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
-    }
-    const int blocks = grid_for(c->g.total, kRedThreads, kRedBlocks);
-    OFDFT_LAUNCH(c, st, "stress_ion", stress_ion_kernel, dim3(blocks), dim3(kRedThreads), 0, (const cplx*)sN, (const cplx*)sQ,
-                 c->kg, (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2,
-                 pme_order == 0 ? (const double*)p.d_cart : (const double*)nullptr, nions, p.tab, c->d_partial);
-    double s7[kStressSpecScalars];
-    if (int rc = fetch_partials(c, blocks, kStressSpecScalars, s7, st)) return rc;
-    const double invN = 1.0 / (double)c->npts;
-    double c6[6];
-    for (int k = 0; k < 6; ++k) c6[k] = -s7[k] * invN / c->vol;
-    sym_store(sigma_host, c6, -s7[6] * invN / c->vol);
-    HIP_TRY(c, hipGetLastError());
-    if (c->profiling) prof_collect(c);
-    return OFDFT_OK;
-}
-
-// Ion-ion interaction energy, forces and stress (ion_utils.py:293-333 with the parameter heuristics of
-// System.__ion_ion_interaction, system.py:733-754; forces / stress = what autograd yields, system.py:913-935).
-// Rc <= 0 selects the reference's default (Rd = 2 h_max, Rc = 3 Rd^2 / h_max); forces_host [nions][3] and
-// stress_host [9] may be NULL.
-int ofdft_ion_ion(ofdft_ctx* c, const double* frac_host, const double* charges_host, int nions, double Rc, double* E_host,
-                  double* forces_host, double* stress_host, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (!c || !frac_host || !charges_host || !E_host || nions < 1) return OFDFT_EINVAL;
-    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const double* B = c->box;
-    // interplanar spacings h_d = 1 / |row d of inv(B^T)| = vol / |cross of the other two lattice vectors|
-    double h[3];
-    for (int d = 0; d < 3; ++d) {
-        const double* u = B + 3 * ((d + 1) % 3);
-        const double* v = B + 3 * ((d + 2) % 3);
-        const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
-        h[d] = c->vol / std::sqrt(cx * cx + cy * cy + cz * cz);
-    }
-    const double h_max = std::max(h[0], std::max(h[1], h[2]));
-    double Rd;
-    if (Rc <= 0.0) {
-        Rd = 2.0 * h_max;
-        Rc = 3.0 * Rd * Rd / h_max;
-    } else {
-        Rd = std::sqrt(h_max * Rc / 3.0);
-    }
-    IonIonGeom g{};
-    std::memcpy(g.box, B, sizeof(g.box));
-    g.Rc = Rc;
-    g.Rd = Rd;
-    std::vector<double> cart(3 * (size_t)nions);
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int a = 0; a < nions; ++a)
-        for (int d = 0; d < 3; ++d) {
-            cart[3 * a + d] = frac_host[3 * a] * B[d] + frac_host[3 * a + 1] * B[3 + d] + frac_host[3 * a + 2] * B[6 + d];
-            lo[d] = std::min(lo[d], frac_host[3 * a + d]);
-            hi[d] = std::max(hi[d], frac_host[3 * a + d]);
-        }
-    long long nshift = 1;
-    for (int d = 0; d < 3; ++d) {
-        g.nmax[d] = (int)std::ceil(Rc / h[d] + (hi[d] - lo[d]));
-        nshift *= 2 * g.nmax[d] + 1;
-    }
-    const long long total = nshift * nions;
-    const int chunks = (int)std::min<long long>(256, (total + kRedThreads * 8 - 1) / (kRedThreads * 8));
-    double *d_cart, *d_z, *d_part;
-    const size_t np = (size_t)nions * chunks * kIonIonScalars;
-    if (int rc = get_ws(c, "ii:cart", sizeof(double) * cart.size(), (void**)&d_cart)) return rc;
-    if (int rc = get_ws(c, "ii:z", sizeof(double) * nions, (void**)&d_z)) return rc;
-    if (int rc = get_ws(c, "ii:part", sizeof(double) * np, (void**)&d_part)) return rc;
-    HIP_TRY(c, hipMemcpyAsync(d_cart, cart.data(), sizeof(double) * cart.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_z, charges_host, sizeof(double) * nions, hipMemcpyHostToDevice, st));
-    OFDFT_LAUNCH(c, st, "ion_ion", ion_ion_kernel, dim3(chunks, nions), dim3(kRedThreads), 0, (const double*)d_cart,
-                 (const double*)d_z, nions, g, d_part);
-    std::vector<double> hp(np);
-    HIP_TRY(c, hipMemcpyAsync(hp.data(), d_part, sizeof(double) * np, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    HIP_TRY(c, hipGetLastError());
-    double ztot = 0.0;
-    for (int a = 0; a < nions; ++a) ztot += charges_host[a];
-    const double rho = ztot / c->vol, spi = std::sqrt(kPi);
-    long double E = 0.0L, sig6[6] = {0, 0, 0, 0, 0, 0}, corr = 0.0L;
-    for (int a = 0; a < nions; ++a) {
-        long double s[kIonIonScalars];
-        for (int k = 0; k < kIonIonScalars; ++k) {
-            s[k] = 0.0L;
-            for (int b = 0; b < chunks; ++b) s[k] += hp[((size_t)a * chunks + b) * kIonIonScalars + k];
-        }
-        const double Z = charges_host[a];
-        const double Q = Z + (double)s[1];
-        const double aux = 0.75 / kPi * Q / rho;
-        const double Ra = std::cbrt(aux);
-        const double ex = std::exp(-Ra * Ra / (Rd * Rd)), er = std::erf(Ra / Rd);
-        E += 0.5L * s[0] - kPi * Z * rho * Ra * Ra + kPi * Z * rho * (Ra * Ra - 0.5 * Rd * Rd) * er + spi * Z * rho * Ra * Rd * ex -
-             Z * Z / spi / Rd;
-        if (forces_host)
-            for (int d = 0; d < 3; ++d) forces_host[3 * a + d] = (double)s[2 + d];
-        for (int k = 0; k < 6; ++k) sig6[k] += 0.5L * s[5 + k];
-        const double e_rho = -kPi * Z * Ra * Ra + kPi * Z * (Ra * Ra - 0.5 * Rd * Rd) * er + spi * Z * Ra * Rd * ex;
-        const double dE_dRa = -2.0 * kPi * Z * rho * Ra + 2.0 * kPi * Z * rho * Ra * er +
-                              kPi * Z * rho * (Ra * Ra - 0.5 * Rd * Rd) * 2.0 / (spi * Rd) * ex +
-                              spi * Z * rho * Rd * ex * (1.0 - 2.0 * Ra * Ra / (Rd * Rd));
-        corr += -rho * e_rho + dE_dRa * Ra / 3.0;
-    }
-    *E_host = (double)E;
-    if (stress_host) {
-        double c6[6];
-        for (int k = 0; k < 6; ++k) c6[k] = (double)sig6[k] / c->vol;
-        sym_store(stress_host, c6, (double)corr / c->vol);
-    }
-    if (c->profiling) prof_collect(c);
-    return OFDFT_OK;
-}
+#include "engine_ions_stress.inc.h"
 
 int ofdft_set_option(ofdft_ctx* c, int option, double value) {
     if (!c) return OFDFT_EINVAL;

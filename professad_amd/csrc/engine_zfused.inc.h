@@ -1,0 +1,629 @@
+// The z-fused pipeline of the engine (five stages, two chains; single- and multi-GPU) and the launchers of the z
+// kernels.  Included once by engine.hip inside its anonymous namespace (one translation unit).
+// ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
+#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
+constexpr int EZ = 4;   // points per lane wanted by the register-hungry fused z kernels
+
+int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
+    if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;
+    return get_twiddle(c, c->n2, twN);
+}
+template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nrows + ZW<M, E>::RPB - 1) / ZW<M, E>::RPB); }
+
+// The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
+// [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
+int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
+                      int nchunks = 1) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
+    SpecGeom gz = c->g;
+#define X(M_)                                                                                                       \
+    case M_: {                                                                                                      \
+        const int nb = z_blocks<M_, 8>(c) / nchunks;                                                                \
+        gz.blk0 = chunk * nb;                                                                                       \
+        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(nb), dim3(256), (ZW<M_, 8>::LDS), ds,    \
+                     out_n, out_s, gz, twM, twN);                                                                   \
+        return 0;                                                                                                   \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    if (chunk == 0)
+        for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
+    SpecGeom gz = c->g;
+#define X(M_)                                                                                                      \
+    case M_: {                                                                                                     \
+        const int nb = z_blocks<M_, ZPick<M_, EZ>::E>(c) / nchunks;                                                \
+        gz.blk0 = chunk * nb;                                                                                      \
+        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),           \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, gz, twM, twN);                                       \
+        return 0;                                                                                                  \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n,
+                int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    if (chunk == 0) c->fft_count += 6;    // three c2r finished + three r2c started on chip
+    SpecGeom gq = c->g;
+#define X(M_)                                                                                                   \
+    case M_: {                                                                                                  \
+        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
+        const int nb = *blocks_out / nchunks;                                                                   \
+        gq.blk0 = chunk * nb;                                                                                   \
+        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),                   \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, gga_sel(c), gq, twM, twN,   \
+                     c->d_partial);                                                                             \
+        return 0;                                                                                               \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    SpecGeom gq = c->g;
+    const size_t park = sizeof(double) * 256 * kCombineScalars;
+#define X(M_)                                                                                                     \
+    case M_: {                                                                                                    \
+        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
+        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
+        const int nb = *blocks_out / nchunks;                                                                     \
+        gq.blk0 = chunk * nb;                                                                                     \
+        if (a.v_part)                                                                                             \
+            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, false>), dim3(nb), dim3(256),          \
+                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
+        else                                                                                                      \
+            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, true>), dim3(nb), dim3(256),           \
+                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
+        return 0;                                                                                                 \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+// split form: the WGC99 part of the combine on the nonlocal chain's stream -> v_part rows + one energy partial per block
+int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, double* v_part, double* partial, int* blocks_out, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+#define X(M_)                                                                                                     \
+    case M_: {                                                                                                    \
+        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
+        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
+        OFDFT_LAUNCH(c, st, "zi_wgc", (zi_wgc_kernel<M_, W::E>), dim3(*blocks_out), dim3(256), (W::LDS), a, v_part, \
+                     c->g, twM, twN, partial);                                                                    \
+        return 0;                                                                                                 \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pbe_sums, double* E_terms, double* vn_int) {
+    const unsigned mask = c->mask;
+    const double dV = c->dV;
+    if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
+    if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
+    if (mask & OFDFT_TF) E_terms[2] = sums[2] * dV;
+    if (mask & OFDFT_VW) E_terms[3] = sums[3] * dV;
+    if (mask & OFDFT_WT_NL) E_terms[4] = sums[4] * dV;
+    if (mask & OFDFT_WGC99_NL) E_terms[5] = sums[5] * dV;
+    if (mask & OFDFT_LDA_X) E_terms[6] = sums[6] * dV;
+    int nc = 0;
+    for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;
+    for (int b = 7; b <= 9; ++b)
+        if ((mask >> b) & 1) E_terms[b] = sums[7] * dV / nc;
+    if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
+    if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
+    if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
+    *vn_int = sums[8] * dV;
+}
+
+// Pipeline with every real-space intermediate kept on chip: z kernels compute their inputs from chi|n on the
+// fly and consume the convolution results straight out of the inverse transform.  It is written as five
+// stages separated by the four points where the spectra change between the x-slab geometry (z, y passes) and
+// the x-pass geometry: on one GPU the two coincide and the stages simply run back to back; on several GPUs
+// each boundary is one all-to-all over the listed arrays (the host does the collective, see ofdft_dist_*).
+//   stage 1  z-forward (+pointwise pre-ops) and y-forward of every input spectrum          -> exchange
+//   stage 2  fused x passes (Hartree, gradient, Laplacian, Lindhard / WGC99 mixing)         -> exchange
+//   stage 3  y-inverse of the results; PBE mid stage on chip; y-forward of the flux          -> exchange
+//   stage 4  fused x pass of the divergence                                                  -> exchange
+//   stage 5  y-inverse of the divergence; combine kernel (potential + energy integrands)
+struct ZRun {
+    DenSrc ds{};
+    double nel = 0.0;
+    const double* vext = nullptr;
+    double* v_out = nullptr;
+    ZCombineArgs za{};
+    double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
+    bool has_h = false, has_g = false, has_vw = false, has_wt = false, has_wgc = false;
+    cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
+    cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* dfdn = nullptr;
+    double wt_pref = 0.0, wt_kf = 1.0;
+    // The evaluation is two independent chains that meet only in the combine kernel:
+    //   chain 0: density spectrum -> Hartree, grad n -> PBE -> divergence;  sqrt(n) -> Laplacian (vW)
+    //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
+    // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
+    std::vector<cplx*> xlist[2];
+    bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
+    std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
+    int stage[2] = {0, 0};
+    int combine_blocks = 0, pbe_blocks = 0;
+    hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
+    hipStream_t sc = nullptr;      // second side stream: vW chain and the second half of the WGC99 chain
+    bool forked = false;
+};
+
+}  // namespace
+struct ofdft_zrun_holder { ZRun r; };
+namespace {
+
+ZRun& zrun(ofdft_ctx* c);
+
+// ---- all-to-all buffers of the slab-decomposed path, one pair per chain (both directions reuse the pair):
+// chain 0 carries at most 5 spectra (Hartree, grad n, vW leaving stage 2), chain 1 at most 8 (2 Wang-Teter + 6 WGC99)
+// x chunks for a loop whose working set is `narr` spectra: the option value is the count for six spectra; more
+// spectra -> proportionally more chunks, so that a chunk's working set stays the same share of the Infinity Cache.
+// Every chunk must be whole workgroups of every z kernel (at most 256 rows each) -> powers of two that divide n0.
+int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
+    if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which)) return 1;
+    // automatic: about 100 MB of spectra per chunk (measured best at 256^3: 8 chunks for the six WGC99 spectra)
+    int want = c->xchunks > 1 ? (c->xchunks * narr + 5) / 6
+                              : (int)std::min<double>(64.0, (double)narr * sizeof(cplx) * (double)c->g.total / 100e6);
+    int n = 1;
+    while (n * 2 <= want && c->n0 % (n * 2) == 0 && ((long long)(c->n0 / (n * 2)) * c->n1) % 256 == 0) n *= 2;
+    return n;
+}
+
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * (chain == 0 ? 5 : 8);
+    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
+    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
+}
+
+// Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.
+int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
+    ZRun& r = zrun(c);
+    const unsigned mask = c->mask;
+    int rc;
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    const bool dx = c->nranks > 1;
+    std::vector<cplx*>& xl = r.xlist[chain];
+    xl.clear();
+    if (chain == 0) {
+        r.has_h = mask & OFDFT_HARTREE;
+        r.has_g = mask & kGgaAny;
+        r.has_vw = mask & OFDFT_VW;
+        r.has_wt = mask & OFDFT_WT_NL;
+        r.has_wgc = mask & OFDFT_WGC99_NL;
+        r.za = ZCombineArgs{};
+        r.za.ds = r.ds;
+        r.za.vext = r.vext;
+        r.za.v_out = r.v_out;
+        r.za.mask = mask;
+        r.za.inv_n = 1.0 / (double)c->npts_g;
+        r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
+        r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
+        if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+        if (r.has_h || r.has_g)
+            if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
+        if (r.has_vw)
+            if ((rc = spec_ws(c, "zs", &r.s_s))) return rc;
+        if (r.s_n || r.s_s) {
+            cplx* both[2];
+            int nb = 0;
+            if (r.s_n) both[nb++] = r.s_n;
+            if (r.s_s) both[nb++] = r.s_s;
+            const int nch = chunks_for(c, nb, 1);
+            if (nch > 1) {        // x-chunked: a chunk's spectra are y-transformed while still in the Infinity Cache
+                for (int ch = 0; ch < nch; ++ch) {
+                    if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st, ch, nch))) return rc;
+                    if ((rc = fast_axis_pass_multi<false>(c, 1, both, nb, st, ch * (c->n0 / nch), c->n0 / nch))) return rc;
+                }
+            } else if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) {
+                return rc;
+            }
+            if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
+                HIP_TRY(c, hipEventRecord(c->ev_a, st));
+                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
+            }
+            if (!dx && nch == 1 && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+            if (!dx && nch == 1 && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
+            if (r.s_n) xl.push_back(r.s_n);
+            if (r.s_s) xl.push_back(r.s_s);
+        }
+    } else {
+        if (r.has_wt) {
+            const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+            const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
+            r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
+            r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+            if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
+            if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
+            PowersArgs pa{};
+            pa.out[0] = r.s_b;
+            pa.out[3] = r.s_a;
+            pa.e0 = be;
+            pa.e1 = al;
+            if ((rc = launch_zf_powers(c, r.ds, pa, sb))) return rc;
+            for (cplx* sp : {r.s_b, r.s_a}) {
+                if (!sp) continue;
+                if (!dx && (rc = fast_axis_pass<false>(c, 1, sp, sb))) return rc;
+                xl.push_back(sp);
+            }
+            r.za.wt_alpha = al;
+            r.za.wt_beta = be;
+            r.za.wt_nbar_pa = std::pow(nbar, al);
+            r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+        }
+        if (r.has_wgc) {
+            const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
+            const long long nel_r = std::llround(r.nel);                         // functionals.py:952
+            double nref;
+            if ((rc = ensure_wgc_tables(c, nel_r, sb, &nref))) return rc;
+            const char* wn[6] = {"zw0", "zw1", "zw2", "zw3", "zw4", "zw5"};
+            PowersArgs pa{};
+            for (int i = 0; i < 6; ++i) {
+                if ((rc = spec_ws(c, wn[i], &r.sw[i]))) return rc;
+                pa.out[i] = r.sw[i];
+            }
+            pa.e0 = be;
+            pa.e1 = al;
+            pa.nref = nref;
+            pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+            // x-chunked form: each chunk's six spectra (6 x C / nchunks) are y-transformed while still in the Infinity Cache
+            const int nch = chunks_for(c, 6, 2);
+            if (nch > 1) {
+                for (int ch = 0; ch < nch; ++ch) {
+                    if ((rc = launch_zf_powers(c, r.ds, pa, sb, ch, nch))) return rc;
+                    if ((rc = fast_axis_pass_multi<false>(c, 1, r.sw, 6, sb, ch * (c->n0 / nch), c->n0 / nch))) return rc;
+                }
+            } else if ((rc = launch_zf_powers(c, r.ds, pa, sb))) {
+                return rc;
+            }
+            if (r.forked) {                    // second half (P, Q, S) continues on the second side stream
+                HIP_TRY(c, hipEventRecord(c->ev_b, sb));
+                HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
+            }
+            for (int i = 0; i < 6; ++i) {
+                if (!dx && nch == 1 && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
+                xl.push_back(r.sw[i]);
+            }
+            r.za.wgc_alpha = al;
+            r.za.wgc_beta = be;
+            r.za.nref = nref;
+            r.za.wgc_sum_53 = pa.sum53;
+        }
+    }
+    if (dx && !xl.empty()) {        // the chain's y-forwards in one launch, written in the exchange layout
+        cplx *send, *recv;
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+    }
+    r.stage[chain] = 1;
+    return 0;
+}
+
+// Stage 2: the fused x passes (forward x, k-space mixing, inverse x).
+int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
+    ZRun& r = zrun(c);
+    int rc;
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    // several ranks: the inputs sit in the chain's receive buffer (slot = position in stage 1's list) and the
+    // outputs are written to its send buffer in the order they are listed here
+    const bool dx = c->nranks > 1;
+    std::vector<cplx*>& xl = r.xlist[chain];
+    const std::vector<cplx*> in_list = xl;
+    xl.clear();
+    cplx *send = nullptr, *recv = nullptr;
+    XfLayout lay{};
+    if (dx) {
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0)
+                                    : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
+        lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
+    }
+    auto in_of = [&](cplx* arr) -> cplx* {
+        if (!dx) return arr;
+        for (size_t i = 0; i < in_list.size(); ++i)
+            if (in_list[i] == arr) return recv + (long long)i * c->xg.arr_sz;
+        return nullptr;
+    };
+    auto out_of = [&](cplx* arr) -> cplx* {       // also records the array as crossing the next boundary
+        xl.push_back(arr);
+        return dx ? send + (long long)(xl.size() - 1) * c->xg.arr_sz : arr;
+    };
+    if (chain == 0) {
+        if (r.s_n) {
+            XfIo io{};
+            io.in[0] = in_of(r.s_n);
+            int no = 0;
+            if (r.has_h) {
+                if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
+                io.out[no++] = out_of(r.s_vh);
+            }
+            if (r.has_g) {
+                const char* gn[3] = {"zgx", "zgy", "zgz"};
+                for (int k = 0; k < 3; ++k) {
+                    if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
+                    io.out[no++] = out_of(r.s_g[k]);
+                }
+            }
+            if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
+            else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
+            else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
+            if (rc) return rc;
+        }
+        if (r.s_s) {
+            XfIo io{};
+            io.in[0] = in_of(r.s_s);
+            io.out[0] = out_of(r.s_s);
+            if ((rc = xfused<1, 1>(c, io, MixScale<SPEC_LAPLACE>{c->kg, 0.0, 0.0}, sc, "xfused_lap", lay))) return rc;
+        }
+    } else {
+        if (r.has_wt) {
+            const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
+            for (cplx* sp : {r.s_b, r.s_a}) {
+                if (!sp) continue;
+                XfIo io{};
+                io.in[0] = in_of(sp);
+                io.out[0] = out_of(sp);
+                if ((rc = xfused<1, 1>(c, io, lind, sb, "xfused_lind", lay))) return rc;
+            }
+        }
+        if (r.has_wgc) {
+            const MixWgc mix{(double*)c->ws["t:wgc"].p};
+            for (int half = 0; half < 2; ++half) {
+                XfIo io{};
+                for (int i = 0; i < 3; ++i) {
+                    io.in[i] = in_of(r.sw[3 * half + i]);
+                    io.out[i] = out_of(r.sw[3 * half + i]);
+                }
+                if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
+            }
+        }
+    }
+    r.stage[chain] = 2;
+    return 0;
+}
+
+// Stage 3: y-inverse of what came back from the x passes (each completes one c2r except grad n); chain 0 then runs
+// the PBE mid stage on chip and starts the three r2c of the flux.
+int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
+    ZRun& r = zrun(c);
+    int rc;
+    hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
+    const bool dx = c->nranks > 1;
+    std::vector<cplx*>& xl = r.xlist[chain];
+    cplx *send = nullptr, *recv = nullptr;
+    if (dx && !xl.empty()) {        // one launch: the chain's y-inverses, read from the exchange layout
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = ypass_xchg<true>(c, xl, recv, st))) return rc;
+    }
+    // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
+    // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
+    const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = chunks_for(c, 6, 4) > 1;
+    for (cplx* sp : xl) {
+        const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
+        const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
+        const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2];
+        if (is_g ? pbe_chunked : chunked) {
+            if (!is_g) r.deferred.push_back(sp);
+        } else if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) {
+            return rc;
+        }
+        if (!is_g) c->fft_count++;
+    }
+    xl.clear();
+    if (chain == 1) {
+        if (r.has_wt) {
+            r.za.conv_b = r.s_b;
+            r.za.conv_a = r.s_a;
+        }
+        if (r.has_wgc)
+            for (int i = 0; i < 3; ++i) {
+                r.za.u[i] = r.sw[i];
+                r.za.gw[i] = r.sw[3 + i];
+            }
+        r.wgc_split = false;
+        if (r.has_wgc && !chunked && c->split_combine) {
+            // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
+            double *vp, *part2;
+            int blocks = 0;
+            if ((rc = real_ws(c, "vpart", &vp))) return rc;
+            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
+            if (r.forked) {
+                HIP_TRY(c, hipEventRecord(c->ev_b, sc));
+                HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
+            }
+            if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
+            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const double*)part2, blocks, 1,
+                         c->d_scal + 2);
+            r.za.v_part = vp;
+            r.wgc_split = true;
+        }
+        r.stage[1] = 3;
+        return 0;
+    }
+    if (r.has_h) r.za.vh = r.s_vh;
+    if (r.s_s) r.za.lap = r.s_s;
+    if (r.has_g) {
+        if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
+        const int nch = chunks_for(c, 6, 4);       // 3 spectra in, 3 out, the density and df/dn rows
+        for (int ch = 0; ch < nch; ++ch) {
+            const int x0 = ch * (c->n0 / nch), cx = c->n0 / nch;
+            if (pbe_chunked && (rc = fast_axis_pass_multi<true>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
+            if ((rc = launch_zpbe(c, r.ds, r.s_g[0], r.s_g[1], r.s_g[2], r.dfdn, r.za.inv_n, &r.pbe_blocks, st, ch, nch)))
+                return rc;
+            if (pbe_chunked && (rc = fast_axis_pass_multi<false>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
+        }
+        // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
+                     kPbeScalars, c->d_reduced + kCombineScalars);
+        for (int k = 0; k < 3; ++k) {
+            if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
+            xl.push_back(r.s_g[k]);
+        }
+        if (dx) {
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+        }
+    }
+    r.stage[0] = 3;
+    return 0;
+}
+
+// Stage 4: fused x pass of the divergence (chain 0 only).
+int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
+    ZRun& r = zrun(c);
+    r.xlist[chain].clear();
+    if (chain == 0 && r.has_g) {
+        XfIo dio{};
+        XfLayout lay{};
+        for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
+        dio.out[0] = r.s_n;      // n^ is no longer needed
+        if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0
+            cplx *send, *recv;
+            if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+            for (int k = 0; k < 3; ++k) dio.in[k] = recv + k * c->xg.arr_sz;
+            dio.out[0] = send;
+            lay = XfLayout{3 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+        }
+        if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div", lay)) return rc;
+        r.xlist[0].push_back(r.s_n);
+    }
+    r.stage[chain] = 4;
+    return 0;
+}
+
+// local sums: sums[0..8] combine scalars, sums[9..10] PBE x / c
+int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
+    ZRun& r = zrun(c);
+    int rc;
+    const bool chunked = chunks_for(c, 6, 8) > 1;
+    if (r.has_g) {
+        if (c->nranks > 1) {
+            cplx *send, *recv;
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
+        } else if (chunked) {
+            r.deferred.push_back(r.s_n);
+        } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
+            return rc;
+        }
+        c->fft_count++;
+        r.za.div = r.s_n;
+        r.za.dfdn = r.dfdn;
+    }
+    r.xlist[0].clear();
+    r.xlist[1].clear();
+    if (r.forked) {       // the combine needs both chains
+        HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
+    }
+    if (chunked) {        // y-inverse of a chunk of every result spectrum, then the combine kernel on the same x planes
+        const int narr = (int)r.deferred.size();
+        const int nch = chunks_for(c, narr + 2, 8);       // + the real rows (chi, v_ext, df/dn, v) the kernel touches
+        for (int ch = 0; ch < nch; ++ch) {
+            if (narr && (rc = fast_axis_pass_multi<true>(c, 1, r.deferred.data(), narr, st, ch * (c->n0 / nch), c->n0 / nch)))
+                return rc;
+            if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st, ch, nch))) return rc;
+        }
+        r.deferred.clear();
+    } else if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) {
+        return rc;
+    }
+    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
+                 r.combine_blocks, kCombineScalars, c->d_reduced);
+    if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
+    r.stage[0] = r.stage[1] = 5;
+    if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
+        if (r.wgc_split)          // fold in the energy sum of the split WGC99 kernel
+            OFDFT_LAUNCH(c, st, "reduce", axpy_kernel, dim3(1), dim3(64), 0, (const double*)(c->d_scal + 2), c->d_reduced + 5,
+                         (long long)1, 1);
+        return 0;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
+    if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
+        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kNSums, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+    if (r.wgc_split) sums[5] += c->h_partial[kNSums];
+    return 0;
+}
+
+int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
+                     double* vn_int, hipStream_t st) {
+    ZRun& r = zrun(c);
+    r.ds = ds;
+    r.nel = nel;
+    r.vext = vext;
+    r.v_out = v_out;
+    r.deferred.clear();
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    int rc;
+    // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
+    // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.
+    r.forked = c->use_side_stream && c->side_stream && c->side_stream2 && (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) &&
+               (c->mask & (OFDFT_HARTREE | OFDFT_VW | kGgaAny));
+    if (r.forked) {
+        r.sb = c->side_stream;
+        r.sc = c->side_stream2;
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(r.sb, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(r.sc, c->ev_fork, 0));
+    }
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage1(c, st, chain))) return rc;
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage2(c, st, chain))) return rc;
+    for (int chain = 0; chain < 2; ++chain)
+        if ((rc = zstage3(c, st, chain))) return rc;
+    if ((rc = zstage4(c, st, 0))) return rc;
+    double sums[kNSums];
+    if ((rc = zstage5(c, sums, st))) return rc;
+    energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
+    return 0;
+}
+
+ZRun& zrun(ofdft_ctx* c) {
+    if (!c->zr) c->zr = new ofdft_zrun_holder();
+    return c->zr->r;
+}
+
+int begin_call(ofdft_ctx* c, hipStream_t st) {
+    if (!c) return OFDFT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
+    c->fft_count = 0;
+    c->launch_count = 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    return 0;
+}
+int end_call(ofdft_ctx* c, hipStream_t st) {
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    HIP_TRY(c, hipGetLastError());
+    if (c->profiling) prof_collect(c);
+    return 0;
+}
+
+}  // namespace
+
