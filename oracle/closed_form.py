@@ -400,6 +400,11 @@ class Evaluator:
             return self.pbe(n, do_x=False)
         if name == 'pbe':
             return self.pbe(n)
+        if name == 'wts_exp':                              # functionals.py:728-782 with f = exp (f'(0) = 1)
+            (Ev, vv), (Et, vt), (En, vn) = self.vw(n), self.tf(n), self.wt_nl(n)
+            fx = math.exp(En / Et)
+            # d/dn [Et f(En/Et)] = vt f + Et f' (vn Et - En vt) / Et^2,  f = f' = exp
+            return Ev + Et * fx, vv + vt * fx + fx * (vn - En / Et * vt)
         if name in ('lkt', 'pg1', 'pgs'):                  # vW + Pauli GGA part (functionals.py:309-403)
             E1, v1 = self.vw(n)
             E2, v2 = self.ggak(n, 'lkt') if name == 'lkt' else self.ggak(n, 'pg', 1.0 if name == 'pg1' else 40 / 27)

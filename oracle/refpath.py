@@ -373,6 +373,12 @@ def pauli_gaussian(mu):
     return f
 
 
+def wt_style_exp(box, den):
+    """functionals.py:728-782 with (alpha, beta, f) = (5/6, 5/6, exp)"""
+    tf = thomas_fermi(box, den)
+    return weizsaecker(box, den) + tf * torch.exp(wt_nonlocal(box, den, 5 / 6, 5 / 6) / tf)
+
+
 def term_table(vext=None):
     """name -> callable(box, den), same keys as tests/golden/cases.py."""
     return {
@@ -383,7 +389,7 @@ def term_table(vext=None):
         'wgc99': Wgc99(),
         'lda_x': lda_exchange, 'pz_c': pz_correlation, 'pw_c': pw_correlation,
         'chachiyo_c': chachiyo_correlation, 'pbe_x': pbe_exchange, 'pbe_c': pbe_correlation,
-        'lkt': lkt, 'pg1': pauli_gaussian(1.0), 'pgs': pauli_gaussian(40 / 27),
+        'lkt': lkt, 'pg1': pauli_gaussian(1.0), 'pgs': pauli_gaussian(40 / 27), 'wts_exp': wt_style_exp,
     }
 
 

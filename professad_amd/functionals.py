@@ -272,3 +272,24 @@ class PauliGaussian:
         return _evaluate(box_vecs, den, ('vw', 'gga_k'), (('ggak_kind', 1.0), ('ggak_mu', abs(float(self.mu)))))
 
     __call__ = forward
+
+
+class WangTeterStyleFunctional:
+    """functionals.py:728-782: T = vW + T_TF f(T_NL / (f'(0) T_TF)) with a Pauli-positivity stabilisation function f
+    (f(0) = 1; default f(x) = 1 + x, i.e. a plain Wang-Teter style functional).  The three energies come from the engine;
+    f acts on the scalars in torch, so its derivative reaches the native potentials through autograd."""
+
+    def __init__(self, init_args=None):
+        self.alpha, self.beta, self.f = (5 / 6, 5 / 6, (lambda t: 1 + t)) if init_args is None else init_args
+        zero = torch.zeros((1,), dtype=torch.double, requires_grad=True)
+        if float(self.f(zero).detach()) != 1.0:
+            raise ValueError('Requires f(0) = 1')
+        self.fprime0 = float(torch.autograd.grad(self.f(zero), zero)[0])
+        self.__name__ = self.__qualname__ = 'WangTeterStyleFunctional'
+
+    def forward(self, box_vecs, den):
+        vW, TF = Weizsaecker(box_vecs, den), ThomasFermi(box_vecs, den)
+        T_NL = non_local_KEF(box_vecs, den, float(self.alpha), float(self.beta)) / self.fprime0
+        return vW + TF * self.f(T_NL / TF)
+
+    __call__ = forward

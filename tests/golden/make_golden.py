@@ -89,6 +89,7 @@ def reference_terms(vext_t):
         'lkt': F.LuoKarasievTrickey,
         'pg1': F.PauliGaussian(init_args=(1.0, 0.0, 0.0, 0.0)),
         'pgs': F.PauliGaussian(init_args=(40 / 27, 0.0, 0.0, 0.0)),
+        'wts_exp': F.WangTeterStyleFunctional(init_args=(5 / 6, 5 / 6, torch.exp)),
     }, wgc99
 
 

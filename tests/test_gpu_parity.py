@@ -68,6 +68,7 @@ _REF_NAME = {
     'pw_c': F.perdew_wang_correlation, 'chachiyo_c': F.chachiyo_correlation,
     'pbe_x': F.pbe_exchange, 'pbe_c': F.pbe_correlation,
     'lkt': F.LuoKarasievTrickey, 'pg1': F.PauliGaussian((1.0, 0.0, 0.0, 0.0)), 'pgs': F.PauliGaussian((40 / 27, 0.0, 0.0, 0.0)),
+    'wts_exp': F.WangTeterStyleFunctional((5 / 6, 5 / 6, torch.exp)),
 }
 
 
