@@ -210,6 +210,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_XCHUNKS     2   /* z kernels + the y passes next to them walk the grid in x chunks: 0 = automatic (default, ~100 MB of spectra per chunk), 1 = off, 2..64 = count for six spectra */
 #define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default), 4 PBE loop, 8 combine loop */
 #define OFDFT_OPT_SPLIT_COMBINE 4 /* 1 (default): with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream */
+#define OFDFT_OPT_BLUESTEIN 5     /* 1 (default): extents that are not powers of two (<= 512) use chirp-z line transforms; 0: plain DFT kernels */
 #define OFDFT_OPT_SIDE_STREAM 1
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 

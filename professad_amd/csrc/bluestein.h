@@ -1,0 +1,95 @@
+// Arbitrary-length line transforms by Bluestein's chirp-z algorithm on top of the power-of-two register/LDS line FFT:
+//   X_k = w_k * sum_n (x_n w_n) conj(w)_{k-n},  w_n = exp(-i pi n^2 / N)
+// i.e. one cyclic convolution of padded length M >= 2N - 1 (two M-point FFTs per line, the filter spectrum precomputed).
+// This is the engine's path for grid extents that are not powers of two -- which is what the reference's own
+// System.ecut2shape (system.py:75-89, always odd extents) produces: O(N log N) per line instead of the O(N^2) of the
+// plain DFT kernels (kept for extents above 512).
+#pragma once
+#include "fft_kernels.h"
+
+namespace ofdft {
+
+// mode: 0 = complex lines along x (axis 0) or y (axis 1) of the internal half-spectrum layout, in place
+//       1 = real rows -> half spectrum along z (r2c);  2 = half spectrum -> real rows along z (c2r, times `scale`)
+struct BsArgs {
+    int N;          // line length
+    int mode, axis, inv;
+    long long nlines;
+    double scale;
+};
+
+template <int M>
+__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __restrict__ spec, const double* __restrict__ rin,
+                                                                    double* __restrict__ rout, SpecGeom g, BsArgs b,
+                                                                    const cplx* __restrict__ chirp,   // w_n, n < N
+                                                                    const cplx* __restrict__ filt,    // FFT_M(b) / M
+                                                                    const cplx* __restrict__ twM) {
+    constexpr int P = PassCfg<M>::P, E = PassCfg<M>::E, LPW = PassCfg<M>::LPW;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int j = tid % P, l = tid / P;
+    const long long L = (long long)blockIdx.x * LPW + l;
+    const bool valid = L < b.nlines;
+    const int N = b.N;
+    // line coordinates
+    int x = 0, y = 0, kz = 0;
+    if (valid) {
+        if (b.mode == 0) {
+            if (b.axis == 0) { y = (int)(L % g.n1); kz = (int)(L / g.n1); }
+            else { x = (int)(L % g.n0); kz = (int)(L / g.n0); }
+        } else {
+            x = (int)(L / g.n1);
+            y = (int)(L % g.n1);
+        }
+    }
+    const bool conj_in = b.inv != 0;      // inverse transform = conjugated chirps and filter
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int e = j + P * q;
+        cplx a = make_double2(0.0, 0.0);
+        if (valid && e < N) {
+            if (b.mode == 0) {
+                a = spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)];
+            } else if (b.mode == 1) {
+                a = make_double2(rin[((long long)x * g.n1 + y) * g.n2 + e], 0.0);
+            } else {            // rebuild the Hermitian line; imaginary parts of k = 0 (and Nyquist) are ignored like irfftn
+                const int k = (e < g.nzc) ? e : N - e;
+                a = spec[spec_index(g, x, y, k)];
+                if (e >= g.nzc) a.y = -a.y;
+                if (e == 0 || (2 * e == N)) a.y = 0.0;
+            }
+            cplx w = chirp[e];
+            if (conj_in) w.y = -w.y;
+            a = cmul(a, w);
+        }
+        v[q] = a;
+    }
+    double* mine = lds + l * LineBuf<M>::STRIDE;
+    line_fft<M, false>(v, j, mine, twM);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        cplx f = filt[j + P * q];
+        if (conj_in) f.y = -f.y;
+        v[q] = cmul(v[q], f);
+    }
+    __syncthreads();
+    line_fft<M, true>(v, j, mine, twM);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int e = j + P * q;
+        if (!valid || e >= N) continue;
+        cplx w = chirp[e];
+        if (conj_in) w.y = -w.y;
+        const cplx r = cmul(v[q], w);
+        if (b.mode == 0) {
+            spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)] = r;
+        } else if (b.mode == 1) {
+            if (e < g.nzc) spec[spec_index(g, x, y, e)] = r;
+        } else {
+            rout[((long long)x * g.n1 + y) * g.n2 + e] = r.x * b.scale;
+        }
+    }
+}
+
+}  // namespace ofdft

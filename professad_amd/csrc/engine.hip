@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/ofdft_hip.h"
+#include "bluestein.h"
 #include "ion_kernels.h"
 #include "stress_kernels.h"
 #include "zpass.h"
@@ -63,6 +64,7 @@ struct ofdft_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
+    bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
     bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
     int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
     int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
@@ -340,6 +342,104 @@ int gen_axis(ofdft_ctx* c, int axis, int inv, cplx*& cur, cplx*& other, hipStrea
     return 0;
 }
 
+// ---- Bluestein tables (bluestein.h): chirp w_n = exp(-i pi n^2 / N) and the filter spectrum FFT_M(conj w, wrapped) / M
+struct BsTables { cplx *chirp = nullptr, *filt = nullptr; int M = 0; };
+
+int bluestein_pad(int N) {
+    int M = 8;
+    while (M < 2 * N - 1) M *= 2;
+    return M;
+}
+
+int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
+    const std::string key = "bs:" + std::to_string(N);
+    const int M = bluestein_pad(N);
+    out->M = M;
+    auto it = c->ws.find(key);
+    if (it != c->ws.end()) {
+        out->chirp = (cplx*)it->second.p;
+        out->filt = out->chirp + N;
+        return 0;
+    }
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<cplx> h((size_t)N + M);
+    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+    for (int n = 0; n < N; ++n) {
+        const long long r = ((long long)n * n) % (2LL * N);          // n^2 mod 2N keeps the angle small and exact
+        const long double ph = -pi * (long double)r / (long double)N;
+        const long double cr = cosl(ph), ci = sinl(ph);
+        h[n] = make_double2((double)cr, (double)ci);
+        br[n] = cr;
+        bi[n] = -ci;                                                   // b_n = conj(w_n), b_{-n} = b_n
+        if (n) {
+            br[M - n] = cr;
+            bi[M - n] = -ci;
+        }
+    }
+    // FFT_M(b) / M by a direct O(M^2) sum in extended precision (once per length; M <= 1024)
+    std::vector<long double> cs(M), sn(M);
+    for (int m = 0; m < M; ++m) {
+        cs[m] = cosl(-2.0L * pi * m / M);
+        sn[m] = sinl(-2.0L * pi * m / M);
+    }
+    for (int k = 0; k < M; ++k) {
+        long double sr = 0.0L, si = 0.0L;
+        for (int n = 0; n < M; ++n) {
+            if (br[n] == 0.0L && bi[n] == 0.0L) continue;
+            const int t = (int)(((long long)k * n) % M);
+            sr += br[n] * cs[t] - bi[n] * sn[t];
+            si += br[n] * sn[t] + bi[n] * cs[t];
+        }
+        h[N + k] = make_double2((double)(sr / M), (double)(si / M));
+    }
+    cplx* d;
+    if (int rc = get_ws(c, key.c_str(), sizeof(cplx) * h.size(), (void**)&d)) return rc;
+    HIP_TRY(c, hipMemcpy(d, h.data(), sizeof(cplx) * h.size(), hipMemcpyHostToDevice));
+    out->chirp = d;
+    out->filt = d + N;
+    return 0;
+}
+
+template <int M>
+int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const double* rin, double* rout, const BsArgs& b, const BsTables& t,
+                       hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, M, &tw)) return rc;
+    using Cfg = PassCfg<M>;
+    const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
+    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, rin, rout, c->g, b,
+                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
+    return 0;
+}
+
+// one generic-length pass: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
+int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const double* rin, double* rout, double scale,
+                   hipStream_t st) {
+    const int N = mode == 0 ? (axis == 0 ? c->n0 : c->n1) : c->n2;
+    BsTables t;
+    if (int rc = get_bluestein(c, N, &t)) return rc;
+    BsArgs b{};
+    b.N = N;
+    b.mode = mode;
+    b.axis = axis;
+    b.inv = inv;
+    b.scale = scale;
+    b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : c->g.nrows;
+    switch (t.M) {
+        case 8: return launch_bluestein_t<8>(c, spec, rin, rout, b, t, st);
+        case 16: return launch_bluestein_t<16>(c, spec, rin, rout, b, t, st);
+        case 32: return launch_bluestein_t<32>(c, spec, rin, rout, b, t, st);
+        case 64: return launch_bluestein_t<64>(c, spec, rin, rout, b, t, st);
+        case 128: return launch_bluestein_t<128>(c, spec, rin, rout, b, t, st);
+        case 256: return launch_bluestein_t<256>(c, spec, rin, rout, b, t, st);
+        case 512: return launch_bluestein_t<512>(c, spec, rin, rout, b, t, st);
+        case 1024: return launch_bluestein_t<1024>(c, spec, rin, rout, b, t, st);
+    }
+    return fail(c, OFDFT_EINVAL, "no Bluestein plan for length %d", N);
+}
+
+bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
+
 // real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
 int rfftn_internal(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
@@ -359,6 +459,11 @@ int rfftn_internal(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
         if (rc) return rc;
         if ((rc = fast_axis_pass<false>(c, 1, spec, st))) return rc;
         return fast_axis_pass<false>(c, 0, spec, st);
+    }
+    if (bluestein_ok(c)) {        // arbitrary extents: chirp-z line transforms, in place
+        if (int rc = bluestein_pass(c, 1, 2, 0, spec, in, nullptr, 1.0, st)) return rc;
+        if (int rc = bluestein_pass(c, 0, 1, 0, spec, nullptr, nullptr, 1.0, st)) return rc;
+        return bluestein_pass(c, 0, 0, 0, spec, nullptr, nullptr, 1.0, st);
     }
     cplx *tw2, *tmp;
     if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
@@ -390,6 +495,11 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStre
             case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
         }
         return fail(c, OFDFT_EINVAL, "bad n2");
+    }
+    if (bluestein_ok(c)) {
+        if (int rc = bluestein_pass(c, 0, 0, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
+        if (int rc = bluestein_pass(c, 0, 1, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
+        return bluestein_pass(c, 2, 2, 1, spec, nullptr, out, scale, st);
     }
     cplx *tw2, *tmp;
     if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
@@ -1356,6 +1466,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
         case OFDFT_OPT_XCHUNKS:
             if (value < 0.0 || value > 64.0) return fail(c, OFDFT_EINVAL, "x chunks must be 0 (automatic) or 1..64");
             c->xchunks = (int)value;
+            return OFDFT_OK;
+        case OFDFT_OPT_BLUESTEIN:
+            c->use_bluestein = value != 0.0;
             return OFDFT_OK;
         case OFDFT_OPT_SPLIT_COMBINE:
             c->split_combine = value != 0.0;

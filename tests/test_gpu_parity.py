@@ -527,3 +527,20 @@ def test_pauli_gaussian_members_and_all_pipelines_for_gga_kinetic():
     eng.close()
     with pytest.raises(NotImplementedError):
         F.PauliGaussian()(dev(box), dev(den))                     # default = PGSL0.25 (needs the reduced Laplacian)
+
+
+def test_generic_extent_paths_agree():
+    """non power-of-two grids: the chirp-z (Bluestein) line transforms against the plain DFT kernels and numpy"""
+    shape = (17, 18, 15)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape)
+    eng = Engine(shape, DEV)
+    ref = np.fft.rfftn(x)
+    res = {}
+    for opt in (1, 0):
+        eng.set_option(5, opt)
+        yk = eng.rfftn(dev(x))
+        assert relerr(yk.cpu().numpy(), ref) < 1e-13, opt
+        res[opt] = eng.irfftn(yk).cpu().numpy()
+        assert relerr(res[opt], x) < 1e-13, opt
+    eng.close()
