@@ -27,7 +27,11 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
     constexpr int P = PassCfg<M>::P, E = PassCfg<M>::E, LPW = PassCfg<M>::LPW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
-    const int j = tid % P, l = tid / P;
+    // complex lines (mode 0): consecutive lanes take consecutive LINES, enumerated kz-fastest, so that a wave's accesses
+    // for one element index fall on the 8 x 16-B runs of the block-8 layout; z rows (modes 1, 2): consecutive lanes take
+    // consecutive elements of one contiguous row
+    const int j = b.mode == 0 ? tid / LPW : tid % P;
+    const int l = b.mode == 0 ? tid % LPW : tid / P;
     const long long L = (long long)blockIdx.x * LPW + l;
     const bool valid = L < b.nlines;
     const int N = b.N;
@@ -35,8 +39,9 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
     int x = 0, y = 0, kz = 0;
     if (valid) {
         if (b.mode == 0) {
-            if (b.axis == 0) { y = (int)(L % g.n1); kz = (int)(L / g.n1); }
-            else { x = (int)(L % g.n0); kz = (int)(L / g.n0); }
+            kz = (int)(L % g.nzc);
+            if (b.axis == 0) y = (int)(L / g.nzc);
+            else x = (int)(L / g.nzc);
         } else {
             x = (int)(L / g.n1);
             y = (int)(L % g.n1);
