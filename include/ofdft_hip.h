@@ -78,7 +78,10 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_P_WGC_KAPPA   5   /* default 1.0 */
 #define OFDFT_P_GGAK_KIND   6   /* 0 = LKT (default), 1 = Pauli-Gaussian exp(-mu s^2) */
 #define OFDFT_P_GGAK_MU     7   /* default 40/27 (PGS); 1.0 = PG1 */
-#define OFDFT_NPARAMS       8
+#define OFDFT_P_GGAK_BETA   8   /* Pauli-Gaussian coefficients of q^2, -q s^2, s^4 (functionals.py:336-403); any non-zero one */
+#define OFDFT_P_GGAK_LAMBDA 9   /* makes the term depend on the reduced Laplacian q: evaluated by the unfused single-GPU     */
+#define OFDFT_P_GGAK_SIGMA  10  /* pipeline (one more c2r and r2c); not available slab-decomposed or for the stress          */
+#define OFDFT_NPARAMS       11
 
 /* ofdft_query selectors */
 #define OFDFT_Q_FFT_COUNT        0  /* 3-D FFTs executed by the last energy call              */

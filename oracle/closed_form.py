@@ -405,6 +405,24 @@ class Evaluator:
             fx = math.exp(En / Et)
             # d/dn [Et f(En/Et)] = vt f + Et f' (vn Et - En vt) / Et^2,  f = f' = exp
             return Ev + Et * fx, vv + vt * fx + fx * (vn - En / Et * vt)
+        if name in ('pgsl025', 'pgslr'):                   # Pauli-Gaussian with q-dependence (tools_for_tests.py:86-118)
+            mu, be, la, si = (40 / 27, 0.25, 0.0, 0.0) if name == 'pgsl025' else (40 / 27, 0.25, 0.4, 0.2)
+            g = self.g
+            nk = g.fwd(n)
+            grad = self._gradient(nk)
+            gn2 = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
+            lap = g.inv(-g.k2 * nk)
+            cs = 0.25 * (3 * PI * PI) ** (-2 / 3)
+            s2, q = cs * gn2 / n ** (8 / 3), cs * lap / n ** (5 / 3)
+            tau = C_TF * n ** (5 / 3)
+            ex = np.exp(-mu * s2)
+            Fe = ex + be * q * q - la * q * s2 + si * s2 * s2
+            Fs, Fq = -mu * ex - la * q + 2 * si * s2, 2 * be * q - la * s2
+            dfdn = (5 / 3) * tau / n * Fe + tau * (Fs * (-(8 / 3) * s2 / n) + Fq * (-(5 / 3) * q / n))
+            dfdg, dfdl = tau * Fs * cs / n ** (8 / 3), tau * Fq * cs / n ** (5 / 3)
+            v = dfdn - 2 * self._divergence([dfdg * c for c in grad]) + g.inv(-g.k2 * g.fwd(dfdl))
+            E1, v1 = self.vw(n)
+            return E1 + g.integral(tau * Fe), v1 + v
         if name in ('lkt', 'pg1', 'pgs'):                  # vW + Pauli GGA part (functionals.py:309-403)
             E1, v1 = self.vw(n)
             E2, v2 = self.ggak(n, 'lkt') if name == 'lkt' else self.ggak(n, 'pg', 1.0 if name == 'pg1' else 40 / 27)

@@ -373,6 +373,19 @@ def pauli_gaussian(mu):
     return f
 
 
+def pauli_gaussian_full(mu, beta, lamb, sigma):
+    """functionals.py:336-403 (reduced Laplacian functional_tools.py:271-287)"""
+    def f(box, den):
+        kx, ky, kz, ksq = recip_grid(box, den.shape)
+        c = 0.25 * (3 * PI * PI) ** (-2 / 3)
+        s2 = c * grad_sq(kx, ky, kz, den) / den.pow(8 / 3)
+        q = c * lap(ksq, den) / den.pow(5 / 3)
+        tf_ked = 0.3 * (3 * PI * PI) ** (2 / 3) * den.pow(5 / 3)
+        F = torch.exp(-abs(mu) * s2) + abs(beta) * q.pow(2) - abs(lamb) * q * s2 + abs(sigma) * s2.pow(2)
+        return weizsaecker(box, den) + torch.mean(tf_ked * F) * _vol(box)
+    return f
+
+
 def wt_style_exp(box, den):
     """functionals.py:728-782 with (alpha, beta, f) = (5/6, 5/6, exp)"""
     tf = thomas_fermi(box, den)
@@ -390,6 +403,7 @@ def term_table(vext=None):
         'lda_x': lda_exchange, 'pz_c': pz_correlation, 'pw_c': pw_correlation,
         'chachiyo_c': chachiyo_correlation, 'pbe_x': pbe_exchange, 'pbe_c': pbe_correlation,
         'lkt': lkt, 'pg1': pauli_gaussian(1.0), 'pgs': pauli_gaussian(40 / 27), 'wts_exp': wt_style_exp,
+        'pgsl025': pauli_gaussian_full(40 / 27, 0.25, 0.0, 0.0), 'pgslr': pauli_gaussian_full(40 / 27, 0.25, 0.4, 0.2),
     }
 
 

@@ -23,7 +23,7 @@ TERM_BITS = {
 TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c',
               'pbe_x', 'pbe_c', 'gga_k']
 NTERMS = 13
-NPARAMS = 8
+NPARAMS = 11
 Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1, 2, 3, 4
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',

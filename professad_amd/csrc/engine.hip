@@ -88,7 +88,14 @@ constexpr int kSumsqSlot = 15;                                         // d_redu
 
 GgaSel gga_sel(const ofdft_ctx* c) {
     return GgaSel{(c->mask & OFDFT_PBE_X) ? 1 : 0, (c->mask & OFDFT_PBE_C) ? 1 : 0, (c->mask & OFDFT_GGA_K) ? 1 : 0,
-                  (int)c->params[OFDFT_P_GGAK_KIND], c->params[OFDFT_P_GGAK_MU]};
+                  (int)c->params[OFDFT_P_GGAK_KIND], c->params[OFDFT_P_GGAK_MU], c->params[OFDFT_P_GGAK_BETA],
+                  c->params[OFDFT_P_GGAK_LAMBDA], c->params[OFDFT_P_GGAK_SIGMA]};
+}
+
+// Pauli-Gaussian member with Laplacian-dependent terms: served by the unfused pipeline only
+bool gga_needs_laplacian(const ofdft_ctx* c) {
+    return (c->mask & OFDFT_GGA_K) && (int)c->params[OFDFT_P_GGAK_KIND] == 1 &&
+           (c->params[OFDFT_P_GGAK_BETA] != 0.0 || c->params[OFDFT_P_GGAK_LAMBDA] != 0.0 || c->params[OFDFT_P_GGAK_SIGMA] != 0.0);
 }
 
 int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
@@ -813,13 +820,25 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = irfftn_internal(c, s2, gy, inv_n, st)) return rc;
             if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
             const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
+            double* lapn = nullptr;
+            cplx* s4 = nullptr;
+            if (gga_needs_laplacian(c)) {            // lap n = F^-1[-k^2 n^]  (reduced Laplacian q, functional_tools.py:271-287)
+                if (int rc = real_ws(c, "lapn", &lapn)) return rc;
+                if (int rc = spec_ws(c, "s4", &s4)) return rc;
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s0, s4, c->kg, 0.0, 0.0);
+                if (int rc = irfftn_internal(c, s4, lapn, inv_n, st)) return rc;
+            }
             OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
-                               gga_sel(c), c->d_partial);
+                               gga_sel(c), c->d_partial, lapn);
             if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
             if (int rc = rfftn_internal(c, gx, s1, st)) return rc;
             if (int rc = rfftn_internal(c, gy, s2, st)) return rc;
             if (int rc = rfftn_internal(c, gz, s3, st)) return rc;
             OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
+            if (lapn) {      // v += lap(df/dL): the combine forms v += df/dn - 2 div, so div -= lap(df/dL) / 2, i.e. s0 += k^2 (df/dL)^ / 2
+                if (int rc = rfftn_internal(c, lapn, s4, st)) return rc;
+                OFDFT_LAUNCH(c, st, "spec_scale", spec_add_lap_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)s4, s0, c->kg, 0.5);
+            }
             if (int rc = irfftn_internal(c, s0, dv, inv_n, st)) return rc;
             ca.dfdn = dfdn;
             ca.div = dv;
@@ -1064,7 +1083,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
 
 int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out, double* vn_int,
               hipStream_t st) {
-    if (c->fast && !c->force_unfused) return run_terms_fast(c, den, vext, E_terms, v_out, vn_int, st);
+    if (c->fast && !c->force_unfused && !gga_needs_laplacian(c)) return run_terms_fast(c, den, vext, E_terms, v_out, vn_int, st);
     return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st);
 }
 
@@ -1117,7 +1136,8 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     while ((1 << c->xg.log_nyl) < c->xg.nyl) c->xg.log_nyl++;
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
-    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0, 0.0, 40.0 / 27.0};
+    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0, 0.0, 40.0 / 27.0,
+                                            0.0, 0.0, 0.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     hipError_t e = hipSetDevice(device_id);
     // partial-sum rows: the pointwise kernels use <= kRedBlocks blocks, the z kernels one block per row group
@@ -1231,7 +1251,7 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     double vn;
-    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
+    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
         double nel = 0.0;
         if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) {
             double nsum;
@@ -1256,7 +1276,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
     double *den, *v;
     if (int rc = real_ws(c, "v", &v)) return rc;
-    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512) {
+    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
         // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
         // z kernels; mean(n) vol = N_e by construction.  One host sync per evaluation (the final sums).
         const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
@@ -1358,6 +1378,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!src_local) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
+    if (gga_needs_laplacian(c)) return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members: single-GPU contexts only");
     ZRun& r = zrun(c);
     if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[15]; it never visits the host
         OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel_global,

@@ -209,6 +209,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_stress: single-GPU contexts only");
+    if (gga_needs_laplacian(c)) return fail(c, OFDFT_EINVAL, "ofdft_stress: Laplacian-dependent Pauli-Gaussian members are not covered");
     const double* den = (const double*)den_dev;
     const unsigned mask = c->mask;
     const long long npts = c->npts;

@@ -154,6 +154,16 @@ __global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict_
     }
 }
 
+// acc += f * k^2 * in   (adds -f * Laplacian in reciprocal space)
+__global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restrict__ acc, KGeom kg, double f) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
+        double kx, ky, kz, k2;
+        kvec(kg, i, kx, ky, kz, k2);
+        const cplx a = in[i], b = acc[i];
+        acc[i] = make_double2(b.x + f * k2 * a.x, b.y + f * k2 * a.y);
+    }
+}
+
 // g_j = i k_j * in (functional_tools.py:183)
 __global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                  cplx* __restrict__ gz, KGeom kg) {
@@ -424,7 +434,7 @@ __device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
 struct PbePoint { double fx, fc, fk, dfdn, dfdg; };
 // which GGA pieces a pass evaluates: PBE exchange / correlation, and the Pauli part of a GGA kinetic functional
 // (kkind 0: LuoKarasievTrickey F = 1/cosh(1.3 s), functionals.py:309-333; 1: Pauli-Gaussian F = exp(-mu s^2), :336-403)
-struct GgaSel { int x, c, k, kkind; double kmu; };
+struct GgaSel { int x, c, k, kkind; double kmu, kbeta, klambda, ksigma; };
 constexpr int kPbeScalars = 3;     // energy sums of a GGA pass: exchange, correlation, kinetic
 
 // PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
@@ -500,12 +510,53 @@ __device__ __forceinline__ PbePoint pbe_point(double n, double gn2, const GgaSel
     return r;
 }
 
+// Pauli-Gaussian with the Laplacian-dependent terms (functionals.py:336-403; tools_for_tests.py:86-118):
+//   f = tau_TF (exp(-mu s^2) + beta q^2 - lambda q s^2 + sigma s^4),  q = lap n / (4 (3 pi^2)^(2/3) n^(5/3))
+// adds f, df/dn, df/d|grad n|^2 to p and returns df/d(lap n)
+__device__ __forceinline__ void pg_laplacian_point(double n, double gn2, double lap, const GgaSel& sel, PbePoint& p,
+                                                   double& dfdl) {
+    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const double n13 = cbrt(n), inv_n = 1.0 / n;
+    const double n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
+    const double s2 = cs * gn2 * n83i, q = cs * lap * n53i;
+    const double tau = ctf * n13 * n13 * n;
+    const double ex = exp(-sel.kmu * s2);
+    const double F = ex + sel.kbeta * q * q - sel.klambda * q * s2 + sel.ksigma * s2 * s2;
+    const double Fs = -sel.kmu * ex - sel.klambda * q + 2.0 * sel.ksigma * s2;       // dF / d(s^2)
+    const double Fq = 2.0 * sel.kbeta * q - sel.klambda * s2;                          // dF / dq
+    p.fk = tau * F;
+    p.dfdn += (5.0 / 3.0) * tau * inv_n * F + tau * (Fs * (-(8.0 / 3.0) * s2 * inv_n) + Fq * (-(5.0 / 3.0) * q * inv_n));
+    p.dfdg += tau * Fs * cs * n83i;
+    dfdl = tau * Fq * cs * n53i;
+}
+
 // PBE mid stage: grad n -> energy partials (x, c), df/dn, flux_j = df/dg * grad_j n (in place)
 __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restrict__ n, double* __restrict__ gx,
                                                           double* __restrict__ gy, double* __restrict__ gz,
                                                           double* __restrict__ dfdn, long long npts, GgaSel sel,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, double* __restrict__ lapn = nullptr) {
     double acc[kPbeScalars] = {0.0, 0.0, 0.0};
+    if (lapn) {      // Pauli-Gaussian members with q-dependence: scalar loop (not a hot path), lapn is overwritten by df/dL
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+            const double a = gx[i], b = gy[i], c = gz[i];
+            GgaSel nk = sel;
+            nk.k = 0;
+            PbePoint p = pbe_point(n[i], a * a + b * b + c * c, nk);
+            double dfdl;
+            pg_laplacian_point(n[i], a * a + b * b + c * c, lapn[i], sel, p, dfdl);
+            acc[0] += p.fx;
+            acc[1] += p.fc;
+            acc[2] += p.fk;
+            dfdn[i] = p.dfdn;
+            gx[i] = p.dfdg * a;
+            gy[i] = p.dfdg * b;
+            gz[i] = p.dfdg * c;
+            lapn[i] = dfdl;
+        }
+        block_reduce_store<kPbeScalars>(acc, partial);
+        return;
+    }
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const double2 d = reinterpret_cast<const double2*>(n)[i];

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* 
             const double g2 = a * a + b * b + c * c;
             for (int which = 0; which < 3; ++which) {
                 if (which == 0 ? !do_px : (which == 1 ? !do_pc : !do_pk)) continue;
-                const GgaSel one{which == 0, which == 1, which == 2, sel.kkind, sel.kmu};
+                const GgaSel one{which == 0, which == 1, which == 2, sel.kkind, sel.kmu, 0.0, 0.0, 0.0};
                 const PbePoint p = pbe_point(d, g2, one);
                 double* o = acc + 3 + 8 * which;
                 o[0] += a * a * p.dfdg;

@@ -245,9 +245,9 @@ def LuoKarasievTrickey(box_vecs, den):
 
 
 class PauliGaussian:
-    """functionals.py:336-403 for the members without the Laplacian-dependent terms (beta = lambda = sigma = 0:
-    PG1, PGS, any mu): vW + int tau_TF exp(-mu s^2).  The reference's DEFAULT parameters are PGSL0.25 (beta = 0.25),
-    whose q^2 term needs the reduced Laplacian: that member is not implemented natively and raises."""
+    """functionals.py:336-403: vW + int tau_TF (exp(-mu s^2) + beta q^2 - lambda q s^2 + sigma s^4); default = PGSL0.25.
+    Members without the Laplacian-dependent terms (PG1, PGS) share the PBE passes of the fused pipelines; the others are
+    evaluated by the engine's unfused pipeline (one more c2r / r2c pair; single GPU, no stress)."""
 
     def __init__(self, init_args=None):
         self.mu, self.beta, self.lamb, self.sigma = (40 / 27, 0.25, 0.0, 0.0) if init_args is None else init_args
@@ -266,10 +266,9 @@ class PauliGaussian:
         self.mu, self.beta, self.lamb, self.sigma = 40 / 27, 0.25, 0.4, 0.2
 
     def forward(self, box_vecs, den):
-        if self.beta or self.lamb or self.sigma:
-            raise NotImplementedError('native PauliGaussian covers beta = lambda = sigma = 0 (PG1, PGS); the Laplacian-'
-                                      'dependent members (PGSL0.25, PGSLr) need the reference torch term')
-        return _evaluate(box_vecs, den, ('vw', 'gga_k'), (('ggak_kind', 1.0), ('ggak_mu', abs(float(self.mu)))))
+        p = (('ggak_kind', 1.0), ('ggak_mu', abs(float(self.mu))), ('ggak_beta', abs(float(self.beta))),
+             ('ggak_lambda', abs(float(self.lamb))), ('ggak_sigma', abs(float(self.sigma))))
+        return _evaluate(box_vecs, den, ('vw', 'gga_k'), p)
 
     __call__ = forward
 

@@ -90,6 +90,8 @@ def reference_terms(vext_t):
         'pg1': F.PauliGaussian(init_args=(1.0, 0.0, 0.0, 0.0)),
         'pgs': F.PauliGaussian(init_args=(40 / 27, 0.0, 0.0, 0.0)),
         'wts_exp': F.WangTeterStyleFunctional(init_args=(5 / 6, 5 / 6, torch.exp)),
+        'pgsl025': F.PauliGaussian(),
+        'pgslr': F.PauliGaussian(init_args=(40 / 27, 0.25, 0.4, 0.2)),
     }, wgc99
 
 

@@ -69,6 +69,7 @@ _REF_NAME = {
     'pbe_x': F.pbe_exchange, 'pbe_c': F.pbe_correlation,
     'lkt': F.LuoKarasievTrickey, 'pg1': F.PauliGaussian((1.0, 0.0, 0.0, 0.0)), 'pgs': F.PauliGaussian((40 / 27, 0.0, 0.0, 0.0)),
     'wts_exp': F.WangTeterStyleFunctional((5 / 6, 5 / 6, torch.exp)),
+    'pgsl025': F.PauliGaussian(), 'pgslr': F.PauliGaussian((40 / 27, 0.25, 0.4, 0.2)),
 }
 
 
@@ -512,8 +513,7 @@ def test_ion_ion_known_answers_forces_and_stress():
 
 
 def test_pauli_gaussian_members_and_all_pipelines_for_gga_kinetic():
-    """the kinetic GGA through every engine pipeline, together with PBE (shared gradient / divergence); the Laplacian-
-    dependent Pauli-Gaussian members are refused"""
+    """the kinetic GGA through every engine pipeline, together with PBE (shared gradient / divergence)"""
     gold = load('terms_g16r.npz')
     box, den, vext, chi, n_elec = cases.make_inputs('g16r')
     eng = Engine(den.shape, DEV).set_cell(dev(box)).set_terms(['vw', 'gga_k', 'pbe_x', 'pbe_c'], {'ggak_kind': 0.0})
@@ -524,9 +524,11 @@ def test_pauli_gaussian_members_and_all_pipelines_for_gga_kinetic():
         E, v = eng.energy_potential(dev(den))
         assert abs(sum(E.values()) - Eref) <= E_RTOL * abs(Eref), mode
         assert relerr(v.cpu().numpy(), vref) < V_RTOL, mode
+    # the Laplacian-dependent members have no stress and no slab-decomposed form: refused, not ignored
+    eng.set_terms(['vw', 'gga_k'], {'ggak_kind': 1.0, 'ggak_beta': 0.25})
+    with pytest.raises(RuntimeError):
+        eng.stress(dev(den))
     eng.close()
-    with pytest.raises(NotImplementedError):
-        F.PauliGaussian()(dev(box), dev(den))                     # default = PGSL0.25 (needs the reduced Laplacian)
 
 
 def test_generic_extent_paths_agree():
