@@ -9,6 +9,30 @@
 
 namespace ofdft {
 
+// history vectors are read once per sweep and the next sweep comes ~2 GB of traffic later: stream them (nt) so that chi,
+// the gradient and the closure's own working set keep the caches
+#ifndef OFDFT_LBFGS_NT
+#define OFDFT_LBFGS_NT 1
+#endif
+__device__ __forceinline__ double2 lb_load2(const double* p, long long i) {
+#if OFDFT_LBFGS_NT
+    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p) + i);
+    return make_double2(t.x, t.y);
+#else
+    return reinterpret_cast<const double2*>(p)[i];
+#endif
+}
+__device__ __forceinline__ void lb_store2(double* p, long long i, double2 v) {
+#if OFDFT_LBFGS_NT
+    dbl2_t t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(p) + i);
+#else
+    reinterpret_cast<double2*>(p)[i] = v;
+#endif
+}
+
 constexpr int kLbfgsMaxHist = 8;
 
 struct LbfgsVecs {
@@ -44,8 +68,8 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, co
         if (have_prev) {
             double2 gp, di;
             if (!tail) {
-                gp = reinterpret_cast<const double2*>(g_prev)[i];
-                di = reinterpret_cast<const double2*>(d)[i];
+                gp = lb_load2(g_prev, i);
+                di = lb_load2(d, i);
             } else {
                 gp = make_double2(g_prev[n - 1], 0.0);
                 di = make_double2(d[n - 1], 0.0);
@@ -53,8 +77,8 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, co
             yi = make_double2(gi.x - gp.x, gi.y - gp.y);
             si = make_double2(t * di.x, t * di.y);
             if (!tail) {
-                reinterpret_cast<double2*>(s_new)[i] = si;
-                reinterpret_cast<double2*>(y_new)[i] = yi;
+                lb_store2(s_new, i, si);
+                lb_store2(y_new, i, yi);
             } else {
                 s_new[n - 1] = si.x;
                 y_new[n - 1] = yi.x;
@@ -64,8 +88,8 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, co
         for (int j = 0; j < K; ++j) {
             double2 a, b;
             if (!tail) {
-                a = reinterpret_cast<const double2*>(v.S[j])[i];
-                b = reinterpret_cast<const double2*>(v.Y[j])[i];
+                a = lb_load2(v.S[j], i);
+                b = lb_load2(v.Y[j], i);
             } else {
                 a = make_double2(v.S[j][n - 1], 0.0);
                 b = make_double2(v.Y[j][n - 1], 0.0);
@@ -101,16 +125,16 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_update_kernel(LbfgsVecs v, 
         double2 di = make_double2(c.cg * gi.x, c.cg * gi.y);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const double2 a = reinterpret_cast<const double2*>(v.S[j])[i], b = reinterpret_cast<const double2*>(v.Y[j])[i];
+            const double2 a = lb_load2(v.S[j], i), b = lb_load2(v.Y[j], i);
             di.x += c.cs[j] * a.x + c.cy[j] * b.x;
             di.y += c.cs[j] * a.y + c.cy[j] * b.y;
         }
         double2 xi = reinterpret_cast<double2*>(x)[i];
         xi.x += t * di.x;
         xi.y += t * di.y;
-        reinterpret_cast<double2*>(d)[i] = di;
+        lb_store2(d, i, di);
         reinterpret_cast<double2*>(x)[i] = xi;
-        reinterpret_cast<double2*>(g_prev)[i] = gi;
+        lb_store2(g_prev, i, gi);
         acc[0] += fabs(t * di.x) + fabs(t * di.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
