@@ -171,7 +171,7 @@ def test_configs_match_oracle_on_seeded_inputs(shape, cell):
 
 
 # ------------------------------------------------------------------------------- size-independent properties
-@pytest.mark.parametrize('n', [128, 256])
+@pytest.mark.parametrize('n', [128, 256, 512])
 def test_periodic_tiling_gives_extensive_energy_and_tiled_potential(n):
     """A 32^3 state tiled (n/32)^3 times on the (n/32)x cell: every term is extensive, so E scales by the
     tile count and the potential is the tiled 32^3 potential (needs no reference on the GPU box)."""
@@ -193,6 +193,14 @@ def test_periodic_tiling_gives_extensive_energy_and_tiled_potential(n):
         assert abs(EN[k] - r ** 3 * E32[k]) <= 2e-10 * max(1.0, abs(EN[k])), (k, EN[k], r ** 3 * E32[k])
     assert relerr(vN[:base, :base, :base].cpu().numpy(), v32) < V_RTOL
     assert relerr(vN[-base:, base:2 * base, -base:].cpu().numpy(), v32) < V_RTOL
+    # the stress is intensive: the tiled cell has the stress tensors of the 32^3 cell (every term, incl. WGC99)
+    bits = F.NativeTerms(['hartree', 'wgc99', 'pbe']).names
+    s32 = Engine((base,) * 3, DEV).set_cell(dev(box32)).set_terms(bits)
+    sN = engine_for((n,) * 3, DEV).set_cell(dev(synth.cubic_cell(n))).set_terms(bits)
+    sig32, sigN = s32.stress(dev(den32)), sN.stress(dev(synth.tile_periodic(den32, n)))
+    for k in sig32:
+        assert np.abs(sigN[k] - sig32[k]).max() <= 1e-9 * max(1e-6, np.abs(sig32[k]).max()), k
+    s32.close()
 
 
 def test_round_trip_and_linearity_256():
