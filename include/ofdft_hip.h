@@ -67,7 +67,9 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_GGA_K         (1u << 12)  /* Pauli part of a GGA kinetic functional, int tau_TF F(s): LuoKarasievTrickey
                                            functionals.py:309-333 (F = 1/cosh(1.3 s)) or PauliGaussian :336-403 with
                                            beta = lambda = sigma = 0 (F = exp(-mu s^2)); the vW part is OFDFT_VW */
-#define OFDFT_NTERMS        13
+#define OFDFT_VWGTF         (1u << 13)  /* local Pauli term of vWGTF1 / vWGTF2, int tau_TF G(n/n0), functionals.py:251-306;
+                                           n0 = round(N_e)/vol; the vW part is OFDFT_VW */
+#define OFDFT_NTERMS        14
 
 /* params[] slots for ofdft_set_terms (missing trailing slots keep their defaults) */
 #define OFDFT_P_WT_ALPHA    0   /* default 5/6 */
@@ -81,7 +83,8 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_P_GGAK_BETA   8   /* Pauli-Gaussian coefficients of q^2, -q s^2, s^4 (functionals.py:336-403); any non-zero one */
 #define OFDFT_P_GGAK_LAMBDA 9   /* makes the term depend on the reduced Laplacian q: evaluated by the unfused single-GPU     */
 #define OFDFT_P_GGAK_SIGMA  10  /* pipeline (one more c2r and r2c); not available slab-decomposed or for the stress          */
-#define OFDFT_NPARAMS       11
+#define OFDFT_P_VWGTF_KIND  11  /* 1 = vWGTF1 (default), 2 = vWGTF2 */
+#define OFDFT_NPARAMS       12
 
 /* ofdft_query selectors */
 #define OFDFT_Q_FFT_COUNT        0  /* 3-D FFTs executed by the last energy call              */
@@ -124,11 +127,11 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
  *     ofdft_dist_sumsq (closure form only) -> all-reduce -> c = N_e / (mean chi^2 vol)
  *     ofdft_dist_begin; for stage in 1..4, for chain in 0..1: [wait for the chain's previous all-to-all]
  *         ofdft_dist_stage(stage, chain) + all_to_all(bytes_per_peer)  (asynchronous if the transport allows);
- *     [wait for both] ofdft_dist_finish -> all-reduce of 12 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
+ *     [wait for both] ofdft_dist_finish -> all-reduce of 13 local sums -> ofdft_dist_energies; ofdft_dist_chi_grad.
  * Device-resident scalars (no host round trip before the final sums): pass local_sum_host = NULL to
  * ofdft_dist_sumsq, all-reduce scalars[15] in place (ofdft_dist_scalars), call ofdft_dist_begin with from_chi = 2
  * (the closure scale is then formed on the device), ofdft_dist_finish with local_sums_host = NULL, all-reduce
- * scalars[0..11] in place and copy them to the host once; ofdft_dist_chi_grad with cscale = 0 uses the device scale.
+ * scalars[0..12] in place and copy them to the host once; ofdft_dist_chi_grad with cscale = 0 uses the device scale.
  * With nranks == 1 the same calls work and every bytes_per_peer is 0.  These stand behind the same reference
  * interfaces as ofdft_energy_potential / ofdft_energy_grad_chi (system.py:830-838, functional_tools.py:9-31). */
 int  ofdft_create_dist(ofdft_ctx** out, int n0_global, int n1_global, int n2, int dtype, int device_id, int nranks, int rank);
@@ -137,9 +140,9 @@ int  ofdft_dist_begin(ofdft_ctx* ctx, const void* src_local_dev, int from_chi, d
                       const void* vext_local_dev, void* v_out_local_dev, void* stream);
 int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
                       void** recvbuf_dev);
-int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[12] or NULL*/, void* stream);
+int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[13] or NULL*/, void* stream);
 int  ofdft_dist_scalars(ofdft_ctx* ctx, void** scalars_dev /* 16 doubles owned by the context */);
-int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[12]*/, double* E_terms_host, double* vn_integral);
+int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[13]*/, double* E_terms_host, double* vn_integral);
 int  ofdft_dist_chi_grad(ofdft_ctx* ctx, const void* chi_local_dev, const void* v_local_dev, void* grad_local_dev,
                          double cscale, double mu, void* stream);
 

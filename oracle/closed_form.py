@@ -405,6 +405,22 @@ class Evaluator:
             fx = math.exp(En / Et)
             # d/dn [Et f(En/Et)] = vt f + Et f' (vn Et - En vt) / Et^2,  f = f' = exp
             return Ev + Et * fx, vv + vt * fx + fx * (vn - En / Et * vt)
+        if name in ('vwgtf1', 'vwgtf2'):                   # functionals.py:251-306
+            g = self.g
+            n0 = round(float(np.mean(n) * g.vol)) / g.vol
+            d = n / n0
+            if name == 'vwgtf1':
+                G = 0.9892 * d ** -1.2994
+                dG = -1.2994 * G / d
+            else:
+                a, b = 5.7001, 0.2563
+                th = np.tanh(a * d ** b - a)
+                elf = 0.5 * (1 + th)
+                G = np.sqrt(1 / elf - 1)
+                dG = -(0.5 * (1 - th * th) * a * b * d ** (b - 1)) / (2 * G * elf * elf)
+            tau = C_TF * n ** (5 / 3)
+            E1, v1 = self.vw(n)
+            return E1 + g.integral(G * tau), v1 + (5 / 3) * tau / n * G + tau * dG / n0
         if name in ('pgsl025', 'pgslr'):                   # Pauli-Gaussian with q-dependence (tools_for_tests.py:86-118)
             mu, be, la, si = (40 / 27, 0.25, 0.0, 0.0) if name == 'pgsl025' else (40 / 27, 0.25, 0.4, 0.2)
             g = self.g

@@ -386,6 +386,20 @@ def pauli_gaussian_full(mu, beta, lamb, sigma):
     return f
 
 
+def vwgtf(kind):
+    """functionals.py:251-306"""
+    def f(box, den):
+        vol = _vol(box)
+        n0 = round((torch.mean(den) * vol).detach().item()) / vol
+        d = den / n0
+        if kind == 1:
+            G = 0.9892 * d.pow(-1.2994)
+        else:
+            G = torch.sqrt(1 / (0.5 * (1 + torch.tanh(5.7001 * d.pow(0.2563) - 5.7001))) - 1)
+        return weizsaecker(box, den) + torch.mean(G * 0.3 * (3 * PI * PI) ** (2 / 3) * den ** (5 / 3)) * vol
+    return f
+
+
 def wt_style_exp(box, den):
     """functionals.py:728-782 with (alpha, beta, f) = (5/6, 5/6, exp)"""
     tf = thomas_fermi(box, den)
@@ -404,6 +418,7 @@ def term_table(vext=None):
         'chachiyo_c': chachiyo_correlation, 'pbe_x': pbe_exchange, 'pbe_c': pbe_correlation,
         'lkt': lkt, 'pg1': pauli_gaussian(1.0), 'pgs': pauli_gaussian(40 / 27), 'wts_exp': wt_style_exp,
         'pgsl025': pauli_gaussian_full(40 / 27, 0.25, 0.0, 0.0), 'pgslr': pauli_gaussian_full(40 / 27, 0.25, 0.4, 0.2),
+        'vwgtf1': vwgtf(1), 'vwgtf2': vwgtf(2),
     }
 
 

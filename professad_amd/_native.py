@@ -18,12 +18,12 @@ F64, F32 = 0, 1
 TERM_BITS = {
     'ion_electron': 1 << 0, 'hartree': 1 << 1, 'tf': 1 << 2, 'vw': 1 << 3, 'wt_nl': 1 << 4, 'wgc99_nl': 1 << 5,
     'lda_x': 1 << 6, 'pz_c': 1 << 7, 'pw_c': 1 << 8, 'chachiyo_c': 1 << 9, 'pbe_x': 1 << 10, 'pbe_c': 1 << 11,
-    'gga_k': 1 << 12,
+    'gga_k': 1 << 12, 'vwgtf': 1 << 13,
 }
 TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c',
-              'pbe_x', 'pbe_c', 'gga_k']
-NTERMS = 13
-NPARAMS = 11
+              'pbe_x', 'pbe_c', 'gga_k', 'vwgtf']
+NTERMS = 14
+NPARAMS = 12
 Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT = 0, 1, 2, 3, 4
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',

@@ -763,6 +763,7 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
     if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
     if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
     if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
+    if (mask & OFDFT_VWGTF) E_terms[13] = sums[9] * dV;
     *vn_int = sums[8] * dV;
     return 0;
 }
@@ -781,7 +782,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
 
     double nsum = 0.0;
-    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL))
+    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF))
         if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
     const double nel = nsum * inv_n * c->vol;       // mean(den) * vol   functionals.py:634,646,952
 
@@ -791,6 +792,8 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
     ca.v_out = v_out;
     ca.npts = npts;
     ca.mask = mask;
+    ca.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
+    ca.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nel) : 0.0;      // n0 = round(N_e) / vol (functionals.py:268-270)
     double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
 
     cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
@@ -933,7 +936,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
 
     double nsum = 0.0;
-    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL))
+    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF))
         if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
     const double nel = nsum * inv_n * c->vol;
 
@@ -943,6 +946,8 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
     ca.v_out = v_out;
     ca.npts = npts;
     ca.mask = mask;
+    ca.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
+    ca.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nel) : 0.0;      // n0 = round(N_e) / vol (functionals.py:268-270)
     double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx* s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     const char* sn[5] = {"s0", "s1", "s2", "s3", "s4"};
@@ -1137,7 +1142,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
     const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0, 0.0, 40.0 / 27.0,
-                                            0.0, 0.0, 0.0};
+                                            0.0, 0.0, 0.0, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     hipError_t e = hipSetDevice(device_id);
     // partial-sum rows: the pointwise kernels use <= kRedBlocks blocks, the z kernels one block per row group
@@ -1253,7 +1258,7 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     double vn;
     if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
         double nel = 0.0;
-        if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL)) {
+        if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF)) {
             double nsum;
             if (int rc = device_sum(c, (const double*)den, false, &nsum, st)) return rc;
             nel = nsum / (double)c->npts * c->vol;

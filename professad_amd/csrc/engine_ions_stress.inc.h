@@ -244,15 +244,18 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             if (int rc = irfftn_internal(c, s3, gz, invN, st)) return rc;
         }
     }
-    if (mask & (OFDFT_TF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | kGgaAny)) {
+    if (mask & (OFDFT_TF | OFDFT_VWGTF | OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C | kGgaAny)) {
         const int blocks = grid_for(npts, kRedThreads, kRedBlocks);
         double r[kStressRealScalars];
         OFDFT_LAUNCH(c, st, "stress_real", stress_real_kernel, dim3(blocks), dim3(kRedThreads), 0, den, (const double*)gx,
-                     (const double*)gy, (const double*)gz, npts, mask, gga_sel(c), c->d_partial);
+                     (const double*)gy, (const double*)gz, npts, mask, gga_sel(c),
+                     (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nsum * c->dV) : 0.0, (int)c->params[OFDFT_P_VWGTF_KIND],
+                     c->d_partial);
         if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
         const double zero6[6] = {0, 0, 0, 0, 0, 0};
         const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
         if (mask & OFDFT_TF) sym_store(sig + 9 * 2, zero6, -2.0 / 3.0 * ctf * r[0] * invN);      // tools_for_tests.py:241-243
+        if (mask & OFDFT_VWGTF) sym_store(sig + 9 * 13, zero6, -2.0 / 3.0 * r[27] * invN);      // E ~ J^(-2/3) at fixed n / n0
         if (mask & OFDFT_LDA_X) sym_store(sig + 9 * 6, zero6, r[1] * invN);                    // :367-370
         int nc = 0;
         for (int b = 7; b <= 9; ++b) nc += (mask >> b) & 1;

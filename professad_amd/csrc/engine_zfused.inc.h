@@ -129,6 +129,7 @@ void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pb
     if (mask & OFDFT_PBE_X) E_terms[10] = pbe_sums[0] * dV;
     if (mask & OFDFT_PBE_C) E_terms[11] = pbe_sums[1] * dV;
     if (mask & OFDFT_GGA_K) E_terms[12] = pbe_sums[2] * dV;
+    if (mask & OFDFT_VWGTF) E_terms[13] = sums[9] * dV;
     *vn_int = sums[8] * dV;
 }
 
@@ -216,6 +217,8 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
         r.za.v_out = r.v_out;
         r.za.mask = mask;
         r.za.inv_n = 1.0 / (double)c->npts_g;
+        r.za.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
+        r.za.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(r.nel) : 0.0;   // functionals.py:268-270
         r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
         r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
         if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");

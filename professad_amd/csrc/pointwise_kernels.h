@@ -604,11 +604,36 @@ struct CombineArgs {
     unsigned mask;
     double wt_alpha, wt_beta, wt_nbar_pa;     // nbar^alpha
     double wgc_alpha, wgc_beta, nref;
+    double gtf_inv_n0;   // vWGTF: 1 / n0, n0 = round(N_e) / vol (functionals.py:268-270)
+    int gtf_kind;        // 1 = vWGTF1, 2 = vWGTF2
     int wt_is_56;        // alpha = beta = 5/6: n^(-1/6) = 1/sqrt(cbrt n), no pow
     int wgc_sum_53;      // alpha + beta = 5/3: n^(alpha-1) = 1/(cbrt(n) n^(beta-1)), one pow instead of two
 };
-// partial scalars: 0 ion-electron, 1 hartree, 2 tf, 3 vw, 4 wt-nl, 5 wgc-nl, 6 lda-x, 7 local-c, 8 sum(v*n)
-constexpr int kCombineScalars = 9;
+// partial scalars: 0 ion-electron, 1 hartree, 2 tf, 3 vw, 4 wt-nl, 5 wgc-nl, 6 lda-x, 7 local-c, 8 sum(v*n), 9 vWGTF
+constexpr int kCombineScalars = 10;
+
+// Pauli enhancement factor of vWGTF1 / vWGTF2 and its derivative with respect to d = n / n0 (functionals.py:251-306)
+__device__ __forceinline__ void vwgtf_factor(double d, int kind, double& G, double& dG) {
+    if (kind == 1) {
+        G = 0.9892 * pow(d, -1.2994);
+        dG = -1.2994 * G / d;
+    } else {
+        const double a = 5.7001, b = 0.2563;
+        const double db = pow(d, b), th = tanh(a * db - a);
+        const double elf = 0.5 * (1.0 + th);
+        const double delf = 0.5 * (1.0 - th * th) * a * b * db / d;
+        G = sqrt(1.0 / elf - 1.0);
+        dG = -delf / (2.0 * G * elf * elf);
+    }
+}
+// e = G tau_TF and its potential d e / d n at one point
+__device__ __forceinline__ void vwgtf_point(double n, double n13, double ctf, double inv_n0, int kind, double& e, double& v) {
+    double G, dG;
+    vwgtf_factor(n * inv_n0, kind, G, dG);
+    const double tau = ctf * n13 * n13 * n;
+    e = G * tau;
+    v = (5.0 / 3.0) * ctf * n13 * n13 * G + tau * dG * inv_n0;
+}
 
 // one grid point of the combine: all inputs already in registers
 struct CombinePoint {
@@ -664,6 +689,12 @@ __device__ __forceinline__ double combine_point(const CombineArgs& a, const Comb
         v += x.vx + x.vc;
     }
     if (a.mask & (7u << 10)) v += p.dfdn - 2.0 * p.div;   // PBE / GGA kinetic  tools_for_tests.py:168-170
+    if (a.mask & (1u << 13)) {                          // vWGTF1 / 2  functionals.py:251-306
+        double e, ve;
+        vwgtf_point(n, n13, ctf, a.gtf_inv_n0, a.gtf_kind, e, ve);
+        acc[9] += e;
+        v += ve;
+    }
     acc[8] += v * n;
     return v;
 }

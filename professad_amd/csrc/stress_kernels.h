@@ -9,7 +9,7 @@
 namespace ofdft {
 
 constexpr int kStressSpecScalars = 7;
-constexpr int kStressRealScalars = 27;
+constexpr int kStressRealScalars = 28;
 
 __device__ __forceinline__ double half_weight(const SpecGeom& g, int z) {
     return (z == 0 || ((g.n2 & 1) == 0 && z == g.n2 / 2)) ? 1.0 : 2.0;
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(kRedThreads) void stress_ion_kernel(const cplx* __r
 
 // real-space sums: [0] n^(5/3); [1] LDA-x (e - v n); [2] LDA-c (e - v n); PBE-x: [3..8] d_i n d_j n df/dg, [9] |grad n|^2 df/dg,
 // [10] f - n df/dn; PBE-c: [11..16], [17], [18]; GGA kinetic (Pauli part): [19..24], [25], [26]
-// (tools_for_tests.py:241-243, 367-472; the kinetic GGA has the same form, :46-118)
+// (tools_for_tests.py:241-243, 367-472; the kinetic GGA has the same form, :46-118); [27] G tau_TF of vWGTF
 __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* __restrict__ n, const double* __restrict__ gx,
                                                                   const double* __restrict__ gy, const double* __restrict__ gz,
                                                                   long long npts, unsigned mask, GgaSel sel,
-                                                                  double* __restrict__ partial) {
+                                                                  double gtf_inv_n0, int gtf_kind, double* __restrict__ partial) {
     double acc[kStressRealScalars];
 #pragma unroll
     for (int i = 0; i < kStressRealScalars; ++i) acc[i] = 0.0;
@@ -184,6 +184,11 @@ __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
         const double d = n[i];
         if (mask & OFDFT_TF) acc[0] += cbrt(d * d) * d;
+        if (mask & OFDFT_VWGTF) {
+            double e, v;
+            vwgtf_point(d, cbrt(d), 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi), gtf_inv_n0, gtf_kind, e, v);
+            acc[27] += e;
+        }
         if (mask & (OFDFT_LDA_X | OFDFT_PZ_C | OFDFT_PW_C | OFDFT_CHACHIYO_C)) {
             const XcLocal r = lda_point(d, mask);
             acc[1] += r.ex - r.vx * d;

@@ -322,6 +322,8 @@ struct ZCombineArgs {
     double inv_n;
     double wt_alpha, wt_beta, wt_nbar_pa;
     double wgc_alpha, wgc_beta, nref;
+    double gtf_inv_n0;
+    int gtf_kind;
     int wt_is_56, wgc_sum_53;
 };
 
@@ -499,6 +501,14 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
             vacc[q].x += (5.0 / 3.0) * ctf * c0 * c0;
             vacc[q].y += (5.0 / 3.0) * ctf * c1 * c1;
+        }
+        if (a.mask & (1u << 13)) {                       // vWGTF1 / 2  functionals.py:251-306
+            double e0, v0, e1, v1;
+            vwgtf_point(n[q].x, cbrt(n[q].x), ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
+            vwgtf_point(n[q].y, cbrt(n[q].y), ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
+            acc[9] += e0 + e1;
+            vacc[q].x += v0;
+            vacc[q].y += v1;
         }
         if (a.mask & (0xFu << 6)) {                      // local XC
             const XcLocal x0 = lda_point(n[q].x, a.mask), x1 = lda_point(n[q].y, a.mask);

@@ -24,7 +24,7 @@ import torch.distributed as dist
 from . import _native as N
 from .engine import Engine
 
-NSUMS = 12   # 9 combine scalars + GGA sums (PBE exchange, correlation, kinetic GGA)
+NSUMS = 13   # 10 combine scalars + GGA sums (PBE exchange, correlation, kinetic GGA)
 SUMSQ_SLOT = 15   # slot of sum chi^2 in the context's device-resident scalar block (16 doubles)
 
 
@@ -127,7 +127,7 @@ class HipStages(Engine):
         super().__init__(shape, device, nranks=nranks, rank=rank)
         p = C.c_void_p(0)
         self._check(self.lib.ofdft_dist_scalars(self._ctx, C.byref(p)), 'ofdft_dist_scalars')
-        # 16 device-resident doubles owned by the context: [0..11] local sums of an evaluation, [15] sum chi^2
+        # 16 device-resident doubles owned by the context: [0..12] local sums of an evaluation, [15] sum chi^2
         self.device_scalars = torch.as_tensor(_RawDeviceBuffer(p.value, 16, '<f8'), device=self.device)
         self._xbuf = {}
 
@@ -164,7 +164,7 @@ class HipStages(Engine):
         return ex
 
     def finish(self, on_device=False):
-        """the 11 local sums: as a numpy vector, or left in device_scalars[0:12] without a host sync"""
+        """the 11 local sums: as a numpy vector, or left in device_scalars[0:13] without a host sync"""
         if on_device:
             self._check(self.lib.ofdft_dist_finish(self._ctx, None, self._stream()), 'ofdft_dist_finish')
             return None

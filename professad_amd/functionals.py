@@ -239,6 +239,16 @@ def get_functional_derivative(box_vecs, den, functional):
     return g / (torch.abs(torch.linalg.det(box_vecs)) / den.numel())
 
 
+def vWGTF1(box_vecs, den):
+    """functionals.py:251-274"""
+    return _evaluate(box_vecs, den, ('vw', 'vwgtf'), (('vwgtf_kind', 1.0),))
+
+
+def vWGTF2(box_vecs, den):
+    """functionals.py:277-306"""
+    return _evaluate(box_vecs, den, ('vw', 'vwgtf'), (('vwgtf_kind', 2.0),))
+
+
 def LuoKarasievTrickey(box_vecs, den):
     """functionals.py:309-333 (vW + int tau_TF / cosh(1.3 s))"""
     return _evaluate(box_vecs, den, ('vw', 'gga_k'), (('ggak_kind', 0.0),))

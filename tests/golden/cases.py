@@ -26,7 +26,8 @@ PER_TERM_CASES = ['g16r', 'g16s', 'g17r', 'g18t']
 FUSED_CASES = ['g16r', 'g17r', 'g20t', 'g32r', 'gmix']
 
 SINGLE_TERMS = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wt', 'perrot', 'sm', 'wgc98',
-                'wgc99', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'lkt', 'pg1', 'pgs', 'wts_exp', 'pgsl025', 'pgslr']
+                'wgc99', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'lkt', 'pg1', 'pgs', 'wts_exp', 'pgsl025', 'pgslr',
+                'vwgtf1', 'vwgtf2']
 
 # fused configurations of BASELINE.json (SURVEY §8d term sets)
 CONFIGS = {

@@ -92,6 +92,7 @@ def reference_terms(vext_t):
         'wts_exp': F.WangTeterStyleFunctional(init_args=(5 / 6, 5 / 6, torch.exp)),
         'pgsl025': F.PauliGaussian(),
         'pgslr': F.PauliGaussian(init_args=(40 / 27, 0.25, 0.4, 0.2)),
+        'vwgtf1': F.vWGTF1, 'vwgtf2': F.vWGTF2,
     }, wgc99
 
 
@@ -320,7 +321,7 @@ if '--ions' in sys.argv:
     gen_ions()
 
 
-STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99', 'lkt', 'pgs']
+STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99', 'lkt', 'pgs', 'vwgtf1', 'vwgtf2']
 
 
 def gen_stress():

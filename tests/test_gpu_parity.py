@@ -70,6 +70,7 @@ _REF_NAME = {
     'lkt': F.LuoKarasievTrickey, 'pg1': F.PauliGaussian((1.0, 0.0, 0.0, 0.0)), 'pgs': F.PauliGaussian((40 / 27, 0.0, 0.0, 0.0)),
     'wts_exp': F.WangTeterStyleFunctional((5 / 6, 5 / 6, torch.exp)),
     'pgsl025': F.PauliGaussian(), 'pgslr': F.PauliGaussian((40 / 27, 0.25, 0.4, 0.2)),
+    'vwgtf1': F.vWGTF1, 'vwgtf2': F.vWGTF2,
 }
 
 
@@ -441,8 +442,9 @@ def test_stress_matches_reference_get_stress(case):
     g = load('stress.npz')
     box, den, vext, chi, n_elec = cases.make_inputs(case)
     eng = Engine(den.shape, DEV).set_cell(dev(box))
-    for name, bits in list(_STRESS_BITS.items()) + [('pgs', ['vw', 'gga_k'])]:
-        sig = eng.set_terms(bits, {'ggak_kind': 1.0 if name == 'pgs' else 0.0}).stress(dev(den))
+    for name, bits in list(_STRESS_BITS.items()) + [('pgs', ['vw', 'gga_k']), ('vwgtf1', ['vw', 'vwgtf']), ('vwgtf2', ['vw', 'vwgtf'])]:
+        sig = eng.set_terms(bits, {'ggak_kind': 1.0 if name == 'pgs' else 0.0,
+                                   'vwgtf_kind': 2.0 if name == 'vwgtf2' else 1.0}).stress(dev(den))
         tot = sum(sig[b] for b in bits)
         ref = g['%s_%s' % (case, name)]
         assert np.abs(tot - ref).max() <= 2e-10 * np.abs(ref).max(), (case, name, np.abs(tot - ref).max() / np.abs(ref).max())
