@@ -82,7 +82,7 @@ int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipS
         *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
         const int nb = *blocks_out / nchunks;                                                                     \
         gq.blk0 = chunk * nb;                                                                                     \
-        if (a.v_part)                                                                                             \
+        if (a.v_part || !(a.mask & OFDFT_WGC99_NL))   /* no inline WGC99 section needed: the lean instantiation */  \
             OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, false>), dim3(nb), dim3(256),          \
                          (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
         else                                                                                                      \
