@@ -279,6 +279,8 @@ class DistEngine:
 
     def set_cell(self, box_vecs):
         self.stages.set_cell(box_vecs)
+        self._box_np = np.ascontiguousarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64).reshape(9)
+        self._box_c = self._box_np.ctypes.data_as(C.POINTER(C.c_double))
         self._vol = float(abs(np.linalg.det(np.asarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64))))
         return self
 
@@ -299,5 +301,34 @@ class DistEngine:
     def query(self, what):
         return self.stages.query(what)
 
+    # ---- once-per-geometry-step quantities (stress, ion forces): not slab-decomposed.  The density is all-gathered
+    # (one grid-sized message per step, against 23 spectra per energy evaluation) and every rank runs the single-GPU
+    # routines on the full grid -- redundant work, no further communication, identical results on all ranks.
+    def gather(self, slab):
+        """this rank's x-slab -> the full grid on every rank"""
+        slab = self.stages._grid_tensor(slab, 'slab')
+        if not self.comm.active:
+            return slab
+        if self.comm.backend == 'nccl':
+            full = torch.empty(self.plan.shape, dtype=slab.dtype, device=slab.device)
+            dist.all_gather_into_tensor(full, slab, group=self.comm.group)
+            return full
+        parts = [torch.empty(self.plan.local_shape, dtype=slab.dtype) for _ in range(self.comm.nranks)]
+        dist.all_gather(parts, slab.cpu(), group=self.comm.group)
+        return torch.cat(parts).to(slab.device)
+
+    def _full_engine(self):
+        if getattr(self, '_full', None) is None:
+            self._full = Engine(self.plan.shape, self.stages.device)
+        self._full._box_key = None
+        self._full.lib.ofdft_set_cell(self._full._ctx, self._box_c)
+        return self._full
+
+    def stress(self, den_slab, names, params=None):
+        """per-term stress tensors of the full system (see Engine.stress) from this rank's density slab"""
+        return self._full_engine().set_terms(names, params).stress(self.gather(den_slab))
+
     def close(self):
         self.stages.close()
+        if getattr(self, '_full', None) is not None:
+            self._full.close()

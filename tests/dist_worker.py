@@ -60,6 +60,15 @@ def main():
                 dv=float(np.abs(vfull - vr.cpu().numpy()).max() / np.abs(vr.cpu().numpy()).max()),
                 ffts=eng.query(0), ffts_ref=ref.query(0))
             ref.close()
+    # stress from a density slab (all-gather + full-grid routine on every rank) vs one GPU
+    bits = NativeTerms(['hartree', 'wgc99', 'pbe']).names
+    sd = eng.stress(t(plan.scatter(den)), bits)
+    if rank == 0:
+        ref = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(bits)
+        sr = ref.stress(t(den))
+        worst['stress'] = dict(dE=max(float(np.abs(sd[k] - sr[k]).max()) for k in sr), dE2=0.0, dmu=0.0, dg=0.0, dv=0.0,
+                               ffts=0, ffts_ref=0)
+        ref.close()
     # density optimisation over slabs (fused L-BFGS sweeps on each rank's slab, all-reduced scalars) vs one GPU
     if shape == (32, 32, 32):
         from professad_amd.optimize import optimize_density
