@@ -214,7 +214,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 /* OFDFT_OPT_SIDE_STREAM: 1 (default) = run the nonlocal-KEDF chain of the z-fused pipeline on a second HIP stream so
  * that it overlaps the Hartree/vW/PBE chain (they only meet in the combine kernel); 0 = everything on the caller's stream. */
 #define OFDFT_OPT_XCHUNKS     2   /* z kernels + the y passes next to them walk the grid in x chunks: 0 = automatic (default, ~100 MB of spectra per chunk), 1 = off, 2..64 = count for six spectra */
-#define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default), 4 PBE loop, 8 combine loop */
+#define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default: measured -4 %), 4 PBE loop, 8 combine loop, 16 WGC99 x pass + y-inverse by kz blocks (all three measured neutral or slower at 256^3) */
 #define OFDFT_OPT_SPLIT_COMBINE 4 /* 1 (default): with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream */
 #define OFDFT_OPT_BLUESTEIN 5     /* 1 (default): extents that are not powers of two (<= 512) use chirp-z line transforms; 0: plain DFT kernels */
 #define OFDFT_OPT_SIDE_STREAM 1

@@ -230,8 +230,10 @@ int launch_cpass_t(ofdft_ctx* c, const ArrList& arrs, int narr, const LineMap& m
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     using Cfg = PassCfg<LEN>;
-    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, main, rem, mb,
+    LineMap mm = main;
+    mm.blk0 = main.blk0 / Cfg::LPW;                     // line offset -> workgroup offset
+    const int mb = (main.nlines - main.blk0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, mm, rem, mb,
                  c->g.main_count, tw);
     return 0;
 }
@@ -253,10 +255,18 @@ void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
 }
 
 // line pass over `narr` spectra in ONE launch; cx > 0 restricts a y pass to the x planes [x0, x0 + cx)
+// kb1 > kb0 restricts a y pass to the kz blocks [kb0, kb1) (the remainder planes ride with the last range)
 template <bool INV>
-int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0) {
+int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0,
+                         int kb0 = 0, int kb1 = 0) {
     LineMap main, rem;
     pass_maps(c, axis, main, rem);
+    if (kb1 > kb0 && axis == 1) {
+        const int per_block = c->g.n0 * 8;              // lines per kz block
+        main.blk0 = kb0 * per_block;                    // converted to workgroups below
+        main.nlines = kb1 * per_block;
+        if (kb1 != c->g.nzm / 8) rem.nlines = 0;
+    }
     if (cx > 0 && axis == 1) {
         main.gc = rem.gc = cx;
         main.gn = rem.gn = c->g.n0;
@@ -561,7 +571,7 @@ int inv_yz(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) 
 // where the x pass finds its spectra: {} = y-slab arrays in the block-8 layout (one GPU); otherwise the exchange
 // buffers of the slab-decomposed path (x-major records, see XchgGeom): element strides along x of the inputs, the
 // outputs and the k-point tables
-struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; };
+struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; int kb0 = 0, kb1 = 0; };   // kb1 > kb0: kz blocks [kb0, kb1) only
 
 template <int LEN, int NIN, int NOUT, class Mix>
 int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
@@ -582,7 +592,15 @@ int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout
         pass_maps(c, 0, main, rem);
     }
     main.lf = rem.lf = Cfg::LPW;
-    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    int line0 = 0;
+    if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
+        const int per_block = c->gx.n1 * 8;
+        line0 = lay.kb0 * per_block;
+        main.nlines = lay.kb1 * per_block;
+        if (lay.kb1 != c->gx.nzm / 8) rem.nlines = 0;
+    }
+    main.blk0 = line0 / Cfg::LPW;
+    const int mb = (main.nlines - line0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
     OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
                  gk, tw, mix, XfStride{lay.se_out, lay.tse});
     return 0;
@@ -1500,7 +1518,7 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             c->split_combine = value != 0.0;
             return OFDFT_OK;
         case OFDFT_OPT_XCHUNK_MASK:
-            c->xchunk_mask = (int)value & 15;
+            c->xchunk_mask = (int)value & 31;
             return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);

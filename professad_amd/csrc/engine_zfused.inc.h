@@ -160,6 +160,7 @@ struct ZRun {
     //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
+    bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
@@ -220,6 +221,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
         r.za.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
         r.za.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(r.nel) : 0.0;   // functionals.py:268-270
         r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
+        r.wgc_yinv_done = false;
         r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
         if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
         if (r.has_h || r.has_g)
@@ -390,13 +392,30 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
         }
         if (r.has_wgc) {
             const MixWgc mix{(double*)c->ws["t:wgc"].p};
+            // kz-chunked form (one GPU): the fused x pass of a range of kz blocks is followed at once by the y-inverse
+            // of the same range, which then reads the x pass' output from the Infinity Cache
+            const int nb = c->g.nzm / 8;
+            int nkz = (!dx && (c->xchunk_mask & 16) && c->xchunks != 1) ? chunks_for(c, 6, 16) : 1;
+            while (nkz > 1 && nb % nkz) nkz >>= 1;
+            r.wgc_yinv_done = nkz > 1;
             for (int half = 0; half < 2; ++half) {
                 XfIo io{};
                 for (int i = 0; i < 3; ++i) {
                     io.in[i] = in_of(r.sw[3 * half + i]);
                     io.out[i] = out_of(r.sw[3 * half + i]);
                 }
-                if ((rc = xfused<3, 3>(c, io, mix, half == 0 ? sb : sc, "xfused_wgc", lay))) return rc;
+                hipStream_t hs = half == 0 ? sb : sc;
+                if (nkz == 1) {
+                    if ((rc = xfused<3, 3>(c, io, mix, hs, "xfused_wgc", lay))) return rc;
+                    continue;
+                }
+                for (int ch = 0; ch < nkz; ++ch) {
+                    XfLayout lk = lay;
+                    lk.kb0 = ch * (nb / nkz);
+                    lk.kb1 = (ch + 1) * (nb / nkz);
+                    if ((rc = xfused<3, 3>(c, io, mix, hs, "xfused_wgc", lk))) return rc;
+                    if ((rc = fast_axis_pass_multi<true>(c, 1, r.sw + 3 * half, 3, hs, 0, 0, lk.kb0, lk.kb1))) return rc;
+                }
             }
         }
     }
@@ -424,7 +443,10 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
         const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2];
-        if (is_g ? pbe_chunked : chunked) {
+        const bool is_w = sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2] || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
+        if (is_w && r.wgc_yinv_done) {
+            // already y-inverted next to the x pass
+        } else if (is_g ? pbe_chunked : chunked) {
             if (!is_g) r.deferred.push_back(sp);
         } else if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) {
             return rc;

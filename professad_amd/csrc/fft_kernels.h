@@ -59,6 +59,7 @@ struct LineMap {
     // optional restriction to a range of an outer index (x-chunked y passes): group G = L / d enumerates (b, xl) with
     // xl < gc; it stands for group (G / gc) * gn + g0 + G % gc of the full array.  gc == 0: no remapping.
     int gc = 0, gn = 0, g0 = 0;
+    int blk0 = 0;   // first workgroup (in units of the kernel's lines-per-workgroup) of a launch that covers a line range
 };
 
 template <int LEN> struct PassCfg {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
     const bool in_rem = (int)blockIdx.x >= main_blocks;
     const LineMap m = in_rem ? m_rem : m_main;
     if (in_rem) data += rem_offset;
-    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x + m.blk0;
     const int l_lo = tid % m.lf;
     const int j = (tid / m.lf) % P;
     const int l = (tid / (m.lf * P)) * m.lf + l_lo;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
     const bool in_rem = (int)blockIdx.x >= main_blocks;
     const LineMap m = in_rem ? m_rem : m_main;
     cplx* data = arrs.p[a] + (in_rem ? rem_offset : 0);
-    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x + m.blk0;
     const int l_lo = tid % m.lf;
     const int j = (tid / m.lf) % P;
     const int l = (tid / (m.lf * P)) * m.lf + l_lo;
@@ -602,6 +603,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
         // the 8 XCDs, so blocks b and b+8 share an L2) -- speed only, never correctness
         bid = (bid & ~15) + ((bid & 7) << 1) + ((bid >> 3) & 1);
     }
+    if (!is_rem) bid += m.blk0;          // launch over a range of kz blocks (multiple of 16 workgroups)
     const long long L = (long long)bid * LPW + l;
     const bool valid = L < m.nlines;
     const long long base = valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0;

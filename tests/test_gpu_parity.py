@@ -299,7 +299,7 @@ def test_all_pipelines_agree(shape):
             assert abs(E0[k] - res[0][0][k]) <= 1e-13 * max(1.0, abs(E0[k])) and abs(Ec0[k] - res[0][2][k]) <= 1e-13 * max(1.0, abs(Ec0[k]))
         assert relerr(v0.cpu().numpy(), res[0][1]) < 1e-13 and relerr(g0.cpu().numpy(), res[0][4]) < 1e-13
         res[0] = (E0, v0.cpu().numpy(), Ec0, mu0, g0.cpu().numpy(), eng.query(0))
-        eng.set_option(3, 15)                          # every stage pair chunked
+        eng.set_option(3, 31)                          # every stage pair chunked (x ranges and kz-block ranges)
         for nch in (1, 2, 8):
             eng.set_option(2, nch)
             E, v = eng.energy_potential(dev(den), dev(vext))
