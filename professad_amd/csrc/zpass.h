@@ -213,7 +213,7 @@ struct PowersArgs {
     int sum53;       // e0 + e1 == 5/3: n^e1 = n^(5/3) / n^e0
 };
 template <int M, int E>
-__global__ __launch_bounds__(256, 3) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
+__global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
                                                         const cplx* __restrict__ twM, const cplx* __restrict__ twN) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const ZLane<M, E> z(g, lds);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void zf_powers_kernel(DenSrc ds, PowersArgs
 // flux_j = df/d|grad n|^2 * d_j n -> spectra again, in place.  (functionals.py:1597-1618;
 // tests/tools_for_tests.py:155-207)
 template <int M, int E>
-__global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                                    cplx* __restrict__ gz, double* __restrict__ dfdn, double inv_n,
                                                    GgaSel sel, SpecGeom g, const cplx* __restrict__ twM,
                                                    const cplx* __restrict__ twN, double* __restrict__ partial) {
@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256, 2) void zpbe_kernel(DenSrc ds, cplx* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// (8-point lanes at M = 512 -- rows of 1024 -- need more than 256 registers in the fused kernels: those instantiations
+// take a whole SIMD's register file, one wave per SIMD, instead of spilling ~1 KB per thread)
 // final stage: every convolution spectrum of a row -> real space -> potential and energy integrands.
 struct ZCombineArgs {
     DenSrc ds;
@@ -386,7 +388,7 @@ __device__ __forceinline__ double wgc_row_section(const cplx (&n)[E], cplx (&vac
 }
 
 template <int M, int E, bool WGC_INLINE>
-__global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
                                                          const cplx* __restrict__ twN, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const ZLane<M, E> z(g, lds);
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void zi_combine_kernel(ZCombineArgs a, Spec
 // The WGC99 part of the combine on its own (split form): chi|n row + the six result spectra -> v_part rows and the
 // energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
 template <int M, int E>
-__global__ __launch_bounds__(256, 2) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
                                                        const cplx* __restrict__ twM, const cplx* __restrict__ twN,
                                                        double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
