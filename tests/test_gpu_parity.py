@@ -556,3 +556,26 @@ def test_generic_extent_paths_agree():
         res[opt] = eng.irfftn(yk).cpu().numpy()
         assert relerr(res[opt], x) < 1e-13, opt
     eng.close()
+
+
+def test_fcc_aluminium_end_to_end_against_profess4_value():
+    """The reference's own end-to-end anchor (tests/test_match_profess4.py:12-24): fcc-Al primitive cell, 18^3 grid,
+    IonIon + IonElectron + Hartree + WangTeter + PBE, density optimised to ntol = 1e-7 -> -57.183329401794985 eV
+    (PROFESS 4.0, atol 1e-4).  Here every piece is native: ionic potential from the recpot table, the closure on a
+    non power-of-two grid (chirp-z transforms), the device L-BFGS, and the ion-ion sum."""
+    from professad_amd.ions import ion_ion, ionic_potential, recpot_table
+    from professad_amd.optimize import EV_PER_HA, optimize_density
+    g = load('ions.npz')
+    tab = recpot_table(g['recpot_raw'], float(g['recpot_kmax']))
+    box = 4.050 / 0.529177210903 * np.array([[0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]])
+    frac = np.zeros((1, 3))
+    shape = (18, 18, 18)
+    eng = Engine(shape, DEV).set_cell(dev(box))
+    vext = ionic_potential(eng, box, [(frac, tab)])
+    eng.set_terms(F.NativeTerms(['ion_electron', 'hartree', 'wt', 'pbe']).names)
+    res = optimize_density(eng, float(tab[2]), vext, volume=abs(np.linalg.det(box)), ntol=1e-7)
+    assert res['converged']
+    E_ii, _, _ = ion_ion(eng, box, frac, [float(tab[2])])
+    E_eV = (res['E_Ha'] + E_ii) * EV_PER_HA
+    assert abs(E_eV - -57.183329401794985) < 1e-4, E_eV
+    eng.close()
