@@ -358,3 +358,29 @@ def gen_stress():
 
 if __name__ == '__main__' and '--stress' in sys.argv:
     gen_stress()
+
+
+def gen_recpots():
+    """Parsed tables of the recpot DATA files the reference's tests hold (tests/potentials/*.recpot), converted exactly as
+    interpolate_recpot does (ion_utils.py:62-73, before the Coulomb tail is added): raw values [Ha bohr^3], k_max [1/bohr]."""
+    import professad.ion_utils as IU
+    out = {}
+    for tag, path in (('al', '/root/reference/tests/potentials/al.gga.recpot'), ('li', '/root/reference/tests/potentials/li.gga.recpot')):
+        pot = []
+        with open(path) as f:
+            for line in f:
+                if 'END COMMENT' in line:
+                    break
+            f.readline()
+            k_max = float(f.readline()) * IU.bohr
+            for line in f:
+                if len(line.split()) == 3:
+                    pot += line.split()
+        out[tag + '_raw'] = np.asarray(pot, dtype=np.float64) * IU.pot_conv_factor
+        out[tag + '_kmax'] = np.float64(k_max)
+    np.savez_compressed(os.path.join(HERE, 'recpots.npz'), **out)
+    print('recpots.npz')
+
+
+if __name__ == '__main__' and '--recpots' in sys.argv:
+    gen_recpots()

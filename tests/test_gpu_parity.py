@@ -579,3 +579,23 @@ def test_fcc_aluminium_end_to_end_against_profess4_value():
     E_eV = (res['E_Ha'] + E_ii) * EV_PER_HA
     assert abs(E_eV - -57.183329401794985) < 1e-4, E_eV
     eng.close()
+
+
+def test_bcc_lithium_end_to_end_against_profess4_value():
+    """second anchor of tests/test_match_profess4.py:26-37: bcc-Li, 18^3, IonIon + IonElectron + Hartree + SmargiassiMadden
+    + PBE -> -14.741886997024537 eV (PROFESS 4.0, atol 1e-4)"""
+    from professad_amd.ions import ion_ion, ionic_potential, recpot_table
+    from professad_amd.optimize import EV_PER_HA, optimize_density
+    g = load('recpots.npz')
+    tab = recpot_table(g['li_raw'], float(g['li_kmax']))
+    assert tab[2] == 1
+    box = 3.48 / 0.529177210903 * np.eye(3)
+    frac = np.array([[0.0, 0.0, 0.0], [0.5, 0.5, 0.5]])
+    eng = Engine((18, 18, 18), DEV).set_cell(dev(box))
+    vext = ionic_potential(eng, box, [(frac, tab)])
+    eng.set_terms(['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'pbe_x', 'pbe_c'], {'wt_alpha': 0.5, 'wt_beta': 0.5})
+    res = optimize_density(eng, 2.0, vext, volume=abs(np.linalg.det(box)), ntol=1e-7)
+    assert res['converged']
+    E_ii, _, _ = ion_ion(eng, box, frac, [1.0, 1.0])
+    assert abs((res['E_Ha'] + E_ii) * EV_PER_HA - -14.741886997024537) < 1e-4
+    eng.close()
