@@ -328,6 +328,20 @@ class DistEngine:
         """per-term stress tensors of the full system (see Engine.stress) from this rank's density slab"""
         return self._full_engine().set_terms(names, params).stress(self.gather(den_slab))
 
+    def ion_electron_forces(self, den_slab, species, pme_order=None):
+        """ion-electron forces of the full system (see ions.ion_electron_forces) from this rank's density slab"""
+        from .ions import ion_electron_forces
+        return ion_electron_forces(self._full_engine(), self._box_np.reshape(3, 3), self.gather(den_slab), species, pme_order)
+
+    def ion_electron_stress(self, den_slab, species, pme_order=None):
+        from .ions import ion_electron_stress
+        return ion_electron_stress(self._full_engine(), self._box_np.reshape(3, 3), self.gather(den_slab), species, pme_order)
+
+    def ionic_potential(self, species, pme_order=None):
+        """this rank's x-slab of v_ext built from the ions (every rank builds the full potential: one small FFT per step)"""
+        from .ions import ionic_potential
+        return ionic_potential(self._full_engine(), self._box_np.reshape(3, 3), species, pme_order)[self.plan.x_range()].contiguous()
+
     def close(self):
         self.stages.close()
         if getattr(self, '_full', None) is not None:

@@ -69,6 +69,20 @@ def main():
         worst['stress'] = dict(dE=max(float(np.abs(sd[k] - sr[k]).max()) for k in sr), dE2=0.0, dmu=0.0, dg=0.0, dv=0.0,
                                ffts=0, ffts_ref=0)
         ref.close()
+    # ionic potential slab and ion-electron forces through the slab-decomposed engine vs one GPU
+    from professad_amd.ions import ion_electron_forces, ionic_potential
+    ks = np.linspace(0.0, 12.0, 400)
+    tab = (ks, -4 * np.pi * 3.0 / (ks ** 2 + 1.5) * np.exp(-0.05 * ks ** 2) + np.where(ks > 0, 4 * np.pi * 3.0 / np.where(ks > 0, ks, 1.0) ** 2, 0.0) * 0 , 3)
+    frac = np.array([[0.1, 0.2, 0.3], [0.6, 0.55, 0.8]])
+    vs = eng.ionic_potential([(frac, tab)], pme_order=4)
+    Fs = eng.ion_electron_forces(t(plan.scatter(den)), [(frac, tab)], pme_order=4)[0]
+    if rank == 0:
+        ref = Engine(shape, dev)
+        vr = ionic_potential(ref, box, [(frac, tab)], pme_order=4)
+        Fr = ion_electron_forces(ref, box, t(den), [(frac, tab)], pme_order=4)[0]
+        worst['ions'] = dict(dE=float((vs - vr[plan.x_range()]).abs().max() / vr.abs().max()), dE2=float(np.abs(Fs - Fr).max()),
+                             dmu=0.0, dg=0.0, dv=0.0, ffts=0, ffts_ref=0)
+        ref.close()
     # density optimisation over slabs (fused L-BFGS sweeps on each rank's slab, all-reduced scalars) vs one GPU
     if shape == (32, 32, 32):
         from professad_amd.optimize import optimize_density
