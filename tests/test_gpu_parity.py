@@ -599,3 +599,42 @@ def test_bcc_lithium_end_to_end_against_profess4_value():
     E_ii, _, _ = ion_ion(eng, box, frac, [1.0, 1.0])
     assert abs((res['E_Ha'] + E_ii) * EV_PER_HA - -14.741886997024537) < 1e-4
     eng.close()
+
+
+def test_total_forces_are_energy_derivatives_at_the_ground_state():
+    """The reference's force test (tests/test_forces.py:11-42) run natively: Li2 in a triclinic cell on the odd grid its
+    ecut2shape gives, IonIon + IonElectron + Hartree + WangTeter + PBE.  Forces from the converged density (analytic
+    ion-electron + ion-ion) against central differences of the re-optimised total energy (Hellmann-Feynman), atol 1e-4 eV/A."""
+    from professad_amd.ions import ion_electron_forces, ion_ion, ionic_potential, recpot_table
+    from professad_amd.optimize import EV_PER_HA, optimize_density
+    A = 0.529177210903
+    g = load('recpots.npz')
+    tab = recpot_table(g['li_raw'], float(g['li_kmax']))
+    box = np.array([[3.54, -0.13, 0.25], [-0.33, 3.82, 0.24], [0.55, 0.04, 3.45]]) / A
+    kcut = np.sqrt(2 * 1600 / EV_PER_HA)
+    shape = tuple(int(1 + 2 * np.ceil(kcut / (2 * np.pi / np.sqrt((box ** 2).sum(1)[i])))) for i in range(3))   # system.py:75-89
+    assert all(s % 2 == 1 for s in shape)
+    frac0 = np.array([[0.0, 0.0, 0.0], [0.35, 0.65, 0.45]])
+    inv = np.linalg.inv(box)
+    vol = abs(np.linalg.det(box))
+    eng = Engine(shape, DEV).set_cell(dev(box)).set_terms(F.NativeTerms(['ion_electron', 'hartree', 'wt', 'pbe']).names)
+
+    def ground_state(frac, chi0=None):
+        vext = ionic_potential(eng, box, [(frac, tab)])
+        res = optimize_density(eng, 2.0, vext, chi0=chi0, volume=vol, ntol=1e-8)
+        assert res['converged']
+        return res, res['E_Ha'] + ion_ion(eng, box, frac, [1.0, 1.0])[0]
+
+    res0, E0 = ground_state(frac0)
+    F_ie = ion_electron_forces(eng, box, res0['den'], [(frac0, tab)])[0]
+    F_tot = (F_ie + ion_ion(eng, box, frac0, [1.0, 1.0])[1]) * EV_PER_HA / A           # eV / Angstrom
+    eps = 1e-4 / A
+    for ion, i in ((0, 0), (1, 1), (1, 2)):
+        E = []
+        for sgn in (+1, -1):
+            cart = frac0 @ box
+            cart[ion, i] += sgn * eps
+            E.append(ground_state(cart @ inv, chi0=res0['chi'])[1])
+        fd = -(E[0] - E[1]) / (2 * eps) * EV_PER_HA / A
+        assert abs(fd - F_tot[ion, i]) < 1e-4, (ion, i, fd, F_tot[ion, i])
+    eng.close()
