@@ -638,3 +638,45 @@ def test_total_forces_are_energy_derivatives_at_the_ground_state():
         fd = -(E[0] - E[1]) / (2 * eps) * EV_PER_HA / A
         assert abs(fd - F_tot[ion, i]) < 1e-4, (ion, i, fd, F_tot[ion, i])
     eng.close()
+
+
+def test_total_stress_is_the_strain_derivative_at_the_ground_state():
+    """Native counterpart of the reference's stress checks (tests/test_stress.py, tests/test_ion_utils.py:149-180): total
+    stress = density-functional terms + ion-electron + ion-ion at the converged density, against central differences of
+    the re-optimised total energy under symmetric strains at fixed fractional coordinates."""
+    from professad_amd.ions import ion_electron_stress, ion_ion, ionic_potential, recpot_table
+    from professad_amd.optimize import EV_PER_HA, optimize_density
+    A = 0.529177210903
+    g = load('recpots.npz')
+    tab = recpot_table(g['li_raw'], float(g['li_kmax']))
+    box0 = np.array([[3.54, -0.13, 0.25], [-0.33, 3.82, 0.24], [0.55, 0.04, 3.45]]) / A
+    kcut = np.sqrt(2 * 1000 / EV_PER_HA)
+    shape = tuple(int(1 + 2 * np.ceil(kcut / (2 * np.pi / np.sqrt((box0 ** 2).sum(1)[i])))) for i in range(3))
+    frac = np.array([[0.0, 0.0, 0.0], [0.35, 0.65, 0.45]])
+    names = F.NativeTerms(['ion_electron', 'hartree', 'wt', 'pbe']).names
+    eng = Engine(shape, DEV)
+
+    def ground_state(box, chi0=None):
+        eng.set_cell(dev(box)).set_terms(names)
+        vext = ionic_potential(eng, box, [(frac, tab)])
+        res = optimize_density(eng, 2.0, vext, chi0=chi0, volume=abs(np.linalg.det(box)), ntol=1e-9)
+        assert res['converged']
+        return res, res['E_Ha'] + ion_ion(eng, box, frac, [1.0, 1.0])[0]
+
+    res0, E0 = ground_state(box0)
+    eng.set_cell(dev(box0)).set_terms(names)
+    sig = sum(eng.stress(res0['den']).values()) + ion_electron_stress(eng, box0, res0['den'], [(frac, tab)]) \
+        + ion_ion(eng, box0, frac, [1.0, 1.0])[2]
+    vol = abs(np.linalg.det(box0))
+    h = 2e-4
+    for i, j in ((0, 0), (2, 2), (0, 1), (1, 2)):
+        eps = np.zeros((3, 3))
+        eps[i, j] += 0.5 * h
+        eps[j, i] += 0.5 * h
+        Ep = ground_state(box0 + box0 @ eps, chi0=res0['chi'])[1]
+        Em = ground_state(box0 - box0 @ eps, chi0=res0['chi'])[1]
+        fd = (Ep - Em) / (2 * h * vol)
+        assert abs(fd - sig[i, j]) < 2e-7, (i, j, fd, sig[i, j])
+    # pressure = -tr(sigma) / 3 (functional_tools.py:104-131)
+    assert abs(sig[0, 1] - sig[1, 0]) < 1e-14
+    eng.close()
