@@ -680,3 +680,29 @@ def test_total_stress_is_the_strain_derivative_at_the_ground_state():
     # pressure = -tr(sigma) / 3 (functional_tools.py:104-131)
     assert abs(sig[0, 1] - sig[1, 0]) < 1e-14
     eng.close()
+
+
+def test_pme_and_exact_structure_factors_give_the_same_physics():
+    """tests/test_particle_mesh_ewald.py:68-89 natively: order-20 particle-mesh Ewald against the exact structure factor
+    through the whole chain -- optimised energy, density, ion-electron forces and stress (np.allclose defaults) for the
+    reference's bcc-Li cell; and non-zero forces for displaced ions (where the spline error is not symmetry-cancelled)."""
+    from professad_amd.ions import ion_electron_forces, ion_electron_stress, ionic_potential, recpot_table
+    from professad_amd.optimize import optimize_density
+    g = load('recpots.npz')
+    tab = recpot_table(g['li_raw'], float(g['li_kmax']))
+    box = 6.96 * np.eye(3)
+    eng = Engine((25, 25, 25), DEV).set_cell(dev(box)).set_terms(F.NativeTerms(['ion_electron', 'hartree', 'wt', 'pbe']).names)
+    for frac, tols in ((np.array([[0.0, 0.0, 0.0], [0.5, 0.5, 0.5]]), dict()),
+                       (np.array([[0.0, 0.0, 0.0], [0.47, 0.52, 0.5]]), dict(rtol=2e-4, atol=1e-7))):
+        out = {}
+        for order in (None, 20):
+            vext = ionic_potential(eng, box, [(frac, tab)], pme_order=order)
+            res = optimize_density(eng, 2.0, vext, volume=6.96 ** 3, ntol=1e-9)
+            assert res['converged']
+            out[order] = (res['E_Ha'], res['den'].cpu().numpy(),
+                          ion_electron_forces(eng, box, res['den'], [(frac, tab)], pme_order=order)[0],
+                          ion_electron_stress(eng, box, res['den'], [(frac, tab)], pme_order=order))
+        for a, b in zip(out[None], out[20]):
+            assert np.allclose(a, b, **tols)
+    assert np.abs(out[None][2]).max() > 1e-3
+    eng.close()
