@@ -62,10 +62,13 @@ struct LineMap {
     int blk0 = 0;   // first workgroup (in units of the kernel's lines-per-workgroup) of a launch that covers a line range
 };
 
+#ifndef OFDFT_CPASS_TPB
+#define OFDFT_CPASS_TPB 256      // threads per workgroup of the line passes (measured: 128 and 512 are not faster at 256^3)
+#endif
 template <int LEN> struct PassCfg {
     static constexpr int P = Plan<LEN>::P;
     static constexpr int E = Plan<LEN>::E;
-    static constexpr int TPB = (8 * P > 256) ? 8 * P : 256;
+    static constexpr int TPB = (8 * P > OFDFT_CPASS_TPB) ? 8 * P : OFDFT_CPASS_TPB;
     static constexpr int LPW = TPB / P;
     static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(double) * LPW * LineBuf<LEN>::STRIDE : 0;
 };

@@ -16,6 +16,13 @@
 
 namespace ofdft {
 
+#ifndef OFDFT_ZPBE_WAVES
+#define OFDFT_ZPBE_WAVES 2
+#endif
+#ifndef OFDFT_ZIWGC_WAVES
+#define OFDFT_ZIWGC_WAVES 2
+#endif
+
 template <int M, int E_> struct ZW {
     using PL = ZPlan<M, E_>;
     static constexpr int E = E_;
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
 // flux_j = df/d|grad n|^2 * d_j n -> spectra again, in place.  (functionals.py:1597-1618;
 // tests/tools_for_tests.py:155-207)
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                                    cplx* __restrict__ gz, double* __restrict__ dfdn, double inv_n,
                                                    GgaSel sel, SpecGeom g, const cplx* __restrict__ twM,
                                                    const cplx* __restrict__ twN, double* __restrict__ partial) {
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 // The WGC99 part of the combine on its own (split form): chi|n row + the six result spectra -> v_part rows and the
 // energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
                                                        const cplx* __restrict__ twM, const cplx* __restrict__ twN,
                                                        double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
