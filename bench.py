@@ -159,6 +159,8 @@ def main():
         raw.set_option(1, 0)
     if os.environ.get('OFDFT_XCHUNKS'):                  # A/B switch: x-chunked z / y stages
         raw.set_option(2, int(os.environ['OFDFT_XCHUNKS']))
+    if os.environ.get('OFDFT_GGA_SPLIT'):
+        raw.set_option(6, int(os.environ['OFDFT_GGA_SPLIT']))
     if os.environ.get('OFDFT_SPLIT_COMBINE'):
         raw.set_option(4, int(os.environ['OFDFT_SPLIT_COMBINE']))
     if os.environ.get('OFDFT_XCHUNK_MASK'):
@@ -190,6 +192,7 @@ def main():
     evals_per_s = a.steps / dt                    # whole-job rate: all ranks work on the same n^3 system
     n_fft = int(eng.query(0))
     n_launch = int(eng.query(4))
+    n_ypass = float(eng.query(5))          # whole-spectrum y line passes actually executed
 
     # ---- per-kernel HIP-event profile (separate pass, not inside the timed region)
     # per-kernel durations are measured with the chains serialised on ONE stream: with the side streams on, kernels
@@ -218,8 +221,9 @@ def main():
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if dom:
-        # per evaluation: every 3-D FFT has one y pass (n_fft spectrum passes), whatever the launch granularity
-        passes = n_fft if dom == 'cpass_y' else prof[dom][1] / nprof
+        # per evaluation: the engine counts its whole-spectrum y passes (fractions for x-range launches), whatever the
+        # launch granularity; the split-derivative GGA chain needs 19 of them for the 23 transforms of the byte model
+        passes = n_ypass if dom == 'cpass_y' else prof[dom][1] / nprof
         launches = prof[dom][1] / nprof
         class_ms = prof[dom][0] / nprof
         avg_ms = class_ms / launches

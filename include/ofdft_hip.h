@@ -92,6 +92,7 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_Q_FAST_PATH        2  /* 1 if the LDS radix FFT path is used, 0 = generic DFT    */
 #define OFDFT_Q_KERNEL_MS        3  /* HIP-event time of the last energy call's device work    */
 #define OFDFT_Q_LAUNCH_COUNT     4  /* kernel launches of the last energy call                 */
+#define OFDFT_Q_YPASS_COUNT      5  /* whole-spectrum y line passes of the last energy call    */
 
 int  ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id);
 void ofdft_destroy(ofdft_ctx* ctx);
@@ -217,6 +218,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default: measured -4 %), 4 PBE loop, 8 combine loop, 16 WGC99 x pass + y-inverse by kz blocks (all three measured neutral or slower at 256^3) */
 #define OFDFT_OPT_SPLIT_COMBINE 4 /* 1 (default): with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream */
 #define OFDFT_OPT_BLUESTEIN 5     /* 1 (default): extents that are not powers of two (<= 512) use chirp-z line transforms; 0: plain DFT kernels */
+#define OFDFT_OPT_GGA_SPLIT 6     /* 1 (default): split-derivative GGA chain -- only the index derivative along x visits the x pass (and the exchange); 0: three Cartesian components */
 #define OFDFT_OPT_SIDE_STREAM 1
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 

@@ -60,11 +60,13 @@ struct ofdft_ctx {
     bool wgc_valid = false;
     // stats
     int fft_count = 0, launch_count = 0;
+    double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
     float last_ms = 0.f;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
     bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
+    bool gga_split = true;       // GGA chain in split-derivative form: only the x index-derivative visits the x pass
     bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
     int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
     int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
@@ -276,6 +278,12 @@ int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, h
     }
     ArrList arrs{};
     for (int a = 0; a < narr; ++a) arrs.p[a] = specs[a];
+    if (axis == 1) {
+        double frac = 1.0;
+        if (cx > 0) frac *= (double)cx / c->g.n0;
+        if (kb1 > kb0) frac *= (double)(kb1 - kb0) * 8.0 / c->g.nzc;
+        c->ypass_count += narr * frac;
+    }
     const int len = axis == 0 ? c->n0g : c->n1;
     const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
 #define OFDFT_CASE(L)                                                   \
@@ -317,6 +325,7 @@ int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStrea
     if (narr > 16) return fail(c, OFDFT_EINVAL, "too many spectra in one exchange (%d)", narr);
     ArrList arrs{};
     for (int a = 0; a < narr; ++a) arrs.p[a] = list[a];
+    c->ypass_count += narr;
 #define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st);
     switch (c->n1) {
         OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
@@ -1514,6 +1523,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
         case OFDFT_OPT_BLUESTEIN:
             c->use_bluestein = value != 0.0;
             return OFDFT_OK;
+        case OFDFT_OPT_GGA_SPLIT:
+            c->gga_split = value != 0.0;
+            return OFDFT_OK;
         case OFDFT_OPT_SPLIT_COMBINE:
             c->split_combine = value != 0.0;
             return OFDFT_OK;
@@ -1553,6 +1565,7 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_FAST_PATH: *out = c->fast ? 1.0 : 0.0; return OFDFT_OK;
         case OFDFT_Q_KERNEL_MS: *out = c->last_ms; return OFDFT_OK;
         case OFDFT_Q_LAUNCH_COUNT: *out = c->launch_count; return OFDFT_OK;
+        case OFDFT_Q_YPASS_COUNT: *out = c->ypass_count; return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown query %d", what);
 }

@@ -13,7 +13,7 @@ template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nr
 // The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
 // [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
 int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
-                      int nchunks = 1) {
+                      int nchunks = 1, double* dzn = nullptr) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
     if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
@@ -23,7 +23,7 @@ int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, 
         const int nb = z_blocks<M_, 8>(c) / nchunks;                                                                \
         gz.blk0 = chunk * nb;                                                                                       \
         OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(nb), dim3(256), (ZW<M_, 8>::LDS), ds,    \
-                     out_n, out_s, gz, twM, twN);                                                                   \
+                     out_n, out_s, gz, twM, twN, dzn);                                                              \
         return 0;                                                                                                   \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
@@ -69,6 +69,54 @@ int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, do
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
 #undef X
     return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+// split-derivative GGA mid stage (zpass.h: zpbe2_kernel)
+int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const double* dzn, double* dfdn, double inv_n,
+                 int* blocks_out, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = z_tables(c, &twM, &twN)) return rc;
+    c->fft_count += 6;    // same six 3-D transforms as the plain form (three c2r finished, three r2c started)
+    Bmat bm{};
+    std::memcpy(bm.b, c->kg.b, sizeof(bm.b));
+#define X(M_)                                                                                                   \
+    case M_: {                                                                                                  \
+        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
+        OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256),         \
+                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm,  \
+                     c->g, twM, twN, c->d_partial);                                                             \
+        return 0;                                                                                               \
+    }
+    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+// index derivative along y of an x-slab spectrum in (kz; y, x) form, in one pass (fft_kernels.h: yderiv_kernel)
+template <int LEN>
+int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    LineMap main, rem;
+    pass_maps(c, 1, main, rem);
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, "yderiv", (yderiv_kernel<LEN>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, in, out, main, rem, mb,
+                 c->g.main_count, (const cplx*)tw, scale);
+    return 0;
+}
+int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+    switch (c->n1) {
+        case 8: return launch_yderiv_t<8>(c, in, out, scale, st);
+        case 16: return launch_yderiv_t<16>(c, in, out, scale, st);
+        case 32: return launch_yderiv_t<32>(c, in, out, scale, st);
+        case 64: return launch_yderiv_t<64>(c, in, out, scale, st);
+        case 128: return launch_yderiv_t<128>(c, in, out, scale, st);
+        case 256: return launch_yderiv_t<256>(c, in, out, scale, st);
+        case 512: return launch_yderiv_t<512>(c, in, out, scale, st);
+        case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st);
+    }
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
 }
 
 int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
@@ -160,6 +208,8 @@ struct ZRun {
     //   chain 1: the nonlocal KEDF (Wang-Teter powers or the six WGC99 spectra)
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
+    bool gsplit = false;           // split-derivative form of the GGA chain (only D_a visits the x pass)
+    double* dzn = nullptr;
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
@@ -222,6 +272,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
         r.za.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(r.nel) : 0.0;   // functionals.py:268-270
         r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
         r.wgc_yinv_done = false;
+        r.s_g[0] = r.s_g[1] = r.s_g[2] = nullptr;
         r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
         if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
         if (r.has_h || r.has_g)
@@ -233,15 +284,23 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             int nb = 0;
             if (r.s_n) both[nb++] = r.s_n;
             if (r.s_s) both[nb++] = r.s_s;
-            const int nch = chunks_for(c, nb, 1);
+            r.gsplit = r.has_g && c->gga_split;
+            if (r.gsplit) {
+                if ((rc = real_ws(c, "dzn", &r.dzn))) return rc;
+                if ((rc = spec_ws(c, "zgx", &r.s_g[0]))) return rc;
+                if ((rc = spec_ws(c, "zgy", &r.s_g[1]))) return rc;
+            }
+            const int nch = r.gsplit ? 1 : chunks_for(c, nb, 1);
             if (nch > 1) {        // x-chunked: a chunk's spectra are y-transformed while still in the Infinity Cache
                 for (int ch = 0; ch < nch; ++ch) {
                     if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st, ch, nch))) return rc;
                     if ((rc = fast_axis_pass_multi<false>(c, 1, both, nb, st, ch * (c->n0 / nch), c->n0 / nch))) return rc;
                 }
-            } else if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st))) {
+            } else if ((rc = launch_zf_density(c, r.ds, r.s_n, r.s_s, st, 0, 1, r.gsplit ? r.dzn : nullptr))) {
                 return rc;
             }
+            // D_b n from the (kz; y, x) spectrum before its in-place y-forward; scaled so that the consumer's 1/N fits
+            if (r.gsplit && (rc = yderiv(c, r.s_n, r.s_g[1], (double)c->n0g, st))) return rc;
             if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
                 HIP_TRY(c, hipEventRecord(c->ev_a, st));
                 HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
@@ -338,7 +397,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
     XfLayout lay{};
     if (dx) {
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? 3 : 0) + (r.s_s ? 1 : 0)
+        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? (r.gsplit ? 1 : 3) : 0) + (r.s_s ? 1 : 0)
                                     : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
         lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
     }
@@ -361,14 +420,18 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
                 if ((rc = spec_ws(c, "zvh", &r.s_vh))) return rc;
                 io.out[no++] = out_of(r.s_vh);
             }
-            if (r.has_g) {
+            if (r.has_g && r.gsplit) {
+                io.out[no++] = out_of(r.s_g[0]);          // (D_a n)^ only
+            } else if (r.has_g) {
                 const char* gn[3] = {"zgx", "zgy", "zgz"};
                 for (int k = 0; k < 3; ++k) {
                     if ((rc = spec_ws(c, gn[k], &r.s_g[k]))) return rc;
                     io.out[no++] = out_of(r.s_g[k]);
                 }
             }
-            if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
+            if (r.gsplit && r.has_h) rc = xfused<1, 2>(c, io, MixDensityA<true>{c->kg}, st, "xfused_n", lay);
+            else if (r.gsplit) rc = xfused<1, 1>(c, io, MixDensityA<false>{c->kg}, st, "xfused_n", lay);
+            else if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
             else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
             else rc = xfused<1, 3>(c, io, MixDensity<false, true>{c->kg}, st, "xfused_n", lay);
             if (rc) return rc;
@@ -438,7 +501,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     }
     // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
     // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
-    const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = chunks_for(c, 6, 4) > 1;
+    const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = !r.gsplit && chunks_for(c, 6, 4) > 1;
     for (cplx* sp : xl) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
@@ -486,7 +549,21 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     }
     if (r.has_h) r.za.vh = r.s_vh;
     if (r.s_s) r.za.lap = r.s_s;
-    if (r.has_g) {
+    if (r.has_g && r.gsplit) {
+        // split-derivative form: A = (D_a n) came back from the x pass and was y-inverted above, B = (D_b n) is local
+        if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
+        if ((rc = launch_zpbe2(c, r.ds, r.s_g[0], r.s_g[1], r.dzn, r.dfdn, r.za.inv_n, &r.pbe_blocks, st))) return rc;
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
+                     kPbeScalars, c->d_reduced + kCombineScalars);
+        // D_b G_b in one y pass, in place (scaled like B); only G_a goes on to the x pass
+        if ((rc = yderiv(c, r.s_g[1], r.s_g[1], (double)c->n0g, st))) return rc;
+        if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[0], st))) return rc;
+        xl.push_back(r.s_g[0]);
+        if (dx) {
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+        }
+    } else if (r.has_g) {
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
         const int nch = chunks_for(c, 6, 4);       // 3 spectra in, 3 out, the density and df/dn rows
         for (int ch = 0; ch < nch; ++ch) {
@@ -516,7 +593,20 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
 int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
     ZRun& r = zrun(c);
     r.xlist[chain].clear();
-    if (chain == 0 && r.has_g) {
+    if (chain == 0 && r.has_g && r.gsplit) {
+        XfIo dio{};
+        XfLayout lay{};
+        dio.in[0] = dio.out[0] = r.s_g[0];
+        if (c->nranks > 1) {     // receive buffer slot 0 -> send buffer slot 0
+            cplx *send, *recv;
+            if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+            dio.in[0] = recv;
+            dio.out[0] = send;
+            lay = XfLayout{c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+        }
+        if (int rc = xfused<1, 1>(c, dio, MixDerivA{c->kg}, st, "xfused_div", lay)) return rc;
+        r.xlist[0].push_back(r.s_g[0]);
+    } else if (chain == 0 && r.has_g) {
         XfIo dio{};
         XfLayout lay{};
         for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
@@ -541,17 +631,19 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     int rc;
     const bool chunked = chunks_for(c, 6, 8) > 1;
     if (r.has_g) {
+        cplx* dsp = r.gsplit ? r.s_g[0] : r.s_n;       // the spectrum that carries the (x part of the) divergence
         if (c->nranks > 1) {
             cplx *send, *recv;
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<true>(c, {r.s_n}, recv, st))) return rc;
+            if ((rc = ypass_xchg<true>(c, {dsp}, recv, st))) return rc;
         } else if (chunked) {
-            r.deferred.push_back(r.s_n);
-        } else if ((rc = fast_axis_pass<true>(c, 1, r.s_n, st))) {
+            r.deferred.push_back(dsp);
+        } else if ((rc = fast_axis_pass<true>(c, 1, dsp, st))) {
             return rc;
         }
         c->fft_count++;
-        r.za.div = r.s_n;
+        r.za.div = dsp;
+        r.za.div2 = r.gsplit ? r.s_g[1] : nullptr;
         r.za.dfdn = r.dfdn;
     }
     r.xlist[0].clear();
@@ -638,6 +730,7 @@ int begin_call(ofdft_ctx* c, hipStream_t st) {
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
     c->fft_count = 0;
     c->launch_count = 0;
+    c->ypass_count = 0.0;
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     return 0;
 }

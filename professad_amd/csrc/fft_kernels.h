@@ -150,6 +150,49 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
 }
 
 // ----------------------------------------------------------------------------------------------
+// index derivative along y in ONE pass: forward FFT of the line, times i f_b (integer frequency, Nyquist positive as in
+// functional_tools.py:152-154) times `scale`, inverse FFT.  Out of place or in place (in == out).
+template <int LEN>
+__global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* __restrict__ in, cplx* __restrict__ out,
+                                                                   LineMap m_main, LineMap m_rem, int main_blocks,
+                                                                   long long rem_offset, const cplx* __restrict__ tw,
+                                                                   double scale) {
+    constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const bool in_rem = (int)blockIdx.x >= main_blocks;
+    const LineMap m = in_rem ? m_rem : m_main;
+    const long long roff = in_rem ? rem_offset : 0;
+    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x + m.blk0;
+    const int l_lo = tid % m.lf;
+    const int j = (tid / m.lf) % P;
+    const int l = (tid / (m.lf * P)) * m.lf + l_lo;
+    const long long L0 = (long long)bid * LPW;
+    const long long L = L0 + l;
+    const bool valid = L < m.nlines;
+    const long long b0 = uniform64(line_base(m, L0));
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const long long qstep = uniform64((long long)P * m.se);
+    cplx v[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = valid ? buf_load_c(in + roff + b0 + q * qstep, voff) : make_double2(0.0, 0.0);
+    double* mine = lds + l * LineBuf<LEN>::STRIDE;
+    line_fft<LEN, false>(v, j, mine, tw);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int e = j + P * q;
+        const double f = scale * (double)(e <= LEN / 2 ? e : e - LEN);
+        v[q] = make_double2(-f * v[q].y, f * v[q].x);
+    }
+    __syncthreads();
+    line_fft<LEN, true>(v, j, mine, tw);
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(out + roff + b0 + q * qstep, voff, v[q]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // y pass of the slab-decomposed path, writing / reading the all-to-all buffers directly (no pack / un-pack copies).
 // Exchange layout (the same for both directions, so the fused x pass can work in place on what it received):
 //   buffer = [peer][xl][array][ main: (b, yl, kin) | planes: (plane, yl) ]      xl: x inside a rank's x-slab

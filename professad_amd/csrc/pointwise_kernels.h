@@ -328,6 +328,31 @@ template <bool HAS_H, bool HAS_G> struct MixDensity {
     }
 };
 
+// split-derivative form: n^ -> [v_H^], i f_a n^  with the INTEGER frequency f_a along x (the Cartesian gradient is assembled
+// from the three index derivatives in zpbe2_kernel)
+template <bool HAS_H> struct MixDensityA {
+    KGeom kg;
+    static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
+        if (HAS_H && O == 0) {
+            double kx, ky, kz, k2;
+            kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+            return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+        }
+        return ifreq(x, kg.g.n0);
+    }
+};
+// G^ -> i f_a G^
+struct MixDerivA {
+    KGeom kg;
+    static __device__ __forceinline__ constexpr bool imag(int) { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I>
+    __device__ __forceinline__ double coef(int x, int, int, long long, unsigned) const { return ifreq(x, kg.g.n0); }
+};
+
 // one spectrum times a real f(k): OP as spec_scale_kernel
 template <int OP> struct MixScale {
     KGeom kg;

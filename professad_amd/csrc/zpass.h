@@ -171,6 +171,92 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
 }
 
+// ---- row transforms that stay on chip (the spectrum lives in registers) -----------------------------------------
+// forward: real pairs in v -> v[q] = coefficient k = j + P q (k < M) of the row's half spectrum; nyq (lane j == 0) =
+// coefficient M (real)
+template <int M, int E>
+__device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
+                                               const cplx* __restrict__ twN, double& nyq) {
+    using W = ZW<M, E>;
+    constexpr int P = W::P;
+    wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
+    double cr_m[E], c0r;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    c0r = z.mine[0];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int k = z.j + P * q;
+        const double ci_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx ev = make_double2(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+        const cplx od = make_double2(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+        v[q] = cadd(ev, cmul(twN[k], od));
+    }
+    nyq = c0r - z.mine[0];
+    exchange_sync<true>();
+}
+
+// inverse of the above: v[q] = coefficient k = j + P q, nyq = coefficient M -> unscaled real pairs
+template <int M, int E>
+__device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
+                                               const cplx* __restrict__ twN, double nyq) {
+    using W = ZW<M, E>;
+    constexpr int P = W::P;
+    double xr_m[E];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) xr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    exchange_sync<true>();
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int k = z.j + P * q;
+        const double xi_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx x = v[q];
+        if (k == 0) {
+            v[q] = make_double2(x.x + nyq, x.x - nyq);
+        } else {
+            const cplx ev = make_double2(x.x + xr_m[q], x.y - xi_m);
+            const cplx d = make_double2(x.x - xr_m[q], x.y + xi_m);
+            const cplx od = cmul(d, cconj(twN[k]));
+            v[q] = make_double2(ev.x - od.y, ev.y + od.x);
+        }
+    }
+    exchange_sync<true>();
+    wave_line_fft<M, E, true>(v, z.j, z.mine, twM);
+    exchange_sync<true>();
+}
+
+// index derivative along the row, D_c f = F^-1[i f_c F[f]] with the integer frequency f_c = k (rfftfreq,
+// functional_tools.py:155): real pairs in -> N2 x (derivative) out.  The k = 0 and Nyquist terms are purely imaginary
+// after the multiplication and drop out of the real inverse, as they do in the reference's irfftn.
+template <int M, int E>
+__device__ __forceinline__ void z_deriv_row(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
+                                            const cplx* __restrict__ twN) {
+    constexpr int P = ZW<M, E>::P;
+    double nyq;
+    z_forward_regs<M, E>(v, z, twM, twN, nyq);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const double k = (double)(z.j + P * q);
+        v[q] = make_double2(-k * v[q].y, k * v[q].x);
+    }
+    z_inverse_regs<M, E>(v, z, twM, twN, 0.0);
+}
+
 // x^y for x >= 0 as exp(y log x): ~2 ulp for the |y log x| = O(1..10) met here, a fraction of the instructions
 // and registers of the fully-general pow() (which the unfused pipeline keeps using as an independent check).
 __device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
@@ -191,7 +277,7 @@ struct DenSrc {
 template <int M, int E>
 __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
                                                          SpecGeom g, const cplx* __restrict__ twM,
-                                                         const cplx* __restrict__ twN) {
+                                                         const cplx* __restrict__ twN, double* __restrict__ dzn = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const ZLane<M, E> z(g, lds);
     cplx x[E], v[E];
@@ -208,6 +294,15 @@ __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __r
             v[q] = make_double2(a != 0.0 ? sqrt(a) : 0.0, b != 0.0 ? sqrt(b) : 0.0);     // functionals.py:242-243
         }
         z_forward_store<M, E>(v, z, out_s, g, twM, twN);
+    }
+    if (dzn) {       // D_c n, the index derivative along z, formed on chip (split-derivative form of the GGA chain)
+        const double sc = 1.0 / (double)(2 * M);
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = make_double2(ds(x[q].x), ds(x[q].y));
+        z_deriv_row<M, E>(v, z, twM, twN);
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[q] = make_double2(v[q].x * sc, v[q].y * sc);
+        z_store_real<M, E>(v, z, dzn);
     }
 }
 
@@ -310,6 +405,63 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
     block_reduce_store<kPbeScalars>(acc, partial + (long long)g.blk0 * kPbeScalars);
 }
 
+// Split-derivative form of the GGA mid stage.  With the index derivatives D_a, D_b, D_c (Cartesian d_j = sum_axis
+// b[axis][j] D_axis) only D_a needs the x transform: D_b comes from a y pass with the i f_b multiply (yderiv_kernel),
+// D_c is formed on chip.  In: A = (D_a n)^ rows, B = (D_b n)^ rows, dzn = D_c n (real);  out: the contravariant flux
+// components G_a, G_b as spectra (in place of A, B) and df/dn - 2 D_c G_c (real) -- the whole z part of the divergence.
+struct Bmat { double b[9]; };
+template <int M, int E>
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
+                                                                      const double* __restrict__ dzn,
+                                                                      double* __restrict__ dfdn, double inv_n, double inv_nz,
+                                                                      GgaSel sel, Bmat bm, SpecGeom g,
+                                                                      const cplx* __restrict__ twM,
+                                                                      const cplx* __restrict__ twN,
+                                                                      double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const ZLane<M, E> z(g, lds);
+    cplx a[E], b[E], c[E], n[E];
+    z_load_inverse<M, E>(a, z, A, g, twM, twN);
+    z_load_inverse<M, E>(b, z, B, g, twM, twN);
+    z_load_real<M, E>(c, z, dzn);
+    z_load_real<M, E>(n, z, ds.src);
+    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
+    cplx d[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double da0 = a[q].x * inv_n, db0 = b[q].x * inv_n, dc0 = c[q].x;
+        const double da1 = a[q].y * inv_n, db1 = b[q].y * inv_n, dc1 = c[q].y;
+        // Cartesian gradient g_j = b[0][j] D_a n + b[1][j] D_b n + b[2][j] D_c n
+        const double gx0 = bm.b[0] * da0 + bm.b[3] * db0 + bm.b[6] * dc0, gx1 = bm.b[0] * da1 + bm.b[3] * db1 + bm.b[6] * dc1;
+        const double gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0, gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
+        const double gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0, gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
+        PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
+        if (z.valid) {
+            p0 = pbe_point(ds(n[q].x), gx0 * gx0 + gy0 * gy0 + gz0 * gz0, sel);
+            p1 = pbe_point(ds(n[q].y), gx1 * gx1 + gy1 * gy1 + gz1 * gz1, sel);
+        }
+        acc[0] += p0.fx + p1.fx;
+        acc[1] += p0.fc + p1.fc;
+        acc[2] += p0.fk + p1.fk;
+        d[q] = make_double2(p0.dfdn, p1.dfdn);
+        // contravariant components of the flux F = df/dg grad n:  G_axis = sum_j b[axis][j] F_j
+        a[q] = make_double2(p0.dfdg * (bm.b[0] * gx0 + bm.b[1] * gy0 + bm.b[2] * gz0),
+                            p1.dfdg * (bm.b[0] * gx1 + bm.b[1] * gy1 + bm.b[2] * gz1));
+        b[q] = make_double2(p0.dfdg * (bm.b[3] * gx0 + bm.b[4] * gy0 + bm.b[5] * gz0),
+                            p1.dfdg * (bm.b[3] * gx1 + bm.b[4] * gy1 + bm.b[5] * gz1));
+        c[q] = make_double2(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
+                            p1.dfdg * (bm.b[6] * gx1 + bm.b[7] * gy1 + bm.b[8] * gz1));
+    }
+    z_forward_store<M, E>(a, z, A, g, twM, twN);
+    z_forward_store<M, E>(b, z, B, g, twM, twN);
+    z_deriv_row<M, E>(c, z, twM, twN);               // N2 x D_c G_c
+#pragma unroll
+    for (int q = 0; q < E; ++q) d[q] = make_double2(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);
+    z_store_real<M, E>(d, z, dfdn);
+    block_reduce_store<kPbeScalars>(acc, partial + (long long)g.blk0 * kPbeScalars);
+}
+
 // ------------------------------------------------------------------------------------------------
 // (8-point lanes at M = 512 -- rows of 1024 -- need more than 256 registers in the fused kernels: those instantiations
 // take a whole SIMD's register file, one wave per SIMD, instead of spilling ~1 KB per thread)
@@ -325,6 +477,7 @@ struct ZCombineArgs {
     const cplx* u[3];
     const cplx* gw[3];
     const cplx* div;
+    const cplx* div2;         // split-derivative form: the D_b part of the divergence (added to div)
     double* v_out;
     const double* v_part;     // split form: the WGC99 potential computed by zi_wgc_kernel (then u / gw are not read here)
     unsigned mask;
@@ -484,6 +637,14 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         for (int q = 0; q < E; ++q) {
             vacc[q].x += d[q].x - 2.0 * w[q].x * sc;
             vacc[q].y += d[q].y - 2.0 * w[q].y * sc;
+        }
+        if (a.div2) {
+            z_load_inverse<M, E>(w, z, a.div2, g, twM, twN);
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                vacc[q].x -= 2.0 * w[q].x * sc;
+                vacc[q].y -= 2.0 * w[q].y * sc;
+            }
         }
     }
     // ---- local terms and the sum of v n

@@ -20,6 +20,7 @@ class LocalRanks:
         self.st = [HipStages(shape, device, nranks=nranks, rank=r) for r in range(nranks)]
         self.npts = int(np.prod(shape))
         self.compute_s = [0.0] * nranks
+        self.exchanged_bytes = 0          # bytes in all ranks' send buffers (incl. the diagonal chunks)
 
     def set_cell(self, box):
         for s in self.st:
@@ -47,6 +48,7 @@ class LocalRanks:
                 ex = [self._timed(r, s.stage, k, chain) for r, s in enumerate(self.st)]
                 if ex[0] is None:
                     continue
+                self.exchanged_bytes += sum(e[0].numel() for e in ex)
                 for r in range(P):
                     rc = ex[r][1].chunk(P)
                     for p in range(P):

@@ -55,6 +55,7 @@ def main():
     loc = LocalRanks(shape, dev, P).set_cell(box).set_terms(names)
     loc.closure(chi, n_elec, vext)
     loc.compute_s = [0.0] * P
+    loc.exchanged_bytes = 0
     loc.st[0].set_option(1, 0)          # serialise rank 0's streams so that its per-kernel event times are clean
     loc.st[0].set_profiling(True)
     for _ in range(reps):
@@ -67,7 +68,7 @@ def main():
     print(json.dumps({'grid': n, 'ranks': P, 'single_gpu_ms': round(single * 1e3, 3), 'staged_protocol_1rank_ms': round(staged1 * 1e3, 3),
                       'local_compute_ms_per_rank_max': round(max(per_rank) * 1e3, 3),
                       'local_compute_ms_per_rank_mean': round(float(np.mean(per_rank)) * 1e3, 3),
-                      'exchange_MB_per_rank_per_eval': round(23 * 16 * (n * n * (n // 2 + 1)) / P * (P - 1) / P / 1e6, 1),
+                      'exchange_MB_per_rank_per_eval': round(loc.exchanged_bytes / reps / P * (P - 1) / P / 1e6, 1),
                       'grad_rel_diff_vs_single': err}))
 
 
