@@ -15,17 +15,17 @@ struct BsArgs {
     int N;          // line length
     int mode, axis, inv;
     long long nlines;
-    double scale;
+    real scale;
 };
 
 template <int M>
-__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __restrict__ spec, const double* __restrict__ rin,
-                                                                    double* __restrict__ rout, SpecGeom g, BsArgs b,
+__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __restrict__ spec, const real* __restrict__ rin,
+                                                                    real* __restrict__ rout, SpecGeom g, BsArgs b,
                                                                     const cplx* __restrict__ chirp,   // w_n, n < N
                                                                     const cplx* __restrict__ filt,    // FFT_M(b) / M
                                                                     const cplx* __restrict__ twM) {
     constexpr int P = PassCfg<M>::P, E = PassCfg<M>::E, LPW = PassCfg<M>::LPW;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     // complex lines (mode 0): consecutive lanes take consecutive LINES, enumerated kz-fastest, so that a wave's accesses
     // for one element index fall on the 8 x 16-B runs of the block-8 layout; z rows (modes 1, 2): consecutive lanes take
@@ -52,12 +52,12 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = j + P * q;
-        cplx a = make_double2(0.0, 0.0);
+        cplx a = mkc(0.0, 0.0);
         if (valid && e < N) {
             if (b.mode == 0) {
                 a = spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)];
             } else if (b.mode == 1) {
-                a = make_double2(rin[((long long)x * g.n1 + y) * g.n2 + e], 0.0);
+                a = mkc(rin[((long long)x * g.n1 + y) * g.n2 + e], 0.0);
             } else {            // rebuild the Hermitian line; imaginary parts of k = 0 (and Nyquist) are ignored like irfftn
                 const int k = (e < g.nzc) ? e : N - e;
                 a = spec[spec_index(g, x, y, k)];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
         }
         v[q] = a;
     }
-    double* mine = lds + l * LineBuf<M>::STRIDE;
+    real* mine = lds + l * LineBuf<M>::STRIDE;
     line_fft<M, false>(v, j, mine, twM);
 #pragma unroll
     for (int q = 0; q < E; ++q) {

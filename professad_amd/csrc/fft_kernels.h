@@ -70,7 +70,7 @@ template <int LEN> struct PassCfg {
     static constexpr int E = Plan<LEN>::E;
     static constexpr int TPB = (8 * P > OFDFT_CPASS_TPB) ? 8 * P : OFDFT_CPASS_TPB;
     static constexpr int LPW = TPB / P;
-    static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(double) * LPW * LineBuf<LEN>::STRIDE : 0;
+    static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(real) * LPW * LineBuf<LEN>::STRIDE : 0;
 };
 
 // uniform base of a tile (first line of the workgroup) and the per-lane byte offset of line L, element j
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
                                                                    const cplx* __restrict__ tw) {
     cplx* data = arrs.p[blockIdx.y];          // one launch may cover several spectra (grid.y)
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     // one grid covers the block-8 main part and the dense remainder planes (Nyquist plane)
     const bool in_rem = (int)blockIdx.x >= main_blocks;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
     const bool valid = L < m.nlines;
     const long long b0 = uniform64(line_base(m, L0));
     cplx* ub = data + b0;                                   // wave-uniform
-    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
     const long long qstep = uniform64((long long)P * m.se); // uniform element stride between a thread's points
     cplx v[E];
     if (valid) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
         for (int q = 0; q < E; ++q) v[q] = buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + q * qstep, voff);
     } else {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
     }
     line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
     if (valid) {
@@ -156,9 +156,9 @@ template <int LEN>
 __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* __restrict__ in, cplx* __restrict__ out,
                                                                    LineMap m_main, LineMap m_rem, int main_blocks,
                                                                    long long rem_offset, const cplx* __restrict__ tw,
-                                                                   double scale) {
+                                                                   real scale) {
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     const bool in_rem = (int)blockIdx.x >= main_blocks;
     const LineMap m = in_rem ? m_rem : m_main;
@@ -171,18 +171,18 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* _
     const long long L = L0 + l;
     const bool valid = L < m.nlines;
     const long long b0 = uniform64(line_base(m, L0));
-    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
     const long long qstep = uniform64((long long)P * m.se);
     cplx v[E];
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = valid ? buf_load_c(in + roff + b0 + q * qstep, voff) : make_double2(0.0, 0.0);
-    double* mine = lds + l * LineBuf<LEN>::STRIDE;
+    for (int q = 0; q < E; ++q) v[q] = valid ? buf_load_c(in + roff + b0 + q * qstep, voff) : mkc(0.0, 0.0);
+    real* mine = lds + l * LineBuf<LEN>::STRIDE;
     line_fft<LEN, false>(v, j, mine, tw);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = j + P * q;
-        const double f = scale * (double)(e <= LEN / 2 ? e : e - LEN);
-        v[q] = make_double2(-f * v[q].y, f * v[q].x);
+        const real f = scale * (real)(e <= LEN / 2 ? e : e - LEN);
+        v[q] = mkc(-f * v[q].y, f * v[q].x);
     }
     __syncthreads();
     line_fft<LEN, true>(v, j, mine, tw);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
                                                                        long long rem_offset,
                                                                        const cplx* __restrict__ tw) {
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     const int a = blockIdx.y;
     const bool in_rem = (int)blockIdx.x >= main_blocks;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
     const bool valid = L < m.nlines;
     const long long b0 = uniform64(line_base(m, L0));
     cplx* ub = data + b0;
-    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * 16) : 0u;
+    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
     const long long qstep = uniform64((long long)P * m.se);
     // buffer side: line part (per lane) and element part (y = j + P*q -> peer, yl)
     long long lb;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
     }
     line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
     if (valid) {
@@ -281,20 +281,20 @@ template <int M> struct ZCfg {
     static constexpr int TPB = (8 * P > 256) ? 8 * P : 256;
     static constexpr int RPW = TPB / P;                 // rows per workgroup
     static constexpr int RS = LineBuf<M>::STRIDE;       // LDS doubles per row
-    static constexpr size_t LDS = sizeof(double) * RPW * RS;
+    static constexpr size_t LDS = sizeof(real) * RPW * RS;
 };
 
 struct PreIdentity {
-    __device__ __forceinline__ double operator()(double a, long long) const { return a; }
+    __device__ __forceinline__ real operator()(real a, long long) const { return a; }
 };
 
 template <int M, class Pre>
-__global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const double* __restrict__ in, cplx* __restrict__ spec,
+__global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const real* __restrict__ in, cplx* __restrict__ spec,
                                                             SpecGeom g, const cplx* __restrict__ twM,
                                                             const cplx* __restrict__ twN, Pre pre) {
     constexpr int P = ZCfg<M>::P, E = ZCfg<M>::E, RPW = ZCfg<M>::RPW, RS = ZCfg<M>::RS, TPB = ZCfg<M>::TPB;
     constexpr int N2 = 2 * M;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     const int j = tid % P, r = tid / P;
     const long long row0 = (long long)blockIdx.x * RPW;
@@ -303,22 +303,22 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const double* __rest
     cplx v[E];
     if (valid) {
         const cplx* ub = reinterpret_cast<const cplx*>(in + row0 * N2);       // wave-uniform
-        const unsigned voff = (unsigned)((r * M + j) * 16);
+        const unsigned voff = (unsigned)((r * M + j) * kCB);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const cplx t = buf_load_c(ub + q * P, voff);
             const long long e = row * N2 + 2 * (j + P * q);
-            v[q] = make_double2(pre(t.x, e), pre(t.y, e + 1));
+            v[q] = mkc(pre(t.x, e), pre(t.y, e + 1));
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
     }
-    double* mine = lds + r * RS;
+    real* mine = lds + r * RS;
     line_fft<M, false>(v, j, mine, twM);
 
     // ---- split post-processing through LDS: X[k] = Ev[k] + W_N^k Od[k]
-    double cr_k[E], cr_m[E], c0r = 0.0, c0i = 0.0;
+    real cr_k[E], cr_m[E], c0r = 0.0, c0i = 0.0;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < E; ++q) mine[lpad(j + P * q)] = v[q].x;
@@ -341,38 +341,38 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zfwd_kernel(const double* __rest
         const int idx = tid + it * TPB;
         const int kin = idx & 7, rr = (idx >> 3) % RPW, b = idx / (8 * RPW);
         const int k = 8 * b + kin, mk = (M - k) & (M - 1);
-        const double ci_k = lds[rr * RS + lpad(k)];
-        const double ci_m = lds[rr * RS + lpad(mk)];
-        const cplx ev = make_double2(0.5 * (cr_k[it] + cr_m[it]), 0.5 * (ci_k - ci_m));
-        const cplx od = make_double2(0.5 * (ci_k + ci_m), -0.5 * (cr_k[it] - cr_m[it]));
+        const real ci_k = lds[rr * RS + lpad(k)];
+        const real ci_m = lds[rr * RS + lpad(mk)];
+        const cplx ev = mkc(0.5 * (cr_k[it] + cr_m[it]), 0.5 * (ci_k - ci_m));
+        const cplx od = mkc(0.5 * (ci_k + ci_m), -0.5 * (cr_k[it] - cr_m[it]));
         const cplx X = cadd(ev, cmul(twN[k], od));
         const long long rg = row0 + rr;
         // block b of rows row0.. is one contiguous 128-B-per-row run: uniform base + (rr*8+kin)*16
         const int bu = (it * TPB) / (8 * RPW);          // compile-time after unrolling: uniform part of b
         if (rg < g.nrows)
             buf_store_c(spec + ((long long)bu * g.nrows + row0) * 8,
-                        (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * 16), X);
+                        (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * kCB), X);
     }
     if (tid < RPW) {
         c0i = lds[tid * RS];
         const long long rg = row0 + tid;
-        if (rg < g.nrows) spec[g.main_count + rg] = make_double2(c0r - c0i, 0.0);
+        if (rg < g.nrows) spec[g.main_count + rg] = mkc(c0r - c0i, 0.0);
     }
 }
 
 struct PostScale {
-    double s;
-    __device__ __forceinline__ double operator()(double a, long long) const { return a * s; }
+    real s;
+    __device__ __forceinline__ real operator()(real a, long long) const { return a * s; }
 };
 
 // z pass, inverse c2r (imaginary parts of the kz=0 and Nyquist entries are ignored, as irfftn does)
 template <int M, class Post>
-__global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restrict__ spec, double* __restrict__ out,
+__global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restrict__ spec, real* __restrict__ out,
                                                             SpecGeom g, const cplx* __restrict__ twM,
                                                             const cplx* __restrict__ twN, Post post) {
     constexpr int P = ZCfg<M>::P, E = ZCfg<M>::E, RPW = ZCfg<M>::RPW, RS = ZCfg<M>::RS, TPB = ZCfg<M>::TPB;
     constexpr int N2 = 2 * M;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     const int j = tid % P, r = tid / P;
     const long long row0 = (long long)blockIdx.x * RPW;
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
         const long long rg = row0 + rr;
         const int bu = (it * TPB) / (8 * RPW);
         xs[it] = (rg < g.nrows) ? buf_load_c(spec + ((long long)bu * g.nrows + row0) * 8,
-                                             (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * 16))
-                                : make_double2(0.0, 0.0);
+                                             (unsigned)((((long long)(b - bu) * g.nrows + rr) * 8 + kin) * kCB))
+                                : mkc(0.0, 0.0);
     }
-    const double nyq = (valid && j == 0) ? spec[g.main_count + row].x : 0.0;
+    const real nyq = (valid && j == 0) ? spec[g.main_count + row].x : 0.0;
 #pragma unroll
     for (int it = 0; it < E; ++it) {
         const int idx = tid + it * TPB;
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
         lds[rr * RS + lpad(8 * b + kin)] = xs[it].x;
     }
     __syncthreads();
-    double* mine = lds + r * RS;
-    double xr_k[E], xr_m[E];
+    real* mine = lds + r * RS;
+    real xr_k[E], xr_m[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int k = j + P * q, mk = (M - k) & (M - 1);
@@ -418,38 +418,38 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int k = j + P * q, mk = (M - k) & (M - 1);
-        const double xi_k = mine[lpad(k)], xi_m = mine[lpad(mk)];
+        const real xi_k = mine[lpad(k)], xi_m = mine[lpad(mk)];
         if (k == 0) {
-            v[q] = make_double2(xr_k[q] + nyq, xr_k[q] - nyq);
+            v[q] = mkc(xr_k[q] + nyq, xr_k[q] - nyq);
         } else {
-            const cplx ev = make_double2(xr_k[q] + xr_m[q], xi_k - xi_m);
-            const cplx d = make_double2(xr_k[q] - xr_m[q], xi_k + xi_m);
+            const cplx ev = mkc(xr_k[q] + xr_m[q], xi_k - xi_m);
+            const cplx d = mkc(xr_k[q] - xr_m[q], xi_k + xi_m);
             const cplx od = cmul(d, cconj(twN[k]));
-            v[q] = make_double2(ev.x - od.y, ev.y + od.x);
+            v[q] = mkc(ev.x - od.y, ev.y + od.x);
         }
     }
     line_fft<M, true>(v, j, mine, twM);
     if (valid) {
         cplx* ub = reinterpret_cast<cplx*>(out + row0 * N2);                  // wave-uniform
-        const unsigned voff = (unsigned)((r * M + j) * 16);
+        const unsigned voff = (unsigned)((r * M + j) * kCB);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const long long e = row * N2 + 2 * (j + P * q);
-            buf_store_c(ub + q * P, voff, make_double2(post(v[q].x, e), post(v[q].y, e + 1)));
+            buf_store_c(ub + q * P, voff, mkc(post(v[q].x, e), post(v[q].y, e + 1)));
         }
     }
 }
 
 // ----------------------------------------------------------------------------------------------
 // generic (any extent) naive DFT kernels -- correctness path for non power-of-two grids
-__global__ void gen_r2c_z_kernel(const double* __restrict__ in, cplx* __restrict__ spec, SpecGeom g,
+__global__ void gen_r2c_z_kernel(const real* __restrict__ in, cplx* __restrict__ spec, SpecGeom g,
                                  const cplx* __restrict__ tw2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.total) return;
     int x, y, kz;
     spec_decode(g, i, x, y, kz);
-    const double* rowp = in + ((long long)x * g.n1 + y) * g.n2;
-    double sr = 0.0, si = 0.0;
+    const real* rowp = in + ((long long)x * g.n1 + y) * g.n2;
+    real sr = 0.0, si = 0.0;
     int t = 0;
     for (int z = 0; z < g.n2; ++z) {
         const cplx w = tw2[t];
@@ -458,7 +458,7 @@ __global__ void gen_r2c_z_kernel(const double* __restrict__ in, cplx* __restrict
         t += kz;
         if (t >= g.n2) t -= g.n2;
     }
-    spec[i] = make_double2(sr, si);
+    spec[i] = mkc(sr, si);
 }
 
 // out-of-place complex DFT along axis 0 (x) or 1 (y)
@@ -470,7 +470,7 @@ __global__ void gen_c2c_kernel(const cplx* __restrict__ in, cplx* __restrict__ o
     spec_decode(g, i, x, y, kz);
     const int n = axis == 0 ? g.n0 : g.n1;
     const int k = axis == 0 ? x : y;
-    double sr = 0.0, si = 0.0;
+    real sr = 0.0, si = 0.0;
     int t = 0;
     for (int e = 0; e < n; ++e) {
         const cplx a = in[axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)];
@@ -481,11 +481,11 @@ __global__ void gen_c2c_kernel(const cplx* __restrict__ in, cplx* __restrict__ o
         t += k;
         if (t >= n) t -= n;
     }
-    out[i] = make_double2(sr, si);
+    out[i] = mkc(sr, si);
 }
 
 template <class Post>
-__global__ void gen_c2r_z_kernel(const cplx* __restrict__ spec, double* __restrict__ out, SpecGeom g,
+__global__ void gen_c2r_z_kernel(const cplx* __restrict__ spec, real* __restrict__ out, SpecGeom g,
                                  const cplx* __restrict__ tw2, Post post) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long npts = g.nrows * g.n2;
@@ -493,7 +493,7 @@ __global__ void gen_c2r_z_kernel(const cplx* __restrict__ spec, double* __restri
     const int z = (int)(i % g.n2);
     const long long row = i / g.n2;
     const int x = (int)(row / g.n1), y = (int)(row % g.n1);
-    double acc = spec[spec_index(g, x, y, 0)].x;
+    real acc = spec[spec_index(g, x, y, 0)].x;
     const int kmax = (g.n2 - 1) / 2;   // strictly-interior frequencies
     int t = 0;
     for (int k = 1; k <= kmax; ++k) {
@@ -563,14 +563,14 @@ template <int LEN, int G, int NOUT> struct XfCfg {
     static constexpr int WANT = (OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8;
     static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
     static constexpr int TPB = G * LPW * P;
-    static constexpr size_t LDS = sizeof(double) * G * LPW * LineBuf<LEN>::STRIDE;
+    static constexpr size_t LDS = sizeof(real) * G * LPW * LineBuf<LEN>::STRIDE;
 };
 
 
 // Mix functor contract (all indices compile-time, so every workgroup runs straight-line code):
 //   static constexpr bool imag(int o)              coefficient of output o is i*c (else c)
 //   template<int O,int I> static constexpr bool present()   whether input I contributes to output O
-//   template<int O,int I> double coef(x, y, kz, uoff, loff)  the real number c at that k-point; uoff + loff =
+//   template<int O,int I> real coef(x, y, kz, uoff, loff)  the real number c at that k-point; uoff + loff =
 //        element offset of the k-point in a spectrum array (uoff wave-uniform) for buffer-load table lookups
 template <int LEN, int LPW_> struct XfMixCtx {
     int j, l, y, kz;
@@ -581,13 +581,13 @@ template <int LEN, int LPW_> struct XfMixCtx {
 // (re, im) += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish).  Both parts
 // of the inputs are in LDS at once (re at pos, im at pos + LEN/2), so every coefficient is fetched ONCE.
 template <int LEN, int LPW, int NIN, int O, int I, class Mix>
-__device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const double* lds, const XfMixCtx<LEN, LPW>& c,
+__device__ __forceinline__ void xf_mix_inputs(real& acr, real& aci, const real* lds, const XfMixCtx<LEN, LPW>& c,
                                               const Mix& mix, int q, int x, int pos) {
     constexpr int STRIDE = LineBuf<LEN>::STRIDE;
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
-            const double cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
-            const double* lb = lds + (I * LPW + c.l) * STRIDE;
+            const real cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
+            const real* lb = lds + (I * LPW + c.l) * STRIDE;
             acr += cf * lb[lpad(pos)];
             aci += cf * lb[lpad(pos + LEN / 2)];
         }
@@ -597,21 +597,21 @@ __device__ __forceinline__ void xf_mix_inputs(double& acr, double& aci, const do
 
 // one output (compile-time O) from all inputs for the half of the thread's points with index HALF
 template <int LEN, int LPW, int NIN, int O, class Mix, int HALF>
-__device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const double* lds, const XfMixCtx<LEN, LPW>& c,
+__device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const real* lds, const XfMixCtx<LEN, LPW>& c,
                                             const Mix& mix) {
     constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E;
 #pragma unroll
     for (int qq = 0; qq < E / 2; ++qq) {
         const int q = qq + HALF * (E / 2);
         const int x = c.j + P * q;
-        double acr = 0.0, aci = 0.0;
+        real acr = 0.0, aci = 0.0;
         xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
-        o[q] = Mix::imag(O) ? make_double2(-aci, acr) : make_double2(acr, aci);     // (i c)(re + i im) = -c im + i c re
+        o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);     // (i c)(re + i im) = -c im + i c re
     }
 }
 
 template <int LEN, int LPW, int NIN, int NOUT, class Mix, int IMPART>
-__device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const double* lds,
+__device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const real* lds,
                                                 const XfMixCtx<LEN, LPW>& c, const Mix& mix) {
     // grp is wave-uniform: a scalar branch into straight-line code specialised per output
     if (grp == 0) xf_mix_part<LEN, LPW, NIN, 0, Mix, IMPART>(o, lds, c, mix);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     constexpr int G = NIN > NOUT ? NIN : NOUT;
     using Cfg = XfCfg<LEN, G, NOUT>;
     constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = LineBuf<LEN>::STRIDE;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     static_assert((LPW * P) % 64 == 0, "a thread group must be whole waves");
     const int grp = __builtin_amdgcn_readfirstlane(tid / (LPW * P));   // wave-uniform by construction
@@ -667,10 +667,10 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
 
     const long long L0 = (long long)bid * LPW;
     const long long b0 = uniform64(region + line_base(m, L0));                 // wave-uniform
-    const unsigned voff = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * m.se) * 16) : 0u;
+    const unsigned voff = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * m.se) * kCB) : 0u;
     const long long qstep = uniform64((long long)P * m.se);
     const long long se_o = xs.se_out ? xs.se_out : m.se, se_t = xs.tse ? xs.tse : m.se;
-    const unsigned voff_o = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * se_o) * 16) : 0u;
+    const unsigned voff_o = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * se_o) * kCB) : 0u;
     const unsigned tloff = valid ? (unsigned)(base - line_base(m, L0) + (long long)j * se_t) : 0u;
     const long long qstep_o = uniform64((long long)P * se_o), tqstep = uniform64((long long)P * se_t);
     cplx v[E];
@@ -682,14 +682,14 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
         for (int q = 0; q < E; ++q) v[q] = buf_load_c_aux<OFDFT_XF_LD_AUX>(ub + q * qstep, voff);
     } else {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(0.0, 0.0);
+        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
     }
-    double* mine = lds + (grp * LPW + l) * STRIDE;
+    real* mine = lds + (grp * LPW + l) * STRIDE;
     line_fft<LEN, false>(v, j, mine, tw);
 
     cplx o[E];
 #pragma unroll
-    for (int q = 0; q < E; ++q) o[q] = make_double2(0.0, 0.0);
+    for (int q = 0; q < E; ++q) o[q] = mkc(0.0, 0.0);
     XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, tqstep, tloff};
     // ---- mix in two halves of the k-points (x < LEN/2, then the rest): the line buffer holds the real parts of a
     // half at [0, LEN/2) and the imaginary parts at [LEN/2, LEN)

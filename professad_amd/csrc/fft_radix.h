@@ -1,4 +1,4 @@
-// In-register radix butterflies and the multi-stage Stockham line FFT (fp64) for gfx950.
+// In-register radix butterflies and the multi-stage Stockham line FFT for gfx950 (fp64; fp32 with -DOFDFT_REAL_F32).
 //
 // A line of LEN complex points is owned by P = LEN/E threads, E points per thread.  On entry and
 // on exit thread j holds v[q] = x[j + P*q], q = 0..E-1 (so global loads/stores with consecutive j
@@ -12,26 +12,42 @@
 
 namespace ofdft {
 
+// The arithmetic type of the grid data.  The library is built once per precision (FFTW-style): the default build is
+// fp64 (the reference's precision, parity 1e-8 Ha/atom), -DOFDFT_REAL_F32 builds the fp32 variant of the same kernels
+// (BASELINE config 5).  Energy sums, their partials and every scalar derived from them are fp64 in both (acc_t).
+#ifdef OFDFT_REAL_F32
+typedef float real;
+typedef float2 cplx;
+#else
+typedef double real;
 typedef double2 cplx;
-
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+typedef double acc_t;
+__host__ __device__ __forceinline__ cplx mkc(real x, real y) {
+    cplx c;
+    c.x = x;
+    c.y = y;
+    return c;
 }
-__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return mkc(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return mkc(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cplx cconj(cplx a) { return mkc(a.x, -a.y); }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) {
-    return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+    return INV ? mkc(-a.y, a.x) : mkc(a.y, -a.x);
 }
 
 // cos(2 pi k / 16), sin(2 pi k / 16)
-__device__ constexpr double kCos16[16] = {
+__device__ constexpr real kCos16[16] = {
     1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
     -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173,
     0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
-__device__ constexpr double kSin16[16] = {
+__device__ constexpr real kSin16[16] = {
     0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
     1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
     0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
@@ -42,12 +58,12 @@ template <int R, int K, bool INV> __device__ __forceinline__ cplx mul_w(cplx a) 
     constexpr int idx = (K * (16 / R)) & 15;
     if constexpr (idx == 0) return a;
     else if constexpr (idx == 4) return mul_mi<INV>(a);
-    else if constexpr (idx == 8) return make_double2(-a.x, -a.y);
+    else if constexpr (idx == 8) return mkc(-a.x, -a.y);
     else if constexpr (idx == 12) return mul_mi<!INV>(a);
     else {
-        constexpr double c = kCos16[idx];
-        constexpr double s = INV ? kSin16[idx] : -kSin16[idx];
-        return make_double2(a.x * c - a.y * s, a.x * s + a.y * c);
+        constexpr real c = kCos16[idx];
+        constexpr real s = INV ? kSin16[idx] : -kSin16[idx];
+        return mkc(a.x * c - a.y * s, a.x * s + a.y * c);
     }
 }
 
@@ -67,36 +83,46 @@ __device__ __forceinline__ long long uniform64(long long v) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffc, 0x00020000);
 }
-__device__ __forceinline__ cplx buf_load_c(const cplx* ubase, unsigned voff_bytes) {
-    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, 0);
-    return *reinterpret_cast<cplx*>(&t);
-}
-__device__ __forceinline__ void buf_store_c(cplx* ubase, unsigned voff_bytes, cplx v) {
-    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, 0);
-}
-// plain-pointer nontemporal accesses (per-lane 64-bit addresses: the exchange-buffer side of the slab-decomposed y pass)
-typedef double dbl2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cplx nt_load_c(const cplx* p) {
-    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
-    return make_double2(t.x, t.y);
-}
-__device__ __forceinline__ void nt_store_c(cplx* p, cplx v) {
-    dbl2_t t;
-    t.x = v.x;
-    t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(p));
-}
-// streaming variants (aux bit 1 = nt): data that is touched once per pass and not re-read before it leaves the caches
+// one complex element = one 16-byte (fp64) or 8-byte (fp32) buffer access
+constexpr unsigned kCB = (unsigned)sizeof(cplx);          // bytes per complex element (byte offsets are built from it)
 template <int AUX> __device__ __forceinline__ cplx buf_load_c_aux(const cplx* ubase, unsigned voff_bytes) {
-    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, AUX);
-    return *reinterpret_cast<cplx*>(&t);
+    if constexpr (sizeof(cplx) == 16) {
+        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+        return *reinterpret_cast<cplx*>(&t);
+    } else {
+        u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+        return *reinterpret_cast<cplx*>(&t);
+    }
 }
 template <int AUX> __device__ __forceinline__ void buf_store_c_aux(cplx* ubase, unsigned voff_bytes, cplx v) {
-    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+    if constexpr (sizeof(cplx) == 16)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+    else
+        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<u32x2*>(&v), make_rsrc(ubase), (int)voff_bytes, 0, AUX);
 }
-__device__ __forceinline__ double buf_load_d(const double* ubase, unsigned voff_bytes) {
-    u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(ubase), (int)voff_bytes, 0, 0);
-    return *reinterpret_cast<double*>(&t);
+// streaming variants: AUX bit 1 = nt, for data that is touched once per pass and not re-read before it leaves the caches
+__device__ __forceinline__ cplx buf_load_c(const cplx* ubase, unsigned voff_bytes) { return buf_load_c_aux<0>(ubase, voff_bytes); }
+__device__ __forceinline__ void buf_store_c(cplx* ubase, unsigned voff_bytes, cplx v) { buf_store_c_aux<0>(ubase, voff_bytes, v); }
+// plain-pointer nontemporal accesses (per-lane 64-bit addresses: the exchange-buffer side of the slab-decomposed y pass)
+typedef real real2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx nt_load_c(const cplx* p) {
+    const real2_t t = __builtin_nontemporal_load(reinterpret_cast<const real2_t*>(p));
+    return mkc(t.x, t.y);
+}
+__device__ __forceinline__ void nt_store_c(cplx* p, cplx v) {
+    real2_t t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<real2_t*>(p));
+}
+__device__ __forceinline__ real buf_load_d(const real* ubase, unsigned voff_bytes) {
+    if constexpr (sizeof(real) == 8) {
+        u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(ubase), (int)voff_bytes, 0, 0);
+        return *reinterpret_cast<real*>(&t);
+    } else {
+        unsigned t = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(ubase), (int)voff_bytes, 0, 0);
+        return *reinterpret_cast<real*>(&t);
+    }
 }
 
 // natural-order in-place DFT of R points held in registers
@@ -190,7 +216,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
     static constexpr int P = PL::P;
     static constexpr int NB = E / R;       // butterflies per thread in this stage (also register stride)
 
-    static __device__ __forceinline__ void run(cplx (&v)[E], int j, double* line, const cplx* __restrict__ tw) {
+    static __device__ __forceinline__ void run(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {
         // ---- twiddle + butterflies
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -231,7 +257,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
 #pragma unroll
                 for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
             exchange_sync<WAVE>();
-            double re[E];
+            real re[E];
 #pragma unroll
             for (int q = 0; q < E; ++q) re[q] = line[lpad(j + P * q)];
             exchange_sync<WAVE>();
@@ -241,7 +267,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
                 for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
             exchange_sync<WAVE>();
 #pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = make_double2(re[q], line[lpad(j + P * q)]);
+            for (int q = 0; q < E; ++q) v[q] = mkc(re[q], line[lpad(j + P * q)]);
             StageP<PL, S + 1, NS * R, INV, WAVE>::run(v, j, line, tw);
         }
     }
@@ -251,7 +277,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
 // the plan has one stage).  `tw` = forward table W_LEN^m, m = 0..LEN-1 (global memory).
 // Every thread of the workgroup must call this (it contains __syncthreads()).
 template <int LEN, bool INV>
-__device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, double* line, const cplx* __restrict__ tw) {
+__device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, real* line, const cplx* __restrict__ tw) {
     StageP<Plan<LEN>, 0, 1, INV, false>::run(v, j, line, tw);
 }
 
@@ -288,7 +314,7 @@ OFDFT_ZPLAN(256, 4, 4, 4, 4, 4, 4)
 template <int M, int WANT> struct ZPick { static constexpr int E = (M / WANT <= 64) ? WANT : 8; };
 
 template <int LEN, int E, bool INV>
-__device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, double* line, const cplx* __restrict__ tw) {
+__device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {
     static_assert(ZPlan<LEN, E>::P <= 64, "a line must fit one wavefront");
     StageP<ZPlan<LEN, E>, 0, 1, INV, true>::run(v, j, line, tw);
 }

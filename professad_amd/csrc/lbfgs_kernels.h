@@ -16,7 +16,7 @@ namespace ofdft {
 #endif
 __device__ __forceinline__ double2 lb_load2(const double* p, long long i) {
 #if OFDFT_LBFGS_NT
-    const dbl2_t t = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p) + i);
+    const real2_t t = __builtin_nontemporal_load(reinterpret_cast<const real2_t*>(p) + i);
     return make_double2(t.x, t.y);
 #else
     return reinterpret_cast<const double2*>(p)[i];
@@ -24,10 +24,10 @@ __device__ __forceinline__ double2 lb_load2(const double* p, long long i) {
 }
 __device__ __forceinline__ void lb_store2(double* p, long long i, double2 v) {
 #if OFDFT_LBFGS_NT
-    dbl2_t t;
+    real2_t t;
     t.x = v.x;
     t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t*>(p) + i);
+    __builtin_nontemporal_store(t, reinterpret_cast<real2_t*>(p) + i);
 #else
     reinterpret_cast<double2*>(p)[i] = v;
 #endif

@@ -15,11 +15,11 @@ constexpr int kMaxScalars = 28;    // scalars reduced by one kernel (27: the rea
 
 // ---- block reduction of NS scalars; thread 0 writes partial[blockIdx.x * NS + s]
 template <int NS>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __restrict__ partial) {
-    __shared__ double red[kRedThreads / 64][NS];
+__device__ __forceinline__ void block_reduce_store(acc_t (&acc)[NS], acc_t* __restrict__ partial) {
+    __shared__ acc_t red[kRedThreads / 64][NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        double v = acc[s];
+        acc_t v = acc[s];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         acc[s] = v;
@@ -33,7 +33,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            double t = 0.0;
+            acc_t t = 0.0;
 #pragma unroll
             for (int ww = 0; ww < kRedThreads / 64; ++ww) t += red[ww][s];
             partial[(long long)blockIdx.x * NS + s] = t;
@@ -42,12 +42,12 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NS], double* __
 }
 
 // second level: partial[rows][ns] -> out[ns], fixed summation order (bitwise reproducible)
-__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const double* __restrict__ partial, int rows, int ns,
-                                                                      double* __restrict__ out) {
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const acc_t* __restrict__ partial, int rows, int ns,
+                                                                      acc_t* __restrict__ out) {
     const int s = blockIdx.x;
-    double acc[1] = {0.0};
+    acc_t acc[1] = {0.0};
     for (int r = threadIdx.x; r < rows; r += kRedThreads) acc[0] += partial[(long long)r * ns + s];
-    __shared__ double red[kRedThreads];
+    __shared__ acc_t red[kRedThreads];
     red[threadIdx.x] = acc[0];
     __syncthreads();
     for (int off = kRedThreads / 2; off > 0; off >>= 1) {
@@ -59,13 +59,13 @@ __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const doub
 
 // sum(a) or sum(a^2)
 template <bool SQUARE>
-__global__ __launch_bounds__(kRedThreads) void sum_kernel(const double* __restrict__ a, long long n,
-                                                          double* __restrict__ partial) {
-    double acc[1] = {0.0};
+__global__ __launch_bounds__(kRedThreads) void sum_kernel(const real* __restrict__ a, long long n,
+                                                          acc_t* __restrict__ partial) {
+    acc_t acc[1] = {0.0};
     const long long n2 = n >> 1;
-    const double2* a2 = reinterpret_cast<const double2*>(a);
+    const cplx* a2 = reinterpret_cast<const cplx*>(a);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 t = a2[i];
+        const cplx t = a2[i];
         acc[0] += SQUARE ? (t.x * t.x + t.y * t.y) : (t.x + t.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc[0] += SQUARE ? a[n - 1] * a[n - 1] : a[n - 1];
@@ -74,35 +74,35 @@ __global__ __launch_bounds__(kRedThreads) void sum_kernel(const double* __restri
 
 // elementwise unary maps (prep of FFT inputs); 16-byte accesses, scalar tail for odd sizes
 enum { MAP_SQRT = 0, MAP_POW = 1, MAP_SCALE_SQ = 2 };
-template <int OP> __device__ __forceinline__ double map_op(double x, double p) {
+template <int OP> __device__ __forceinline__ real map_op(real x, real p) {
     if (OP == MAP_SQRT) return (x != 0.0) ? sqrt(x) : 0.0;        // functionals.py:242-243
     if (OP == MAP_POW) return pow(x, p);
     return p * x * x;                                               // n = c chi^2, system.py:834
 }
 template <int OP>
-__global__ void map_kernel(const double* __restrict__ a, double* __restrict__ out, long long n, double p) {
+__global__ void map_kernel(const real* __restrict__ a, real* __restrict__ out, long long n, real p) {
     const long long n2 = n >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 x = reinterpret_cast<const double2*>(a)[i];
-        reinterpret_cast<double2*>(out)[i] = make_double2(map_op<OP>(x.x, p), map_op<OP>(x.y, p));
+        const cplx x = reinterpret_cast<const cplx*>(a)[i];
+        reinterpret_cast<cplx*>(out)[i] = mkc(map_op<OP>(x.x, p), map_op<OP>(x.y, p));
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = map_op<OP>(a[n - 1], p);
 }
 
 // WGC99 real-space inputs: A = n^e, B = A theta, C = A theta^2 / 2 (functionals.py:974-981)
-__global__ void wgc_prep_kernel(const double* __restrict__ n, double* __restrict__ A, double* __restrict__ B,
-                                double* __restrict__ C, long long npts, double expo, double nref) {
+__global__ void wgc_prep_kernel(const real* __restrict__ n, real* __restrict__ A, real* __restrict__ B,
+                                real* __restrict__ C, long long npts, real expo, real nref) {
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 d = reinterpret_cast<const double2*>(n)[i];
-        const double t0 = d.x - nref, t1 = d.y - nref, a0 = pow(d.x, expo), a1 = pow(d.y, expo);
-        reinterpret_cast<double2*>(A)[i] = make_double2(a0, a1);
-        reinterpret_cast<double2*>(B)[i] = make_double2(a0 * t0, a1 * t1);
-        reinterpret_cast<double2*>(C)[i] = make_double2(0.5 * a0 * t0 * t0, 0.5 * a1 * t1 * t1);
+        const cplx d = reinterpret_cast<const cplx*>(n)[i];
+        const real t0 = d.x - nref, t1 = d.y - nref, a0 = pow(d.x, expo), a1 = pow(d.y, expo);
+        reinterpret_cast<cplx*>(A)[i] = mkc(a0, a1);
+        reinterpret_cast<cplx*>(B)[i] = mkc(a0 * t0, a1 * t1);
+        reinterpret_cast<cplx*>(C)[i] = mkc(0.5 * a0 * t0 * t0, 0.5 * a1 * t1 * t1);
     }
     if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long i = npts - 1;
-        const double d = n[i], th = d - nref, a = pow(d, expo);
+        const real d = n[i], th = d - nref, a = pow(d, expo);
         A[i] = a;
         B[i] = a * th;
         C[i] = 0.5 * a * th * th;
@@ -112,17 +112,17 @@ __global__ void wgc_prep_kernel(const double* __restrict__ n, double* __restrict
 // ---- reciprocal space -------------------------------------------------------------------------
 struct KGeom {
     SpecGeom g;
-    double b[9];   // b = 2 pi inv(box^T), row-major (functional_tools.py:149)
+    real b[9];   // b = 2 pi inv(box^T), row-major (functional_tools.py:149)
     int y0;        // first global y index held by this rank in the x-pass (y-slab) geometry; 0 on one GPU
     int n1g;       // global extent of axis 1 (= g.n1 on one GPU)
 };
 
-__device__ __forceinline__ double ifreq(int i, int n) { return (double)(i <= n / 2 ? i : i - n); }   // :152-154
+__device__ __forceinline__ real ifreq(int i, int n) { return (real)(i <= n / 2 ? i : i - n); }   // :152-154
 
-__device__ __forceinline__ void kvec(const KGeom& kg, long long i, double& kx, double& ky, double& kz, double& k2) {
+__device__ __forceinline__ void kvec(const KGeom& kg, long long i, real& kx, real& ky, real& kz, real& k2) {
     int x, y, z;
     spec_decode(kg.g, i, x, y, z);
-    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (double)z;     // :155 rfftfreq
+    const real fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (real)z;     // :155 rfftfreq
     kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];                                  // :158-160
     ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
     kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
@@ -130,8 +130,8 @@ __device__ __forceinline__ void kvec(const KGeom& kg, long long i, double& kx, d
 }
 
 // 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648)
-__device__ __forceinline__ double lindhard_shape(double eta) {
-    double ginv;
+__device__ __forceinline__ real lindhard_shape(real eta) {
+    real ginv;
     if (eta == 0.0) ginv = 1.0;
     else if (eta == 1.0) ginv = 0.5;
     else ginv = 0.5 + ((1.0 - eta * eta) / (4.0 * eta)) * log(fabs((1.0 + eta) / (1.0 - eta)));
@@ -141,26 +141,26 @@ __device__ __forceinline__ double lindhard_shape(double eta) {
 enum { SPEC_HARTREE = 0, SPEC_LAPLACE = 1, SPEC_LINDHARD = 2 };
 // out = in * f(k); p0,p1 parameters (LINDHARD: p0 = prefactor, p1 = 1/(2 kF))
 template <int OP>
-__global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict__ out, KGeom kg, double p0, double p1) {
+__global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict__ out, KGeom kg, real p0, real p1) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
-        double kx, ky, kz, k2;
+        real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
-        double f;
+        real f;
         if (OP == SPEC_HARTREE) f = (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;              // functionals.py:67-70
         else if (OP == SPEC_LAPLACE) f = -k2;                                       // functional_tools.py:227
         else f = p0 * lindhard_shape((k2 != 0.0) ? sqrt(k2) * p1 : 0.0);            // functionals.py:637-638,648
         const cplx a = in[i];
-        out[i] = make_double2(a.x * f, a.y * f);
+        out[i] = mkc(a.x * f, a.y * f);
     }
 }
 
 // acc += f * k^2 * in   (adds -f * Laplacian in reciprocal space)
-__global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restrict__ acc, KGeom kg, double f) {
+__global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restrict__ acc, KGeom kg, real f) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
-        double kx, ky, kz, k2;
+        real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
         const cplx a = in[i], b = acc[i];
-        acc[i] = make_double2(b.x + f * k2 * a.x, b.y + f * k2 * a.y);
+        acc[i] = mkc(b.x + f * k2 * a.x, b.y + f * k2 * a.y);
     }
 }
 
@@ -168,12 +168,12 @@ __global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restric
 __global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                  cplx* __restrict__ gz, KGeom kg) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
-        double kx, ky, kz, k2;
+        real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
         const cplx a = in[i];
-        gx[i] = make_double2(-kx * a.y, kx * a.x);
-        gy[i] = make_double2(-ky * a.y, ky * a.x);
-        gz[i] = make_double2(-kz * a.y, kz * a.x);
+        gx[i] = mkc(-kx * a.y, kx * a.x);
+        gy[i] = mkc(-ky * a.y, ky * a.x);
+        gz[i] = mkc(-kz * a.y, kz * a.x);
     }
 }
 
@@ -181,33 +181,33 @@ __global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__
 __global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* __restrict__ fy, const cplx* __restrict__ fz,
                                 cplx* __restrict__ out, KGeom kg) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
-        double kx, ky, kz, k2;
+        real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
         const cplx a = fx[i], b = fy[i], c = fz[i];
-        out[i] = make_double2(-(kx * a.y + ky * b.y + kz * c.y), kx * a.x + ky * b.x + kz * c.x);
+        out[i] = mkc(-(kx * a.y + ky * b.y + kz * c.y), kx * a.x + ky * b.x + kz * c.x);
     }
 }
 
 // WGC99 spectral mixing, in place: (A,B,C) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A)   SURVEY §8a-8
 __global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, cplx* __restrict__ C,
-                                    const double* __restrict__ w0, const double* __restrict__ K1,
-                                    const double* __restrict__ K2, const double* __restrict__ K3, long long total) {
+                                    const real* __restrict__ w0, const real* __restrict__ K1,
+                                    const real* __restrict__ K2, const real* __restrict__ K3, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const cplx a = A[i], b = B[i], c = C[i];
-        const double t0 = w0[4 * i], t1 = K1[4 * i], t2 = K2[4 * i], t3 = K3[4 * i];   // interleaved (w0,K1,K2,K3) per k-point
-        A[i] = make_double2(t0 * a.x + t1 * b.x + t2 * c.x, t0 * a.y + t1 * b.y + t2 * c.y);
-        B[i] = make_double2(t1 * a.x + t3 * b.x, t1 * a.y + t3 * b.y);
-        C[i] = make_double2(t2 * a.x, t2 * a.y);
+        const real t0 = w0[4 * i], t1 = K1[4 * i], t2 = K2[4 * i], t3 = K3[4 * i];   // interleaved (w0,K1,K2,K3) per k-point
+        A[i] = mkc(t0 * a.x + t1 * b.x + t2 * c.x, t0 * a.y + t1 * b.y + t2 * c.y);
+        B[i] = mkc(t1 * a.x + t3 * b.x, t1 * a.y + t3 * b.y);
+        C[i] = mkc(t2 * a.x, t2 * a.y);
     }
 }
 
 // WGC99 kernel tables on the k grid (functionals.py:845-939 for w,w',w''; :968-972 for T,K1,K2,K3).
 struct WgcSeries {
-    double u, v, c1, c2;      // homogeneous-solution constants
-    double gamma, nref, pref; // pref = 20 nref^(5/3-alpha-beta)
-    double inv2kf;
-    const double* ca;         // [nt] A_i / ((u+2i)^2 - v)
-    const double* cb;         // [nt] B_i / ((u-2i)^2 - v)
+    real u, v, c1, c2;      // homogeneous-solution constants
+    real gamma, nref, pref; // pref = 20 nref^(5/3-alpha-beta)
+    real inv2kf;
+    const real* ca;         // [nt] A_i / ((u+2i)^2 - v)
+    const real* cb;         // [nt] B_i / ((u-2i)^2 - v)
     int nt;
 };
 
@@ -218,52 +218,52 @@ struct TabMap { int on, nyl, nzm; long long arr_sz; };
 // w, w', w'' (and w''' when THIRD) of the WGC99 kernel at eta != 0, before the prefactor (functionals.py:845-939):
 // homogeneous solution + particular series by Horner in eta^2 (inside) or eta^-2 (outside)
 template <bool THIRD>
-__device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, double& w0, double& w1, double& w2, double& w3) {
+__device__ __forceinline__ void wgc_series(real eta, const WgcSeries& s, real& w0, real& w1, real& w2, real& w3) {
     const bool inner = eta <= 1.0;
     const bool on = (s.u >= 0.0) ? inner : !inner;
-    const double C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
-    const double le = log(eta);
-    double H0, H1, H2, H3 = 0.0;
+    const real C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
+    const real le = log(eta);
+    real H0, H1, H2, H3 = 0.0;
     if (s.v > 0.0) {
-        const double rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
-        const double px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
+        const real rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
+        const real px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
         H0 = (C1 * px + C2 * py) * eta * eta;
         H1 = (C1 * x * px + C2 * y * py) * eta;
         H2 = C1 * x * (x - 1.0) * px + C2 * y * (y - 1.0) * py;
         if (THIRD) H3 = (C1 * x * (x - 1.0) * (x - 2.0) * px + C2 * y * (y - 1.0) * (y - 2.0) * py) / eta;
     } else if (s.v == 0.0) {
-        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        const real pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
         H0 = pu * (C2 * le + C1);
         H1 = C2 * pu1 * (1.0 + s.u * le) + C1 * s.u * pu1;
         H2 = C2 * ((s.u - 1.0) * pu2 * (1.0 + s.u * le) + pu2) + C1 * s.u * (s.u - 1.0) * pu2;
         // third derivative of eta^u (C2 ln eta + C1)
         if (THIRD) {
-            const double a3 = s.u * (s.u - 1.0) * (s.u - 2.0), b3 = 3.0 * s.u * s.u - 6.0 * s.u + 2.0;
+            const real a3 = s.u * (s.u - 1.0) * (s.u - 2.0), b3 = 3.0 * s.u * s.u - 6.0 * s.u + 2.0;
             H3 = pu2 / eta * (C2 * (a3 * le + b3) + C1 * a3);
         }
     } else {
-        const double rv = sqrt(-s.v);
-        const double tc = cos(rv * le), ts = sin(rv * le);
-        const double p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
-        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        const real rv = sqrt(-s.v);
+        const real tc = cos(rv * le), ts = sin(rv * le);
+        const real p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
+        const real pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
         H0 = pu * (C1 * tc + C2 * ts);
         H1 = pu1 * (C1 * p + C2 * q);
         H2 = pu2 * ((s.u - 1.0) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q));
         if (THIRD) {      // H = Re[(C1 - i C2) eta^z], z = u + i rv:  H''' = Re[(C1 - i C2) z (z-1) (z-2) eta^(z-3)]
-            const double zr = s.u, zi = rv;
-            double ar = zr * (zr - 1.0) - zi * zi, ai = zi * (2.0 * zr - 1.0);           // z (z-1)
-            const double br = ar * (zr - 2.0) - ai * zi, bi = ar * zi + ai * (zr - 2.0);  // ... (z-2)
-            const double dr = C1 * br + C2 * bi, di = C1 * bi - C2 * br;                  // (C1 - i C2) * that
+            const real zr = s.u, zi = rv;
+            real ar = zr * (zr - 1.0) - zi * zi, ai = zi * (2.0 * zr - 1.0);           // z (z-1)
+            const real br = ar * (zr - 2.0) - ai * zi, bi = ar * zi + ai * (zr - 2.0);  // ... (z-2)
+            const real dr = C1 * br + C2 * bi, di = C1 * bi - C2 * br;                  // (C1 - i C2) * that
             H3 = pu2 / eta * (dr * tc - di * ts);
         }
     }
-    const double x = inner ? eta * eta : 1.0 / (eta * eta);
-    double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
+    const real x = inner ? eta * eta : 1.0 / (eta * eta);
+    real P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
     for (int t = s.nt - 1; t >= 0; --t) {
-        const double ti = 2.0 * t;
-        const double c = inner ? s.cb[t] : s.ca[t];
-        const double d1 = inner ? ti * c : -ti * c;
-        const double d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
+        const real ti = 2.0 * t;
+        const real c = inner ? s.cb[t] : s.ca[t];
+        const real d1 = inner ? ti * c : -ti * c;
+        const real d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
         P0 = P0 * x + c;
         P1 = P1 * x + d1;
         P2 = P2 * x + d2;
@@ -277,10 +277,10 @@ __device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, doubl
     w3 = THIRD ? H3 + P3 / (eta * eta * eta) : 0.0;
 }
 
-__global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ K1o, double* __restrict__ K2o,
-                                 double* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
+__global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict__ K1o, real* __restrict__ K2o,
+                                 real* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
     for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < kg.g.total; ii += (long long)gridDim.x * blockDim.x) {
-        double kx, ky, kz, k2;
+        real kx, ky, kz, k2;
         kvec(kg, ii, kx, ky, kz, k2);
         long long i = ii;
         if (tm.on) {
@@ -289,8 +289,8 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
             i = x * tm.arr_sz + (z < tm.nzm ? (((long long)(z >> 3) * tm.nyl + y) * 8 + (z & 7))
                                             : ((long long)tm.nzm * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y));
         }
-        const double eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
-        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;
+        const real eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
+        real w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;
         if (eta != 0.0) wgc_series<false>(eta, s, w0, w1, w2, w3);
         w0 *= s.pref;
         w1 *= s.pref;
@@ -304,9 +304,9 @@ __global__ void wgc_table_kernel(double* __restrict__ w0o, double* __restrict__ 
 }
 
 // ---- mixing functors of the fused x pass (see xfused_kernel in fft_kernels.h) ----------------------
-__device__ __forceinline__ void kvec_xyz(const KGeom& kg, int x, int y, int z, double& kx, double& ky, double& kz,
-                                         double& k2) {
-    const double fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (double)z;
+__device__ __forceinline__ void kvec_xyz(const KGeom& kg, int x, int y, int z, real& kx, real& ky, real& kz,
+                                         real& k2) {
+    const real fa = ifreq(x, kg.g.n0), fb = ifreq(y + kg.y0, kg.n1g), fc = (real)z;
     kx = fa * kg.b[0] + fb * kg.b[3] + fc * kg.b[6];
     ky = fa * kg.b[1] + fb * kg.b[4] + fc * kg.b[7];
     kz = fa * kg.b[2] + fb * kg.b[5] + fc * kg.b[8];
@@ -319,8 +319,8 @@ template <bool HAS_H, bool HAS_G> struct MixDensity {
     static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
-        double kx, ky, kz, k2;
+    __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
+        real kx, ky, kz, k2;
         kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
         if (HAS_H && O == 0) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
         constexpr int c = O - (HAS_H ? 1 : 0);
@@ -335,9 +335,9 @@ template <bool HAS_H> struct MixDensityA {
     static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
+    __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         if (HAS_H && O == 0) {
-            double kx, ky, kz, k2;
+            real kx, ky, kz, k2;
             kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
             return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
         }
@@ -350,18 +350,18 @@ struct MixDerivA {
     static __device__ __forceinline__ constexpr bool imag(int) { return true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int x, int, int, long long, unsigned) const { return ifreq(x, kg.g.n0); }
+    __device__ __forceinline__ real coef(int x, int, int, long long, unsigned) const { return ifreq(x, kg.g.n0); }
 };
 
 // one spectrum times a real f(k): OP as spec_scale_kernel
 template <int OP> struct MixScale {
     KGeom kg;
-    double p0, p1;
+    real p0, p1;
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
-        double kx, ky, kz, k2;
+    __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
+        real kx, ky, kz, k2;
         kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
         if (OP == SPEC_HARTREE) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
         if (OP == SPEC_LAPLACE) return -k2;
@@ -375,8 +375,8 @@ struct MixDiv {
     static __device__ __forceinline__ constexpr bool imag(int) { return true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int x, int y, int z, long long, unsigned) const {
-        double kx, ky, kz, k2;
+    __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
+        real kx, ky, kz, k2;
         kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
         return I == 0 ? kx : (I == 1 ? ky : kz);
     }
@@ -384,12 +384,12 @@ struct MixDiv {
 
 // WGC99: (A^,B^,C^) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) with tables in the spectrum layout
 struct MixWgc {
-    const double* tab;     // interleaved (w0, K1, K2, K3) per k-point, spectrum order
+    const real* tab;     // interleaved (w0, K1, K2, K3) per k-point, spectrum order
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return O + I <= 2; }
     template <int O, int I>
-    __device__ __forceinline__ double coef(int, int, int, long long uoff, unsigned loff) const {
+    __device__ __forceinline__ real coef(int, int, int, long long uoff, unsigned loff) const {
         // 16-byte loads of (w0,K1) or (K2,K3): identical loads of one k-point are merged by the compiler
         const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff + ((O + I == 2) ? 1 : 0);
         const cplx pr = buf_load_c(t2, loff * 32);
@@ -399,39 +399,39 @@ struct MixWgc {
 
 // ---- XC pointwise math -------------------------------------------------------------------------
 // PW92 eps_c(rs) and d eps_c / d rs (functionals.py:1524-1530; tests/tools_for_tests.py:136-144)
-__device__ __forceinline__ void pw92(double rs, double& eps, double& deps_drs) {
-    const double A = 0.0310907, a1 = 0.2137, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
-    const double sr = sqrt(rs);
-    const double zeta = 2.0 * A * (b1 * sr + b2 * rs + b3 * rs * sr + b4 * rs * rs);
-    const double izeta = 1.0 / zeta;
-    const double lg = log(1.0 + izeta);
+__device__ __forceinline__ void pw92(real rs, real& eps, real& deps_drs) {
+    const real A = 0.0310907, a1 = 0.2137, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    const real sr = sqrt(rs);
+    const real zeta = 2.0 * A * (b1 * sr + b2 * rs + b3 * rs * sr + b4 * rs * rs);
+    const real izeta = 1.0 / zeta;
+    const real lg = log(1.0 + izeta);
     eps = -2.0 * A * (1.0 + a1 * rs) * lg;
-    const double dzeta = 2.0 * A * (0.5 * b1 / sr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
+    const real dzeta = 2.0 * A * (0.5 * b1 / sr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
     deps_drs = -2.0 * A * a1 * lg + 2.0 * A * (1.0 + a1 * rs) * dzeta * izeta / (zeta + 1.0);
 }
 
-struct XcLocal { double ex, vx, ec, vc; };   // energy densities (per volume) and potentials
+struct XcLocal { real ex, vx, ec, vc; };   // energy densities (per volume) and potentials
 
 // LDA exchange + one of PZ / PW / Chachiyo correlation (functionals.py:1510-1537; tools_for_tests.py:121-152)
-__device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
+__device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
     XcLocal r = {0.0, 0.0, 0.0, 0.0};
-    const double cx = -0.75 * cbrt(3.0 / kPi);
-    const double n13 = cbrt(n);
+    const real cx = -0.75 * cbrt(3.0 / kPi);
+    const real n13 = cbrt(n);
     if (mask & (1u << 6)) {
         r.ex = cx * n13 * n;
         r.vx = (4.0 / 3.0) * cx * n13;
     }
     if (mask & ((1u << 7) | (1u << 8) | (1u << 9))) {
-        const double rs = cbrt(3.0 / (4.0 * kPi * n));
+        const real rs = cbrt(3.0 / (4.0 * kPi * n));
         if (mask & (1u << 7)) {
-            const double gm = -0.1423, b1 = 1.0529, b2 = 0.3334, A = 0.0311, B = -0.048, C = 0.002, D = -0.0116;
-            double eps, v;
+            const real gm = -0.1423, b1 = 1.0529, b2 = 0.3334, A = 0.0311, B = -0.048, C = 0.002, D = -0.0116;
+            real eps, v;
             if (rs < 1.0) {
-                const double lr = log(rs);
+                const real lr = log(rs);
                 eps = A * lr + B + C * rs * lr + D * rs;
                 v = lr * (A + (2.0 / 3.0) * C * rs) + (B - A / 3.0) + rs / 3.0 * (2.0 * D - C);
             } else {
-                const double sr = sqrt(rs), den = 1.0 + b1 * sr + b2 * rs;
+                const real sr = sqrt(rs), den = 1.0 + b1 * sr + b2 * rs;
                 eps = gm / den;
                 v = gm * (1.0 + (7.0 / 6.0) * b1 * sr + (4.0 / 3.0) * b2 * rs) / (den * den);
             }
@@ -439,16 +439,16 @@ __device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
             r.vc += v;
         }
         if (mask & (1u << 8)) {
-            double eps, d;
+            real eps, d;
             pw92(rs, eps, d);
             r.ec += eps * n;
             r.vc += eps - rs / 3.0 * d;
         }
         if (mask & (1u << 9)) {
-            const double a = (log(2.0) - 1.0) / (2.0 * kPi * kPi), b = 20.4562557;
-            const double arg = 1.0 + b / rs + b / (rs * rs);
-            const double eps = a * log(arg);
-            const double d = a / arg * (-b / (rs * rs) - 2.0 * b / (rs * rs * rs));
+            const real a = (log(2.0) - 1.0) / (2.0 * kPi * kPi), b = 20.4562557;
+            const real arg = 1.0 + b / rs + b / (rs * rs);
+            const real eps = a * log(arg);
+            const real d = a / arg * (-b / (rs * rs) - 2.0 * b / (rs * rs * rs));
             r.ec += eps * n;
             r.vc += eps - rs / 3.0 * d;
         }
@@ -456,30 +456,30 @@ __device__ __forceinline__ XcLocal lda_point(double n, unsigned mask) {
     return r;
 }
 
-struct PbePoint { double fx, fc, fk, dfdn, dfdg; };
+struct PbePoint { real fx, fc, fk, dfdn, dfdg; };
 // which GGA pieces a pass evaluates: PBE exchange / correlation, and the Pauli part of a GGA kinetic functional
 // (kkind 0: LuoKarasievTrickey F = 1/cosh(1.3 s), functionals.py:309-333; 1: Pauli-Gaussian F = exp(-mu s^2), :336-403)
-struct GgaSel { int x, c, k, kkind; double kmu, kbeta, klambda, ksigma; };
+struct GgaSel { int x, c, k, kkind; real kmu, kbeta, klambda, ksigma; };
 constexpr int kPbeScalars = 3;     // energy sums of a GGA pass: exchange, correlation, kinetic
 
 // PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
 // (fp64 division costs ~10x a multiply on gfx950, so every quotient below goes through a shared reciprocal)
-__device__ __forceinline__ PbePoint pbe_point(double n, double gn2, const GgaSel& sel) {
+__device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& sel) {
     PbePoint r = {0.0, 0.0, 0.0, 0.0, 0.0};
-    const double n13 = cbrt(n);
-    const double inv_n = 1.0 / n;
+    const real n13 = cbrt(n);
+    const real inv_n = 1.0 / n;
     const bool do_x = sel.x != 0, do_c = sel.c != 0;
     if (sel.k) {
         // f = tau_TF F(s^2), tau_TF = C_TF n^(5/3), s^2 = |grad n|^2 / (4 (3 pi^2)^(2/3) n^(8/3))  (functional_tools.py:230-268)
-        const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
-        const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
-        const double n83i = inv_n * inv_n * inv_n * n13;
-        const double s2 = cs * gn2 * n83i;
-        const double tau = ctf * n13 * n13 * n;
-        double F, dF;                       // F and dF / d(s^2)
+        const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+        const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+        const real n83i = inv_n * inv_n * inv_n * n13;
+        const real s2 = cs * gn2 * n83i;
+        const real tau = ctf * n13 * n13 * n;
+        real F, dF;                       // F and dF / d(s^2)
         if (sel.kkind == 0) {
-            const double a = 1.3, s = fmin(sqrt(s2), 100.0);                  // clamp as functionals.py:330
-            const double ch = cosh(a * s);
+            const real a = 1.3, s = fmin(sqrt(s2), 100.0);                  // clamp as functionals.py:330
+            const real ch = cosh(a * s);
             F = 1.0 / ch;
             dF = (s > 1e-8 && s < 100.0) ? -a * tanh(a * s) * F / (2.0 * s) : (s < 100.0 ? -0.5 * a * a : 0.0);
         } else {
@@ -491,43 +491,43 @@ __device__ __forceinline__ PbePoint pbe_point(double n, double gn2, const GgaSel
         r.dfdg += tau * dF * cs * n83i;
     }
     if (do_x) {
-        const double kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
-        const double cx = -0.75 * cbrt(3.0 / kPi);
-        const double ex = cx * n13;
-        const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);     // 0.25 (3 pi^2)^(-2/3)
-        const double n83i = inv_n * inv_n * inv_n * n13;                 // n^(-8/3)
-        const double s2 = cs * gn2 * n83i;
-        const double iden = 1.0 / (1.0 + (mu / kappa) * s2);
-        const double Fx = 1.0 + kappa - kappa * iden;
-        const double dF = mu * iden * iden;
+        const real kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
+        const real cx = -0.75 * cbrt(3.0 / kPi);
+        const real ex = cx * n13;
+        const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);     // 0.25 (3 pi^2)^(-2/3)
+        const real n83i = inv_n * inv_n * inv_n * n13;                 // n^(-8/3)
+        const real s2 = cs * gn2 * n83i;
+        const real iden = 1.0 / (1.0 + (mu / kappa) * s2);
+        const real Fx = 1.0 + kappa - kappa * iden;
+        const real dF = mu * iden * iden;
         r.fx = Fx * ex * n;
         r.dfdn += Fx * (4.0 / 3.0) * ex + dF * (-(8.0 / 3.0) * s2 * inv_n) * ex * n;
         r.dfdg += dF * cs * n83i * ex * n;
     }
     if (do_c) {
-        const double beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi), igam = 1.0 / gam;
-        const double rs = cbrt(3.0 / (4.0 * kPi)) * (n13 * n13 * inv_n);  // c n^(-1/3)
-        double eps, deps_drs;
+        const real beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi), igam = 1.0 / gam;
+        const real rs = cbrt(3.0 / (4.0 * kPi)) * (n13 * n13 * inv_n);  // c n^(-1/3)
+        real eps, deps_drs;
         pw92(rs, eps, deps_drs);
-        const double deps_dn = -rs * (1.0 / 3.0) * inv_n * deps_drs;
-        const double ee = exp(-eps * igam);
-        const double A = beta * igam / (ee - 1.0 + 1e-30);
-        const double dAdn = A * A * (1.0 / beta) * ee * deps_dn;
-        const double ct = (1.0 / 16.0) * cbrt(kPi / 3.0);
-        const double n43 = n13 * n;
-        const double in73 = 1.0 / (n43 * n + 1e-30);
-        const double t2 = ct * gn2 * in73;
-        const double dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 * in73 * in73;
-        const double dt2dg = ct * in73;
-        const double At2 = A * t2;
-        const double num = 1.0 + At2, num2 = 1.0 + 2.0 * At2;
-        const double iden = 1.0 / (1.0 + At2 + At2 * At2);
-        const double arg = 1.0 + beta * igam * t2 * num * iden;
-        const double H = gam * log(arg);
-        const double common = t2 * num * iden * iden * num2;
-        const double dQn = (dt2dn * num2 + dAdn * t2 * t2) * iden - common * (dt2dn * A + dAdn * t2);
-        const double dQg = dt2dg * num2 * iden - common * (dt2dg * A);
-        const double boa = beta / arg;
+        const real deps_dn = -rs * (1.0 / 3.0) * inv_n * deps_drs;
+        const real ee = exp(-eps * igam);
+        const real A = beta * igam / (ee - 1.0 + 1e-30);
+        const real dAdn = A * A * (1.0 / beta) * ee * deps_dn;
+        const real ct = (1.0 / 16.0) * cbrt(kPi / 3.0);
+        const real n43 = n13 * n;
+        const real in73 = 1.0 / (n43 * n + 1e-30);
+        const real t2 = ct * gn2 * in73;
+        const real dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 * in73 * in73;
+        const real dt2dg = ct * in73;
+        const real At2 = A * t2;
+        const real num = 1.0 + At2, num2 = 1.0 + 2.0 * At2;
+        const real iden = 1.0 / (1.0 + At2 + At2 * At2);
+        const real arg = 1.0 + beta * igam * t2 * num * iden;
+        const real H = gam * log(arg);
+        const real common = t2 * num * iden * iden * num2;
+        const real dQn = (dt2dn * num2 + dAdn * t2 * t2) * iden - common * (dt2dn * A + dAdn * t2);
+        const real dQg = dt2dg * num2 * iden - common * (dt2dg * A);
+        const real boa = beta / arg;
         r.fc = (eps + H) * n;
         r.dfdn += eps + H + n * (deps_dn + boa * dQn);
         r.dfdg += n * boa * dQg;
@@ -538,18 +538,18 @@ __device__ __forceinline__ PbePoint pbe_point(double n, double gn2, const GgaSel
 // Pauli-Gaussian with the Laplacian-dependent terms (functionals.py:336-403; tools_for_tests.py:86-118):
 //   f = tau_TF (exp(-mu s^2) + beta q^2 - lambda q s^2 + sigma s^4),  q = lap n / (4 (3 pi^2)^(2/3) n^(5/3))
 // adds f, df/dn, df/d|grad n|^2 to p and returns df/d(lap n)
-__device__ __forceinline__ void pg_laplacian_point(double n, double gn2, double lap, const GgaSel& sel, PbePoint& p,
-                                                   double& dfdl) {
-    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
-    const double cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
-    const double n13 = cbrt(n), inv_n = 1.0 / n;
-    const double n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
-    const double s2 = cs * gn2 * n83i, q = cs * lap * n53i;
-    const double tau = ctf * n13 * n13 * n;
-    const double ex = exp(-sel.kmu * s2);
-    const double F = ex + sel.kbeta * q * q - sel.klambda * q * s2 + sel.ksigma * s2 * s2;
-    const double Fs = -sel.kmu * ex - sel.klambda * q + 2.0 * sel.ksigma * s2;       // dF / d(s^2)
-    const double Fq = 2.0 * sel.kbeta * q - sel.klambda * s2;                          // dF / dq
+__device__ __forceinline__ void pg_laplacian_point(real n, real gn2, real lap, const GgaSel& sel, PbePoint& p,
+                                                   real& dfdl) {
+    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real n13 = cbrt(n), inv_n = 1.0 / n;
+    const real n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
+    const real s2 = cs * gn2 * n83i, q = cs * lap * n53i;
+    const real tau = ctf * n13 * n13 * n;
+    const real ex = exp(-sel.kmu * s2);
+    const real F = ex + sel.kbeta * q * q - sel.klambda * q * s2 + sel.ksigma * s2 * s2;
+    const real Fs = -sel.kmu * ex - sel.klambda * q + 2.0 * sel.ksigma * s2;       // dF / d(s^2)
+    const real Fq = 2.0 * sel.kbeta * q - sel.klambda * s2;                          // dF / dq
     p.fk = tau * F;
     p.dfdn += (5.0 / 3.0) * tau * inv_n * F + tau * (Fs * (-(8.0 / 3.0) * s2 * inv_n) + Fq * (-(5.0 / 3.0) * q * inv_n));
     p.dfdg += tau * Fs * cs * n83i;
@@ -557,18 +557,18 @@ __device__ __forceinline__ void pg_laplacian_point(double n, double gn2, double 
 }
 
 // PBE mid stage: grad n -> energy partials (x, c), df/dn, flux_j = df/dg * grad_j n (in place)
-__global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restrict__ n, double* __restrict__ gx,
-                                                          double* __restrict__ gy, double* __restrict__ gz,
-                                                          double* __restrict__ dfdn, long long npts, GgaSel sel,
-                                                          double* __restrict__ partial, double* __restrict__ lapn = nullptr) {
-    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
+__global__ __launch_bounds__(kRedThreads) void pbe_kernel(const real* __restrict__ n, real* __restrict__ gx,
+                                                          real* __restrict__ gy, real* __restrict__ gz,
+                                                          real* __restrict__ dfdn, long long npts, GgaSel sel,
+                                                          acc_t* __restrict__ partial, real* __restrict__ lapn = nullptr) {
+    acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     if (lapn) {      // Pauli-Gaussian members with q-dependence: scalar loop (not a hot path), lapn is overwritten by df/dL
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
-            const double a = gx[i], b = gy[i], c = gz[i];
+            const real a = gx[i], b = gy[i], c = gz[i];
             GgaSel nk = sel;
             nk.k = 0;
             PbePoint p = pbe_point(n[i], a * a + b * b + c * c, nk);
-            double dfdl;
+            real dfdl;
             pg_laplacian_point(n[i], a * a + b * b + c * c, lapn[i], sel, p, dfdl);
             acc[0] += p.fx;
             acc[1] += p.fc;
@@ -584,22 +584,22 @@ __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restri
     }
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 d = reinterpret_cast<const double2*>(n)[i];
-        const double2 a = reinterpret_cast<double2*>(gx)[i], b = reinterpret_cast<double2*>(gy)[i],
-                      c = reinterpret_cast<double2*>(gz)[i];
+        const cplx d = reinterpret_cast<const cplx*>(n)[i];
+        const cplx a = reinterpret_cast<cplx*>(gx)[i], b = reinterpret_cast<cplx*>(gy)[i],
+                      c = reinterpret_cast<cplx*>(gz)[i];
         const PbePoint p0 = pbe_point(d.x, a.x * a.x + b.x * b.x + c.x * c.x, sel);
         const PbePoint p1 = pbe_point(d.y, a.y * a.y + b.y * b.y + c.y * c.y, sel);
         acc[0] += p0.fx + p1.fx;
         acc[1] += p0.fc + p1.fc;
         acc[2] += p0.fk + p1.fk;
-        reinterpret_cast<double2*>(dfdn)[i] = make_double2(p0.dfdn, p1.dfdn);
-        reinterpret_cast<double2*>(gx)[i] = make_double2(p0.dfdg * a.x, p1.dfdg * a.y);
-        reinterpret_cast<double2*>(gy)[i] = make_double2(p0.dfdg * b.x, p1.dfdg * b.y);
-        reinterpret_cast<double2*>(gz)[i] = make_double2(p0.dfdg * c.x, p1.dfdg * c.y);
+        reinterpret_cast<cplx*>(dfdn)[i] = mkc(p0.dfdn, p1.dfdn);
+        reinterpret_cast<cplx*>(gx)[i] = mkc(p0.dfdg * a.x, p1.dfdg * a.y);
+        reinterpret_cast<cplx*>(gy)[i] = mkc(p0.dfdg * b.x, p1.dfdg * b.y);
+        reinterpret_cast<cplx*>(gz)[i] = mkc(p0.dfdg * c.x, p1.dfdg * c.y);
     }
     if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long i = npts - 1;
-        const double a = gx[i], b = gy[i], c = gz[i];
+        const real a = gx[i], b = gy[i], c = gz[i];
         const PbePoint p = pbe_point(n[i], a * a + b * b + c * c, sel);
         acc[0] += p.fx;
         acc[1] += p.fc;
@@ -614,22 +614,22 @@ __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const double* __restri
 
 // ---- final combine: potential + all energy integrands -------------------------------------------
 struct CombineArgs {
-    const double* n;
-    const double* vext;
-    const double* vh;
-    const double* lap_s;
-    const double* conv_b;
-    const double* conv_a;
-    const double* u0; const double* u1; const double* u2;
-    const double* gA; const double* gB; const double* gC;
-    const double* dfdn;
-    const double* div;
-    double* v_out;
+    const real* n;
+    const real* vext;
+    const real* vh;
+    const real* lap_s;
+    const real* conv_b;
+    const real* conv_a;
+    const real* u0; const real* u1; const real* u2;
+    const real* gA; const real* gB; const real* gC;
+    const real* dfdn;
+    const real* div;
+    real* v_out;
     long long npts;
     unsigned mask;
-    double wt_alpha, wt_beta, wt_nbar_pa;     // nbar^alpha
-    double wgc_alpha, wgc_beta, nref;
-    double gtf_inv_n0;   // vWGTF: 1 / n0, n0 = round(N_e) / vol (functionals.py:268-270)
+    real wt_alpha, wt_beta, wt_nbar_pa;     // nbar^alpha
+    real wgc_alpha, wgc_beta, nref;
+    real gtf_inv_n0;   // vWGTF: 1 / n0, n0 = round(N_e) / vol (functionals.py:268-270)
     int gtf_kind;        // 1 = vWGTF1, 2 = vWGTF2
     int wt_is_56;        // alpha = beta = 5/6: n^(-1/6) = 1/sqrt(cbrt n), no pow
     int wgc_sum_53;      // alpha + beta = 5/3: n^(alpha-1) = 1/(cbrt(n) n^(beta-1)), one pow instead of two
@@ -638,36 +638,36 @@ struct CombineArgs {
 constexpr int kCombineScalars = 10;
 
 // Pauli enhancement factor of vWGTF1 / vWGTF2 and its derivative with respect to d = n / n0 (functionals.py:251-306)
-__device__ __forceinline__ void vwgtf_factor(double d, int kind, double& G, double& dG) {
+__device__ __forceinline__ void vwgtf_factor(real d, int kind, real& G, real& dG) {
     if (kind == 1) {
         G = 0.9892 * pow(d, -1.2994);
         dG = -1.2994 * G / d;
     } else {
-        const double a = 5.7001, b = 0.2563;
-        const double db = pow(d, b), th = tanh(a * db - a);
-        const double elf = 0.5 * (1.0 + th);
-        const double delf = 0.5 * (1.0 - th * th) * a * b * db / d;
+        const real a = 5.7001, b = 0.2563;
+        const real db = pow(d, b), th = tanh(a * db - a);
+        const real elf = 0.5 * (1.0 + th);
+        const real delf = 0.5 * (1.0 - th * th) * a * b * db / d;
         G = sqrt(1.0 / elf - 1.0);
         dG = -delf / (2.0 * G * elf * elf);
     }
 }
 // e = G tau_TF and its potential d e / d n at one point
-__device__ __forceinline__ void vwgtf_point(double n, double n13, double ctf, double inv_n0, int kind, double& e, double& v) {
-    double G, dG;
+__device__ __forceinline__ void vwgtf_point(real n, real n13, real ctf, real inv_n0, int kind, real& e, real& v) {
+    real G, dG;
     vwgtf_factor(n * inv_n0, kind, G, dG);
-    const double tau = ctf * n13 * n13 * n;
+    const real tau = ctf * n13 * n13 * n;
     e = G * tau;
     v = (5.0 / 3.0) * ctf * n13 * n13 * G + tau * dG * inv_n0;
 }
 
 // one grid point of the combine: all inputs already in registers
 struct CombinePoint {
-    double n, vext, vh, lap, cb, cva, u0, u1, u2, gA, gB, gC, dfdn, div;
+    real n, vext, vh, lap, cb, cva, u0, u1, u2, gA, gB, gC, dfdn, div;
 };
-__device__ __forceinline__ double combine_point(const CombineArgs& a, const CombinePoint& p, double ctf,
-                                                double (&acc)[kCombineScalars]) {
-    const double n = p.n;
-    double v = 0.0;
+__device__ __forceinline__ real combine_point(const CombineArgs& a, const CombinePoint& p, real ctf,
+                                                acc_t (&acc)[kCombineScalars]) {
+    const real n = p.n;
+    real v = 0.0;
     if (a.mask & 1u) {                                  // ion-electron  functionals.py:46
         acc[0] += n * p.vext;
         v += p.vext;
@@ -676,33 +676,33 @@ __device__ __forceinline__ double combine_point(const CombineArgs& a, const Comb
         acc[1] += 0.5 * n * p.vh;
         v += p.vh;
     }
-    const double n13 = cbrt(n);
+    const real n13 = cbrt(n);
     if (a.mask & 4u) {                                  // TF  functionals.py:223; tools_for_tests.py:19-20
-        const double n23 = n13 * n13;
+        const real n23 = n13 * n13;
         acc[2] += ctf * n23 * n;
         v += (5.0 / 3.0) * ctf * n23;
     }
     if (a.mask & 8u) {                                  // vW  functionals.py:245; tools_for_tests.py:23-26
-        const double s = (n != 0.0) ? sqrt(n) : 0.0;
+        const real s = (n != 0.0) ? sqrt(n) : 0.0;
         acc[3] += -0.5 * s * p.lap;
         if (n != 0.0) v += -0.5 * p.lap / s;
     }
     if (a.mask & 16u) {                                 // WT-family NL  functionals.py:650-651; tools_for_tests.py:29-39
-        const double pa1 = a.wt_is_56 ? 1.0 / sqrt(n13) : pow(n, a.wt_alpha - 1.0);
+        const real pa1 = a.wt_is_56 ? 1.0 / sqrt(n13) : pow(n, a.wt_alpha - 1.0);
         acc[4] += ctf * (pa1 * n - a.wt_nbar_pa) * p.cb;
         if (a.conv_a) {
-            const double pb1 = pow(n, a.wt_beta - 1.0);
+            const real pb1 = pow(n, a.wt_beta - 1.0);
             v += ctf * (a.wt_alpha * pa1 * p.cb + a.wt_beta * pb1 * p.cva);
         } else {
             v += ctf * 2.0 * a.wt_alpha * pa1 * p.cb;
         }
     }
     if (a.mask & 32u) {                                 // WGC99 NL  SURVEY §8a-8
-        const double th = n - a.nref;
-        const double pb1 = pow(n, a.wgc_beta - 1.0);
-        const double pa1 = a.wgc_sum_53 ? 1.0 / (n13 * pb1) : pow(n, a.wgc_alpha - 1.0);
-        const double P = pa1 * n, A = pb1 * n, dA = a.wgc_beta * pb1;
-        const double conv = p.u0 + th * p.u1 + 0.5 * th * th * p.u2;
+        const real th = n - a.nref;
+        const real pb1 = pow(n, a.wgc_beta - 1.0);
+        const real pa1 = a.wgc_sum_53 ? 1.0 / (n13 * pb1) : pow(n, a.wgc_alpha - 1.0);
+        const real P = pa1 * n, A = pb1 * n, dA = a.wgc_beta * pb1;
+        const real conv = p.u0 + th * p.u1 + 0.5 * th * th * p.u2;
         acc[5] += ctf * P * conv;
         v += ctf * (a.wgc_alpha * pa1 * conv + P * (p.u1 + th * p.u2) + p.gA * dA + p.gB * (dA * th + A)
                     + p.gC * (0.5 * dA * th * th + A * th));
@@ -715,7 +715,7 @@ __device__ __forceinline__ double combine_point(const CombineArgs& a, const Comb
     }
     if (a.mask & (7u << 10)) v += p.dfdn - 2.0 * p.div;   // PBE / GGA kinetic  tools_for_tests.py:168-170
     if (a.mask & (1u << 13)) {                          // vWGTF1 / 2  functionals.py:251-306
-        double e, ve;
+        real e, ve;
         vwgtf_point(n, n13, ctf, a.gtf_inv_n0, a.gtf_kind, e, ve);
         acc[9] += e;
         v += ve;
@@ -727,29 +727,29 @@ __device__ __forceinline__ double combine_point(const CombineArgs& a, const Comb
 // Every array pointer in CombineArgs is valid (the host points unused ones at `n`), so all loads of an
 // iteration are issued together as 16-byte loads ahead of the arithmetic instead of one dependent load
 // per term behind a branch.
-__global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, double* __restrict__ partial) {
-    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);   // 0.3 (3 pi^2)^(2/3)
-    double acc[kCombineScalars];
+__global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc_t* __restrict__ partial) {
+    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);   // 0.3 (3 pi^2)^(2/3)
+    acc_t acc[kCombineScalars];
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
     const long long n2 = a.npts >> 1;
-#define LD2(ptr) reinterpret_cast<const double2*>(ptr)[i]
+#define LD2(ptr) reinterpret_cast<const cplx*>(ptr)[i]
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 n = LD2(a.n), ve = LD2(a.vext), vh = LD2(a.vh), lp = LD2(a.lap_s), cb = LD2(a.conv_b),
+        const cplx n = LD2(a.n), ve = LD2(a.vext), vh = LD2(a.vh), lp = LD2(a.lap_s), cb = LD2(a.conv_b),
                       cva = LD2(a.conv_a ? a.conv_a : a.n), u0 = LD2(a.u0), u1 = LD2(a.u1), u2 = LD2(a.u2),
                       gA = LD2(a.gA), gB = LD2(a.gB), gC = LD2(a.gC), df = LD2(a.dfdn), dv = LD2(a.div);
         const CombinePoint p0{n.x, ve.x, vh.x, lp.x, cb.x, cva.x, u0.x, u1.x, u2.x, gA.x, gB.x, gC.x, df.x, dv.x};
         const CombinePoint p1{n.y, ve.y, vh.y, lp.y, cb.y, cva.y, u0.y, u1.y, u2.y, gA.y, gB.y, gC.y, df.y, dv.y};
-        const double v0 = combine_point(a, p0, ctf, acc);
-        const double v1 = combine_point(a, p1, ctf, acc);
-        if (a.v_out) reinterpret_cast<double2*>(a.v_out)[i] = make_double2(v0, v1);
+        const real v0 = combine_point(a, p0, ctf, acc);
+        const real v1 = combine_point(a, p1, ctf, acc);
+        if (a.v_out) reinterpret_cast<cplx*>(a.v_out)[i] = mkc(v0, v1);
     }
 #undef LD2
     if ((a.npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long i = a.npts - 1;
         const CombinePoint p{a.n[i], a.vext[i], a.vh[i], a.lap_s[i], a.conv_b[i], (a.conv_a ? a.conv_a : a.n)[i], a.u0[i],
                              a.u1[i], a.u2[i], a.gA[i], a.gB[i], a.gC[i], a.dfdn[i], a.div[i]};
-        const double v = combine_point(a, p, ctf, acc);
+        const real v = combine_point(a, p, ctf, acc);
         if (a.v_out) a.v_out[i] = v;
     }
     block_reduce_store<kCombineScalars>(acc, partial);
@@ -757,19 +757,19 @@ __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, dou
 
 // chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
 // c = N_e / (mean(chi^2) vol) from the reduced sum of chi^2, left on the device (system.py:833-834)
-__global__ void closure_scale_kernel(const double* __restrict__ sumsq, double* __restrict__ cscale, double n_elec,
-                                     double vol_over_npts) {
+__global__ void closure_scale_kernel(const real* __restrict__ sumsq, real* __restrict__ cscale, real n_elec,
+                                     real vol_over_npts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
 }
 
-__global__ void chi_grad_kernel(const double* __restrict__ chi, const double* __restrict__ v, double* __restrict__ g,
-                                long long npts, double c2dV_host, const double* __restrict__ cscale_dev, double two_dV,
-                                double mu) {
-    const double c2dV = cscale_dev ? cscale_dev[0] * two_dV : c2dV_host;
+__global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
+                                long long npts, real c2dV_host, const real* __restrict__ cscale_dev, real two_dV,
+                                real mu) {
+    const real c2dV = cscale_dev ? cscale_dev[0] * two_dV : c2dV_host;
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 x = reinterpret_cast<const double2*>(chi)[i], w = reinterpret_cast<const double2*>(v)[i];
-        reinterpret_cast<double2*>(g)[i] = make_double2(c2dV * x.x * (w.x - mu), c2dV * x.y * (w.y - mu));
+        const cplx x = reinterpret_cast<const cplx*>(chi)[i], w = reinterpret_cast<const cplx*>(v)[i];
+        reinterpret_cast<cplx*>(g)[i] = mkc(c2dV * x.x * (w.x - mu), c2dV * x.y * (w.y - mu));
     }
     if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) g[npts - 1] = c2dV * chi[npts - 1] * (v[npts - 1] - mu);
 }

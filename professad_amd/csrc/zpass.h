@@ -31,7 +31,7 @@ template <int M, int E_> struct ZW {
     static constexpr int TPB = 256;
     static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
     static constexpr int RS = LineBuf<M>::STRIDE;   // LDS doubles per row
-    static constexpr size_t LDS = sizeof(double) * RPB * RS;
+    static constexpr size_t LDS = sizeof(real) * RPB * RS;
     static constexpr int N2 = 2 * M;
 };
 
@@ -42,8 +42,8 @@ template <int M, int E> struct ZLane {
     long long row_u;  // first row of this wave (wave-uniform)
     long long row;    // this lane's row
     bool valid;
-    double* mine;     // LDS buffer of this row
-    __device__ __forceinline__ ZLane(const SpecGeom& g, double* lds) {
+    real* mine;     // LDS buffer of this row
+    __device__ __forceinline__ ZLane(const SpecGeom& g, real* lds) {
         using W = ZW<M, E>;
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -58,18 +58,18 @@ template <int M, int E> struct ZLane {
 
 // ---- real rows: lane holds (a[2(j+Pq)], a[2(j+Pq)+1]) for q = 0..7
 template <int M, int E>
-__device__ __forceinline__ void z_load_real(cplx (&v)[E], const ZLane<M, E>& z, const double* __restrict__ a) {
+__device__ __forceinline__ void z_load_real(cplx (&v)[E], const ZLane<M, E>& z, const real* __restrict__ a) {
     using W = ZW<M, E>;
     const cplx* ub = reinterpret_cast<const cplx*>(a + z.row_u * W::N2);
-    const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
+    const unsigned voff = (unsigned)((z.rw * M + z.j) * kCB);
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c_aux<OFDFT_ZR_LD_AUX>(ub + q * W::P, voff) : make_double2(0.0, 0.0);
+    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c_aux<OFDFT_ZR_LD_AUX>(ub + q * W::P, voff) : mkc(0.0, 0.0);
 }
 template <int M, int E>
-__device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, E>& z, double* __restrict__ a) {
+__device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, E>& z, real* __restrict__ a) {
     using W = ZW<M, E>;
     cplx* ub = reinterpret_cast<cplx*>(a + z.row_u * W::N2);
-    const unsigned voff = (unsigned)((z.rw * M + z.j) * 16);
+    const unsigned voff = (unsigned)((z.rw * M + z.j) * kCB);
     if (z.valid) {
 #pragma unroll
         for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_ZR_ST_AUX>(ub + q * W::P, voff, v[q]);
@@ -79,7 +79,7 @@ __device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, 
 // spectrum element k = j + P q of row `row` lives at ((k>>3)*nrows + row)*8 + (k&7); the (P q)>>3 part of
 // the block index is wave-uniform (folded into the base), the rest is the per-lane offset
 template <int M, int E> __device__ __forceinline__ unsigned z_spec_voff(const ZLane<M, E>& z, const SpecGeom& g) {
-    return (unsigned)((((long long)(z.j >> 3) * g.nrows + z.rw) * 8 + (z.j & 7)) * 16);
+    return (unsigned)((((long long)(z.j >> 3) * g.nrows + z.rw) * 8 + (z.j & 7)) * kCB);
 }
 template <int M, int E, int Q> __device__ __forceinline__ long long z_spec_ubase(const ZLane<M, E>& z, const SpecGeom& g) {
     constexpr int bu = (ZW<M, E>::P * Q) >> 3;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     using W = ZW<M, E>;
     constexpr int P = W::P;
     wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
-    double cr_m[E], c0r;
+    real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
@@ -111,15 +111,15 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     static_for<E>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const int k = z.j + P * q;
-        const double ci_m = z.mine[lpad((M - k) & (M - 1))];
-        const cplx ev = make_double2(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
-        const cplx od = make_double2(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+        const real ci_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+        const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
         const cplx X = cadd(ev, cmul(twN[k], od));
         if (z.valid) buf_store_c_aux<OFDFT_ZS_ST_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
     });
     if (z.j == 0 && z.valid) {
-        const double c0i = z.mine[0];
-        spec[g.main_count + z.row] = make_double2(c0r - c0i, 0.0);
+        const real c0i = z.mine[0];
+        spec[g.main_count + z.row] = mkc(c0r - c0i, 0.0);
     }
     exchange_sync<true>();
 }
@@ -138,10 +138,10 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
     const unsigned voff = z_spec_voff<M, E>(z, g);
     static_for<E>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : make_double2(0.0, 0.0);
+        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : mkc(0.0, 0.0);
     });
-    const double nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
-    double xr_m[E];
+    const real nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
+    real xr_m[E];
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
@@ -155,15 +155,15 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int k = z.j + P * q;
-        const double xi_m = z.mine[lpad((M - k) & (M - 1))];
+        const real xi_m = z.mine[lpad((M - k) & (M - 1))];
         const cplx x = v[q];
         if (k == 0) {
-            v[q] = make_double2(x.x + nyq, x.x - nyq);
+            v[q] = mkc(x.x + nyq, x.x - nyq);
         } else {
-            const cplx ev = make_double2(x.x + xr_m[q], x.y - xi_m);
-            const cplx d = make_double2(x.x - xr_m[q], x.y + xi_m);
+            const cplx ev = mkc(x.x + xr_m[q], x.y - xi_m);
+            const cplx d = mkc(x.x - xr_m[q], x.y + xi_m);
             const cplx od = cmul(d, cconj(twN[k]));
-            v[q] = make_double2(ev.x - od.y, ev.y + od.x);
+            v[q] = mkc(ev.x - od.y, ev.y + od.x);
         }
     }
     exchange_sync<true>();
@@ -176,11 +176,11 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
 // coefficient M (real)
 template <int M, int E>
 __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
-                                               const cplx* __restrict__ twN, double& nyq) {
+                                               const cplx* __restrict__ twN, real& nyq) {
     using W = ZW<M, E>;
     constexpr int P = W::P;
     wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
-    double cr_m[E], c0r;
+    real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
@@ -195,9 +195,9 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int k = z.j + P * q;
-        const double ci_m = z.mine[lpad((M - k) & (M - 1))];
-        const cplx ev = make_double2(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
-        const cplx od = make_double2(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+        const real ci_m = z.mine[lpad((M - k) & (M - 1))];
+        const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+        const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
         v[q] = cadd(ev, cmul(twN[k], od));
     }
     nyq = c0r - z.mine[0];
@@ -207,10 +207,10 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
 // inverse of the above: v[q] = coefficient k = j + P q, nyq = coefficient M -> unscaled real pairs
 template <int M, int E>
 __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
-                                               const cplx* __restrict__ twN, double nyq) {
+                                               const cplx* __restrict__ twN, real nyq) {
     using W = ZW<M, E>;
     constexpr int P = W::P;
-    double xr_m[E];
+    real xr_m[E];
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
@@ -224,15 +224,15 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int k = z.j + P * q;
-        const double xi_m = z.mine[lpad((M - k) & (M - 1))];
+        const real xi_m = z.mine[lpad((M - k) & (M - 1))];
         const cplx x = v[q];
         if (k == 0) {
-            v[q] = make_double2(x.x + nyq, x.x - nyq);
+            v[q] = mkc(x.x + nyq, x.x - nyq);
         } else {
-            const cplx ev = make_double2(x.x + xr_m[q], x.y - xi_m);
-            const cplx d = make_double2(x.x - xr_m[q], x.y + xi_m);
+            const cplx ev = mkc(x.x + xr_m[q], x.y - xi_m);
+            const cplx d = mkc(x.x - xr_m[q], x.y + xi_m);
             const cplx od = cmul(d, cconj(twN[k]));
-            v[q] = make_double2(ev.x - od.y, ev.y + od.x);
+            v[q] = mkc(ev.x - od.y, ev.y + od.x);
         }
     }
     exchange_sync<true>();
@@ -247,27 +247,27 @@ template <int M, int E>
 __device__ __forceinline__ void z_deriv_row(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                             const cplx* __restrict__ twN) {
     constexpr int P = ZW<M, E>::P;
-    double nyq;
+    real nyq;
     z_forward_regs<M, E>(v, z, twM, twN, nyq);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const double k = (double)(z.j + P * q);
-        v[q] = make_double2(-k * v[q].y, k * v[q].x);
+        const real k = (real)(z.j + P * q);
+        v[q] = mkc(-k * v[q].y, k * v[q].x);
     }
     z_inverse_regs<M, E>(v, z, twM, twN, 0.0);
 }
 
 // x^y for x >= 0 as exp(y log x): ~2 ulp for the |y log x| = O(1..10) met here, a fraction of the instructions
 // and registers of the fully-general pow() (which the unfused pipeline keeps using as an independent check).
-__device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
+__device__ __forceinline__ real pow_pos(real x, real y) { return exp(y * log(x)); }
 
 // density of a point from the kernel's source array: n = cscale * x^2 (source = chi) or n = x (source = den)
 struct DenSrc {
-    const double* src;
-    double cscale;
+    const real* src;
+    real cscale;
     int from_chi;
-    const double* cscale_dev;    // when set, the scale is read from device memory (no host round trip after sum chi^2)
-    __device__ __forceinline__ double operator()(double x) const {
+    const acc_t* cscale_dev;    // when set, the scale is read from device memory (no host round trip after sum chi^2)
+    __device__ __forceinline__ real operator()(real x) const {
         return from_chi ? (cscale_dev ? *cscale_dev : cscale) * x * x : x;
     }
 };
@@ -277,31 +277,31 @@ struct DenSrc {
 template <int M, int E>
 __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
                                                          SpecGeom g, const cplx* __restrict__ twM,
-                                                         const cplx* __restrict__ twN, double* __restrict__ dzn = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                         const cplx* __restrict__ twN, real* __restrict__ dzn = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
     cplx x[E], v[E];
     z_load_real<M, E>(x, z, ds.src);
     if (out_n) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(ds(x[q].x), ds(x[q].y));
+        for (int q = 0; q < E; ++q) v[q] = mkc(ds(x[q].x), ds(x[q].y));
         z_forward_store<M, E>(v, z, out_n, g, twM, twN);
     }
     if (out_s) {
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            const double a = ds(x[q].x), b = ds(x[q].y);
-            v[q] = make_double2(a != 0.0 ? sqrt(a) : 0.0, b != 0.0 ? sqrt(b) : 0.0);     // functionals.py:242-243
+            const real a = ds(x[q].x), b = ds(x[q].y);
+            v[q] = mkc(a != 0.0 ? sqrt(a) : 0.0, b != 0.0 ? sqrt(b) : 0.0);     // functionals.py:242-243
         }
         z_forward_store<M, E>(v, z, out_s, g, twM, twN);
     }
     if (dzn) {       // D_c n, the index derivative along z, formed on chip (split-derivative form of the GGA chain)
-        const double sc = 1.0 / (double)(2 * M);
+        const real sc = 1.0 / (real)(2 * M);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(ds(x[q].x), ds(x[q].y));
+        for (int q = 0; q < E; ++q) v[q] = mkc(ds(x[q].x), ds(x[q].y));
         z_deriv_row<M, E>(v, z, twM, twN);
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = make_double2(v[q].x * sc, v[q].y * sc);
+        for (int q = 0; q < E; ++q) v[q] = mkc(v[q].x * sc, v[q].y * sc);
         z_store_real<M, E>(v, z, dzn);
     }
 }
@@ -311,21 +311,21 @@ __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __r
 // (and out[3] when alpha != beta), theta unused.  One pow per point when e0 + e1 = 5/3.
 struct PowersArgs {
     cplx* out[6];
-    double e0, e1, nref;
+    real e0, e1, nref;
     int sum53;       // e0 + e1 == 5/3: n^e1 = n^(5/3) / n^e0
 };
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
                                                         const cplx* __restrict__ twM, const cplx* __restrict__ twN) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
     cplx n[E], a[E], v[E];
     z_load_real<M, E>(n, z, ds.src);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        n[q] = make_double2(ds(n[q].x), ds(n[q].y));
-        a[q] = make_double2(pow_pos(n[q].x, pa.e0), pow_pos(n[q].y, pa.e0));
+        n[q] = mkc(ds(n[q].x), ds(n[q].y));
+        a[q] = mkc(pow_pos(n[q].x, pa.e0), pow_pos(n[q].y, pa.e0));
     }
     for (int half = 0; half < 2; ++half) {
         if (half == 1) {
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 if (pa.sum53) {
-                    const double cx = cbrt(n[q].x), cy = cbrt(n[q].y);
-                    a[q] = make_double2(n[q].x * cx * cx / a[q].x, n[q].y * cy * cy / a[q].y);
+                    const real cx = cbrt(n[q].x), cy = cbrt(n[q].y);
+                    a[q] = mkc(n[q].x * cx * cx / a[q].x, n[q].y * cy * cy / a[q].y);
                 } else {
-                    a[q] = make_double2(pow_pos(n[q].x, pa.e1), pow_pos(n[q].y, pa.e1));
+                    a[q] = mkc(pow_pos(n[q].x, pa.e1), pow_pos(n[q].y, pa.e1));
                 }
             }
         }
@@ -348,14 +348,14 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
         }
         if (o[1]) {
 #pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = make_double2(a[q].x * (n[q].x - pa.nref), a[q].y * (n[q].y - pa.nref));
+            for (int q = 0; q < E; ++q) v[q] = mkc(a[q].x * (n[q].x - pa.nref), a[q].y * (n[q].y - pa.nref));
             z_forward_store<M, E>(v, z, o[1], g, twM, twN);
         }
         if (o[2]) {
 #pragma unroll
             for (int q = 0; q < E; ++q) {
-                const double tx = n[q].x - pa.nref, ty = n[q].y - pa.nref;
-                v[q] = make_double2(0.5 * a[q].x * tx * tx, 0.5 * a[q].y * ty * ty);
+                const real tx = n[q].x - pa.nref, ty = n[q].y - pa.nref;
+                v[q] = mkc(0.5 * a[q].x * tx * tx, 0.5 * a[q].y * ty * ty);
             }
             z_forward_store<M, E>(v, z, o[2], g, twM, twN);
         }
@@ -368,23 +368,23 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
 // tests/tools_for_tests.py:155-207)
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
-                                                   cplx* __restrict__ gz, double* __restrict__ dfdn, double inv_n,
+                                                   cplx* __restrict__ gz, real* __restrict__ dfdn, real inv_n,
                                                    GgaSel sel, SpecGeom g, const cplx* __restrict__ twM,
-                                                   const cplx* __restrict__ twN, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                   const cplx* __restrict__ twN, acc_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
     z_load_inverse<M, E>(a, z, gx, g, twM, twN);
     z_load_inverse<M, E>(b, z, gy, g, twM, twN);
     z_load_inverse<M, E>(c, z, gz, g, twM, twN);
     z_load_real<M, E>(n, z, ds.src);
-    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
+    acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        const double ax = a[q].x * inv_n, bx = b[q].x * inv_n, cx = c[q].x * inv_n;
-        const double ay = a[q].y * inv_n, by = b[q].y * inv_n, cy = c[q].y * inv_n;
+        const real ax = a[q].x * inv_n, bx = b[q].x * inv_n, cx = c[q].x * inv_n;
+        const real ay = a[q].y * inv_n, by = b[q].y * inv_n, cy = c[q].y * inv_n;
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
         if (z.valid) {
             p0 = pbe_point(ds(n[q].x), ax * ax + bx * bx + cx * cx, sel);
@@ -393,10 +393,10 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
         acc[0] += p0.fx + p1.fx;
         acc[1] += p0.fc + p1.fc;
         acc[2] += p0.fk + p1.fk;
-        d[q] = make_double2(p0.dfdn, p1.dfdn);
-        a[q] = make_double2(p0.dfdg * ax, p1.dfdg * ay);
-        b[q] = make_double2(p0.dfdg * bx, p1.dfdg * by);
-        c[q] = make_double2(p0.dfdg * cx, p1.dfdg * cy);
+        d[q] = mkc(p0.dfdn, p1.dfdn);
+        a[q] = mkc(p0.dfdg * ax, p1.dfdg * ay);
+        b[q] = mkc(p0.dfdg * bx, p1.dfdg * by);
+        c[q] = mkc(p0.dfdg * cx, p1.dfdg * cy);
     }
     z_store_real<M, E>(d, z, dfdn);
     z_forward_store<M, E>(a, z, gx, g, twM, twN);
@@ -409,33 +409,33 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
 // b[axis][j] D_axis) only D_a needs the x transform: D_b comes from a y pass with the i f_b multiply (yderiv_kernel),
 // D_c is formed on chip.  In: A = (D_a n)^ rows, B = (D_b n)^ rows, dzn = D_c n (real);  out: the contravariant flux
 // components G_a, G_b as spectra (in place of A, B) and df/dn - 2 D_c G_c (real) -- the whole z part of the divergence.
-struct Bmat { double b[9]; };
+struct Bmat { real b[9]; };
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
-                                                                      const double* __restrict__ dzn,
-                                                                      double* __restrict__ dfdn, double inv_n, double inv_nz,
+                                                                      const real* __restrict__ dzn,
+                                                                      real* __restrict__ dfdn, real inv_n, real inv_nz,
                                                                       GgaSel sel, Bmat bm, SpecGeom g,
                                                                       const cplx* __restrict__ twM,
                                                                       const cplx* __restrict__ twN,
-                                                                      double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                                      acc_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
     z_load_inverse<M, E>(a, z, A, g, twM, twN);
     z_load_inverse<M, E>(b, z, B, g, twM, twN);
     z_load_real<M, E>(c, z, dzn);
     z_load_real<M, E>(n, z, ds.src);
-    double acc[kPbeScalars] = {0.0, 0.0, 0.0};
+    acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
-        const double da0 = a[q].x * inv_n, db0 = b[q].x * inv_n, dc0 = c[q].x;
-        const double da1 = a[q].y * inv_n, db1 = b[q].y * inv_n, dc1 = c[q].y;
+        const real da0 = a[q].x * inv_n, db0 = b[q].x * inv_n, dc0 = c[q].x;
+        const real da1 = a[q].y * inv_n, db1 = b[q].y * inv_n, dc1 = c[q].y;
         // Cartesian gradient g_j = b[0][j] D_a n + b[1][j] D_b n + b[2][j] D_c n
-        const double gx0 = bm.b[0] * da0 + bm.b[3] * db0 + bm.b[6] * dc0, gx1 = bm.b[0] * da1 + bm.b[3] * db1 + bm.b[6] * dc1;
-        const double gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0, gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
-        const double gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0, gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
+        const real gx0 = bm.b[0] * da0 + bm.b[3] * db0 + bm.b[6] * dc0, gx1 = bm.b[0] * da1 + bm.b[3] * db1 + bm.b[6] * dc1;
+        const real gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0, gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
+        const real gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0, gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
         if (z.valid) {
             p0 = pbe_point(ds(n[q].x), gx0 * gx0 + gy0 * gy0 + gz0 * gz0, sel);
@@ -444,20 +444,20 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         acc[0] += p0.fx + p1.fx;
         acc[1] += p0.fc + p1.fc;
         acc[2] += p0.fk + p1.fk;
-        d[q] = make_double2(p0.dfdn, p1.dfdn);
+        d[q] = mkc(p0.dfdn, p1.dfdn);
         // contravariant components of the flux F = df/dg grad n:  G_axis = sum_j b[axis][j] F_j
-        a[q] = make_double2(p0.dfdg * (bm.b[0] * gx0 + bm.b[1] * gy0 + bm.b[2] * gz0),
+        a[q] = mkc(p0.dfdg * (bm.b[0] * gx0 + bm.b[1] * gy0 + bm.b[2] * gz0),
                             p1.dfdg * (bm.b[0] * gx1 + bm.b[1] * gy1 + bm.b[2] * gz1));
-        b[q] = make_double2(p0.dfdg * (bm.b[3] * gx0 + bm.b[4] * gy0 + bm.b[5] * gz0),
+        b[q] = mkc(p0.dfdg * (bm.b[3] * gx0 + bm.b[4] * gy0 + bm.b[5] * gz0),
                             p1.dfdg * (bm.b[3] * gx1 + bm.b[4] * gy1 + bm.b[5] * gz1));
-        c[q] = make_double2(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
+        c[q] = mkc(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
                             p1.dfdg * (bm.b[6] * gx1 + bm.b[7] * gy1 + bm.b[8] * gz1));
     }
     z_forward_store<M, E>(a, z, A, g, twM, twN);
     z_forward_store<M, E>(b, z, B, g, twM, twN);
     z_deriv_row<M, E>(c, z, twM, twN);               // N2 x D_c G_c
 #pragma unroll
-    for (int q = 0; q < E; ++q) d[q] = make_double2(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);
+    for (int q = 0; q < E; ++q) d[q] = mkc(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);
     z_store_real<M, E>(d, z, dfdn);
     block_reduce_store<kPbeScalars>(acc, partial + (long long)g.blk0 * kPbeScalars);
 }
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
 // final stage: every convolution spectrum of a row -> real space -> potential and energy integrands.
 struct ZCombineArgs {
     DenSrc ds;
-    const double* vext;
-    const double* dfdn;       // real array from zpbe
+    const real* vext;
+    const real* dfdn;       // real array from zpbe
     const cplx* vh;
     const cplx* lap;
     const cplx* conv_b;
@@ -478,57 +478,57 @@ struct ZCombineArgs {
     const cplx* gw[3];
     const cplx* div;
     const cplx* div2;         // split-derivative form: the D_b part of the divergence (added to div)
-    double* v_out;
-    const double* v_part;     // split form: the WGC99 potential computed by zi_wgc_kernel (then u / gw are not read here)
+    real* v_out;
+    const real* v_part;     // split form: the WGC99 potential computed by zi_wgc_kernel (then u / gw are not read here)
     unsigned mask;
-    double inv_n;
-    double wt_alpha, wt_beta, wt_nbar_pa;
-    double wgc_alpha, wgc_beta, nref;
-    double gtf_inv_n0;
+    real inv_n;
+    real wt_alpha, wt_beta, wt_nbar_pa;
+    real wgc_alpha, wgc_beta, nref;
+    real gtf_inv_n0;
     int gtf_kind;
     int wt_is_56, wgc_sum_53;
 };
 
 // WGC99 nonlocal part of one row (SURVEY §8a-8 closed form): adds the potential to vacc, returns the thread's energy sum
 template <int M, int E>
-__device__ __forceinline__ double wgc_row_section(const cplx (&n)[E], cplx (&vacc)[E], cplx (&w)[E], const ZLane<M, E>& z,
+__device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)[E], cplx (&w)[E], const ZLane<M, E>& z,
                                                   const ZCombineArgs& a, const SpecGeom& g, const cplx* __restrict__ twM,
-                                                  const cplx* __restrict__ twN, double sc, double ctf) {
+                                                  const cplx* __restrict__ twN, real sc, real ctf) {
     cplx t1[E], t2[E];
-    double e = 0.0;
+    real e = 0.0;
     z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
 #pragma unroll
-    for (int q = 0; q < E; ++q) t1[q] = make_double2(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
+    for (int q = 0; q < E; ++q) t1[q] = mkc(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
     z_load_inverse<M, E>(w, z, a.u[1], g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+        const real x0 = w[q].x * sc, x1 = w[q].y * sc;
         t1[q].x += (n[q].x - a.nref) * x0;
         t1[q].y += (n[q].y - a.nref) * x1;
-        t2[q] = make_double2(x0, x1);                                                            // S_1 = u1 + ...
+        t2[q] = mkc(x0, x1);                                                            // S_1 = u1 + ...
     }
     z_load_inverse<M, E>(w, z, a.u[2], g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);      // one point pair at a time: pow_pos() is register-hungry
-        const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-        const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+        const real x0 = w[q].x * sc, x1 = w[q].y * sc;
+        const real h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
         t1[q].x += 0.5 * h0 * h0 * x0;
         t1[q].y += 0.5 * h1 * h1 * x1;
         t2[q].x += h0 * x0;
         t2[q].y += h1 * x1;
         // fold: e_NL = ctf n^alpha S_e ; v += ctf n^(alpha-1) (alpha S_e + n S_1); keep n^(beta-1) in t2
-        const double pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
-        const double pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
-        const double pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
+        const real pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
+        const real pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
+        const real pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
         e += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
         vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
         vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
-        t2[q] = make_double2(pb0, pb1);
+        t2[q] = mkc(pb0, pb1);
     }
     z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
 #pragma unroll
-    for (int q = 0; q < E; ++q) t1[q] = make_double2(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
+    for (int q = 0; q < E; ++q) t1[q] = mkc(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
     z_load_inverse<M, E>(w, z, a.gw[1], g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
@@ -538,7 +538,7 @@ __device__ __forceinline__ double wgc_row_section(const cplx (&n)[E], cplx (&vac
     z_load_inverse<M, E>(w, z, a.gw[2], g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const double h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
+        const real h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
         t1[q].x += (0.5 * a.wgc_beta * h0 * h0 + n[q].x * h0) * w[q].x * sc;
         t1[q].y += (0.5 * a.wgc_beta * h1 * h1 + n[q].y * h1) * w[q].y * sc;
         vacc[q].x += ctf * t2[q].x * t1[q].x;
@@ -549,30 +549,30 @@ __device__ __forceinline__ double wgc_row_section(const cplx (&n)[E], cplx (&vac
 
 template <int M, int E, bool WGC_INLINE>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
-                                                         const cplx* __restrict__ twN, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                         const cplx* __restrict__ twN, acc_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
-    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
     // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
     // a thread only reads what it wrote).  The final reduction order is unchanged.
-    double* park = lds + ZW<M, E>::LDS / sizeof(double) + threadIdx.x;
+    real* park = lds + ZW<M, E>::LDS / sizeof(real) + threadIdx.x;
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        n[q] = z.valid ? make_double2(a.ds(n[q].x), a.ds(n[q].y)) : make_double2(1.0, 1.0);
-        vacc[q] = make_double2(0.0, 0.0);
+        n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
+        vacc[q] = mkc(0.0, 0.0);
     }
-    const double sc = a.inv_n;
+    const real sc = a.inv_n;
     if (a.mask & 2u) {                                   // Hartree  functionals.py:72
         z_load_inverse<M, E>(w, z, a.vh, g, twM, twN);
-        double e = 0.0;
+        real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
+            const real x0 = w[q].x * sc, x1 = w[q].y * sc;
             e += 0.5 * (n[q].x * x0 + n[q].y * x1);
             vacc[q].x += x0;
             vacc[q].y += x1;
@@ -581,11 +581,11 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     }
     if (a.mask & 8u) {                                   // vW  functionals.py:245; tools_for_tests.py:23-26
         z_load_inverse<M, E>(w, z, a.lap, g, twM, twN);
-        double e = 0.0;
+        real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-            const double s0 = n[q].x != 0.0 ? sqrt(n[q].x) : 0.0, s1 = n[q].y != 0.0 ? sqrt(n[q].y) : 0.0;
+            const real x0 = w[q].x * sc, x1 = w[q].y * sc;
+            const real s0 = n[q].x != 0.0 ? sqrt(n[q].x) : 0.0, s1 = n[q].y != 0.0 ? sqrt(n[q].y) : 0.0;
             e += -0.5 * (s0 * x0 + s1 * x1);
             if (n[q].x != 0.0) vacc[q].x += -0.5 * x0 / s0;
             if (n[q].y != 0.0) vacc[q].y += -0.5 * x1 / s1;
@@ -595,15 +595,15 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     if (a.mask & 16u) {                                  // WT family  functionals.py:650-651; tools_for_tests.py:29-39
         z_load_inverse<M, E>(w, z, a.conv_b, g, twM, twN);
         cplx pa1[E];
-        double e = 0.0;
+        real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             __builtin_amdgcn_sched_barrier(0);
-            const double x0 = w[q].x * sc, x1 = w[q].y * sc;
-            pa1[q] = a.wt_is_56 ? make_double2(1.0 / sqrt(cbrt(n[q].x)), 1.0 / sqrt(cbrt(n[q].y)))
-                                : make_double2(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
+            const real x0 = w[q].x * sc, x1 = w[q].y * sc;
+            pa1[q] = a.wt_is_56 ? mkc(1.0 / sqrt(cbrt(n[q].x)), 1.0 / sqrt(cbrt(n[q].y)))
+                                : mkc(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
             e += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
-            const double f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
+            const real f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
             vacc[q].x += ctf * f * pa1[q].x * x0;
             vacc[q].y += ctf * f * pa1[q].y * x1;
         }
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     if (a.mask & 1u) {
         cplx ve[E];
         z_load_real<M, E>(ve, z, a.vext);
-        double e = 0.0;
+        real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             e += n[q].x * ve[q].x + n[q].y * ve[q].y;
@@ -660,20 +660,20 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         }
         park[0] = e;
     }
-    double acc[kCombineScalars];
+    acc_t acc[kCombineScalars];
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         if (a.mask & 4u) {                               // TF  functionals.py:223
-            const double c0 = cbrt(n[q].x), c1 = cbrt(n[q].y);
+            const real c0 = cbrt(n[q].x), c1 = cbrt(n[q].y);
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
             vacc[q].x += (5.0 / 3.0) * ctf * c0 * c0;
             vacc[q].y += (5.0 / 3.0) * ctf * c1 * c1;
         }
         if (a.mask & (1u << 13)) {                       // vWGTF1 / 2  functionals.py:251-306
-            double e0, v0, e1, v1;
+            real e0, v0, e1, v1;
             vwgtf_point(n[q].x, cbrt(n[q].x), ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
             vwgtf_point(n[q].y, cbrt(n[q].y), ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
             acc[9] += e0 + e1;
@@ -705,20 +705,20 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 // The WGC99 part of the combine on its own (split form): chi|n row + the six result spectra -> v_part rows and the
 // energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wgc_kernel(ZCombineArgs a, double* __restrict__ v_part, SpecGeom g,
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wgc_kernel(ZCombineArgs a, real* __restrict__ v_part, SpecGeom g,
                                                        const cplx* __restrict__ twM, const cplx* __restrict__ twN,
-                                                       double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                       acc_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
-    const double ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        n[q] = z.valid ? make_double2(a.ds(n[q].x), a.ds(n[q].y)) : make_double2(1.0, 1.0);
-        vacc[q] = make_double2(0.0, 0.0);
+        n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
+        vacc[q] = mkc(0.0, 0.0);
     }
-    double acc[1];
+    acc_t acc[1];
     acc[0] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, a.inv_n, ctf);
     if (!z.valid) acc[0] = 0.0;
     z_store_real<M, E>(vacc, z, v_part);
