@@ -49,7 +49,7 @@ typedef struct ofdft_ctx ofdft_ctx;
 
 /* dtype */
 #define OFDFT_F64 0
-#define OFDFT_F32 1             /* reserved (config 5); not implemented yet */
+#define OFDFT_F32 1             /* served by libofdft_hip_f32.so: the same sources built with -DOFDFT_REAL_F32 */
 
 /* term bits; index of a term in E_terms[] is its bit position */
 #define OFDFT_ION_ELECTRON  (1u << 0)   /* functionals.py:31-46   (needs vext)                    */

@@ -6,15 +6,17 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
-LIB = os.path.join(LIBDIR, 'libofdft_hip.so')
+LIB = os.path.join(LIBDIR, 'libofdft_hip.so')            # fp64 (the reference's precision)
+LIB_F32 = os.path.join(LIBDIR, 'libofdft_hip_f32.so')    # same sources with -DOFDFT_REAL_F32 (BASELINE config 5)
 SOURCES = ['engine.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'ofdft_hip.h')]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _stale(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     for f in SOURCES + HEADERS:
         p = os.path.join(CSRC, f)
         if os.path.exists(p) and os.path.getmtime(p) > t:
@@ -22,22 +24,37 @@ def _stale():
     return False
 
 
-def build(force=False, verbose=True, extra_flags=(), out=None):
-    """Compile csrc/*.hip into lib/libofdft_hip.so with hipcc (cross-compiles without a GPU).
-    `extra_flags` / `out` build an experiment variant (A/B runs select it with OFDFT_LIB=<path>)."""
-    if out is None and not force and not _stale():
-        return LIB
+def _command(extra_flags, out):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
            '-ffp-contract=on', '-Wall', '-Wno-unused-function',
            '-I', os.path.join(PKG, '..', 'include')]
     cmd += list(extra_flags)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out or LIB]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return out or LIB
+    return cmd + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out]
+
+
+def build(force=False, verbose=True, extra_flags=(), out=None):
+    """Compile csrc/*.hip with hipcc (cross-compiles without a GPU) into lib/libofdft_hip.so (fp64) and
+    lib/libofdft_hip_f32.so (fp32 build of the same sources); the two compile side by side.
+    `extra_flags` / `out` build ONE experiment variant instead (A/B runs select it with OFDFT_LIB=<path>)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if out is not None:
+        cmd = _command(extra_flags, out)
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return out
+    jobs = []
+    for lib, flags in ((LIB, []), (LIB_F32, ['-DOFDFT_REAL_F32'])):
+        if force or _stale(lib):
+            cmd = _command(list(extra_flags) + flags, lib)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    return LIB
 
 
 if __name__ == '__main__':

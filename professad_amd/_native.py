@@ -10,7 +10,7 @@ import torch  # noqa: F401,E402
 
 from . import _build
 
-_LIB = None
+_LIBS = {}
 
 # mirror of the #defines in include/ofdft_hip.h
 OK, EINVAL, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4
@@ -37,23 +37,24 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
-def lib_path():
-    return _build.LIB
+def lib_path(dtype=F64):
+    return _build.LIB_F32 if dtype == F32 else _build.LIB
 
 
-def load():
-    """Load (building if stale and hipcc is present) the HIP engine.  Raises if it cannot."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = os.environ.get('OFDFT_LIB') or _build.LIB      # OFDFT_LIB: an experiment build for A/B measurements
-    if os.environ.get('OFDFT_LIB'):
+def load(dtype=F64):
+    """Load (building if stale and hipcc is present) the HIP engine of one precision: libofdft_hip.so (fp64) or
+    libofdft_hip_f32.so (the fp32 build of the same sources, same symbols).  Raises if it cannot."""
+    if dtype in _LIBS:
+        return _LIBS[dtype]
+    env = 'OFDFT_LIB_F32' if dtype == F32 else 'OFDFT_LIB'    # an experiment build for A/B measurements
+    path = os.environ.get(env) or lib_path(dtype)
+    if os.environ.get(env):
         pass
-    elif not os.path.exists(path) or (os.path.exists('/opt/rocm/bin/hipcc') and _build._stale()):
+    elif not os.path.exists(path) or (os.path.exists('/opt/rocm/bin/hipcc') and _build._stale(path)):
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
-            raise NativeLibraryError('libofdft_hip.so is missing and could not be built: %r' % (e,))
+            raise NativeLibraryError('%s is missing and could not be built: %r' % (os.path.basename(path), e))
     try:
         lib = C.CDLL(path)
     except OSError as e:
@@ -128,5 +129,5 @@ def load():
     lib.ofdft_profile_count.restype = ip
     lib.ofdft_profile_get.argtypes = [vp, ip, C.c_char_p, ip, dp, C.POINTER(C.c_longlong)]
     lib.ofdft_profile_get.restype = ip
-    _LIB = lib
+    _LIBS[dtype] = lib
     return lib

@@ -12,8 +12,10 @@
 
 #include "../../include/ofdft_hip.h"
 #include "bluestein.h"
+#ifndef OFDFT_REAL_F32
 #include "ion_kernels.h"
 #include "stress_kernels.h"
+#endif
 #include "zpass.h"
 
 using namespace ofdft;
@@ -90,8 +92,8 @@ constexpr int kSumsqSlot = 15;                                         // d_redu
 
 GgaSel gga_sel(const ofdft_ctx* c) {
     return GgaSel{(c->mask & OFDFT_PBE_X) ? 1 : 0, (c->mask & OFDFT_PBE_C) ? 1 : 0, (c->mask & OFDFT_GGA_K) ? 1 : 0,
-                  (int)c->params[OFDFT_P_GGAK_KIND], c->params[OFDFT_P_GGAK_MU], c->params[OFDFT_P_GGAK_BETA],
-                  c->params[OFDFT_P_GGAK_LAMBDA], c->params[OFDFT_P_GGAK_SIGMA]};
+                  (int)c->params[OFDFT_P_GGAK_KIND], (real)c->params[OFDFT_P_GGAK_MU], (real)c->params[OFDFT_P_GGAK_BETA],
+                  (real)c->params[OFDFT_P_GGAK_LAMBDA], (real)c->params[OFDFT_P_GGAK_SIGMA]};
 }
 
 // Pauli-Gaussian member with Laplacian-dependent terms: served by the unfused pipeline only
@@ -147,14 +149,14 @@ int get_twiddle(ofdft_ctx* c, int n, cplx** out) {
     std::vector<cplx> h(n);
     for (int m = 0; m < n; ++m) {
         const long double ph = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
-        h[m] = make_double2((double)cosl(ph), (double)sinl(ph));
+        h[m] = mkc((double)cosl(ph), (double)sinl(ph));
     }
     // exact values on the axes
-    h[0] = make_double2(1.0, 0.0);
-    if (n % 2 == 0) h[n / 2] = make_double2(-1.0, 0.0);
+    h[0] = mkc(1.0, 0.0);
+    if (n % 2 == 0) h[n / 2] = mkc(-1.0, 0.0);
     if (n % 4 == 0) {
-        h[n / 4] = make_double2(0.0, -1.0);
-        h[3 * n / 4] = make_double2(0.0, 1.0);
+        h[n / 4] = mkc(0.0, -1.0);
+        h[3 * n / 4] = mkc(0.0, 1.0);
     }
     cplx* d = nullptr;
     HIP_TRY(c, hipMalloc(&d, sizeof(cplx) * n));
@@ -181,8 +183,8 @@ int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out) {
     *out = b.p;
     return 0;
 }
-int real_ws(ofdft_ctx* c, const char* name, double** out) {
-    return get_ws(c, std::string("r:") + name, sizeof(double) * (size_t)c->npts, (void**)out);
+int real_ws(ofdft_ctx* c, const char* name, real** out) {
+    return get_ws(c, std::string("r:") + name, sizeof(real) * (size_t)c->npts, (void**)out);
 }
 int spec_ws(ofdft_ctx* c, const char* name, cplx** out) {
     return get_ws(c, std::string("s:") + name, sizeof(cplx) * (size_t)c->g.total, (void**)out);
@@ -336,7 +338,7 @@ int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStrea
 }
 
 template <int M>
-int launch_zfwd_t(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+int launch_zfwd_t(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = get_twiddle(c, M, &twM)) return rc;
     if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
@@ -347,13 +349,13 @@ int launch_zfwd_t(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
     return 0;
 }
 template <int M>
-int launch_zinv_t(ofdft_ctx* c, const cplx* spec, double* out, double scale, hipStream_t st) {
+int launch_zinv_t(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = get_twiddle(c, M, &twM)) return rc;
     if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
     using Cfg = ZCfg<M>;
     const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
-    PostScale post{scale};
+    PostScale post{(real)scale};
     OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
                        twN, post);
     return 0;
@@ -394,7 +396,7 @@ int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
         const long long r = ((long long)n * n) % (2LL * N);          // n^2 mod 2N keeps the angle small and exact
         const long double ph = -pi * (long double)r / (long double)N;
         const long double cr = cosl(ph), ci = sinl(ph);
-        h[n] = make_double2((double)cr, (double)ci);
+        h[n] = mkc((double)cr, (double)ci);
         br[n] = cr;
         bi[n] = -ci;                                                   // b_n = conj(w_n), b_{-n} = b_n
         if (n) {
@@ -416,7 +418,7 @@ int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
             sr += br[n] * cs[t] - bi[n] * sn[t];
             si += br[n] * sn[t] + bi[n] * cs[t];
         }
-        h[N + k] = make_double2((double)(sr / M), (double)(si / M));
+        h[N + k] = mkc((double)(sr / M), (double)(si / M));
     }
     cplx* d;
     if (int rc = get_ws(c, key.c_str(), sizeof(cplx) * h.size(), (void**)&d)) return rc;
@@ -427,7 +429,7 @@ int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
 }
 
 template <int M>
-int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const double* rin, double* rout, const BsArgs& b, const BsTables& t,
+int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const real* rin, real* rout, const BsArgs& b, const BsTables& t,
                        hipStream_t st) {
     cplx* tw;
     if (int rc = get_twiddle(c, M, &tw)) return rc;
@@ -439,7 +441,7 @@ int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const double* rin, double* rout
 }
 
 // one generic-length pass: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
-int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const double* rin, double* rout, double scale,
+int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const real* rin, real* rout, double scale,
                    hipStream_t st) {
     const int N = mode == 0 ? (axis == 0 ? c->n0 : c->n1) : c->n2;
     BsTables t;
@@ -467,7 +469,7 @@ int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const 
 bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
 
 // real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
-int rfftn_internal(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
     if (c->fast) {
         int rc;
@@ -504,7 +506,7 @@ int rfftn_internal(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
 }
 
 // internal half spectrum (destroyed) -> real, scaled by `scale` (1/N for irfftn semantics)
-int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) {
+int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
     c->fft_count++;
     if (c->fast) {
         int rc;
@@ -533,7 +535,7 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStre
     cplx *cur = spec, *other = tmp;
     if (int rc = gen_axis(c, 0, 1, cur, other, st)) return rc;
     if (int rc = gen_axis(c, 1, 1, cur, other, st)) return rc;
-    PostScale post{scale};
+    PostScale post{(real)scale};
     OFDFT_LAUNCH(c, st, "gen_c2r_z", (gen_c2r_z_kernel<PostScale>), dim3((unsigned)((c->npts + 255) / 256)), dim3(256), 0, cur, out,
                        c->g, tw2, post);
     return 0;
@@ -542,7 +544,7 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStre
 
 // ---------------------------------------------------------------------------------- fused-pipeline pieces
 // z-forward + y-forward (the x transform is left to the fused x pass)
-int fwd_zy(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
+int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
     int rc;
     switch (c->n2 / 2) {
@@ -561,7 +563,7 @@ int fwd_zy(ofdft_ctx* c, const double* in, cplx* spec, hipStream_t st) {
 }
 
 // y-inverse + z-inverse (c2r) of a spectrum whose x axis is already back in real space
-int inv_yz(ofdft_ctx* c, cplx* spec, double* out, double scale, hipStream_t st) {
+int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
     c->fft_count++;
     if (int rc = fast_axis_pass<true>(c, 1, spec, st)) return rc;
     switch (c->n2 / 2) {
@@ -652,7 +654,7 @@ int fetch_partials(ofdft_ctx* c, int rows, int ns, double* sums, hipStream_t st)
     return 0;
 }
 
-int device_sum(ofdft_ctx* c, const double* a, bool square, double* out, hipStream_t st) {
+int device_sum(ofdft_ctx* c, const real* a, bool square, double* out, hipStream_t st) {
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     if (square)
         OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, a, c->npts, c->d_partial);
@@ -741,8 +743,8 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     if (c->wgc_valid && c->wgc_key_nel == nel_rounded) return 0;
     WgcSeries s{};
     if (int rc = wgc_series_setup(c, nel_rounded, st, &s)) return rc;
-    double *w0, *K1, *K2, *K3;
-    const size_t tb = sizeof(double) * (size_t)c->g.total;
+    real *w0, *K1, *K2, *K3;
+    const size_t tb = sizeof(real) * (size_t)c->g.total;
     if (int rc = get_ws(c, "t:wgc", 4 * tb, (void**)&w0)) return rc;      // interleaved (w0,K1,K2,K3) per k-point
     K1 = w0 + 1;
     K2 = w0 + 2;
@@ -762,7 +764,7 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
     const long long npts = c->npts;
     const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
     CombineArgs cb = ca;     // every pointer valid: unused inputs alias the density (their terms are masked off)
-    const double* d = cb.n;
+    const real* d = cb.n;
     if (!cb.vext) cb.vext = d;
     if (!cb.vh) cb.vh = d;
     if (!cb.lap_s) cb.lap_s = d;
@@ -798,7 +800,7 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
 
 // ---------------------------------------------------------------------------------- the energy pipeline
 // den: density on device.  Fills E_terms (host), writes v_out (device, may be NULL), returns sum(v n) dV.
-int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out,
+int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E_terms, real* v_out,
                       double* vn_int, hipStream_t st) {
     const unsigned mask = c->mask;
     const long long npts = c->npts;
@@ -830,14 +832,14 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
         if (int rc = rfftn_internal(c, den, s0, st)) return rc;             // n^ (shared)
         if (int rc = spec_ws(c, "s1", &s1)) return rc;
         if (mask & OFDFT_HARTREE) {
-            double* vh;
+            real* vh;
             if (int rc = real_ws(c, "vh", &vh)) return rc;
             OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, s1, c->kg, 0.0, 0.0);
             if (int rc = irfftn_internal(c, s1, vh, inv_n, st)) return rc;
             ca.vh = vh;
         }
         if (mask & kGgaAny) {
-            double *gx, *gy, *gz, *dfdn, *dv;
+            real *gx, *gy, *gz, *dfdn, *dv;
             if (int rc = spec_ws(c, "s2", &s2)) return rc;
             if (int rc = spec_ws(c, "s3", &s3)) return rc;
             if (int rc = real_ws(c, "gx", &gx)) return rc;
@@ -850,7 +852,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = irfftn_internal(c, s2, gy, inv_n, st)) return rc;
             if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
             const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
-            double* lapn = nullptr;
+            real* lapn = nullptr;
             cplx* s4 = nullptr;
             if (gga_needs_laplacian(c)) {            // lap n = F^-1[-k^2 n^]  (reduced Laplacian q, functional_tools.py:271-287)
                 if (int rc = real_ws(c, "lapn", &lapn)) return rc;
@@ -875,7 +877,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
         }
     }
     if (mask & OFDFT_VW) {
-        double *tmp, *lap;
+        real *tmp, *lap;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "lap", &lap)) return rc;
         OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
@@ -889,7 +891,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
         const double nbar = nel / c->vol;                                    // functionals.py:646-647
         const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
         const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-        double *tmp, *cb;
+        real *tmp, *cb;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "conv_b", &cb)) return rc;
         OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
@@ -900,7 +902,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
         ca.conv_b = cb;
         ca.conv_a = nullptr;
         if (al != be) {
-            double* cva;
+            real* cva;
             if (int rc = real_ws(c, "conv_a", &cva)) return rc;
             OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
             if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
@@ -919,7 +921,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
         const long long nel_r = std::llround(nel);                           // functionals.py:952
         double nref;
         if (int rc = ensure_wgc_tables(c, nel_r, st, &nref)) return rc;
-        double *t0, *t1, *t2, *o[6];
+        real *t0, *t1, *t2, *o[6];
         if (int rc = real_ws(c, "t0", &t0)) return rc;
         if (int rc = real_ws(c, "t1", &t1)) return rc;
         if (int rc = real_ws(c, "t2", &t2)) return rc;
@@ -928,7 +930,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         if (int rc = spec_ws(c, "s1", &s1)) return rc;
         if (int rc = spec_ws(c, "s2", &s2)) return rc;
-        const double *w0 = (double*)c->ws["t:wgc"].p, *K1 = w0 + 1, *K2 = w0 + 2, *K3 = w0 + 3;
+        const real *w0 = (real*)c->ws["t:wgc"].p, *K1 = w0 + 1, *K2 = w0 + 2, *K3 = w0 + 3;
         for (int pass = 0; pass < 2; ++pass) {
             OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
                                nref);
@@ -953,7 +955,7 @@ int run_terms_unfused(ofdft_ctx* c, const double* den, const double* vext, doubl
 
 // Fused pipeline (power-of-two grids): every spectral multiply rides inside the x pass (xfused_kernel), so a
 // forward/inverse FFT pair costs  z + y + (x fused) + y + z  = 5 passes instead of 6 + a multiply pass.
-int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out,
+int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_terms, real* v_out,
                    double* vn_int, hipStream_t st) {
     const unsigned mask = c->mask;
     const long long npts = c->npts;
@@ -986,7 +988,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
         XfIo io{};
         io.in[0] = s[0];
         int no = 0;
-        double *vh = nullptr, *gr[3] = {nullptr, nullptr, nullptr}, *dfdn = nullptr, *dv = nullptr;
+        real *vh = nullptr, *gr[3] = {nullptr, nullptr, nullptr}, *dfdn = nullptr, *dv = nullptr;
         if (has_h) {
             if (int rc = spec_ws(c, sn[1], &s[1])) return rc;
             if (int rc = real_ws(c, "vh", &vh)) return rc;
@@ -1030,7 +1032,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
         }
     }
     if (mask & OFDFT_VW) {
-        double *tmp, *lap;
+        real *tmp, *lap;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "lap", &lap)) return rc;
         OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
@@ -1047,10 +1049,10 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
         const double nbar = nel / c->vol;
         const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
         const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
-        double *tmp, *cb;
+        real *tmp, *cb;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "conv_b", &cb)) return rc;
-        const MixScale<SPEC_LINDHARD> lind{c->kg, pref, 1.0 / (2.0 * kf)};
+        const MixScale<SPEC_LINDHARD> lind{c->kg, (real)pref, (real)(1.0 / (2.0 * kf))};
         XfIo io{};
         io.in[0] = s[0];
         io.out[0] = s[0];
@@ -1061,7 +1063,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
         ca.conv_b = cb;
         ca.conv_a = nullptr;
         if (al != be) {
-            double* cva;
+            real* cva;
             if (int rc = real_ws(c, "conv_a", &cva)) return rc;
             OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
             if (int rc = fwd_zy(c, tmp, s[0], st)) return rc;
@@ -1079,7 +1081,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
         const long long nel_r = std::llround(nel);
         double nref;
         if (int rc = ensure_wgc_tables(c, nel_r, st, &nref)) return rc;
-        double *t[3], *o[6];
+        real *t[3], *o[6];
         const char* tn[3] = {"t0", "t1", "t2"};
         const char* names[6] = {"u0", "u1", "u2", "gA", "gB", "gC"};
         for (int i = 0; i < 3; ++i)
@@ -1088,7 +1090,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         for (int i = 1; i < 3; ++i)
             if (int rc = spec_ws(c, sn[i], &s[i])) return rc;
-        const MixWgc mix{(double*)c->ws["t:wgc"].p};
+        const MixWgc mix{(real*)c->ws["t:wgc"].p};
         XfIo io{};
         for (int i = 0; i < 3; ++i) {
             io.in[i] = s[i];
@@ -1113,7 +1115,7 @@ int run_terms_fast(ofdft_ctx* c, const double* den, const double* vext, double* 
     return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
 }
 
-int run_terms(ofdft_ctx* c, const double* den, const double* vext, double* E_terms, double* v_out, double* vn_int,
+int run_terms(ofdft_ctx* c, const real* den, const real* vext, double* E_terms, real* v_out, double* vn_int,
               hipStream_t st) {
     if (c->fast && !c->force_unfused && !gga_needs_laplacian(c)) return run_terms_fast(c, den, vext, E_terms, v_out, vn_int, st);
     return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st);
@@ -1134,7 +1136,13 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     if (nranks > 1 && (n0g % nranks || n1g % nranks))
         return fail(nullptr, OFDFT_EINVAL, "slab decomposition needs n0 and n1 divisible by the rank count %d", nranks);
     const int n0 = n0g / nranks, n1 = n1g;
-    if (dtype != OFDFT_F64) return fail(nullptr, OFDFT_EINVAL, "only OFDFT_F64 is implemented");
+#ifdef OFDFT_REAL_F32
+    if (dtype != OFDFT_F32)
+        return fail(nullptr, OFDFT_EINVAL, "this is the fp32 build (libofdft_hip_f32.so): create OFDFT_F64 contexts with libofdft_hip.so");
+#else
+    if (dtype != OFDFT_F64)
+        return fail(nullptr, OFDFT_EINVAL, "this is the fp64 build (libofdft_hip.so): create OFDFT_F32 contexts with libofdft_hip_f32.so");
+#endif
     int ndev = 0;
     hipError_t e0 = hipGetDeviceCount(&ndev);
     if (e0 != hipSuccess || ndev <= 0)
@@ -1287,14 +1295,14 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
         double nel = 0.0;
         if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF)) {
             double nsum;
-            if (int rc = device_sum(c, (const double*)den, false, &nsum, st)) return rc;
+            if (int rc = device_sum(c, (const real*)den, false, &nsum, st)) return rc;
             nel = nsum / (double)c->npts * c->vol;
         }
-        const DenSrc ds{(const double*)den, 1.0, 0, nullptr};
-        if (int rc = run_terms_zfused(c, ds, nel, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
+        const DenSrc ds{(const real*)den, 1.0, 0, nullptr};
+        if (int rc = run_terms_zfused(c, ds, nel, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
         return end_call(c, st);
     }
-    if (int rc = run_terms(c, (const double*)den, (const double*)vext, E_terms, (double*)dEdn, &vn, st)) return rc;
+    if (int rc = run_terms(c, (const real*)den, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
     return end_call(c, st);
 }
 
@@ -1306,43 +1314,43 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
-    double *den, *v;
+    real *den, *v;
     if (int rc = real_ws(c, "v", &v)) return rc;
     if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
         // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
         // z kernels; mean(n) vol = N_e by construction.  One host sync per evaluation (the final sums).
         const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
-        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)chi, c->npts,
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const real*)chi, c->npts,
                      c->d_partial);
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
                      c->d_reduced + kSumsqSlot);
         OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, n_electrons,
                      c->vol / (double)c->npts);
-        const DenSrc ds{(const double*)chi, 0.0, 1, c->d_scal};
+        const DenSrc ds{(const real*)chi, 0.0, 1, c->d_scal};
         double vn;
-        if (int rc = run_terms_zfused(c, ds, n_electrons, (const double*)vext, E_terms, v, &vn, st)) return rc;
+        if (int rc = run_terms_zfused(c, ds, n_electrons, (const real*)vext, E_terms, v, &vn, st)) return rc;
         const double mu = vn / n_electrons;
         if (mu_host) *mu_host = mu;
         if (grad) {
-            OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi,
-                         v, (double*)grad, c->npts, 0.0, (const double*)c->d_scal, 2.0 * c->dV, mu);
+            OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi,
+                         v, (real*)grad, c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, mu);
         }
         return end_call(c, st);
     }
     double s2;
-    if (int rc = device_sum(c, (const double*)chi, true, &s2, st)) return rc;
+    if (int rc = device_sum(c, (const real*)chi, true, &s2, st)) return rc;
     const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
     const double cfac = n_electrons / ntilde;                                         // system.py:834
     if (int rc = real_ws(c, "den", &den)) return rc;
-    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, den,
+    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi, den,
                        c->npts, cfac);
     double vn;
-    if (int rc = run_terms(c, den, (const double*)vext, E_terms, v, &vn, st)) return rc;
+    if (int rc = run_terms(c, den, (const real*)vext, E_terms, v, &vn, st)) return rc;
     const double mu = vn / n_electrons;                                               // system.py:851
     if (mu_host) *mu_host = mu;
     if (grad) {
-        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi, v, (double*)grad,
-                           c->npts, cfac * 2.0 * c->dV, (const double*)nullptr, 0.0, mu);
+        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi, v, (real*)grad,
+                           c->npts, cfac * 2.0 * c->dV, (const acc_t*)nullptr, 0.0, mu);
     }
     return end_call(c, st);
 }
@@ -1353,7 +1361,7 @@ int ofdft_rfftn(ofdft_ctx* c, const void* real_dev, void* spec_dev, void* stream
     HIP_TRY(c, hipSetDevice(c->device));
     cplx* s;
     if (int rc = spec_ws(c, "io", &s)) return rc;
-    if (int rc = rfftn_internal(c, (const double*)real_dev, s, st)) return rc;
+    if (int rc = rfftn_internal(c, (const real*)real_dev, s, st)) return rc;
     OFDFT_LAUNCH(c, st, "spec_to_standard", spec_to_standard_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, s,
                        (cplx*)spec_dev, c->g);
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -1370,7 +1378,7 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
     if (int rc = spec_ws(c, "io", &s)) return rc;
     OFDFT_LAUNCH(c, st, "spec_to_internal", spec_to_internal_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0,
                  (const cplx*)spec_dev, s, c->g);
-    if (int rc = irfftn_internal(c, s, (double*)real_dev, 1.0 / (double)c->npts, st)) return rc;
+    if (int rc = irfftn_internal(c, s, (real*)real_dev, 1.0 / (double)c->npts, st)) return rc;
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
@@ -1382,14 +1390,14 @@ int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* loca
     hipStream_t st = (hipStream_t)stream;
     if (!c || !x_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (local_sum) return device_sum(c, (const double*)x_local, square != 0, local_sum, st);
+    if (local_sum) return device_sum(c, (const real*)x_local, square != 0, local_sum, st);
     // device-resident form: the local sum goes to scalars[15] (ofdft_dist_scalars), no host synchronisation
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     if (square)
-        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const real*)x_local, c->npts,
                      c->d_partial);
     else
-        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, (const double*)x_local, c->npts,
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, (const real*)x_local, c->npts,
                      c->d_partial);
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
                  c->d_reduced + kSumsqSlot);
@@ -1415,13 +1423,13 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[15]; it never visits the host
         OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel_global,
                      c->vol / (double)c->npts_g);
-        r.ds = DenSrc{(const double*)src_local, 0.0, 1, c->d_scal};
+        r.ds = DenSrc{(const real*)src_local, 0.0, 1, c->d_scal};
     } else {
-        r.ds = DenSrc{(const double*)src_local, cscale, from_chi, nullptr};
+        r.ds = DenSrc{(const real*)src_local, (real)cscale, from_chi, nullptr};
     }
     r.nel = nel_global;
-    r.vext = (const double*)vext_local;
-    r.v_out = (double*)v_out_local;
+    r.vext = (const real*)vext_local;
+    r.v_out = (real*)v_out_local;
     r.stage[0] = r.stage[1] = 0;
     r.deferred.clear();
     r.forked = false;
@@ -1497,14 +1505,37 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
     hipStream_t st = (hipStream_t)stream;
     if (!c || !chi_local || !v_local || !grad_local) return OFDFT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const double*)chi_local,
-                 (const double*)v_local, (double*)grad_local, c->npts, cscale * 2.0 * c->dV,
-                 cscale > 0.0 ? (const double*)nullptr : (const double*)c->d_scal, 2.0 * c->dV, mu);
+    OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi_local,
+                 (const real*)v_local, (real*)grad_local, c->npts, cscale * 2.0 * c->dV,
+                 cscale > 0.0 ? (const acc_t*)nullptr : (const acc_t*)c->d_scal, 2.0 * c->dV, mu);
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
 
+#ifndef OFDFT_REAL_F32
 #include "engine_ions_stress.inc.h"
+#else
+// The fp32 build serves the density-optimisation hot path only.  The once-per-geometry-step quantities (ionic potential,
+// forces, stress, ion-ion sum) are fp64 work: callers run them on the fp64 library (professad_amd.ions does).
+#define OFDFT_F64_ONLY(c) fail(c, OFDFT_EINVAL, "%s is served by the fp64 library (libofdft_hip.so) only", __func__)
+extern "C" {
+int ofdft_ionic_potential(ofdft_ctx* c, const double*, int, const double*, const double*, int, double, int, void*, int, void*) {
+    return OFDFT_F64_ONLY(c);
+}
+int ofdft_ion_electron_forces(ofdft_ctx* c, const void*, const double*, int, const double*, const double*, int, double, int,
+                              double*, void*) {
+    return OFDFT_F64_ONLY(c);
+}
+int ofdft_stress(ofdft_ctx* c, const void*, double*, void*) { return OFDFT_F64_ONLY(c); }
+int ofdft_ion_electron_stress(ofdft_ctx* c, const void*, const double*, int, const double*, const double*, int, double, int,
+                              double*, void*) {
+    return OFDFT_F64_ONLY(c);
+}
+int ofdft_ion_ion(ofdft_ctx* c, const double*, const double*, int, double, double*, double*, double*, void*) {
+    return OFDFT_F64_ONLY(c);
+}
+}
+#endif
 
 int ofdft_set_option(ofdft_ctx* c, int option, double value) {
     if (!c) return OFDFT_EINVAL;

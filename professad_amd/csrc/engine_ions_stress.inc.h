@@ -114,7 +114,7 @@ int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, cons
                      1.0 / c->vol);
     }
     if (int rc = irfftn_internal(c, sF, tmp, 1.0, st)) return rc;              // norm='forward': no 1/N  (ion_utils.py:118)
-    OFDFT_LAUNCH(c, st, "axpy", axpy_kernel, dim3(grid_for(c->npts)), dim3(256), 0, (const double*)tmp, (double*)vext_dev,
+    OFDFT_LAUNCH(c, st, "axpy", (axpy_kernel<double>), dim3(grid_for(c->npts)), dim3(256), 0, (const double*)tmp, (double*)vext_dev,
                  c->npts, accumulate);
     HIP_TRY(c, hipStreamSynchronize(st));      // `p` (host staging) must outlive the async copies
     HIP_TRY(c, hipGetLastError());

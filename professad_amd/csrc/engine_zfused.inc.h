@@ -13,7 +13,7 @@ template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nr
 // The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
 // [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
 int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
-                      int nchunks = 1, double* dzn = nullptr) {
+                      int nchunks = 1, real* dzn = nullptr) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
     if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
@@ -50,7 +50,7 @@ int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipSt
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
-int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, double* dfdn, double inv_n,
+int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, real* dfdn, double inv_n,
                 int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
@@ -72,7 +72,7 @@ int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, do
 }
 
 // split-derivative GGA mid stage (zpass.h: zpbe2_kernel)
-int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const double* dzn, double* dfdn, double inv_n,
+int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const real* dzn, real* dfdn, double inv_n,
                  int* blocks_out, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
@@ -144,7 +144,7 @@ int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipS
 }
 
 // split form: the WGC99 part of the combine on the nonlocal chain's stream -> v_part rows + one energy partial per block
-int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, double* v_part, double* partial, int* blocks_out, hipStream_t st) {
+int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, real* v_part, double* partial, int* blocks_out, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
 #define X(M_)                                                                                                     \
@@ -194,14 +194,14 @@ void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pb
 struct ZRun {
     DenSrc ds{};
     double nel = 0.0;
-    const double* vext = nullptr;
-    double* v_out = nullptr;
+    const real* vext = nullptr;
+    real* v_out = nullptr;
     ZCombineArgs za{};
     double pbe_sums[kPbeScalars] = {0.0, 0.0, 0.0};
     bool has_h = false, has_g = false, has_vw = false, has_wt = false, has_wgc = false;
     cplx *s_n = nullptr, *s_s = nullptr, *s_vh = nullptr, *s_g[3] = {nullptr, nullptr, nullptr};
     cplx *s_b = nullptr, *s_a = nullptr, *sw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double* dfdn = nullptr;
+    real* dfdn = nullptr;
     double wt_pref = 0.0, wt_kf = 1.0;
     // The evaluation is two independent chains that meet only in the combine kernel:
     //   chain 0: density spectrum -> Hartree, grad n -> PBE -> divergence;  sqrt(n) -> Laplacian (vW)
@@ -209,7 +209,7 @@ struct ZRun {
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
     bool gsplit = false;           // split-derivative form of the GGA chain (only D_a visits the x pass)
-    double* dzn = nullptr;
+    real* dzn = nullptr;
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
@@ -444,7 +444,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
         }
     } else {
         if (r.has_wt) {
-            const MixScale<SPEC_LINDHARD> lind{c->kg, r.wt_pref, 1.0 / (2.0 * r.wt_kf)};
+            const MixScale<SPEC_LINDHARD> lind{c->kg, (real)r.wt_pref, (real)(1.0 / (2.0 * r.wt_kf))};
             for (cplx* sp : {r.s_b, r.s_a}) {
                 if (!sp) continue;
                 XfIo io{};
@@ -454,7 +454,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
             }
         }
         if (r.has_wgc) {
-            const MixWgc mix{(double*)c->ws["t:wgc"].p};
+            const MixWgc mix{(real*)c->ws["t:wgc"].p};
             // kz-chunked form (one GPU): the fused x pass of a range of kz blocks is followed at once by the y-inverse
             // of the same range, which then reads the x pass' output from the Infinity Cache
             const int nb = c->g.nzm / 8;
@@ -530,7 +530,8 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         r.wgc_split = false;
         if (r.has_wgc && !chunked && c->split_combine) {
             // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
-            double *vp, *part2;
+            real* vp;
+            acc_t* part2;
             int blocks = 0;
             if ((rc = real_ws(c, "vpart", &vp))) return rc;
             if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
@@ -539,7 +540,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
                 HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
             }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
-            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const double*)part2, blocks, 1,
+            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 1,
                          c->d_scal + 2);
             r.za.v_part = vp;
             r.wgc_split = true;
@@ -672,7 +673,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     r.stage[0] = r.stage[1] = 5;
     if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
         if (r.wgc_split)          // fold in the energy sum of the split WGC99 kernel
-            OFDFT_LAUNCH(c, st, "reduce", axpy_kernel, dim3(1), dim3(64), 0, (const double*)(c->d_scal + 2), c->d_reduced + 5,
+            OFDFT_LAUNCH(c, st, "reduce", (axpy_kernel<acc_t>), dim3(1), dim3(64), 0, (const acc_t*)(c->d_scal + 2), c->d_reduced + 5,
                          (long long)1, 1);
         return 0;
     }
@@ -685,7 +686,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     return 0;
 }
 
-int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const double* vext, double* E_terms, double* v_out,
+int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, double* E_terms, real* v_out,
                      double* vn_int, hipStream_t st) {
     ZRun& r = zrun(c);
     r.ds = ds;

@@ -98,11 +98,6 @@ __global__ void ion_potential_spec_kernel(const cplx* __restrict__ Qk, cplx* __r
     }
 }
 
-__global__ void axpy_kernel(const double* __restrict__ x, double* __restrict__ y, long long n, int accumulate) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        y[i] = accumulate ? y[i] + x[i] : x[i];
-}
-
 }  // namespace ofdft
 
 namespace ofdft {

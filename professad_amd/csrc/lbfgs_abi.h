@@ -10,9 +10,9 @@ struct ofdft_lbfgs {
     int hist = 0, device = 0;
     int count = 0;                 // stored pairs
     int order[kLbfgsMaxHist + 1];  // physical slot of the logical pair j (oldest first); order[count] = free slot
-    double* S[kLbfgsMaxHist + 1] = {nullptr};
-    double* Y[kLbfgsMaxHist + 1] = {nullptr};
-    double *d = nullptr, *g_prev = nullptr;
+    real* S[kLbfgsMaxHist + 1] = {nullptr};
+    real* Y[kLbfgsMaxHist + 1] = {nullptr};
+    real *d = nullptr, *g_prev = nullptr;
     double *d_partial = nullptr, *d_out = nullptr, *h_out = nullptr;
     bool have_prev = false;        // a step (d, t) and the gradient before it exist
     bool pending = false;          // a candidate pair sits in the free slot
@@ -42,13 +42,13 @@ LbfgsVecs logical(const ofdft_lbfgs* o, int count) {
 }
 
 template <int K>
-void launch_dots(ofdft_lbfgs* o, const LbfgsVecs& v, const double* g, int blocks, hipStream_t st) {
+void launch_dots(ofdft_lbfgs* o, const LbfgsVecs& v, const real* g, int blocks, hipStream_t st) {
     const int slot = o->order[o->count];
     hipLaunchKernelGGL((lbfgs_dots_kernel<K>), dim3(blocks), dim3(kRedThreads), 0, st, v, g, o->g_prev, o->d, o->t_prev,
                        o->have_prev ? 1 : 0, o->S[slot], o->Y[slot], o->n, o->d_partial);
 }
 template <int K>
-void launch_update(ofdft_lbfgs* o, const LbfgsVecs& v, const LbfgsCoef& c, const double* g, double t, double* x, int blocks,
+void launch_update(ofdft_lbfgs* o, const LbfgsVecs& v, const LbfgsCoef& c, const real* g, double t, real* x, int blocks,
                    hipStream_t st) {
     hipLaunchKernelGGL((lbfgs_update_kernel<K>), dim3(blocks), dim3(kRedThreads), 0, st, v, c, g, t, o->d, x, o->g_prev, o->n,
                        o->d_partial);
@@ -67,7 +67,7 @@ int ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history, int de
     o->hist = history;
     o->device = device_id;
     hipError_t e = hipSetDevice(device_id);
-    const size_t vb = sizeof(double) * (size_t)n_local;
+    const size_t vb = sizeof(real) * (size_t)n_local;
     for (int i = 0; i <= history && e == hipSuccess; ++i) {
         e = hipMalloc((void**)&o->S[i], vb);
         if (e == hipSuccess) e = hipMalloc((void**)&o->Y[i], vb);
@@ -112,7 +112,7 @@ int ofdft_lbfgs_dots(ofdft_lbfgs* o, const void* g_dev, double* dots_host, int* 
     const LbfgsVecs v = logical(o, K);
     long long want = (o->n / 2 + kRedThreads) / kRedThreads;
     const int blocks = (int)(want < 1 ? 1 : (want > kRedBlocks ? kRedBlocks : want));
-    const double* g = (const double*)g_dev;
+    const real* g = (const real*)g_dev;
     switch (K) {
         case 0: launch_dots<0>(o, v, g, blocks, st); break;
         case 1: launch_dots<1>(o, v, g, blocks, st); break;
@@ -167,8 +167,8 @@ int ofdft_lbfgs_update(ofdft_lbfgs* o, const double* coef_s, const double* coef_
     c.cg = coef_g;
     long long want = (o->n / 2 + kRedThreads) / kRedThreads;
     const int blocks = (int)(want < 1 ? 1 : (want > kRedBlocks ? kRedBlocks : want));
-    const double* g = (const double*)g_dev;
-    double* x = (double*)x_dev;
+    const real* g = (const real*)g_dev;
+    real* x = (real*)x_dev;
     switch (K) {
         case 0: launch_update<0>(o, v, c, g, t, x, blocks, st); break;
         case 1: launch_update<1>(o, v, c, g, t, x, blocks, st); break;

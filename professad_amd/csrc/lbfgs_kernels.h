@@ -14,30 +14,30 @@ namespace ofdft {
 #ifndef OFDFT_LBFGS_NT
 #define OFDFT_LBFGS_NT 1
 #endif
-__device__ __forceinline__ double2 lb_load2(const double* p, long long i) {
+__device__ __forceinline__ cplx lb_load2(const real* p, long long i) {
 #if OFDFT_LBFGS_NT
     const real2_t t = __builtin_nontemporal_load(reinterpret_cast<const real2_t*>(p) + i);
-    return make_double2(t.x, t.y);
+    return mkc(t.x, t.y);
 #else
-    return reinterpret_cast<const double2*>(p)[i];
+    return reinterpret_cast<const cplx*>(p)[i];
 #endif
 }
-__device__ __forceinline__ void lb_store2(double* p, long long i, double2 v) {
+__device__ __forceinline__ void lb_store2(real* p, long long i, cplx v) {
 #if OFDFT_LBFGS_NT
     real2_t t;
     t.x = v.x;
     t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<real2_t*>(p) + i);
 #else
-    reinterpret_cast<double2*>(p)[i] = v;
+    reinterpret_cast<cplx*>(p)[i] = v;
 #endif
 }
 
 constexpr int kLbfgsMaxHist = 8;
 
 struct LbfgsVecs {
-    const double* S[kLbfgsMaxHist];   // stored steps, oldest first
-    const double* Y[kLbfgsMaxHist];   // stored gradient differences
+    const real* S[kLbfgsMaxHist];   // stored steps, oldest first
+    const real* Y[kLbfgsMaxHist];   // stored gradient differences
 };
 struct LbfgsCoef {
     double cs[kLbfgsMaxHist], cy[kLbfgsMaxHist], cg;
@@ -50,32 +50,32 @@ __host__ __device__ constexpr int lbfgs_nscal(int K) { return 6 * K + 7; }
 // Sweep 1: forms the candidate pair y = g - g_prev, s = t d (written to s_new / y_new; zeros when there is no
 // previous step) and accumulates every inner product of {s, y, g} with the stored vectors and with each other.
 template <int K>
-__global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, const double* __restrict__ g,
-                                                                 const double* __restrict__ g_prev,
-                                                                 const double* __restrict__ d, double t, int have_prev,
-                                                                 double* __restrict__ s_new, double* __restrict__ y_new,
-                                                                 long long n, double* __restrict__ partial) {
+__global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, const real* __restrict__ g,
+                                                                 const real* __restrict__ g_prev,
+                                                                 const real* __restrict__ d, real t, int have_prev,
+                                                                 real* __restrict__ s_new, real* __restrict__ y_new,
+                                                                 long long n, acc_t* __restrict__ partial) {
     constexpr int NS = lbfgs_nscal(K);
-    double acc[NS];
+    acc_t acc[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) acc[i] = 0.0;
     const long long n2 = n >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2 + (n & 1); i += (long long)gridDim.x * blockDim.x) {
         const bool tail = i == n2;          // odd length: the last element alone
-        double2 gi, si = make_double2(0.0, 0.0), yi = make_double2(0.0, 0.0);
-        if (!tail) gi = reinterpret_cast<const double2*>(g)[i];
-        else gi = make_double2(g[n - 1], 0.0);
+        cplx gi, si = mkc(0.0, 0.0), yi = mkc(0.0, 0.0);
+        if (!tail) gi = reinterpret_cast<const cplx*>(g)[i];
+        else gi = mkc(g[n - 1], 0.0);
         if (have_prev) {
-            double2 gp, di;
+            cplx gp, di;
             if (!tail) {
                 gp = lb_load2(g_prev, i);
                 di = lb_load2(d, i);
             } else {
-                gp = make_double2(g_prev[n - 1], 0.0);
-                di = make_double2(d[n - 1], 0.0);
+                gp = mkc(g_prev[n - 1], 0.0);
+                di = mkc(d[n - 1], 0.0);
             }
-            yi = make_double2(gi.x - gp.x, gi.y - gp.y);
-            si = make_double2(t * di.x, t * di.y);
+            yi = mkc(gi.x - gp.x, gi.y - gp.y);
+            si = mkc(t * di.x, t * di.y);
             if (!tail) {
                 lb_store2(s_new, i, si);
                 lb_store2(y_new, i, yi);
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, co
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            double2 a, b;
+            cplx a, b;
             if (!tail) {
                 a = lb_load2(v.S[j], i);
                 b = lb_load2(v.Y[j], i);
             } else {
-                a = make_double2(v.S[j][n - 1], 0.0);
-                b = make_double2(v.Y[j][n - 1], 0.0);
+                a = mkc(v.S[j][n - 1], 0.0);
+                b = mkc(v.Y[j][n - 1], 0.0);
             }
             acc[3 * j + 0] += si.x * a.x + si.y * a.y;
             acc[3 * j + 1] += yi.x * a.x + yi.y * a.y;
@@ -114,32 +114,32 @@ __global__ __launch_bounds__(kRedThreads) void lbfgs_dots_kernel(LbfgsVecs v, co
 
 // Sweep 2: d = cg g + sum_j cs_j S_j + cy_j Y_j;  x += t d;  g_prev = g;  partial sums of |t d|.
 template <int K>
-__global__ __launch_bounds__(kRedThreads) void lbfgs_update_kernel(LbfgsVecs v, LbfgsCoef c, const double* __restrict__ g,
-                                                                   double t, double* __restrict__ d, double* __restrict__ x,
-                                                                   double* __restrict__ g_prev, long long n,
-                                                                   double* __restrict__ partial) {
-    double acc[1] = {0.0};
+__global__ __launch_bounds__(kRedThreads) void lbfgs_update_kernel(LbfgsVecs v, LbfgsCoef c, const real* __restrict__ g,
+                                                                   real t, real* __restrict__ d, real* __restrict__ x,
+                                                                   real* __restrict__ g_prev, long long n,
+                                                                   acc_t* __restrict__ partial) {
+    acc_t acc[1] = {0.0};
     const long long n2 = n >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const double2 gi = reinterpret_cast<const double2*>(g)[i];
-        double2 di = make_double2(c.cg * gi.x, c.cg * gi.y);
+        const cplx gi = reinterpret_cast<const cplx*>(g)[i];
+        cplx di = mkc(c.cg * gi.x, c.cg * gi.y);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const double2 a = lb_load2(v.S[j], i), b = lb_load2(v.Y[j], i);
+            const cplx a = lb_load2(v.S[j], i), b = lb_load2(v.Y[j], i);
             di.x += c.cs[j] * a.x + c.cy[j] * b.x;
             di.y += c.cs[j] * a.y + c.cy[j] * b.y;
         }
-        double2 xi = reinterpret_cast<double2*>(x)[i];
+        cplx xi = reinterpret_cast<cplx*>(x)[i];
         xi.x += t * di.x;
         xi.y += t * di.y;
         lb_store2(d, i, di);
-        reinterpret_cast<double2*>(x)[i] = xi;
+        reinterpret_cast<cplx*>(x)[i] = xi;
         lb_store2(g_prev, i, gi);
         acc[0] += fabs(t * di.x) + fabs(t * di.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long i = n - 1;
-        double di = c.cg * g[i];
+        real di = c.cg * g[i];
         for (int j = 0; j < K; ++j) di += c.cs[j] * v.S[j][i] + c.cy[j] * v.Y[j][i];
         d[i] = di;
         x[i] += t * di;

@@ -201,13 +201,14 @@ __global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, 
     }
 }
 
-// WGC99 kernel tables on the k grid (functionals.py:845-939 for w,w',w''; :968-972 for T,K1,K2,K3).
+// WGC99 kernel tables on the k grid (functionals.py:845-939 for w,w',w''; :968-972 for T,K1,K2,K3).  The series is
+// summed in fp64 in both builds (once per cell); only the stored tables take the grid precision.
 struct WgcSeries {
-    real u, v, c1, c2;      // homogeneous-solution constants
-    real gamma, nref, pref; // pref = 20 nref^(5/3-alpha-beta)
-    real inv2kf;
-    const real* ca;         // [nt] A_i / ((u+2i)^2 - v)
-    const real* cb;         // [nt] B_i / ((u-2i)^2 - v)
+    double u, v, c1, c2;      // homogeneous-solution constants
+    double gamma, nref, pref; // pref = 20 nref^(5/3-alpha-beta)
+    double inv2kf;
+    const double* ca;         // [nt] A_i / ((u+2i)^2 - v)
+    const double* cb;         // [nt] B_i / ((u-2i)^2 - v)
     int nt;
 };
 
@@ -218,52 +219,52 @@ struct TabMap { int on, nyl, nzm; long long arr_sz; };
 // w, w', w'' (and w''' when THIRD) of the WGC99 kernel at eta != 0, before the prefactor (functionals.py:845-939):
 // homogeneous solution + particular series by Horner in eta^2 (inside) or eta^-2 (outside)
 template <bool THIRD>
-__device__ __forceinline__ void wgc_series(real eta, const WgcSeries& s, real& w0, real& w1, real& w2, real& w3) {
+__device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, double& w0, double& w1, double& w2, double& w3) {
     const bool inner = eta <= 1.0;
     const bool on = (s.u >= 0.0) ? inner : !inner;
-    const real C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
-    const real le = log(eta);
-    real H0, H1, H2, H3 = 0.0;
+    const double C1 = on ? s.c1 : 0.0, C2 = on ? s.c2 : 0.0;
+    const double le = log(eta);
+    double H0, H1, H2, H3 = 0.0;
     if (s.v > 0.0) {
-        const real rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
-        const real px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
+        const double rv = sqrt(s.v), x = s.u + rv, y = s.u - rv;
+        const double px = pow(eta, x - 2.0), py = pow(eta, y - 2.0);
         H0 = (C1 * px + C2 * py) * eta * eta;
         H1 = (C1 * x * px + C2 * y * py) * eta;
         H2 = C1 * x * (x - 1.0) * px + C2 * y * (y - 1.0) * py;
         if (THIRD) H3 = (C1 * x * (x - 1.0) * (x - 2.0) * px + C2 * y * (y - 1.0) * (y - 2.0) * py) / eta;
     } else if (s.v == 0.0) {
-        const real pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
         H0 = pu * (C2 * le + C1);
         H1 = C2 * pu1 * (1.0 + s.u * le) + C1 * s.u * pu1;
         H2 = C2 * ((s.u - 1.0) * pu2 * (1.0 + s.u * le) + pu2) + C1 * s.u * (s.u - 1.0) * pu2;
         // third derivative of eta^u (C2 ln eta + C1)
         if (THIRD) {
-            const real a3 = s.u * (s.u - 1.0) * (s.u - 2.0), b3 = 3.0 * s.u * s.u - 6.0 * s.u + 2.0;
+            const double a3 = s.u * (s.u - 1.0) * (s.u - 2.0), b3 = 3.0 * s.u * s.u - 6.0 * s.u + 2.0;
             H3 = pu2 / eta * (C2 * (a3 * le + b3) + C1 * a3);
         }
     } else {
-        const real rv = sqrt(-s.v);
-        const real tc = cos(rv * le), ts = sin(rv * le);
-        const real p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
-        const real pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
+        const double rv = sqrt(-s.v);
+        const double tc = cos(rv * le), ts = sin(rv * le);
+        const double p = s.u * tc - rv * ts, q = s.u * ts + rv * tc;
+        const double pu2 = pow(eta, s.u - 2.0), pu1 = pu2 * eta, pu = pu1 * eta;
         H0 = pu * (C1 * tc + C2 * ts);
         H1 = pu1 * (C1 * p + C2 * q);
         H2 = pu2 * ((s.u - 1.0) * (C1 * p + C2 * q) + rv * (C2 * p - C1 * q));
         if (THIRD) {      // H = Re[(C1 - i C2) eta^z], z = u + i rv:  H''' = Re[(C1 - i C2) z (z-1) (z-2) eta^(z-3)]
-            const real zr = s.u, zi = rv;
-            real ar = zr * (zr - 1.0) - zi * zi, ai = zi * (2.0 * zr - 1.0);           // z (z-1)
-            const real br = ar * (zr - 2.0) - ai * zi, bi = ar * zi + ai * (zr - 2.0);  // ... (z-2)
-            const real dr = C1 * br + C2 * bi, di = C1 * bi - C2 * br;                  // (C1 - i C2) * that
+            const double zr = s.u, zi = rv;
+            double ar = zr * (zr - 1.0) - zi * zi, ai = zi * (2.0 * zr - 1.0);           // z (z-1)
+            const double br = ar * (zr - 2.0) - ai * zi, bi = ar * zi + ai * (zr - 2.0);  // ... (z-2)
+            const double dr = C1 * br + C2 * bi, di = C1 * bi - C2 * br;                  // (C1 - i C2) * that
             H3 = pu2 / eta * (dr * tc - di * ts);
         }
     }
-    const real x = inner ? eta * eta : 1.0 / (eta * eta);
-    real P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
+    const double x = inner ? eta * eta : 1.0 / (eta * eta);
+    double P0 = 0.0, P1 = 0.0, P2 = 0.0, P3 = 0.0;
     for (int t = s.nt - 1; t >= 0; --t) {
-        const real ti = 2.0 * t;
-        const real c = inner ? s.cb[t] : s.ca[t];
-        const real d1 = inner ? ti * c : -ti * c;
-        const real d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
+        const double ti = 2.0 * t;
+        const double c = inner ? s.cb[t] : s.ca[t];
+        const double d1 = inner ? ti * c : -ti * c;
+        const double d2 = inner ? ti * (ti - 1.0) * c : ti * (ti + 1.0) * c;
         P0 = P0 * x + c;
         P1 = P1 * x + d1;
         P2 = P2 * x + d2;
@@ -289,8 +290,8 @@ __global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict__ K1o,
             i = x * tm.arr_sz + (z < tm.nzm ? (((long long)(z >> 3) * tm.nyl + y) * 8 + (z & 7))
                                             : ((long long)tm.nzm * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y));
         }
-        const real eta = (k2 != 0.0) ? sqrt(k2) * s.inv2kf : 0.0;
-        real w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;
+        const double eta = (k2 != 0.0) ? sqrt((double)k2) * s.inv2kf : 0.0;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;
         if (eta != 0.0) wgc_series<false>(eta, s, w0, w1, w2, w3);
         w0 *= s.pref;
         w1 *= s.pref;
@@ -392,7 +393,7 @@ struct MixWgc {
     __device__ __forceinline__ real coef(int, int, int, long long uoff, unsigned loff) const {
         // 16-byte loads of (w0,K1) or (K2,K3): identical loads of one k-point are merged by the compiler
         const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff + ((O + I == 2) ? 1 : 0);
-        const cplx pr = buf_load_c(t2, loff * 32);
+        const cplx pr = buf_load_c(t2, loff * (unsigned)(4 * sizeof(real)));
         return (O + I == 0) ? pr.x : ((O + I == 1) ? pr.y : ((O == 1) ? pr.y : pr.x));
     }
 };
@@ -755,17 +756,24 @@ __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc
     block_reduce_store<kCombineScalars>(acc, partial);
 }
 
+// y = x or y += x (grid arrays: T = real; device-resident energy sums: T = acc_t)
+template <class T>
+__global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = accumulate ? y[i] + x[i] : x[i];
+}
+
 // chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
 // c = N_e / (mean(chi^2) vol) from the reduced sum of chi^2, left on the device (system.py:833-834)
-__global__ void closure_scale_kernel(const real* __restrict__ sumsq, real* __restrict__ cscale, real n_elec,
-                                     real vol_over_npts) {
+__global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc_t* __restrict__ cscale, acc_t n_elec,
+                                     acc_t vol_over_npts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
 }
 
 __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
-                                long long npts, real c2dV_host, const real* __restrict__ cscale_dev, real two_dV,
+                                long long npts, real c2dV_host, const acc_t* __restrict__ cscale_dev, real two_dV,
                                 real mu) {
-    const real c2dV = cscale_dev ? cscale_dev[0] * two_dV : c2dV_host;
+    const real c2dV = cscale_dev ? (real)(cscale_dev[0] * two_dV) : c2dV_host;
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const cplx x = reinterpret_cast<const cplx*>(chi)[i], w = reinterpret_cast<const cplx*>(v)[i];

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
     // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
     // a thread only reads what it wrote).  The final reduction order is unchanged.
-    real* park = lds + ZW<M, E>::LDS / sizeof(real) + threadIdx.x;
+    acc_t* park = reinterpret_cast<acc_t*>(lds + ZW<M, E>::LDS / sizeof(real)) + threadIdx.x;
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];

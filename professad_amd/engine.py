@@ -19,11 +19,18 @@ def _ptr(t):
 class Engine:
     """energy + functional derivative of a set of OFDFT terms on a fixed grid shape."""
 
-    def __init__(self, shape, device=None, nranks=1, rank=0):
+    def __init__(self, shape, device=None, nranks=1, rank=0, dtype=torch.double):
+        """dtype: torch.double (the reference's precision; libofdft_hip.so) or torch.float32 (the fp32 build of the
+        same kernels, libofdft_hip_f32.so: hot path and L-BFGS only; energy sums stay fp64)."""
+        if dtype not in (torch.double, torch.float32):
+            raise TypeError('dtype must be torch.double or torch.float32')
+        self.dtype = dtype
+        self.cdtype = torch.complex128 if dtype == torch.double else torch.complex64
+        self._code = N.F64 if dtype == torch.double else N.F32
         if not torch.cuda.is_available():
             raise N.NativeLibraryError('professad_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
                                        'there is no CPU fallback')
-        self.lib = N.load()
+        self.lib = N.load(self._code)
         self.device = torch.device(device if device is not None else 'cuda:0')
         if self.device.type != 'cuda':
             raise ValueError('Engine tensors must live on a GPU device, got %s' % self.device)
@@ -34,7 +41,7 @@ class Engine:
         self.shape = (self.global_shape[0] // int(nranks),) + self.global_shape[1:]
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._ctx = C.c_void_p(0)
-        rc = self.lib.ofdft_create_dist(C.byref(self._ctx), *self.global_shape, N.F64, idx, int(nranks), int(rank))
+        rc = self.lib.ofdft_create_dist(C.byref(self._ctx), *self.global_shape, self._code, idx, int(nranks), int(rank))
         if rc != 0:
             raise RuntimeError('ofdft_create failed (%d): %s' % (rc, self.lib.ofdft_last_error(None).decode()))
         self._box_key = None
@@ -65,8 +72,9 @@ class Engine:
         if t.device != self.device and not (t.device.type == 'cuda' and self.device.type == 'cuda'
                                             and (t.device.index or 0) == (self.device.index or 0)):
             raise ValueError('%s is on %s, engine is on %s' % (name, t.device, self.device))
-        if t.dtype != torch.double:
-            raise TypeError('%s must be torch.double (the reference is fp64 throughout)' % name)
+        if t.dtype != self.dtype:
+            raise TypeError('%s must be %s for this engine (the reference is fp64 throughout; an fp32 engine takes '
+                            'torch.float32 only)' % (name, self.dtype))
         if tuple(t.shape) != self.shape:
             raise ValueError('%s has shape %s, engine grid is %s' % (name, tuple(t.shape), self.shape))
         return t.detach().contiguous()
@@ -127,16 +135,16 @@ class Engine:
     # -- validation entry points
     def rfftn(self, x):
         x = self._grid_tensor(x, 'x')
-        out = torch.empty(self.shape[0], self.shape[1], self.shape[2] // 2 + 1, dtype=torch.complex128, device=self.device)
+        out = torch.empty(self.shape[0], self.shape[1], self.shape[2] // 2 + 1, dtype=self.cdtype, device=self.device)
         self._check(self.lib.ofdft_rfftn(self._ctx, _ptr(x), _ptr(out), self._stream()), 'ofdft_rfftn')
         return out
 
     def irfftn(self, xk):
         want = (self.shape[0], self.shape[1], self.shape[2] // 2 + 1)
-        if tuple(xk.shape) != want or xk.dtype != torch.complex128:
-            raise ValueError('spectrum must be complex128 of shape %s' % (want,))
+        if tuple(xk.shape) != want or xk.dtype != self.cdtype:
+            raise ValueError('spectrum must be %s of shape %s' % (self.cdtype, want))
         xk = xk.detach().contiguous()
-        out = torch.empty(self.shape, dtype=torch.double, device=self.device)
+        out = torch.empty(self.shape, dtype=self.dtype, device=self.device)
         self._check(self.lib.ofdft_irfftn(self._ctx, _ptr(xk), _ptr(out), self._stream()), 'ofdft_irfftn')
         return out
 
@@ -179,11 +187,11 @@ class Engine:
 _ENGINES = {}
 
 
-def engine_for(shape, device):
-    """One cached Engine per (shape, device)."""
+def engine_for(shape, device, dtype=torch.double):
+    """One cached Engine per (shape, device, dtype)."""
     dev = torch.device(device)
-    key = (tuple(int(s) for s in shape), dev.type, dev.index if dev.index is not None else 0)
+    key = (tuple(int(s) for s in shape), dev.type, dev.index if dev.index is not None else 0, dtype)
     e = _ENGINES.get(key)
     if e is None:
-        e = _ENGINES[key] = Engine(shape, dev)
+        e = _ENGINES[key] = Engine(shape, dev, dtype=dtype)
     return e
