@@ -122,9 +122,9 @@ class _RawDeviceBuffer:
 class HipStages(Engine):
     """`stages` interface on top of the ofdft_dist_* C ABI (one slab per rank)."""
 
-    def __init__(self, shape, device, nranks=1, rank=0):
+    def __init__(self, shape, device, nranks=1, rank=0, dtype=torch.double):
         self.plan = SlabPlan(shape, nranks, rank)
-        super().__init__(shape, device, nranks=nranks, rank=rank)
+        super().__init__(shape, device, nranks=nranks, rank=rank, dtype=dtype)
         p = C.c_void_p(0)
         self._check(self.lib.ofdft_dist_scalars(self._ctx, C.byref(p)), 'ofdft_dist_scalars')
         # 16 device-resident doubles owned by the context: [0..12] local sums of an evaluation, [15] sum chi^2
@@ -270,9 +270,11 @@ class DistEngine:
     """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
     as `Engine`, on this rank's slab."""
 
-    def __init__(self, shape, device, group=None):
+    def __init__(self, shape, device, group=None, dtype=torch.double):
+        """dtype=torch.float32 runs the slab-decomposed hot path on the fp32 build (half the bytes on every link);
+        stress and ion forces are then formed by the fp64 routines from the gathered density."""
         self.comm = Comm(group)
-        self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank)
+        self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
         self.plan = self.stages.plan
         self.npts_global = int(np.prod(self.plan.shape))
         self._vol = None
@@ -306,7 +308,7 @@ class DistEngine:
     # routines on the full grid -- redundant work, no further communication, identical results on all ranks.
     def gather(self, slab):
         """this rank's x-slab -> the full grid on every rank"""
-        slab = self.stages._grid_tensor(slab, 'slab')
+        slab = self.stages._grid_tensor(slab, 'slab').double()      # the per-geometry-step routines are fp64
         if not self.comm.active:
             return slab
         if self.comm.backend == 'nccl':
@@ -340,7 +342,8 @@ class DistEngine:
     def ionic_potential(self, species, pme_order=None):
         """this rank's x-slab of v_ext built from the ions (every rank builds the full potential: one small FFT per step)"""
         from .ions import ionic_potential
-        return ionic_potential(self._full_engine(), self._box_np.reshape(3, 3), species, pme_order)[self.plan.x_range()].contiguous()
+        return ionic_potential(self._full_engine(), self._box_np.reshape(3, 3), species,
+                               pme_order)[self.plan.x_range()].to(self.stages.dtype).contiguous()
 
     def close(self):
         self.stages.close()

@@ -161,6 +161,13 @@ class Engine:
         """per-term stress tensors {term name: 3x3 numpy array, Ha/bohr^3} for the active terms at fixed electron number
         (get_stress semantics, functional_tools.py:73-101); the ion-electron entry is zero (see ions.ion_electron_stress)"""
         den = self._grid_tensor(den, 'den')
+        if self.dtype != torch.double:       # stress is fp64 work: widen the density and use the fp64 sibling engine
+            sib = engine_for(self.global_shape, self.device)
+            sib._box_key, sib._terms_key = None, None
+            sib.lib.ofdft_set_cell(sib._ctx, np.frombuffer(self._box_key, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+            sib.lib.ofdft_set_terms(sib._ctx, self._terms_key[0],
+                                    np.frombuffer(self._terms_key[1], dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double)), N.NPARAMS)
+            return sib.stress(den.double())
         buf = (C.c_double * (N.NTERMS * 9))()
         self._check(self.lib.ofdft_stress(self._ctx, C.c_void_p(den.data_ptr()), buf, self._stream()), 'ofdft_stress')
         a = np.array(list(buf), dtype=np.float64).reshape(N.NTERMS, 3, 3)

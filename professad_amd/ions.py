@@ -44,9 +44,20 @@ def read_recpot(path):
     return recpot_table(raw, k_max)
 
 
+def _f64(engine):
+    """The once-per-geometry-step routines are fp64 work: an fp32 engine hands them to its fp64 sibling (same grid,
+    same device); densities are widened on the way in, the potential is narrowed on the way out."""
+    if engine.dtype == torch.double:
+        return engine
+    from .engine import engine_for
+    return engine_for(engine.global_shape, engine.device)
+
+
 def ionic_potential(engine, box_vecs, species, pme_order=None):
     """v_ext on the engine's grid.  species: iterable of (frac_coords [n,3], (ks, v, z)) per ion type.
     pme_order None -> exact O(N_ion N_k) structure factor; even int >= 2 -> particle-mesh Ewald."""
+    want = engine.dtype
+    engine = _f64(engine)
     engine.set_cell(box_vecs)
     out = torch.zeros(engine.shape, dtype=torch.double, device=engine.device)
     dp = C.POINTER(C.c_double)
@@ -60,14 +71,15 @@ def ionic_potential(engine, box_vecs, species, pme_order=None):
                                               v.ctypes.data_as(dp), ks.size, float(z), 0 if pme_order is None else int(pme_order),
                                               C.c_void_p(out.data_ptr()), 1 if i else 0, engine._stream())
         engine._check(rc, 'ofdft_ionic_potential')
-    return out
+    return out.to(want)
 
 
 def ion_electron_forces(engine, box_vecs, den, species, pme_order=None):
     """Forces F = -dU/dR of U = int n v_ext on every ion (Ha/bohr), species by species -> list of [n,3] arrays
     (the IonElectron part of System.forces(), system.py:913-923)."""
+    den = engine._grid_tensor(den, 'den').double()
+    engine = _f64(engine)
     engine.set_cell(box_vecs)
-    den = engine._grid_tensor(den, 'den')
     dp = C.POINTER(C.c_double)
     out = []
     for frac, (ks, v, z) in species:
@@ -87,8 +99,9 @@ def ion_electron_forces(engine, box_vecs, den, species, pme_order=None):
 def ion_electron_stress(engine, box_vecs, den, species, pme_order=None):
     """Ion-electron stress (3x3, Ha/bohr^3) with the potential rebuilt from the ions at fixed fractional coordinates
     (the IonElectron part of System.stress(), system.py:925-935), summed over species."""
+    den = engine._grid_tensor(den, 'den').double()
+    engine = _f64(engine)
     engine.set_cell(box_vecs)
-    den = engine._grid_tensor(den, 'den')
     dp = C.POINTER(C.c_double)
     total = np.zeros((3, 3))
     for frac, (ks, v, z) in species:
@@ -108,6 +121,7 @@ def ion_electron_stress(engine, box_vecs, den, species, pme_order=None):
 def ion_ion(engine, box_vecs, frac, charges, Rc=None):
     """Ion-ion energy [Ha], forces [n,3] (Ha/bohr) and stress [3,3] (Ha/bohr^3): ion_interaction_sum with System's
     parameter heuristics (ion_utils.py:293-333, system.py:733-754) and its autograd derivatives (system.py:913-935)."""
+    engine = _f64(engine)
     engine.set_cell(box_vecs)
     dp = C.POINTER(C.c_double)
     frac = np.ascontiguousarray(np.asarray(torch.as_tensor(frac).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 3))

@@ -125,9 +125,10 @@ class FixedStepLBFGS:
 class HipLbfgsBackend:
     """History and sweeps on the device (ofdft_lbfgs_* in libofdft_hip.so; no CPU fallback)."""
 
-    def __init__(self, n, history, device):
+    def __init__(self, n, history, device, dtype=torch.double):
         from . import _native as N
-        self.lib = N.load()
+        self.dtype = dtype
+        self.lib = N.load(N.F64 if dtype == torch.double else N.F32)      # the vectors take the library's precision
         self.device = torch.device(device)
         self._h = C.c_void_p(0)
         rc = self.lib.ofdft_lbfgs_create(C.byref(self._h), int(n), int(history), self.device.index or 0)
@@ -144,8 +145,8 @@ class HipLbfgsBackend:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _vec(self, t, name):
-        if not (t.is_cuda and t.dtype == torch.double and t.is_contiguous() and t.numel() == self.n):
-            raise ValueError('%s must be a contiguous fp64 device tensor of %d elements' % (name, self.n))
+        if not (t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and t.numel() == self.n):
+            raise ValueError('%s must be a contiguous %s device tensor of %d elements' % (name, self.dtype, self.n))
         return C.c_void_p(t.data_ptr())
 
     def dots(self, g):
@@ -316,10 +317,10 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     comm = getattr(engine, 'comm', None)                    # DistEngine
     multi = comm is not None and comm.active
     if comm is not None:
-        shape, dev = engine.plan.local_shape, engine.stages.device
+        shape, dev, dtype = engine.plan.local_shape, engine.stages.device, engine.stages.dtype
         npts_global = engine.npts_global
     else:
-        shape, dev = engine.shape, engine.device
+        shape, dev, dtype = engine.shape, engine.device, engine.dtype
         npts_global = int(np.prod(shape))
 
     def gsum(x):                                            # sum over ranks of a python float
@@ -335,9 +336,9 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     if chi0 is None:
         if volume is None:
             raise ValueError('volume is needed for the uniform start')
-        chi = torch.full(shape, math.sqrt(n_elec / volume), dtype=torch.double, device=dev)
+        chi = torch.full(shape, math.sqrt(n_elec / volume), dtype=dtype, device=dev)
     else:
-        chi = chi0.detach().clone().to(dev)
+        chi = chi0.detach().clone().to(device=dev, dtype=dtype)
     state = {}
 
     def closure():
@@ -347,7 +348,7 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
 
     if optimizer == 'fused':        # device-resident history, two sweeps per inner iteration
         hook = (lambda v: comm.all_reduce_sum(np.ascontiguousarray(v, dtype=np.float64), dev)) if multi else None
-        opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev), lr=n_step_size, history_size=8, max_iter=6,
+        opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev, dtype), lr=n_step_size, history_size=8, max_iter=6,
                               all_reduce=hook)
     elif optimizer == 'torch' and not multi:      # op-by-op form on torch tensors
         opt = FixedStepLBFGS(chi, lr=n_step_size, history_size=8, max_iter=6)
@@ -374,7 +375,7 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         if conv == n_conv_cond_count:
             break
     E_terms, mu, g = engine.energy_grad_chi(chi, n_elec, vext)
-    ntilde = gsum(float((chi * chi).sum())) / npts_global * (volume if volume is not None else 1.0)
+    ntilde = gsum(float((chi.double() * chi.double()).sum())) / npts_global * (volume if volume is not None else 1.0)
     den = (n_elec / ntilde) * chi * chi if volume is not None else None
     return dict(chi=chi, den=den, E_Ha=sum(E_terms.values()), E_terms=E_terms, mu=mu, iterations=it,
                 converged=conv == n_conv_cond_count, history=history, func_evals=opt.func_evals)

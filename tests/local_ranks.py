@@ -14,10 +14,10 @@ from professad_amd.distributed import HipStages
 
 
 class LocalRanks:
-    def __init__(self, shape, device, nranks):
+    def __init__(self, shape, device, nranks, dtype=torch.double):
         self.P = nranks
         self.dev = device
-        self.st = [HipStages(shape, device, nranks=nranks, rank=r) for r in range(nranks)]
+        self.st = [HipStages(shape, device, nranks=nranks, rank=r, dtype=dtype) for r in range(nranks)]
         self.npts = int(np.prod(shape))
         self.compute_s = [0.0] * nranks
         self.exchanged_bytes = 0          # bytes in all ranks' send buffers (incl. the diagonal chunks)

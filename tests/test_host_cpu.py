@@ -12,8 +12,10 @@ from professad_amd import functionals as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
-    lib = N.load()
+@pytest.mark.parametrize('dtype', [N.F64, N.F32])
+def test_library_exports_every_declared_symbol(dtype):
+    """both precisions (libofdft_hip.so, libofdft_hip_f32.so) carry the whole ABI of include/ofdft_hip.h"""
+    lib = N.load(dtype)
     header = open(os.path.join(ROOT, 'include', 'ofdft_hip.h')).read()
     declared = sorted(set(re.findall(r'\b(ofdft_[a-z_]+)\s*\(', header)))
     assert declared == sorted(N.EXPORTS)
@@ -36,7 +38,13 @@ def test_error_paths_without_gpu():
     # invalid extents are rejected before any device work
     assert lib.ofdft_create(ctypes.byref(ctx), 1, 8, 8, N.F64, 0) == N.EINVAL
     assert b'extents' in lib.ofdft_last_error(None)
+    # a context's precision is its library's: each build refuses the other dtype and names the library to use
     assert lib.ofdft_create(ctypes.byref(ctx), 8, 8, 16, N.F32, 0) == N.EINVAL
+    assert b'libofdft_hip_f32.so' in lib.ofdft_last_error(None)
+    lib32 = N.load(N.F32)
+    assert lib32.ofdft_create(ctypes.byref(ctx), 8, 8, 16, N.F64, 0) == N.EINVAL
+    assert b'libofdft_hip.so' in lib32.ofdft_last_error(None)
+    assert lib32.ofdft_stress(None, None, None, None) == N.EINVAL       # per-geometry-step routines: fp64 library only
     assert lib.ofdft_set_cell(None, None) == N.EINVAL
     if not torch.cuda.is_available():
         rc = lib.ofdft_create(ctypes.byref(ctx), 16, 16, 16, N.F64, 0)
