@@ -35,20 +35,20 @@ CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c']
 CFG2 = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c']
 
 
-def algorithmic_bytes(n, cfg):
-    """SURVEY.md §8d byte model: n_fft (R + 5C) + n_pw R."""
-    R = 8.0 * n ** 3
-    Cc = 16.0 * n * n * (n // 2 + 1)
+def algorithmic_bytes(n, cfg, word=8):
+    """SURVEY.md §8d byte model: n_fft (R + 5C) + n_pw R (fp32: half of everything)."""
+    R = float(word) * n ** 3
+    Cc = 2.0 * word * n * n * (n // 2 + 1)
     n_fft, n_pw = (23, 25) if cfg == 'cfg3' else (6, 10)
     return n_fft * (R + 5 * Cc) + n_pw * R, R, Cc
 
 
-def kernel_alg_bytes(name, n):
+def kernel_alg_bytes(name, n, word=8):
     """Algorithmic bytes of ONE spectrum pass of a kernel class (what it must read + write once).  A launch may cover
     several spectra or only an x range of them (batched / x-chunked y passes), so rooflines are formed per evaluation:
     passes x bytes / time of the class."""
-    R = 8.0 * n ** 3
-    Cc = 16.0 * n * n * (n // 2 + 1)
+    R = float(word) * n ** 3
+    Cc = 2.0 * word * n * n * (n // 2 + 1)
     table = {'cpass_x': 2 * Cc, 'cpass_y': 2 * Cc, 'zfwd': R + Cc, 'zinv': R + Cc}
     return table.get(name)
 
@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--grid', type=int, default=256)
     ap.add_argument('--cfg', default='cfg3', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
+                    help='f64: the reference precision (BASELINE metric); f32: the fp32 build (config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-grid', type=int, default=128)
     a = ap.parse_args()
@@ -141,20 +143,22 @@ def main():
     device = torch.device('cuda', local_rank)
 
     n = a.grid
+    tdtype = torch.double if a.dtype == 'f64' else torch.float32
+    word = 8 if a.dtype == 'f64' else 4
     names = CFG3 if a.cfg == 'cfg3' else CFG2
     # ONE n^3 system for the whole job: on N > 1 GPUs it is slab-decomposed (rank r owns x-slab r) and every
     # 3-D FFT is transposed with an RCCL all-to-all -- strong scaling of the BASELINE workload.
     box, chi_h, vext_h, n_elec, src = make_inputs(n, 0)
     if world > 1:
-        eng = DistEngine((n, n, n), device).set_cell(torch.as_tensor(box)).set_terms(names)
+        eng = DistEngine((n, n, n), device, dtype=tdtype).set_cell(torch.as_tensor(box)).set_terms(names)
         xs = eng.plan.x_range()
         chi_h, vext_h = np.ascontiguousarray(chi_h[xs]), np.ascontiguousarray(vext_h[xs])
         raw = eng.stages
     else:
-        eng = Engine((n, n, n), device).set_cell(torch.as_tensor(box)).set_terms(names)
+        eng = Engine((n, n, n), device, dtype=tdtype).set_cell(torch.as_tensor(box)).set_terms(names)
         raw = eng
-    chi = torch.as_tensor(chi_h, dtype=torch.double, device=device)
-    vext = torch.as_tensor(vext_h, dtype=torch.double, device=device)
+    chi = torch.as_tensor(chi_h, dtype=tdtype, device=device)
+    vext = torch.as_tensor(vext_h, dtype=tdtype, device=device)
     if os.environ.get('OFDFT_SIDE_STREAM') == '0':       # A/B switch: everything on one stream
         raw.set_option(1, 0)
     if os.environ.get('OFDFT_XCHUNKS'):                  # A/B switch: x-chunked z / y stages
@@ -211,13 +215,13 @@ def main():
         ys = [prof.pop(k) for k in ('ypass_send', 'ypass_recv') if k in prof]
         prof['cpass_y'] = (sum(v[0] for v in ys), sum(v[1] for v in ys))
     tot_ms = sum(v[0] for v in prof.values()) or 1.0
-    dom = max((k for k in prof if kernel_alg_bytes(k, n)), key=lambda k: prof[k][0], default=None)
+    dom = max((k for k in prof if kernel_alg_bytes(k, n, word)), key=lambda k: prof[k][0], default=None)
     roofline = None
     kernels = {k: {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof,
                    'share': round(v[0] / tot_ms, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     pmc = None
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_r01.json')
-    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3':     # counters were collected on this workload
+    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3' and a.dtype == 'f64':     # counters were collected on this workload
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if dom:
@@ -227,24 +231,24 @@ def main():
         launches = prof[dom][1] / nprof
         class_ms = prof[dom][0] / nprof
         avg_ms = class_ms / launches
-        ach = kernel_alg_bytes(dom, n) / world * passes / (class_ms * 1e-3) / 1e9      # per GPU: a rank holds 1/world of a spectrum
+        ach = kernel_alg_bytes(dom, n, word) / world * passes / (class_ms * 1e-3) / 1e9      # per GPU: a rank holds 1/world of a spectrum
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 4),
                     'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
                                 if pmc and dom in pmc.get('kernels', {}) else None),
                     'launches_per_eval': launches, 'spectrum_passes_per_eval': passes,
                     'traffic_source': ('profiles/pmc_traffic_r01.json: ' + pmc['source']) if pmc else None,
-                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n) / world * passes / launches,
+                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n, word) / world * passes / launches,
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
-    alg, R, Cc = algorithmic_bytes(n, a.cfg)
+    alg, R, Cc = algorithmic_bytes(n, a.cfg, word)
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU
 
     out = {
         'metric': 'energy+grad evals/sec', 'value': round(evals_per_s, 3), 'unit': 'evals/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%d^3 grid, fp64, IonElectron+Hartree+WGC99(+TF+vW)+PBE closure chi->(E,dE/dchi)' % n
-                   if a.cfg == 'cfg3' else '%d^3 grid, fp64, IonElectron+Hartree+WT(+TF+vW)+PZ-LDA closure' % n,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': '%d^3 grid, %s, IonElectron+Hartree+WGC99(+TF+vW)+PBE closure chi->(E,dE/dchi)' % (n, a.dtype)
+                   if a.cfg == 'cfg3' else '%d^3 grid, %s, IonElectron+Hartree+WT(+TF+vW)+PZ-LDA closure' % (n, a.dtype),
                    'grid': [n, n, n], 'terms': names, 'density': src,
                    'parallelism': 'single GPU' if world == 1 else
                    'x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world},

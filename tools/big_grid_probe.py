@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-GPU sanity / timing probe at a large grid with inputs generated on the device (no host-side grid arrays):
-usage: big_grid_probe.py N [cfg2|cfg3]"""
+usage: big_grid_probe.py N [cfg2|cfg3] [f64|f32]"""
 import json
 import os
 import sys
@@ -19,15 +19,16 @@ from professad_amd.functionals import NativeTerms  # noqa: E402
 def main():
     n = int(sys.argv[1])
     cfg = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'
+    dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == 'f32') else torch.double
     names = NativeTerms(['ion_electron', 'hartree', 'wt', 'pz'] if cfg == 'cfg2' else ['ion_electron', 'hartree', 'wgc99', 'pbe']).names
     dev = torch.device('cuda:0')
     shape = (n, n, n)
     box = torch.as_tensor(synth.cubic_cell(n))
     torch.manual_seed(1)
-    chi = torch.sqrt(0.03 * (1 + 0.2 * torch.rand(shape, dtype=torch.double, device=dev)))
-    vext = -0.1 * torch.rand(shape, dtype=torch.double, device=dev)
+    chi = torch.sqrt(0.03 * (1 + 0.2 * torch.rand(shape, dtype=dt, device=dev)))
+    vext = -0.1 * torch.rand(shape, dtype=dt, device=dev)
     n_elec = 12.0 * (n // 32) ** 3
-    eng = Engine(shape, dev).set_cell(box).set_terms(names)
+    eng = Engine(shape, dev, dtype=dt).set_cell(box).set_terms(names)
     E, mu, g = eng.energy_grad_chi(chi, n_elec, vext)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -37,7 +38,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     # extensivity against the same random field restricted to a 1/8 corner is not available (random): report sanity only
-    print(json.dumps({'grid': n, 'cfg': cfg, 'ms_per_eval': round(ms, 2), 'E_per_electron': sum(E.values()) / n_elec, 'mu': mu,
+    print(json.dumps({'grid': n, 'cfg': cfg, 'dtype': str(dt), 'ms_per_eval': round(ms, 2), 'E_per_electron': sum(E.values()) / n_elec, 'mu': mu,
                       'grad_finite': bool(torch.isfinite(g).all()), 'workspace_GB': round(eng.query(1) / 1e9, 1),
                       'torch_alloc_GB': round(torch.cuda.max_memory_allocated() / 1e9, 1)}))
 
