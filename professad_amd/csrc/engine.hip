@@ -725,7 +725,7 @@ int wgc_series_setup(ofdft_ctx* c, long long nel_rounded, hipStream_t st, WgcSer
     }
     s.gamma = ga;
     s.nref = nref;
-    s.pref = 20.0 * std::pow(nref, 5.0 / 3.0 - al - be);
+    s.pref = 20.0 * std::pow(nref, kFiveThirds - al - be);
     s.inv2kf = 1.0 / (2.0 * std::cbrt(3.0 * kPi * kPi * nref));
     s.nt = nt;
     if (!c->d_wgc_coef) HIP_TRY(c, hipMalloc((void**)&c->d_wgc_coef, sizeof(double) * 2 * nt));
@@ -890,7 +890,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
         const double nbar = nel / c->vol;                                    // functionals.py:646-647
         const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - kFiveThirds));
         real *tmp, *cb;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "conv_b", &cb)) return rc;
@@ -914,7 +914,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         ca.wt_alpha = al;
         ca.wt_beta = be;
         ca.wt_nbar_pa = std::pow(nbar, al);
-        ca.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+        ca.wt_is_56 = (al == kFiveSixths && be == kFiveSixths) ? 1 : 0;
     }
     if (mask & OFDFT_WGC99_NL) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
@@ -947,7 +947,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         ca.wgc_alpha = al;
         ca.wgc_beta = be;
         ca.nref = nref;
-        ca.wgc_sum_53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+        ca.wgc_sum_53 = (std::fabs(al + be - kFiveThirds) < 4e-16) ? 1 : 0;
     }
     return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
 }
@@ -1048,7 +1048,7 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
         const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
         const double nbar = nel / c->vol;
         const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - kFiveThirds));
         real *tmp, *cb;
         if (int rc = real_ws(c, "t0", &tmp)) return rc;
         if (int rc = real_ws(c, "conv_b", &cb)) return rc;
@@ -1074,7 +1074,7 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
         ca.wt_alpha = al;
         ca.wt_beta = be;
         ca.wt_nbar_pa = std::pow(nbar, al);
-        ca.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+        ca.wt_is_56 = (al == kFiveSixths && be == kFiveSixths) ? 1 : 0;
     }
     if (mask & OFDFT_WGC99_NL) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
@@ -1110,7 +1110,7 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
         ca.wgc_alpha = al;
         ca.wgc_beta = be;
         ca.nref = nref;
-        ca.wgc_sum_53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+        ca.wgc_sum_53 = (std::fabs(al + be - kFiveThirds) < 4e-16) ? 1 : 0;
     }
     return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
 }
@@ -1176,7 +1176,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     while ((1 << c->xg.log_nyl) < c->xg.nyl) c->xg.log_nyl++;
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
-    const double defaults[OFDFT_NPARAMS] = {5.0 / 6.0, 5.0 / 6.0, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, 2.7, 1.0, 0.0, 40.0 / 27.0,
+    const double defaults[OFDFT_NPARAMS] = {kFiveSixths, kFiveSixths, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, (double)27 / 10, 1.0, 0.0, (double)40 / 27,
                                             0.0, 0.0, 0.0, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     hipError_t e = hipSetDevice(device_id);

@@ -315,7 +315,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
             const double nbar = r.nel / c->vol;                                  // functionals.py:646-647
             r.wt_kf = std::cbrt(3.0 * kPi * kPi * nbar);
-            r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - 5.0 / 3.0));
+            r.wt_pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - kFiveThirds));
             if ((rc = spec_ws(c, "zwb", &r.s_b))) return rc;
             if (al != be && (rc = spec_ws(c, "zwa", &r.s_a))) return rc;
             PowersArgs pa{};
@@ -332,7 +332,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             r.za.wt_alpha = al;
             r.za.wt_beta = be;
             r.za.wt_nbar_pa = std::pow(nbar, al);
-            r.za.wt_is_56 = (al == 5.0 / 6.0 && be == 5.0 / 6.0) ? 1 : 0;
+            r.za.wt_is_56 = (al == kFiveSixths && be == kFiveSixths) ? 1 : 0;
         }
         if (r.has_wgc) {
             const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
@@ -348,7 +348,7 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             pa.e0 = be;
             pa.e1 = al;
             pa.nref = nref;
-            pa.sum53 = (std::fabs(al + be - 5.0 / 3.0) < 4e-16) ? 1 : 0;
+            pa.sum53 = (std::fabs(al + be - kFiveThirds) < 4e-16) ? 1 : 0;
             // x-chunked form: each chunk's six spectra (6 x C / nchunks) are y-transformed while still in the Infinity Cache
             const int nch = chunks_for(c, 6, 2);
             if (nch > 1) {

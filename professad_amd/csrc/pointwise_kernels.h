@@ -8,7 +8,10 @@
 
 namespace ofdft {
 
-constexpr double kPi = 3.14159265358979323846264338327950288;
+// host-side fp64 constants are spelled so that they stay exact when the fp32 build compiles with single-precision
+// floating literals (-cl-single-precision-constant): long-double literal / integer operands
+constexpr double kPi = (double)3.14159265358979323846264338327950288L;
+constexpr double kFiveThirds = (double)5 / 3, kFiveSixths = (double)5 / 6;
 constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
 constexpr int kRedThreads = 256;
 constexpr int kMaxScalars = 28;    // scalars reduced by one kernel (27: the real-space stress sums)
