@@ -27,6 +27,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Work is enqueued on it and
  *     the call returns after the scalar results are on the host (one stream sync).
  *   - a ctx is bound to one device and is not re-entrant.
+ *   - precision: the ABI is built once per precision from the same sources -- libofdft_hip.so (OFDFT_F64, the
+ *     reference's precision) and libofdft_hip_f32.so (OFDFT_F32, same symbols; grid arrays are float / float2, every
+ *     host-visible scalar stays double).  ofdft_create refuses the dtype of the other build.  The fp32 library serves
+ *     the evaluation path and ofdft_lbfgs_*; the ion / stress entry points are fp64-only and return OFDFT_EINVAL there.
  *   - energies are Hartree; lengths bohr; box_vecs rows are the lattice vectors (reference layout).
  */
 #ifndef OFDFT_HIP_H

@@ -560,7 +560,8 @@ template <int LEN, int G, int NOUT> struct XfCfg {
 #ifndef OFDFT_XF_WANT4
 #define OFDFT_XF_WANT4 1
 #endif
-    static constexpr int WANT = (OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8;
+    // (line counts for 16-byte elements; the fp32 build doubles them to keep the same 64-B / 128-B runs)
+    static constexpr int WANT = ((OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8) * (16 / (int)sizeof(cplx));
     static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
     static constexpr int TPB = G * LPW * P;
     static constexpr size_t LDS = sizeof(real) * G * LPW * LineBuf<LEN>::STRIDE;
@@ -644,8 +645,8 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     const bool is_rem = (int)blockIdx.x >= main_blocks;    // one grid: main part, then the remainder planes
     const LineMap m = is_rem ? m_rem : m_main;
     int bid = is_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
-    if (LPW < 8 && !is_rem && bid < (main_blocks & ~15)) {
-        // two 4-line tiles share every 128-B line: put the pair on ONE XCD (blocks are dealt round-robin over
+    if (LPW * sizeof(cplx) < 128 && !is_rem && bid < (main_blocks & ~15)) {
+        // two half-line tiles (4 lines of fp64, 8 of fp32 elements) share every 128-B line: put the pair on ONE XCD (blocks are dealt round-robin over
         // the 8 XCDs, so blocks b and b+8 share an L2) -- speed only, never correctness
         bid = (bid & ~15) + ((bid & 7) << 1) + ((bid >> 3) & 1);
     }

@@ -12,6 +12,7 @@ namespace ofdft {
 // floating literals (-cl-single-precision-constant): long-double literal / integer operands
 constexpr double kPi = (double)3.14159265358979323846264338327950288L;
 constexpr double kFiveThirds = (double)5 / 3, kFiveSixths = (double)5 / 6;
+constexpr real kPiR = (real)kPi;      // pi in the grid precision (device math on `real` operands)
 constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
 constexpr int kRedThreads = 256;
 constexpr int kMaxScalars = 28;    // scalars reduced by one kernel (27: the real-space stress sums)
@@ -149,7 +150,7 @@ __global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict_
         real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
         real f;
-        if (OP == SPEC_HARTREE) f = (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;              // functionals.py:67-70
+        if (OP == SPEC_HARTREE) f = (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;              // functionals.py:67-70
         else if (OP == SPEC_LAPLACE) f = -k2;                                       // functional_tools.py:227
         else f = p0 * lindhard_shape((k2 != 0.0) ? sqrt(k2) * p1 : 0.0);            // functionals.py:637-638,648
         const cplx a = in[i];
@@ -326,7 +327,7 @@ template <bool HAS_H, bool HAS_G> struct MixDensity {
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         real kx, ky, kz, k2;
         kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
-        if (HAS_H && O == 0) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+        if (HAS_H && O == 0) return (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;
         constexpr int c = O - (HAS_H ? 1 : 0);
         return c == 0 ? kx : (c == 1 ? ky : kz);
     }
@@ -343,7 +344,7 @@ template <bool HAS_H> struct MixDensityA {
         if (HAS_H && O == 0) {
             real kx, ky, kz, k2;
             kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
-            return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+            return (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;
         }
         return ifreq(x, kg.g.n0);
     }
@@ -367,7 +368,7 @@ template <int OP> struct MixScale {
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         real kx, ky, kz, k2;
         kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
-        if (OP == SPEC_HARTREE) return (k2 != 0.0) ? 4.0 * kPi / k2 : 0.0;
+        if (OP == SPEC_HARTREE) return (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;
         if (OP == SPEC_LAPLACE) return -k2;
         return p0 * lindhard_shape((k2 != 0.0) ? sqrt(k2) * p1 : 0.0);
     }
@@ -419,14 +420,14 @@ struct XcLocal { real ex, vx, ec, vc; };   // energy densities (per volume) and 
 // LDA exchange + one of PZ / PW / Chachiyo correlation (functionals.py:1510-1537; tools_for_tests.py:121-152)
 __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
     XcLocal r = {0.0, 0.0, 0.0, 0.0};
-    const real cx = -0.75 * cbrt(3.0 / kPi);
+    const real cx = -0.75 * cbrt(3.0 / kPiR);
     const real n13 = cbrt(n);
     if (mask & (1u << 6)) {
         r.ex = cx * n13 * n;
         r.vx = (4.0 / 3.0) * cx * n13;
     }
     if (mask & ((1u << 7) | (1u << 8) | (1u << 9))) {
-        const real rs = cbrt(3.0 / (4.0 * kPi * n));
+        const real rs = cbrt(3.0 / (4.0 * kPiR * n));
         if (mask & (1u << 7)) {
             const real gm = -0.1423, b1 = 1.0529, b2 = 0.3334, A = 0.0311, B = -0.048, C = 0.002, D = -0.0116;
             real eps, v;
@@ -449,7 +450,7 @@ __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
             r.vc += eps - rs / 3.0 * d;
         }
         if (mask & (1u << 9)) {
-            const real a = (log(2.0) - 1.0) / (2.0 * kPi * kPi), b = 20.4562557;
+            const real a = (log(2.0) - 1.0) / (2.0 * kPiR * kPiR), b = 20.4562557;
             const real arg = 1.0 + b / rs + b / (rs * rs);
             const real eps = a * log(arg);
             const real d = a / arg * (-b / (rs * rs) - 2.0 * b / (rs * rs * rs));
@@ -475,8 +476,8 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
     const bool do_x = sel.x != 0, do_c = sel.c != 0;
     if (sel.k) {
         // f = tau_TF F(s^2), tau_TF = C_TF n^(5/3), s^2 = |grad n|^2 / (4 (3 pi^2)^(2/3) n^(8/3))  (functional_tools.py:230-268)
-        const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
-        const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+        const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
+        const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
         const real n83i = inv_n * inv_n * inv_n * n13;
         const real s2 = cs * gn2 * n83i;
         const real tau = ctf * n13 * n13 * n;
@@ -495,10 +496,10 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
         r.dfdg += tau * dF * cs * n83i;
     }
     if (do_x) {
-        const real kappa = 0.804, mu = 0.066725 * kPi * kPi / 3.0;
-        const real cx = -0.75 * cbrt(3.0 / kPi);
+        const real kappa = 0.804, mu = 0.066725 * kPiR * kPiR / 3.0;
+        const real cx = -0.75 * cbrt(3.0 / kPiR);
         const real ex = cx * n13;
-        const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);     // 0.25 (3 pi^2)^(-2/3)
+        const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);     // 0.25 (3 pi^2)^(-2/3)
         const real n83i = inv_n * inv_n * inv_n * n13;                 // n^(-8/3)
         const real s2 = cs * gn2 * n83i;
         const real iden = 1.0 / (1.0 + (mu / kappa) * s2);
@@ -509,15 +510,15 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
         r.dfdg += dF * cs * n83i * ex * n;
     }
     if (do_c) {
-        const real beta = 0.066725, gam = (1.0 - log(2.0)) / (kPi * kPi), igam = 1.0 / gam;
-        const real rs = cbrt(3.0 / (4.0 * kPi)) * (n13 * n13 * inv_n);  // c n^(-1/3)
+        const real beta = 0.066725, gam = (1.0 - log(2.0)) / (kPiR * kPiR), igam = 1.0 / gam;
+        const real rs = cbrt(3.0 / (4.0 * kPiR)) * (n13 * n13 * inv_n);  // c n^(-1/3)
         real eps, deps_drs;
         pw92(rs, eps, deps_drs);
         const real deps_dn = -rs * (1.0 / 3.0) * inv_n * deps_drs;
         const real ee = exp(-eps * igam);
         const real A = beta * igam / (ee - 1.0 + 1e-30);
         const real dAdn = A * A * (1.0 / beta) * ee * deps_dn;
-        const real ct = (1.0 / 16.0) * cbrt(kPi / 3.0);
+        const real ct = (1.0 / 16.0) * cbrt(kPiR / 3.0);
         const real n43 = n13 * n;
         const real in73 = 1.0 / (n43 * n + 1e-30);
         const real t2 = ct * gn2 * in73;
@@ -544,8 +545,8 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
 // adds f, df/dn, df/d|grad n|^2 to p and returns df/d(lap n)
 __device__ __forceinline__ void pg_laplacian_point(real n, real gn2, real lap, const GgaSel& sel, PbePoint& p,
                                                    real& dfdl) {
-    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
-    const real cs = 0.25 / cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
+    const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     const real n13 = cbrt(n), inv_n = 1.0 / n;
     const real n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
     const real s2 = cs * gn2 * n83i, q = cs * lap * n53i;
@@ -732,7 +733,7 @@ __device__ __forceinline__ real combine_point(const CombineArgs& a, const Combin
 // iteration are issued together as 16-byte loads ahead of the arithmetic instead of one dependent load
 // per term behind a branch.
 __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc_t* __restrict__ partial) {
-    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);   // 0.3 (3 pi^2)^(2/3)
+    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);   // 0.3 (3 pi^2)^(2/3)
     acc_t acc[kCombineScalars];
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;

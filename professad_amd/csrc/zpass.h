@@ -268,7 +268,8 @@ struct DenSrc {
     int from_chi;
     const acc_t* cscale_dev;    // when set, the scale is read from device memory (no host round trip after sum chi^2)
     __device__ __forceinline__ real operator()(real x) const {
-        return from_chi ? (cscale_dev ? *cscale_dev : cscale) * x * x : x;
+        const real c = cscale_dev ? (real)*cscale_dev : cscale;
+        return from_chi ? c * x * x : x;
     }
 };
 
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
                                                          const cplx* __restrict__ twN, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
-    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
     // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
     // a thread only reads what it wrote).  The final reduction order is unchanged.
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wg
                                                        acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const ZLane<M, E> z(g, lds);
-    const real ctf = 0.3 * cbrt(9.0 * kPi * kPi * kPi * kPi);
+    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
 #pragma unroll
