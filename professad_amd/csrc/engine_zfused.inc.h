@@ -2,7 +2,10 @@
 // kernels.  Included once by engine.hip inside its anonymous namespace (one translation unit).
 // ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
 #define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
-constexpr int EZ = 4;   // points per lane wanted by the register-hungry fused z kernels
+#ifndef OFDFT_EZ
+#define OFDFT_EZ 4
+#endif
+constexpr int EZ = OFDFT_EZ;   // points per lane wanted by the register-hungry fused z kernels
 
 int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
     if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;

@@ -26,6 +26,7 @@ CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_elec
 def main():
     shape = tuple(int(x) for x in sys.argv[1].split('x'))
     out = sys.argv[2]
+    dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == 'f32') else torch.double
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device('cuda:0')
@@ -34,8 +35,8 @@ def main():
     vext = synth.random_potential(shape, seed=42)
     chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(43).random(shape))
     n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=dev)  # noqa: E731
-    eng = DistEngine(shape, dev).set_cell(torch.as_tensor(box))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
+    eng = DistEngine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box))
     plan = eng.plan
     worst = {}
     for cfg in ('cfg1', 'cfg2', 'cfg3'):
@@ -43,12 +44,12 @@ def main():
         eng.set_terms(names)
         E, mu, g = eng.energy_grad_chi(t(plan.scatter(chi)), n_elec, t(plan.scatter(vext)))
         E2, v = eng.energy_potential(t(plan.scatter(den)), t(plan.scatter(vext)))
-        parts_g = [torch.empty(plan.local_shape, dtype=torch.double) for _ in range(world)]
-        parts_v = [torch.empty(plan.local_shape, dtype=torch.double) for _ in range(world)]
+        parts_g = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
+        parts_v = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
         dist.all_gather(parts_g, g.cpu())
         dist.all_gather(parts_v, v.cpu())
         if rank == 0:
-            ref = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(names)
+            ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(names)
             Er, mur, gr = ref.energy_grad_chi(t(chi), n_elec, t(vext))
             Er2, vr = ref.energy_potential(t(den), t(vext))
             gfull, vfull = torch.cat(parts_g).numpy(), torch.cat(parts_v).numpy()
@@ -64,7 +65,7 @@ def main():
     bits = NativeTerms(['hartree', 'wgc99', 'pbe']).names
     sd = eng.stress(t(plan.scatter(den)), bits)
     if rank == 0:
-        ref = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(bits)
+        ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(bits)
         sr = ref.stress(t(den))
         worst['stress'] = dict(dE=max(float(np.abs(sd[k] - sr[k]).max()) for k in sr), dE2=0.0, dmu=0.0, dg=0.0, dv=0.0,
                                ffts=0, ffts_ref=0)
@@ -79,7 +80,7 @@ def main():
     if rank == 0:
         ref = Engine(shape, dev)
         vr = ionic_potential(ref, box, [(frac, tab)], pme_order=4)
-        Fr = ion_electron_forces(ref, box, t(den), [(frac, tab)], pme_order=4)[0]
+        Fr = ion_electron_forces(ref, box, t(den).double(), [(frac, tab)], pme_order=4)[0]
         worst['ions'] = dict(dE=float((vs - vr[plan.x_range()]).abs().max() / vr.abs().max()), dE2=float(np.abs(Fs - Fr).max()),
                              dmu=0.0, dg=0.0, dv=0.0, ffts=0, ffts_ref=0)
         ref.close()
@@ -90,10 +91,10 @@ def main():
         vol = abs(np.linalg.det(box))
         eng.set_terms(names)
         res = optimize_density(eng, n_elec, t(plan.scatter(vext)), volume=vol, n_maxiter=8)
-        parts = [torch.empty(plan.local_shape, dtype=torch.double) for _ in range(world)]
+        parts = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
         dist.all_gather(parts, res['chi'].cpu())
         if rank == 0:
-            ref = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(names)
+            ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(names)
             rr = optimize_density(ref, n_elec, t(vext), volume=vol, n_maxiter=8)
             worst['opt'] = dict(dE=abs(res['E_Ha'] - rr['E_Ha']) / abs(rr['E_Ha']), dE2=0.0, dmu=0.0, dv=0.0,
                                 dg=float((torch.cat(parts) - rr['chi'].cpu()).abs().max() / rr['chi'].abs().max()),
