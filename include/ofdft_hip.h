@@ -97,6 +97,7 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_Q_KERNEL_MS        3  /* HIP-event time of the last energy call's device work    */
 #define OFDFT_Q_LAUNCH_COUNT     4  /* kernel launches of the last energy call                 */
 #define OFDFT_Q_YPASS_COUNT      5  /* whole-spectrum y line passes of the last energy call    */
+#define OFDFT_Q_GRAPH_REPLAYS     6  /* ofdft_energy_grad_chi calls served by a hipGraph replay so far */
 
 int  ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id);
 void ofdft_destroy(ofdft_ctx* ctx);
@@ -223,6 +224,10 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_SPLIT_COMBINE 4 /* 1 (default): with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream */
 #define OFDFT_OPT_BLUESTEIN 5     /* 1 (default): extents that are not powers of two (<= 512) use chirp-z line transforms; 0: plain DFT kernels */
 #define OFDFT_OPT_GGA_SPLIT 6     /* 1 (default): split-derivative GGA chain -- only the index derivative along x visits the x pass (and the exchange); 0: three Cartesian components */
+#define OFDFT_OPT_GRAPH 7         /* 1 (default): ofdft_energy_grad_chi replays a hipGraph captured on the second call with the same
+                                     arguments (device pointers, electron number, cell, terms, options): one graph launch instead
+                                     of ~25-50 kernel launches, which is what bounds grids up to ~64^3 (used up to 128^3 points, where
+                                     OFDFT_OPT_SPLIT_COMBINE is then ignored); 0: always launch kernel by kernel */
 #define OFDFT_OPT_SIDE_STREAM 1
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 

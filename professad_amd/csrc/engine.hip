@@ -64,7 +64,7 @@ struct ofdft_ctx {
     int fft_count = 0, launch_count = 0;
     double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
     float last_ms = 0.f;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
     bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
@@ -81,6 +81,22 @@ struct ofdft_ctx {
     struct Acc { double ms = 0.0; long long launches = 0; };
     std::map<std::string, Acc> prof;
     struct ofdft_zrun_holder* zr = nullptr;
+    // hipGraph replay of the closure evaluation (ofdft_energy_grad_chi): one entry per argument set
+    struct GraphEntry {
+        const void *chi = nullptr, *vext = nullptr, *grad = nullptr;
+        double nel = 0.0;
+        unsigned long long version = 0;      // configuration the graph was captured under
+        int seen = 0;                        // calls with these arguments so far (the first one runs uncaptured: it allocates)
+        hipGraphExec_t exec = nullptr;
+        bool wgc_split = false;
+        int fft_count = 0, launch_count = 0;
+        double ypass_count = 0.0;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long version = 1;          // bumped by set_cell / set_terms / set_option
+    bool use_graph = true;
+    long long graph_replays = 0;
+    hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
     char err[512] = "";
 };
 
@@ -120,6 +136,11 @@ int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
 
+void graph_drop(ofdft_ctx* c);
+// hipGraph replay serves the launch-bound regime only (up to 128^3 points; above that launches are hidden behind the
+// kernels).  There the WGC99 part of the combine stays inside the combine kernel: the forked + split stream topology
+// crashes this ROCm's stream capture, and fewer launches is the better trade on small grids anyway.
+bool graph_eligible(const ofdft_ctx* c) { return c->use_graph && c->npts <= (1LL << 21); }
 void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name);
 void prof_end(ofdft_ctx* c, hipStream_t st);
 
@@ -179,6 +200,7 @@ int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out) {
         HIP_TRY(c, hipMalloc(&b.p, bytes));
         b.bytes = bytes;
         c->ws_bytes += bytes;
+        c->version++;        // captured graphs hold workspace addresses
     }
     *out = b.p;
     return 0;
@@ -1197,6 +1219,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side_stream2, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -1215,6 +1238,8 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
 void ofdft_destroy(ofdft_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    graph_drop(c);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
@@ -1232,6 +1257,7 @@ void ofdft_destroy(ofdft_ctx* c) {
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_c) (void)hipEventDestroy(c->ev_c);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->side_stream2) (void)hipStreamDestroy(c->side_stream2);
     delete c;
@@ -1241,6 +1267,7 @@ const char* ofdft_last_error(const ofdft_ctx* c) { return c ? c->err : g_create_
 
 int ofdft_set_cell(ofdft_ctx* c, const double box[9]) {
     if (!c || !box) return OFDFT_EINVAL;
+    c->version++;
     // det and inverse-transpose of the 3x3 (rows = lattice vectors)
     const double* a = box;
     const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
@@ -1281,6 +1308,7 @@ int ofdft_set_terms(ofdft_ctx* c, uint32_t mask, const double* params, int npara
         c->params[i] = params[i];
     }
     c->mask = mask;
+    c->version++;
     return OFDFT_OK;
 }
 
@@ -1306,6 +1334,91 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     return end_call(c, st);
 }
 
+// ---- the closure evaluation chi -> (sums, grad) as ONE host-free enqueue, and its hipGraph replay --------------------
+}  // extern "C"
+namespace {
+
+int closure_enqueue(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st) {
+    const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+    OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
+    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
+                 c->d_reduced + kSumsqSlot);
+    OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel,
+                 c->vol / (double)c->npts);
+    const DenSrc ds{chi, 0.0, 1, c->d_scal};
+    if (int rc = zfused_enqueue(c, ds, nel, vext, v, c->h_partial /* any non-null: host copy wanted */, st, true)) return rc;
+    if (grad) {
+        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v, grad,
+                     c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV, nel);
+    }
+    return 0;
+}
+
+void graph_drop(ofdft_ctx* c) {
+    for (auto& g : c->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
+// Serve the call from a captured graph when one exists for exactly these arguments; capture one on the second call
+// with the same arguments (the first call runs kernel by kernel: workspaces and tables are allocated there, which a
+// capture may not do).  *done = false -> the caller runs the ordinary path.  Any capture failure disables the feature
+// for this context (results never depend on it).
+int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, double* sums,
+                  bool* done) {
+    *done = false;
+    if (!graph_eligible(c) || c->profiling) return 0;
+    ofdft_ctx::GraphEntry* ge = nullptr;
+    for (auto& g : c->graphs)
+        if (g.chi == chi && g.vext == vext && g.grad == grad && g.nel == nel && g.version == c->version) ge = &g;
+    if (!ge) {
+        if (c->graphs.size() >= 8 || (!c->graphs.empty() && c->graphs.front().version != c->version)) graph_drop(c);
+        ofdft_ctx::GraphEntry g;
+        g.chi = chi; g.vext = vext; g.grad = grad; g.nel = nel; g.version = c->version;
+        c->graphs.push_back(g);
+        ge = &c->graphs.back();
+    }
+    if (++ge->seen == 1) return 0;
+    if (!ge->exec) {
+        if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+            c->use_graph = false;
+            (void)hipGetLastError();
+            return 0;
+        }
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int rc = closure_enqueue(c, chi, vext, nel, v, grad, c->cap_stream);
+            ok = hipStreamEndCapture(c->cap_stream, &graph) == hipSuccess && rc == 0 && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {
+            (void)hipGetLastError();
+            ge->exec = nullptr;
+            c->use_graph = false;
+            graph_drop(c);
+            return 0;
+        }
+        ge->wgc_split = zrun(c).wgc_split;
+        ge->fft_count = c->fft_count;
+        ge->launch_count = c->launch_count;
+        ge->ypass_count = c->ypass_count;
+    }
+    c->fft_count = ge->fft_count;
+    c->launch_count = ge->launch_count;
+    c->ypass_count = ge->ypass_count;
+    HIP_TRY(c, hipGraphLaunch(ge->exec, st));
+    if (int rc = end_call(c, st)) return rc;
+    zfused_collect(c, ge->wgc_split, sums);
+    c->graph_replays++;
+    *done = true;
+    return 0;
+}
+
+}  // namespace
+extern "C" {
+
 int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, double n_electrons, double* E_terms,
                           double* mu_host, void* grad, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -1318,24 +1431,21 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (int rc = real_ws(c, "v", &v)) return rc;
     if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
         // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
-        // z kernels; mean(n) vol = N_e by construction.  One host sync per evaluation (the final sums).
-        const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
-        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, (const real*)chi, c->npts,
-                     c->d_partial);
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
-                     c->d_reduced + kSumsqSlot);
-        OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, n_electrons,
-                     c->vol / (double)c->npts);
-        const DenSrc ds{(const real*)chi, 0.0, 1, c->d_scal};
-        double vn;
-        if (int rc = run_terms_zfused(c, ds, n_electrons, (const real*)vext, E_terms, v, &vn, st)) return rc;
-        const double mu = vn / n_electrons;
-        if (mu_host) *mu_host = mu;
-        if (grad) {
-            OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi,
-                         v, (real*)grad, c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, mu);
+        // z kernels; mean(n) vol = N_e by construction; mu is formed on the device too.  One host sync per evaluation
+        // (the final sums), nothing in between: the sequence is graph-capturable (closure_graph).
+        double sums[kNSums];
+        bool done = false;
+        if (int rc = closure_graph(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, sums, &done)) return rc;
+        if (!done) {
+            if (int rc = closure_enqueue(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st)) return rc;
+            if (int rc = end_call(c, st)) return rc;
+            zfused_collect(c, zrun(c).wgc_split, sums);
         }
-        return end_call(c, st);
+        double vn;
+        for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+        energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
+        if (mu_host) *mu_host = vn / n_electrons;
+        return OFDFT_OK;
     }
     double s2;
     if (int rc = device_sum(c, (const real*)chi, true, &s2, st)) return rc;
@@ -1539,7 +1649,11 @@ int ofdft_ion_ion(ofdft_ctx* c, const double*, const double*, int, double, doubl
 
 int ofdft_set_option(ofdft_ctx* c, int option, double value) {
     if (!c) return OFDFT_EINVAL;
+    c->version++;
     switch (option) {
+        case OFDFT_OPT_GRAPH:
+            c->use_graph = value != 0.0;
+            return OFDFT_OK;
         case OFDFT_OPT_PIPELINE:
             c->force_unfused = value == 1.0;
             c->pipeline = (int)value;
@@ -1597,6 +1711,7 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_KERNEL_MS: *out = c->last_ms; return OFDFT_OK;
         case OFDFT_Q_LAUNCH_COUNT: *out = c->launch_count; return OFDFT_OK;
         case OFDFT_Q_YPASS_COUNT: *out = c->ypass_count; return OFDFT_OK;
+        case OFDFT_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown query %d", what);
 }

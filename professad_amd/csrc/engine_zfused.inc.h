@@ -531,7 +531,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
                 r.za.gw[i] = r.sw[3 + i];
             }
         r.wgc_split = false;
-        if (r.has_wgc && !chunked && c->split_combine) {
+        if (r.has_wgc && !chunked && c->split_combine && !graph_eligible(c)) {
             // both halves of the chain are done -> its part of the combine runs here, beside the other chain's PBE tail
             real* vp;
             acc_t* part2;
@@ -539,8 +539,9 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
             if ((rc = real_ws(c, "vpart", &vp))) return rc;
             if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
             if (r.forked) {
-                HIP_TRY(c, hipEventRecord(c->ev_b, sc));
-                HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_b, 0));
+                // (its own event: one event recorded on two different streams inside a stream capture crashes the runtime)
+                HIP_TRY(c, hipEventRecord(c->ev_c, sc));
+                HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_c, 0));
             }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
             OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 1,
@@ -629,8 +630,17 @@ int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
     return 0;
 }
 
+// the local sums of an evaluation from the pinned host mirror (after the stream that copied them has been drained)
+void zfused_collect(const ofdft_ctx* c, bool wgc_split, double* sums) {
+    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+    if (wgc_split) sums[5] += c->h_partial[kNSums];
+}
+
 // local sums: sums[0..8] combine scalars, sums[9..10] PBE x / c
-int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
+// `sums` == nullptr: the caller reduces the device-resident sums itself (slab-decomposed path).  `defer`: the sums are
+// copied to the pinned host mirror but nothing waits here (zfused_collect reads them after the caller's stream sync --
+// the graph-capturable form)
+int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
     ZRun& r = zrun(c);
     int rc;
     const bool chunked = chunks_for(c, 6, 8) > 1;
@@ -683,21 +693,22 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st) {
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
     if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
         HIP_TRY(c, hipMemcpyAsync(c->h_partial + kNSums, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (defer) return 0;
     HIP_TRY(c, hipStreamSynchronize(st));
-    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
-    if (r.wgc_split) sums[5] += c->h_partial[kNSums];
+    zfused_collect(c, r.wgc_split, sums);
     return 0;
 }
 
-int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, double* E_terms, real* v_out,
-                     double* vn_int, hipStream_t st) {
+// stages 1-5 of one evaluation enqueued on `st` (and the side streams forked from / joined to it); with `defer` nothing
+// touches the host: the sequence can be captured into a hipGraph
+int zfused_enqueue(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, real* v_out, double* sums, hipStream_t st,
+                   bool defer) {
     ZRun& r = zrun(c);
     r.ds = ds;
     r.nel = nel;
     r.vext = vext;
     r.v_out = v_out;
     r.deferred.clear();
-    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     int rc;
     // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
     // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.
@@ -717,8 +728,14 @@ int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vex
     for (int chain = 0; chain < 2; ++chain)
         if ((rc = zstage3(c, st, chain))) return rc;
     if ((rc = zstage4(c, st, 0))) return rc;
+    return zstage5(c, sums, st, defer);
+}
+
+int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, double* E_terms, real* v_out,
+                     double* vn_int, hipStream_t st) {
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     double sums[kNSums];
-    if ((rc = zstage5(c, sums, st))) return rc;
+    if (int rc = zfused_enqueue(c, ds, nel, vext, v_out, sums, st, false)) return rc;
     energies_from_sums(c, sums, sums + kCombineScalars, E_terms, vn_int);
     return 0;
 }

@@ -776,8 +776,11 @@ __global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc_t* __r
 
 __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
                                 long long npts, real c2dV_host, const acc_t* __restrict__ cscale_dev, real two_dV,
-                                real mu) {
+                                real mu_host, const acc_t* __restrict__ vn_dev = nullptr, acc_t dV = 0.0, acc_t n_elec = 1.0) {
     const real c2dV = cscale_dev ? (real)(cscale_dev[0] * two_dV) : c2dV_host;
+    // mu = (sum(v n) dV) / N_e: from the host, or formed here from the device-resident sum (no host round trip: the
+    // graph-captured evaluation); same operations in the same order as the host form
+    const real mu = vn_dev ? (real)((vn_dev[0] * dV) / n_elec) : mu_host;
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const cplx x = reinterpret_cast<const cplx*>(chi)[i], w = reinterpret_cast<const cplx*>(v)[i];
