@@ -220,8 +220,9 @@ def main():
     kernels = {k: {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof,
                    'share': round(v[0] / tot_ms, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     pmc = None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic_r01.json')
-    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3' and a.dtype == 'f64':     # counters were collected on this workload
+    pmc_name = 'pmc_traffic_r01.json' if a.dtype == 'f64' else 'pmc_traffic_r01_f32.json'
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', pmc_name)
+    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3':     # counters were collected on this workload
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if dom:
@@ -237,7 +238,7 @@ def main():
                     'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
                                 if pmc and dom in pmc.get('kernels', {}) else None),
                     'launches_per_eval': launches, 'spectrum_passes_per_eval': passes,
-                    'traffic_source': ('profiles/pmc_traffic_r01.json: ' + pmc['source']) if pmc else None,
+                    'traffic_source': ('profiles/%s: ' % pmc_name + pmc['source']) if pmc else None,
                     'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n, word) / world * passes / launches,
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg, word)
