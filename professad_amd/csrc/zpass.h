@@ -22,6 +22,12 @@ namespace ofdft {
 #ifndef OFDFT_ZIWGC_WAVES
 #define OFDFT_ZIWGC_WAVES 2
 #endif
+#ifndef OFDFT_Z_PREFETCH
+#define OFDFT_Z_PREFETCH 0
+#endif
+#ifndef OFDFT_Z_LDS_TWIDDLES
+#define OFDFT_Z_LDS_TWIDDLES 1
+#endif
 
 template <int M, int E_> struct ZW {
     using PL = ZPlan<M, E_>;
@@ -31,7 +37,12 @@ template <int M, int E_> struct ZW {
     static constexpr int TPB = 256;
     static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
     static constexpr int RS = LineBuf<M>::STRIDE;   // LDS doubles per row
-    static constexpr size_t LDS = sizeof(real) * RPB * RS;
+    static constexpr int ROWS = RPB * RS;           // reals of the row buffers; the staged twiddle tables follow them
+#if OFDFT_Z_LDS_TWIDDLES
+    static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * 2 * M;
+#else
+    static constexpr size_t LDS = sizeof(real) * ROWS;
+#endif
     static constexpr int N2 = 2 * M;
 };
 
@@ -55,6 +66,27 @@ template <int M, int E> struct ZLane {
         mine = lds + (wave * W::RPWV + rw) * W::RS;
     }
 };
+
+// The row transforms read ~9 twiddle factors per row and array; as global loads each of them was a dependent L2 round
+// trip whose s_waitcnt vmcnt(0) also drained the row loads in flight (the vm counter retires in order).  The z kernels
+// therefore copy the two tables (W_M^k and W_2M^k, k < M) into LDS once per workgroup and read them with ds_read.
+template <int M, int E>
+__device__ __forceinline__ void z_stage_twiddles(real* lds, const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g,
+                                                 const cplx*& twM, const cplx*& twN) {
+#if OFDFT_Z_LDS_TWIDDLES
+    cplx* t = reinterpret_cast<cplx*>(lds + ZW<M, E>::ROWS);
+    for (int i = threadIdx.x; i < M; i += ZW<M, E>::TPB) {
+        t[i] = twM_g[i];
+        t[M + i] = twN_g[i];
+    }
+    __syncthreads();
+    twM = t;
+    twN = t + M;
+#else
+    twM = twM_g;
+    twN = twN_g;
+#endif
+}
 
 // ---- real rows: lane holds (a[2(j+Pq)], a[2(j+Pq)+1]) for q = 0..7
 template <int M, int E>
@@ -171,6 +203,19 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
 }
 
+// the loads of z_load_inverse on their own: issue them one array AHEAD of the transform that consumes them (software
+// pipeline of depth one: E more complex registers buy a second row of HBM requests in flight per wave)
+template <int M, int E>
+__device__ __forceinline__ void z_issue_row(cplx (&v)[E], real& nyq, const ZLane<M, E>& z, const cplx* __restrict__ spec,
+                                            const SpecGeom& g) {
+    const unsigned voff = z_spec_voff<M, E>(z, g);
+    static_for<E>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : mkc(0.0, 0.0);
+    });
+    nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
+}
+
 // ---- row transforms that stay on chip (the spectrum lives in registers) -----------------------------------------
 // forward: real pairs in v -> v[q] = coefficient k = j + P q (k < M) of the row's half spectrum; nyq (lane j == 0) =
 // coefficient M (real)
@@ -277,9 +322,11 @@ struct DenSrc {
 // chi|n -> n^ and (sqrt n)^      (functionals.py:65 rfftn(den); :245 laplacian(k2, sqrt_den))
 template <int M, int E>
 __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
-                                                         SpecGeom g, const cplx* __restrict__ twM,
-                                                         const cplx* __restrict__ twN, real* __restrict__ dzn = nullptr) {
+                                                         SpecGeom g, const cplx* __restrict__ twM_g,
+                                                         const cplx* __restrict__ twN_g, real* __restrict__ dzn = nullptr) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     cplx x[E], v[E];
     z_load_real<M, E>(x, z, ds.src);
@@ -317,8 +364,10 @@ struct PowersArgs {
 };
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
-                                                        const cplx* __restrict__ twM, const cplx* __restrict__ twN) {
+                                                        const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     cplx n[E], a[E], v[E];
     z_load_real<M, E>(n, z, ds.src);
@@ -370,9 +419,11 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                                    cplx* __restrict__ gz, real* __restrict__ dfdn, real inv_n,
-                                                   GgaSel sel, SpecGeom g, const cplx* __restrict__ twM,
-                                                   const cplx* __restrict__ twN, acc_t* __restrict__ partial) {
+                                                   GgaSel sel, SpecGeom g, const cplx* __restrict__ twM_g,
+                                                   const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
     z_load_inverse<M, E>(a, z, gx, g, twM, twN);
@@ -416,10 +467,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
                                                                       const real* __restrict__ dzn,
                                                                       real* __restrict__ dfdn, real inv_n, real inv_nz,
                                                                       GgaSel sel, Bmat bm, SpecGeom g,
-                                                                      const cplx* __restrict__ twM,
-                                                                      const cplx* __restrict__ twN,
+                                                                      const cplx* __restrict__ twM_g,
+                                                                      const cplx* __restrict__ twN_g,
                                                                       acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
     z_load_inverse<M, E>(a, z, A, g, twM, twN);
@@ -497,10 +550,25 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
                                                   const cplx* __restrict__ twN, real sc, real ctf) {
     cplx t1[E], t2[E];
     real e = 0.0;
-    z_load_inverse<M, E>(w, z, a.u[0], g, twM, twN);
+#if OFDFT_Z_PREFETCH
+    // depth-one software pipeline over the six spectra: the next array's row is requested before this one is transformed
+    cplx nx[E];
+    real nyq_nx, nyq_w;
+    z_issue_row<M, E>(nx, nyq_nx, z, a.u[0], g);
+#define OFDFT_ZROW(cur, nxt)                                                          \
+    {                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < E; ++q) w[q] = nx[q];                   \
+        nyq_w = nyq_nx;                                                               \
+        if ((nxt) != nullptr) z_issue_row<M, E>(nx, nyq_nx, z, (nxt), g);             \
+        z_inverse_regs<M, E>(w, z, twM, twN, nyq_w);                                  \
+    }
+#else
+#define OFDFT_ZROW(cur, nxt) z_load_inverse<M, E>(w, z, (cur), g, twM, twN);
+#endif
+    OFDFT_ZROW(a.u[0], a.u[1])
 #pragma unroll
     for (int q = 0; q < E; ++q) t1[q] = mkc(w[q].x * sc, w[q].y * sc);                 // S_e = u0 + ...
-    z_load_inverse<M, E>(w, z, a.u[1], g, twM, twN);
+    OFDFT_ZROW(a.u[1], a.u[2])
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const real x0 = w[q].x * sc, x1 = w[q].y * sc;
@@ -508,7 +576,7 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
         t1[q].y += (n[q].y - a.nref) * x1;
         t2[q] = mkc(x0, x1);                                                            // S_1 = u1 + ...
     }
-    z_load_inverse<M, E>(w, z, a.u[2], g, twM, twN);
+    OFDFT_ZROW(a.u[2], a.gw[0])
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);      // one point pair at a time: pow_pos() is register-hungry
@@ -527,16 +595,16 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
         vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
         t2[q] = mkc(pb0, pb1);
     }
-    z_load_inverse<M, E>(w, z, a.gw[0], g, twM, twN);
+    OFDFT_ZROW(a.gw[0], a.gw[1])
 #pragma unroll
     for (int q = 0; q < E; ++q) t1[q] = mkc(a.wgc_beta * w[q].x * sc, a.wgc_beta * w[q].y * sc);
-    z_load_inverse<M, E>(w, z, a.gw[1], g, twM, twN);
+    OFDFT_ZROW(a.gw[1], a.gw[2])
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         t1[q].x += (a.wgc_beta * (n[q].x - a.nref) + n[q].x) * w[q].x * sc;
         t1[q].y += (a.wgc_beta * (n[q].y - a.nref) + n[q].y) * w[q].y * sc;
     }
-    z_load_inverse<M, E>(w, z, a.gw[2], g, twM, twN);
+    OFDFT_ZROW(a.gw[2], nullptr)
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const real h0 = n[q].x - a.nref, h1 = n[q].y - a.nref;
@@ -545,13 +613,16 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
         vacc[q].x += ctf * t2[q].x * t1[q].x;
         vacc[q].y += ctf * t2[q].y * t1[q].y;
     }
+#undef OFDFT_ZROW
     return e;
 }
 
 template <int M, int E, bool WGC_INLINE>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM,
-                                                         const cplx* __restrict__ twN, acc_t* __restrict__ partial) {
+__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM_g,
+                                                         const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
@@ -707,9 +778,11 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 // energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
 template <int M, int E>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wgc_kernel(ZCombineArgs a, real* __restrict__ v_part, SpecGeom g,
-                                                       const cplx* __restrict__ twM, const cplx* __restrict__ twN,
+                                                       const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g,
                                                        acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     cplx n[E], vacc[E], w[E];
