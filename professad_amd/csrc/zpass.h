@@ -23,7 +23,7 @@ namespace ofdft {
 #define OFDFT_ZIWGC_WAVES 2
 #endif
 #ifndef OFDFT_Z_PREFETCH
-#define OFDFT_Z_PREFETCH 0
+#define OFDFT_Z_PREFETCH 1     // depth-one software pipeline over the spectra a fused z kernel consumes (z_issue_row)
 #endif
 #ifndef OFDFT_Z_LDS_TWIDDLES
 #define OFDFT_Z_LDS_TWIDDLES 1
@@ -475,8 +475,18 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
+#if OFDFT_Z_PREFETCH
+    {       // B's row is requested before A's is transformed (depth-one software pipeline, see z_issue_row)
+        real nyq_a, nyq_b;
+        z_issue_row<M, E>(a, nyq_a, z, A, g);
+        z_issue_row<M, E>(b, nyq_b, z, B, g);
+        z_inverse_regs<M, E>(a, z, twM, twN, nyq_a);
+        z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
+    }
+#else
     z_load_inverse<M, E>(a, z, A, g, twM, twN);
     z_load_inverse<M, E>(b, z, B, g, twM, twN);
+#endif
     z_load_real<M, E>(c, z, dzn);
     z_load_real<M, E>(n, z, ds.src);
     acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
@@ -639,8 +649,38 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         vacc[q] = mkc(0.0, 0.0);
     }
     const real sc = a.inv_n;
+    // Depth-one software pipeline over the spectra this kernel consumes (lean instantiation): chain[i] = the i-th
+    // spectrum or null; a section takes its row from the registers filled one section earlier and requests the next
+    // present one before transforming its own (z_issue_row).
+    constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE;
+    const bool gga = (a.mask & (7u << 10)) != 0;
+    const cplx* chain[6] = {(a.mask & 2u) ? a.vh : nullptr,  (a.mask & 8u) ? a.lap : nullptr, (a.mask & 16u) ? a.conv_b : nullptr,
+                            (a.mask & 16u) ? a.conv_a : nullptr, gga ? a.div : nullptr, gga ? a.div2 : nullptr};
+    cplx nx[PIPE ? E : 1];
+    real nyq_nx = 0.0;
+    auto request_after = [&](auto ic) {       // rows of the first present spectrum after section I -> nx
+        constexpr int I = decltype(ic)::value;
+        const cplx* p = nullptr;
+#pragma unroll
+        for (int k = 5; k > I; --k)
+            if (chain[k]) p = chain[k];
+        if constexpr (PIPE)
+            if (p) z_issue_row<M, E>(nx, nyq_nx, z, p, g);
+    };
+    auto take_row = [&](auto ic, const cplx* spec) {      // section I's row -> w (real space, unscaled)
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) w[q] = nx[q];
+            const real nyq_w = nyq_nx;
+            request_after(ic);
+            z_inverse_regs<M, E>(w, z, twM, twN, nyq_w);
+        } else {
+            z_load_inverse<M, E>(w, z, spec, g, twM, twN);
+        }
+    };
+    request_after(std::integral_constant<int, -1>{});
     if (a.mask & 2u) {                                   // Hartree  functionals.py:72
-        z_load_inverse<M, E>(w, z, a.vh, g, twM, twN);
+        take_row(std::integral_constant<int, 0>{}, a.vh);
         real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         park[1 * 256] = e;
     }
     if (a.mask & 8u) {                                   // vW  functionals.py:245; tools_for_tests.py:23-26
-        z_load_inverse<M, E>(w, z, a.lap, g, twM, twN);
+        take_row(std::integral_constant<int, 1>{}, a.lap);
         real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
@@ -665,7 +705,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         park[3 * 256] = e;
     }
     if (a.mask & 16u) {                                  // WT family  functionals.py:650-651; tools_for_tests.py:29-39
-        z_load_inverse<M, E>(w, z, a.conv_b, g, twM, twN);
+        take_row(std::integral_constant<int, 2>{}, a.conv_b);
         cplx pa1[E];
         real e = 0.0;
 #pragma unroll
@@ -681,7 +721,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         }
         park[4 * 256] = e;
         if (a.conv_a) {
-            z_load_inverse<M, E>(w, z, a.conv_a, g, twM, twN);
+            take_row(std::integral_constant<int, 3>{}, a.conv_a);
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 vacc[q].x += ctf * a.wt_beta * pow_pos(n[q].x, a.wt_beta - 1.0) * w[q].x * sc;
@@ -702,7 +742,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         }
     }
     if (a.mask & (7u << 10)) {                           // PBE / GGA kinetic: v += df/dn - 2 div  (tools_for_tests.py:168-170)
-        z_load_inverse<M, E>(w, z, a.div, g, twM, twN);
+        take_row(std::integral_constant<int, 4>{}, a.div);
         cplx d[E];
         z_load_real<M, E>(d, z, a.dfdn);
 #pragma unroll
@@ -711,7 +751,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
             vacc[q].y += d[q].y - 2.0 * w[q].y * sc;
         }
         if (a.div2) {
-            z_load_inverse<M, E>(w, z, a.div2, g, twM, twN);
+            take_row(std::integral_constant<int, 5>{}, a.div2);
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 vacc[q].x -= 2.0 * w[q].x * sc;
