@@ -316,6 +316,14 @@ struct DenSrc {
         const real c = cscale_dev ? (real)*cscale_dev : cscale;
         return from_chi ? c * x * x : x;
     }
+    // the same source with the device-resident scale read ONCE (a kernel calls this first: left in memory, the scale
+    // was re-read -- a dependent L2 round trip -- at every point, because the kernel's stores might alias it)
+    __device__ __forceinline__ DenSrc resolved() const {
+        DenSrc r = *this;
+        if (cscale_dev) r.cscale = (real)*cscale_dev;
+        r.cscale_dev = nullptr;
+        return r;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __r
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx x[E], v[E];
     z_load_real<M, E>(x, z, ds.src);
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx n[E], a[E], v[E];
     z_load_real<M, E>(n, z, ds.src);
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
     z_load_inverse<M, E>(a, z, gx, g, twM, twN);
@@ -473,6 +484,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
 #if OFDFT_Z_PREFETCH
@@ -633,6 +645,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
@@ -823,6 +836,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wg
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     cplx n[E], vacc[E], w[E];
