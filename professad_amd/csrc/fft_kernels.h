@@ -95,6 +95,9 @@ struct ArrList { cplx* p[16]; };
 #ifndef OFDFT_XF_LD_AUX
 #define OFDFT_XF_LD_AUX 0
 #endif
+#ifndef OFDFT_XF_BATCH_TABLES
+#define OFDFT_XF_BATCH_TABLES 1    // table-driven fused x pass (WGC99): request a half's coefficients in one batch
+#endif
 #ifndef OFDFT_XF_ST_AUX
 #define OFDFT_XF_ST_AUX 2     // fused x pass: nt stores (-8 % on the WGC99 kernel); nt LOADS cost +14 % (partner half-lines in L2)
 #endif
@@ -596,18 +599,65 @@ __device__ __forceinline__ void xf_mix_inputs(real& acr, real& aci, const real* 
     }
 }
 
+// coefficient functors whose coef() is a table LOAD declare `static constexpr bool kTables = true` (MixWgc)
+template <class Mix, class = void> struct mix_has_tables : std::false_type {};
+template <class Mix> struct mix_has_tables<Mix, std::void_t<decltype(Mix::kTables)>> : std::bool_constant<Mix::kTables> {};
+
+// table-driven mixing: all coefficients of the half are requested first (one batch of loads in flight), then used
+template <int LEN, int LPW, int NIN, int O, int I, class Mix>
+__device__ __forceinline__ void xf_fetch_coefs(real (&cf)[NIN], const XfMixCtx<LEN, LPW>& c, const Mix& mix, int q, int x) {
+    if constexpr (I < NIN) {
+        if constexpr (Mix::template present<O, I>()) cf[I] = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
+        else cf[I] = 0.0;
+        xf_fetch_coefs<LEN, LPW, NIN, O, I + 1, Mix>(cf, c, mix, q, x);
+    }
+}
+template <int LEN, int LPW, int NIN, int O, int I, class Mix>
+__device__ __forceinline__ void xf_apply_coefs(real& acr, real& aci, const real (&cf)[NIN], const real* lds,
+                                               const XfMixCtx<LEN, LPW>& c, int pos) {
+    constexpr int STRIDE = LineBuf<LEN>::STRIDE;
+    if constexpr (I < NIN) {
+        if constexpr (Mix::template present<O, I>()) {
+            const real* lb = lds + (I * LPW + c.l) * STRIDE;
+            acr += cf[I] * lb[lpad(pos)];
+            aci += cf[I] * lb[lpad(pos + LEN / 2)];
+        }
+        xf_apply_coefs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, cf, lds, c, pos);
+    }
+}
+
 // one output (compile-time O) from all inputs for the half of the thread's points with index HALF
 template <int LEN, int LPW, int NIN, int O, class Mix, int HALF>
 __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const real* lds, const XfMixCtx<LEN, LPW>& c,
                                             const Mix& mix) {
     constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E;
+    if constexpr (mix_has_tables<Mix>::value && OFDFT_XF_BATCH_TABLES) {
+        // Left to the compiler, the table loads came one at a time, each waited for before the next was issued: ~24
+        // dependent HBM / L2 round trips per thread, i.e. the workgroup's whole lifetime.
+        real cf[E / 2][NIN];
 #pragma unroll
-    for (int qq = 0; qq < E / 2; ++qq) {
-        const int q = qq + HALF * (E / 2);
-        const int x = c.j + P * q;
-        real acr = 0.0, aci = 0.0;
-        xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
-        o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);     // (i c)(re + i im) = -c im + i c re
+        for (int qq = 0; qq < E / 2; ++qq) {
+            const int q = qq + HALF * (E / 2);
+            xf_fetch_coefs<LEN, LPW, NIN, O, 0, Mix>(cf[qq], c, mix, q, c.j + P * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < E / 2; ++qq) {
+            const int q = qq + HALF * (E / 2);
+            const int x = c.j + P * q;
+            real acr = 0.0, aci = 0.0;
+            xf_apply_coefs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, cf[qq], lds, c, x - HALF * (LEN / 2));
+            o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);
+        }
+    } else {
+#pragma unroll
+        for (int qq = 0; qq < E / 2; ++qq) {
+            const int q = qq + HALF * (E / 2);
+            const int x = c.j + P * q;
+            real acr = 0.0, aci = 0.0;
+            xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
+            o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);     // (i c)(re + i im) = -c im + i c re
+        }
     }
 }
 

@@ -389,6 +389,7 @@ struct MixDiv {
 
 // WGC99: (A^,B^,C^) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) with tables in the spectrum layout
 struct MixWgc {
+    static constexpr bool kTables = true;     // coef() is a load: the fused x pass requests a half's worth in one batch
     const real* tab;     // interleaved (w0, K1, K2, K3) per k-point, spectrum order
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
