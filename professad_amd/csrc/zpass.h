@@ -70,14 +70,37 @@ template <int M, int E> struct ZLane {
 // The row transforms read ~9 twiddle factors per row and array; as global loads each of them was a dependent L2 round
 // trip whose s_waitcnt vmcnt(0) also drained the row loads in flight (the vm counter retires in order).  The z kernels
 // therefore copy the two tables (W_M^k and W_2M^k, k < M) into LDS once per workgroup and read them with ds_read.
+// Two phases, so that the copy costs no latency of its own: the table elements are REQUESTED first thing in the kernel,
+// the kernel then issues its first row loads, and only then are the elements written to LDS (z_tw_commit, one barrier).
+template <int M, int E> struct ZTwReq {
+    static constexpr int CNT = (M + ZW<M, E>::TPB - 1) / ZW<M, E>::TPB;
+    cplx m[CNT], n[CNT];
+};
 template <int M, int E>
-__device__ __forceinline__ void z_stage_twiddles(real* lds, const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g,
-                                                 const cplx*& twM, const cplx*& twN) {
+__device__ __forceinline__ ZTwReq<M, E> z_tw_request(const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
+    ZTwReq<M, E> r;
+#if OFDFT_Z_LDS_TWIDDLES
+#pragma unroll
+    for (int c = 0; c < ZTwReq<M, E>::CNT; ++c) {
+        const int i = threadIdx.x + c * ZW<M, E>::TPB;
+        r.m[c] = twM_g[i < M ? i : 0];
+        r.n[c] = twN_g[i < M ? i : 0];
+    }
+#endif
+    return r;
+}
+template <int M, int E>
+__device__ __forceinline__ void z_tw_commit(real* lds, const ZTwReq<M, E>& r, const cplx* __restrict__ twM_g,
+                                            const cplx* __restrict__ twN_g, const cplx*& twM, const cplx*& twN) {
 #if OFDFT_Z_LDS_TWIDDLES
     cplx* t = reinterpret_cast<cplx*>(lds + ZW<M, E>::ROWS);
-    for (int i = threadIdx.x; i < M; i += ZW<M, E>::TPB) {
-        t[i] = twM_g[i];
-        t[M + i] = twN_g[i];
+#pragma unroll
+    for (int c = 0; c < ZTwReq<M, E>::CNT; ++c) {
+        const int i = threadIdx.x + c * ZW<M, E>::TPB;
+        if (i < M) {
+            t[i] = r.m[c];
+            t[M + i] = r.n[c];
+        }
     }
     __syncthreads();
     twM = t;
@@ -334,11 +357,12 @@ __global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __r
                                                          const cplx* __restrict__ twN_g, real* __restrict__ dzn = nullptr) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx x[E], v[E];
     z_load_real<M, E>(x, z, ds.src);
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
     if (out_n) {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = mkc(ds(x[q].x), ds(x[q].y));
@@ -376,11 +400,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
                                                         const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx n[E], a[E], v[E];
     z_load_real<M, E>(n, z, ds.src);
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
@@ -433,10 +458,11 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
                                                    const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
     z_load_inverse<M, E>(a, z, gx, g, twM, twN);
     z_load_inverse<M, E>(b, z, gy, g, twM, twN);
     z_load_inverse<M, E>(c, z, gz, g, twM, twN);
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
                                                                       acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
@@ -492,10 +518,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         real nyq_a, nyq_b;
         z_issue_row<M, E>(a, nyq_a, z, A, g);
         z_issue_row<M, E>(b, nyq_b, z, B, g);
+        z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
         z_inverse_regs<M, E>(a, z, twM, twN, nyq_a);
         z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
     }
 #else
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
     z_load_inverse<M, E>(a, z, A, g, twM, twN);
     z_load_inverse<M, E>(b, z, B, g, twM, twN);
 #endif
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
                                                          const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
@@ -656,6 +684,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
@@ -835,12 +864,13 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wg
                                                        acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
-    z_stage_twiddles<M, E>(lds, twM_g, twN_g, twM, twN);
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
     const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
