@@ -694,7 +694,9 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     // Depth-one software pipeline over the spectra this kernel consumes (lean instantiation): chain[i] = the i-th
     // spectrum or null; a section takes its row from the registers filled one section earlier and requests the next
     // present one before transforming its own (z_issue_row).
-    constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE;
+    // (not at M = 512 -- rows of 1024 -- where E = 8: the extra row would push the kernel past 256 registers, i.e. from
+    // two waves per SIMD to one)
+    constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE && M < 512;
     const bool gga = (a.mask & (7u << 10)) != 0;
     const cplx* chain[6] = {(a.mask & 2u) ? a.vh : nullptr,  (a.mask & 8u) ? a.lap : nullptr, (a.mask & 16u) ? a.conv_b : nullptr,
                             (a.mask & 16u) ? a.conv_a : nullptr, gga ? a.div : nullptr, gga ? a.div2 : nullptr};

@@ -29,14 +29,22 @@ def main():
     vext = -0.1 * torch.rand(shape, dtype=dt, device=dev)
     n_elec = 12.0 * (n // 32) ** 3
     eng = Engine(shape, dev, dtype=dt).set_cell(box).set_terms(names)
-    E, mu, g = eng.energy_grad_chi(chi, n_elec, vext)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
+    for _ in range(2):
         E, mu, g = eng.energy_grad_chi(chi, n_elec, vext)
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
+    times = []
+    for _ in range(4):          # best of four: the first timed calls on a fresh box run at ramping clocks
+        t0 = time.perf_counter()
+        E, mu, g = eng.energy_grad_chi(chi, n_elec, vext)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = min(times)
+    if '--profile' in sys.argv:
+        eng.set_option(1, 0)
+        eng.set_profiling(True)
+        eng.energy_grad_chi(chi, n_elec, vext)
+        print(json.dumps({k: (round(v[0], 3), v[1]) for k, v in sorted(eng.profile().items(), key=lambda kv: -kv[1][0])}))
+        eng.set_profiling(False)
     # extensivity against the same random field restricted to a 1/8 corner is not available (random): report sanity only
     print(json.dumps({'grid': n, 'cfg': cfg, 'dtype': str(dt), 'ms_per_eval': round(ms, 2), 'E_per_electron': sum(E.values()) / n_elec, 'mu': mu,
                       'grad_finite': bool(torch.isfinite(g).all()), 'workspace_GB': round(eng.query(1) / 1e9, 1),
