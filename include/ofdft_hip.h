@@ -226,7 +226,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_GGA_SPLIT 6     /* 1 (default): split-derivative GGA chain -- only the index derivative along x visits the x pass (and the exchange); 0: three Cartesian components */
 #define OFDFT_OPT_GRAPH 7         /* 1 (default): ofdft_energy_grad_chi replays a hipGraph captured on the second call with the same
                                      arguments (device pointers, electron number, cell, terms, options): one graph launch instead
-                                     of ~25-50 kernel launches, which is what bounds grids up to ~64^3 (used up to 128^3 points, where
+                                     of ~25-50 kernel launches, which is what bounds grids up to ~64^3 (used by single-GPU contexts up to 2^19 points, where
                                      OFDFT_OPT_SPLIT_COMBINE is then ignored); 0: always launch kernel by kernel */
 #define OFDFT_OPT_SIDE_STREAM 1
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);

@@ -137,10 +137,10 @@ int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
 struct ProfRec { const char* name; hipEvent_t a, b; };
 
 void graph_drop(ofdft_ctx* c);
-// hipGraph replay serves the launch-bound regime only (up to 128^3 points; above that launches are hidden behind the
-// kernels).  There the WGC99 part of the combine stays inside the combine kernel: the forked + split stream topology
+// hipGraph replay serves the launch-bound regime only (single-GPU contexts up to 2^19 points, e.g. 64 x 64 x 128; above
+// that launches are hidden behind the kernels and the measured gain is nil).  There the WGC99 part of the combine stays inside the combine kernel: the forked + split stream topology
 // crashes this ROCm's stream capture, and fewer launches is the better trade on small grids anyway.
-bool graph_eligible(const ofdft_ctx* c) { return c->use_graph && c->npts <= (1LL << 21); }
+bool graph_eligible(const ofdft_ctx* c) { return c->use_graph && c->nranks == 1 && c->npts <= (1LL << 19); }
 void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name);
 void prof_end(ofdft_ctx* c, hipStream_t st);
 
