@@ -133,9 +133,10 @@ __device__ __forceinline__ void kvec(const KGeom& kg, long long i, real& kx, rea
     k2 = kx * kx + ky * ky + kz * kz;
 }
 
-// 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648)
-__device__ __forceinline__ real lindhard_shape(real eta) {
-    real ginv;
+// 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648).  Always evaluated in fp64: G cancels 0.5 against -0.5 + O(eta^-2)
+// and its reciprocal then cancels against 3 eta^2; in fp32 that left 5e-4 of the Wang-Teter energy of a rough density.
+__device__ __forceinline__ double lindhard_shape(double eta) {
+    double ginv;
     if (eta == 0.0) ginv = 1.0;
     else if (eta == 1.0) ginv = 0.5;
     else ginv = 0.5 + ((1.0 - eta * eta) / (4.0 * eta)) * log(fabs((1.0 + eta) / (1.0 - eta)));

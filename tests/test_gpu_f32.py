@@ -181,3 +181,31 @@ def test_f32_slab_decomposed_stages_match_single_engine(ranks):
     assert err < V_RTOL, err
     one.close()
     loc.close()
+
+
+@pytest.mark.parametrize('shape', [(64, 32, 128), (32, 32, 1024), (8, 64, 32)])
+def test_f32_pipelines_agree(shape):
+    """fp32 build: z-fused (default), x-fused-only and unfused pipelines on one input (rows of 1024 take the 8-point
+    lanes of the z kernels), against each other and against the fp64 engine"""
+    box = torch.as_tensor(cases.make_cell(('tri', 1.7)))
+    den = synth.random_density(shape, seed=31)
+    vext = synth.random_potential(shape, seed=32)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(33).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box.numpy()))) + 0.3)
+    e32 = Engine(shape, DEV, dtype=F32).set_cell(box)
+    e64 = Engine(shape, DEV).set_cell(box)
+    for cfg, names in _CFG_TERMS.items():
+        terms = F.NativeTerms(names).names
+        e64.set_terms(terms)
+        E64, mu64, g64 = e64.energy_grad_chi(torch.as_tensor(chi, device=DEV), n_elec, torch.as_tensor(vext, device=DEV))
+        e32.set_terms(terms)
+        for mode in (0, 1, 2):
+            e32.set_option(0, mode)
+            E, mu, g = e32.energy_grad_chi(dev32(chi), n_elec, dev32(vext))
+            for k in E64:
+                assert abs(E[k] - E64[k]) <= E_RTOL * max(abs(E64[k]), 1e-3), (cfg, mode, k, E[k], E64[k])
+            assert abs(mu - mu64) < 5e-6 * max(1.0, abs(mu64))
+            assert relerr(g.cpu().numpy(), g64.cpu().numpy()) < V_RTOL, (cfg, mode)
+        e32.set_option(0, 0)
+    e32.close()
+    e64.close()
