@@ -209,3 +209,34 @@ def test_f32_pipelines_agree(shape):
         e32.set_option(0, 0)
     e32.close()
     e64.close()
+
+
+_TERM_SETS = [
+    (['lda_x', 'pw_c'], {}), (['lda_x', 'chachiyo_c'], {}), (['pz_c'], {}),
+    (['tf', 'vw', 'wt_nl'], {'wt_alpha': 5 / 6 + 0.2, 'wt_beta': 5 / 6 - 0.2}),          # WGC98-style exponents (alpha != beta)
+    (['tf', 'vw', 'wt_nl'], {'wt_alpha': 1.0, 'wt_beta': 1.0}),                          # Perrot
+    (['vw', 'gga_k'], {'ggak_kind': 0.0}),                                               # Luo-Karasiev-Trickey
+    (['vw', 'gga_k'], {'ggak_kind': 1.0, 'ggak_mu': 40 / 27}),                           # Pauli-Gaussian PGS
+    (['vw', 'gga_k'], {'ggak_kind': 1.0, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25}),        # PGSL0.25 (Laplacian member, unfused)
+    (['vw', 'vwgtf'], {'vwgtf_kind': 1.0}), (['vw', 'vwgtf'], {'vwgtf_kind': 2.0}),
+    (['hartree', 'pbe_x'], {}), (['pbe_c'], {}),
+]
+
+
+@pytest.mark.parametrize('idx', range(len(_TERM_SETS)))
+def test_f32_every_term_tracks_f64_on_a_rough_density(idx):
+    """every term family of the engine, fp32 against fp64 on a random (full-spectrum) density: catches formulas that are
+    fine in fp64 but cancel catastrophically in fp32 (as the Lindhard function did)"""
+    names, params = _TERM_SETS[idx]
+    shape = (32, 16, 64)
+    box = torch.as_tensor(cases.make_cell(('tri', 1.7)))
+    den = synth.random_density(shape, seed=51)
+    e64 = Engine(shape, DEV).set_cell(box).set_terms(names, params)
+    e32 = Engine(shape, DEV, dtype=F32).set_cell(box).set_terms(names, params)
+    E64, v64 = e64.energy_potential(torch.as_tensor(den, device=DEV))
+    E32, v32 = e32.energy_potential(dev32(den))
+    for k in E64:
+        assert abs(E32[k] - E64[k]) <= E_RTOL * max(abs(E64[k]), 1e-3), (names, params, k, E32[k], E64[k])
+    assert relerr(v32.cpu().numpy(), v64.cpu().numpy()) < V_RTOL, (names, params)
+    e64.close()
+    e32.close()
