@@ -313,7 +313,9 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     this rank's x-slabs and every rank runs this function; the optimiser's scalars are all-reduced, so all ranks take
     identical decisions); `volume` = cell volume (needed when chi0 is None to start from the uniform density, as
     System.optimize_density does after System.__init__).  `optimizer`: 'fused' (HIP sweeps, `VectorFreeLBFGS`) or
-    'torch' (`FixedStepLBFGS` on torch tensors; single GPU only)."""
+    'torch' (`FixedStepLBFGS` on torch tensors; single GPU only).
+    With an fp32 engine the energies carry ~1e-6 relative round-off: choose `ntol` above that noise (the default 1e-7 eV
+    suits fp64) or the loop runs to `n_maxiter`."""
     comm = getattr(engine, 'comm', None)                    # DistEngine
     multi = comm is not None and comm.active
     if comm is not None:
