@@ -222,7 +222,7 @@ def main():
     pmc = None
     pmc_name = 'pmc_traffic_r01.json' if a.dtype == 'f64' else 'pmc_traffic_r01_f32.json'
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', pmc_name)
-    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3':     # counters were collected on this workload
+    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3' and world == 1:     # counters were collected on this workload
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if dom:
