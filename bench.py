@@ -113,8 +113,8 @@ def cpu_baseline(sample_n, full_n, budget_s=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--grid', type=int, default=256)
     ap.add_argument('--cfg', default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
