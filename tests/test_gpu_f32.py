@@ -240,3 +240,29 @@ def test_f32_every_term_tracks_f64_on_a_rough_density(idx):
     assert relerr(v32.cpu().numpy(), v64.cpu().numpy()) < V_RTOL, (names, params)
     e64.close()
     e32.close()
+
+
+def test_f32_engine_hands_ion_routines_to_the_fp64_sibling():
+    """ionic potential / forces / stress / ion-ion asked of an fp32 engine: computed by the fp64 routines (potential
+    narrowed to fp32, densities widened), identical to asking the fp64 engine directly"""
+    from professad_amd.ions import ion_electron_forces, ion_electron_stress, ion_ion, ionic_potential
+    shape = (32, 32, 32)
+    box = cases.make_cell(('tri', 1.3))
+    den = synth.random_density(shape, seed=7)
+    ks = np.linspace(0.0, 12.0, 300)
+    tab = (ks, -4 * np.pi * 3.0 / (ks ** 2 + 1.5) * np.exp(-0.05 * ks ** 2), 3)
+    frac = np.array([[0.1, 0.2, 0.3], [0.6, 0.55, 0.8]])
+    e32 = Engine(shape, DEV, dtype=F32)
+    e64 = Engine(shape, DEV)
+    v32 = ionic_potential(e32, box, [(frac, tab)], pme_order=4)
+    v64 = ionic_potential(e64, box, [(frac, tab)], pme_order=4)
+    assert v32.dtype == F32 and torch.equal(v32, v64.to(F32))
+    d32 = dev32(den)
+    d64 = d32.double()
+    assert np.array_equal(ion_electron_forces(e32, box, d32, [(frac, tab)], pme_order=4)[0],
+                          ion_electron_forces(e64, box, d64, [(frac, tab)], pme_order=4)[0])
+    assert np.array_equal(ion_electron_stress(e32, box, d32, [(frac, tab)]), ion_electron_stress(e64, box, d64, [(frac, tab)]))
+    a, b = ion_ion(e32, box, frac, [3.0, 3.0]), ion_ion(e64, box, frac, [3.0, 3.0])
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    e32.close()
+    e64.close()
