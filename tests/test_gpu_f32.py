@@ -256,12 +256,14 @@ def test_f32_engine_hands_ion_routines_to_the_fp64_sibling():
     e64 = Engine(shape, DEV)
     v32 = ionic_potential(e32, box, [(frac, tab)], pme_order=4)
     v64 = ionic_potential(e64, box, [(frac, tab)], pme_order=4)
-    assert v32.dtype == F32 and torch.equal(v32, v64.to(F32))
+    # (the PME spreading adds with atomics: two runs may differ in the last bits, so no bitwise comparison here)
+    assert v32.dtype == F32 and relerr(v32.cpu().numpy(), v64.cpu().numpy()) < 2e-7
     d32 = dev32(den)
     d64 = d32.double()
-    assert np.array_equal(ion_electron_forces(e32, box, d32, [(frac, tab)], pme_order=4)[0],
-                          ion_electron_forces(e64, box, d64, [(frac, tab)], pme_order=4)[0])
-    assert np.array_equal(ion_electron_stress(e32, box, d32, [(frac, tab)]), ion_electron_stress(e64, box, d64, [(frac, tab)]))
+    assert np.allclose(ion_electron_forces(e32, box, d32, [(frac, tab)], pme_order=4)[0],
+                       ion_electron_forces(e64, box, d64, [(frac, tab)], pme_order=4)[0], rtol=1e-11, atol=1e-14)
+    assert np.allclose(ion_electron_stress(e32, box, d32, [(frac, tab)]), ion_electron_stress(e64, box, d64, [(frac, tab)]),
+                       rtol=1e-11, atol=1e-16)
     a, b = ion_ion(e32, box, frac, [3.0, 3.0]), ion_ion(e64, box, frac, [3.0, 3.0])
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     e32.close()
