@@ -1527,6 +1527,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (int rc = begin_call(c, st)) return rc;
     if (!src_local) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if ((c->mask & OFDFT_ION_ELECTRON) && !vext_local) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
     if (gga_needs_laplacian(c)) return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members: single-GPU contexts only");
     ZRun& r = zrun(c);

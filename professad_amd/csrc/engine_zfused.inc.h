@@ -703,6 +703,8 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
 // touches the host: the sequence can be captured into a hipGraph
 int zfused_enqueue(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, real* v_out, double* sums, hipStream_t st,
                    bool defer) {
+    if ((c->mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    if (!ds.src) return fail(c, OFDFT_EINVAL, "null density pointer");
     ZRun& r = zrun(c);
     r.ds = ds;
     r.nel = nel;

@@ -741,3 +741,19 @@ def test_graph_replay_is_bitwise_the_kernel_by_kernel_path(shape, cfg):
     assert Ea == Eb and mua == mub and torch.equal(ga, gb)
     plain.close()
     eng.close()
+
+
+def test_missing_vext_is_an_error_not_a_fault():
+    """IonElectron without v_ext: every pipeline refuses the call (a null row pointer in a kernel would be a GPU fault)"""
+    shape = (16, 16, 16)
+    eng = Engine(shape, DEV).set_cell(dev(synth.cubic_cell(16))).set_terms(['ion_electron', 'hartree', 'tf'])
+    den = dev(synth.smooth_density(shape, seed=3))
+    for mode in (0, 1, 2):
+        eng.set_option(0, mode)
+        with pytest.raises(RuntimeError, match='needs vext'):
+            eng.energy_potential(den, None)
+        with pytest.raises(RuntimeError, match='needs vext'):
+            eng.energy_grad_chi(torch.sqrt(den), 4.0, None)
+    E, v = eng.set_option(0, 0).energy_potential(den, den, want_potential=False)      # energy only: no output array
+    assert v is None and E['hartree'] > 0.0
+    eng.close()
