@@ -243,6 +243,18 @@ def main():
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg, word)
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU
+    # the box's own streaming ceiling beside the 8 TB/s spec figure: device-to-device copy of 512 MiB, read + write
+    cp_a = torch.empty(64 * 1024 * 1024, dtype=torch.double, device=device)
+    cp_b = torch.empty_like(cp_a)
+    cp_b.copy_(cp_a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        cp_b.copy_(cp_a)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    copy_gbs = 10 * 2 * cp_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del cp_a, cp_b
 
     out = {
         'metric': 'energy+grad evals/sec', 'value': round(evals_per_s, 3), 'unit': 'evals/s',
@@ -255,7 +267,7 @@ def main():
                    'x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world},
         'roofline': roofline,
         'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
-                          'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'ffts_executed': n_fft,
+                          'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'measured_copy_GBs': round(copy_gbs, 1), 'ffts_executed': n_fft,
                           'kernel_launches': n_launch, 'device_ms_last_eval': round(raw.query(3), 4)},
         'kernels': kernels,
         'energy_Ha': sum(E.values()), 'mu': mu,
