@@ -242,6 +242,10 @@ def main():
                     'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n, word) / world * passes / launches,
                     'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg, word)
+    measured_hbm = None
+    if pmc:       # rocprofv3 FETCH_SIZE / WRITE_SIZE of every kernel of the committed profile, per evaluation
+        evs = pmc['kernels'].get('chi_grad', {}).get('launches', 12)
+        measured_hbm = sum(k['launches'] * (k['read_MB'] + k['write_MB']) for k in pmc['kernels'].values()) / evs * 1e6
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU
     # the box's own streaming ceiling beside the 8 TB/s spec figure: device-to-device copy of 512 MiB, read + write
     cp_a = torch.empty(64 * 1024 * 1024, dtype=torch.double, device=device)
@@ -267,7 +271,8 @@ def main():
                    'x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world},
         'roofline': roofline,
         'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
-                          'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'measured_copy_GBs': round(copy_gbs, 1), 'ffts_executed': n_fft,
+                          'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'measured_copy_GBs': round(copy_gbs, 1),
+                          'measured_hbm_bytes_per_eval': measured_hbm, 'ffts_executed': n_fft,
                           'kernel_launches': n_launch, 'device_ms_last_eval': round(raw.query(3), 4)},
         'kernels': kernels,
         'energy_Ha': sum(E.values()), 'mu': mu,
