@@ -43,35 +43,50 @@ def algorithmic_bytes(n, cfg, word=8):
     return n_fft * (R + 5 * Cc) + n_pw * R, R, Cc
 
 
-def kernel_alg_bytes(name, n, word=8):
-    """Algorithmic bytes of ONE spectrum pass of a kernel class (what it must read + write once).  A launch may cover
-    several spectra or only an x range of them (batched / x-chunked y passes), so rooflines are formed per evaluation:
-    passes x bytes / time of the class."""
+def class_alg_bytes(cfg, n, word, n_ypass):
+    """ALGORITHMIC bytes per evaluation of every kernel class of the default (z-fused, split-derivative) pipeline: what
+    the class must read + write once, whatever the launch granularity (a class may run as several x- or kz-chunked
+    launches).  R = one real grid, C = one half spectrum; DESIGN.md section 4 lists the arrays behind each entry.
+    Classes that move no grid-sized data (second-level reductions, scalar kernels, table generation once per cell) have
+    no entry."""
     R = float(word) * n ** 3
     Cc = 2.0 * word * n * n * (n // 2 + 1)
-    table = {'cpass_x': 2 * Cc, 'cpass_y': 2 * Cc, 'zfwd': R + Cc, 'zinv': R + Cc}
-    return table.get(name)
+    t = {'sum': R,                       # chi
+         'chi_grad': 3 * R,              # chi, v -> grad
+         'cpass_y': n_ypass * 2 * Cc, 'cpass_x': 2 * Cc, 'zfwd': R + Cc, 'zinv': R + Cc,
+         'xfused_lap': 2 * Cc}
+    if cfg == 'cfg3':
+        t.update({'zf_density': 2 * R + 2 * Cc,         # chi -> n^, (sqrt n)^, D_c n
+                  'yderiv': 2 * 2 * Cc,                 # D_b n (out of place) and D_b G_b (in place)
+                  'xfused_n': 3 * Cc,                   # n^ -> vH^, i f_a n^
+                  'xfused_div': 2 * Cc,
+                  'xfused_wgc': 2 * (6 * Cc + 2 * Cc),  # two 3 -> 3 launches, each + its (w0,K1,K2,K3) tables = 2C
+                  'zpbe': 4 * Cc + 3 * R,               # A, B in/out; D_c n, chi in; df/dn - 2 D_c G_c out
+                  'zf_powers': R + 6 * Cc,
+                  'zi_wgc': 6 * Cc + 2 * R,             # six result spectra + chi -> v_part
+                  'zi_combine': 4 * Cc + 5 * R})        # vH, lap, D_a G_a, D_b G_b; chi, v_ext, df/dn, v_part -> v
+    else:
+        t.update({'zf_density': R + 2 * Cc, 'zf_powers': R + Cc, 'xfused_n': 2 * Cc, 'xfused_lind': 2 * Cc,
+                  'zi_combine': 3 * Cc + 3 * R})        # vH, lap, K*n^beta; chi, v_ext -> v
+    return t
+
+
+def source_stamp():
+    """sha256 (16 hex digits) over the native sources the library is built from: ties a committed PMC file to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'professad_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)) + [os.path.join('..', '..', 'include', 'ofdft_hip.h')]:
+        if f.endswith(('.h', '.hip', '.inc')):
+            with open(os.path.join(csrc, f), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def make_inputs(n, rank=0):
-    """chi, v_ext, box, N_e for an n^3 grid (n multiple of 32)."""
-    fx = os.path.join(ROOT, 'tests', 'golden', 'cfg1_fccAl_32.npz')
-    if os.path.exists(fx) and n % 32 == 0:
-        d = np.load(fx)
-        r = n // 32
-        box = d['box'] * r
-        n_elec = float(d['n_elec']) * r ** 3
-        den = synth.tile_periodic(d['den'], n)
-        vext = synth.tile_periodic(d['vext'], n)
-        den = synth.perturbed(den, box, n_elec, seed=20240601 + rank)
-        src = 'converged fcc-Al 32^3 fixture tiled %d^3 + 1e-3 low-|k| perturbation' % r
-    else:
-        box = synth.cubic_cell(n)
-        den = synth.random_density((n, n, n), seed=1234 + rank)
-        vext = synth.random_potential((n, n, n), seed=77)
-        n_elec = float(round(den.mean() * abs(np.linalg.det(box))))
-        src = 'n0(1+0.2U) random density'
-    return box, np.sqrt(den), vext, n_elec, src
+    """chi, v_ext, box, N_e for an n^3 grid (professad_amd.synth.bench_inputs; the same recipe the golden generator pins
+    against the reference, tests/golden/bench_scalars.json)."""
+    return synth.bench_inputs(n, os.path.join(ROOT, 'tests', 'golden'), rank)
 
 
 def _time_cpu_closure(n, reps, budget_s):
@@ -91,16 +106,30 @@ def _time_cpu_closure(n, reps, budget_s):
     return (min(times) if times else first), first, len(times)
 
 
+def host_cores():
+    """CPU threads this process may really use: the scheduler affinity, capped by the cgroup CPU quota when one is set
+    (a one-GPU box grants a share of a bigger host); OFDFT_CPU_THREADS overrides."""
+    if os.environ.get('OFDFT_CPU_THREADS'):
+        return int(os.environ['OFDFT_CPU_THREADS'])
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sample_n, full_n, budget_s=45.0):
     """The oracle's op-for-op restatement of the reference path (autograd through torch.fft on the host cores),
     timed on a bounded sample of the same workload: the 128^3 sample always; the full grid too when the sample
     predicts it fits the budget (then the full-grid figure is reported, un-scaled)."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    # a 1-GPU box grants a 16-core CPU share even when more cores are visible
-    torch.set_num_threads(int(os.environ.get('OFDFT_CPU_THREADS', min(avail, 16))))
+    torch.set_num_threads(host_cores())
     best, first, cnt = _time_cpu_closure(sample_n, 5, 30.0)
     res = {'n': sample_n, 'best': best, 'first': first, 'count': cnt, 'cores': torch.get_num_threads(), 'full': None}
     ratio = (full_n / sample_n) ** 3 * 1.6            # grid points x cache/log-N penalty seen in the survey
@@ -110,12 +139,67 @@ def cpu_baseline(sample_n, full_n, budget_s=45.0):
     return res
 
 
+def launch_workers(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RCCL) from this parent,
+    which makes no GPU call itself (torch.cuda.device_count() does not initialise the device).  The workers are
+    ordinary children, never an exec of a process that touched the GPU; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    share = os.environ.get('OFDFT_BENCH_SHARE_GPU') == '1'        # rehearsal on a one-GPU box (gloo, every rank on cuda:0)
+    ndev = torch.cuda.device_count()
+    if ndev < n and not share:
+        sys.stderr.write('bench.py: --gpus %d asked for, %d visible (set OFDFT_BENCH_SHARE_GPU=1 OFDFT_BENCH_BACKEND=gloo '
+                         'to rehearse on one GPU)\n' % (n, ndev))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    from professad_amd import _build
+    _build.build(verbose=False)                    # once, before the ranks start (they only load the library)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:                      # a failed rank leaves the others in a collective: end exactly those
+                    q.terminate()
+    sys.exit(rc)
+
+
+def reference_check(n, cfg, dtype, E, mu):
+    """The bench workload pinned to the reference (tests/golden/bench_scalars.json, written by make_golden.py --bench
+    from the reference's own closure on these inputs).  Outside the timed region."""
+    fn = os.path.join(ROOT, 'tests', 'golden', 'bench_scalars.json')
+    if cfg != 'cfg3' or not os.path.exists(fn):
+        return None
+    with open(fn) as fh:
+        ref = json.load(fh).get('cfg3_%d' % n)
+    if not ref:
+        return None
+    tol = 1e-10 if dtype == 'f64' else 5e-6
+    dE = abs(E - ref['E']) / abs(ref['E'])
+    dmu = abs(mu - ref['mu']) / max(abs(ref['mu']), 1e-300)
+    return {'E_ref_Ha': ref['E'], 'rel_dE': dE, 'mu_ref': ref['mu'], 'rel_dmu': dmu, 'tol': tol,
+            'ok': bool(dE < tol and dmu < max(tol, 1e-9)), 'source': 'tests/golden/bench_scalars.json (reference closure, system.py:830-838)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--grid', type=int, default=256)
+    ap.add_argument('--grid', type=int, default=256, help='n of the n^3 grid (512: the 1-GPU / 8-GPU pair of the slab target)')
     ap.add_argument('--cfg', default='cfg3', choices=['cfg2', 'cfg3'])
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
                     help='f64: the reference precision (BASELINE metric); f32: the fp32 build (config 5)')
@@ -123,9 +207,13 @@ def main():
     ap.add_argument('--cpu-sample-grid', type=int, default=128)
     a = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        launch_workers(a.gpus, sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d ranks; running %d\n' % (a.gpus, world, world))
     dist = None
     # rehearsal switches for a one-GPU box (never set by the driver): OFDFT_BENCH_BACKEND=gloo stages the exchange
     # through the host, OFDFT_BENCH_SHARE_GPU=1 puts every rank on cuda:0
@@ -148,7 +236,8 @@ def main():
     names = CFG3 if a.cfg == 'cfg3' else CFG2
     # ONE n^3 system for the whole job: on N > 1 GPUs it is slab-decomposed (rank r owns x-slab r) and every
     # 3-D FFT is transposed with an RCCL all-to-all -- strong scaling of the BASELINE workload.
-    box, chi_h, vext_h, n_elec, src = make_inputs(n, 0)
+    box, chi_full, vext_full, n_elec, src = make_inputs(n, 0)
+    chi_h, vext_h = chi_full, vext_full
     if world > 1:
         eng = DistEngine((n, n, n), device, dtype=tdtype).set_cell(torch.as_tensor(box)).set_terms(names)
         xs = eng.plan.x_range()
@@ -159,16 +248,12 @@ def main():
         raw = eng
     chi = torch.as_tensor(chi_h, dtype=tdtype, device=device)
     vext = torch.as_tensor(vext_h, dtype=tdtype, device=device)
-    if os.environ.get('OFDFT_SIDE_STREAM') == '0':       # A/B switch: everything on one stream
-        raw.set_option(1, 0)
-    if os.environ.get('OFDFT_XCHUNKS'):                  # A/B switch: x-chunked z / y stages
-        raw.set_option(2, int(os.environ['OFDFT_XCHUNKS']))
-    if os.environ.get('OFDFT_GGA_SPLIT'):
-        raw.set_option(6, int(os.environ['OFDFT_GGA_SPLIT']))
-    if os.environ.get('OFDFT_SPLIT_COMBINE'):
-        raw.set_option(4, int(os.environ['OFDFT_SPLIT_COMBINE']))
-    if os.environ.get('OFDFT_XCHUNK_MASK'):
-        raw.set_option(3, int(os.environ['OFDFT_XCHUNK_MASK']))
+    default_options = True
+    for env, opt in (('OFDFT_SIDE_STREAM', 1), ('OFDFT_XCHUNKS', 2), ('OFDFT_XCHUNK_MASK', 3), ('OFDFT_SPLIT_COMBINE', 4),
+                     ('OFDFT_GGA_SPLIT', 6)):          # A/B switches (never set by the driver)
+        if os.environ.get(env):
+            raw.set_option(opt, int(os.environ[env]))
+            default_options = False
 
     def step():
         return eng.energy_grad_chi(chi, n_elec, vext)
@@ -197,10 +282,11 @@ def main():
     n_fft = int(eng.query(0))
     n_launch = int(eng.query(4))
     n_ypass = float(eng.query(5))          # whole-spectrum y line passes actually executed
+    dev_ms = raw.query(3)                  # begin .. end of the last evaluation on this rank's stream (HIP events)
 
-    # ---- per-kernel HIP-event profile (separate pass, not inside the timed region)
-    # per-kernel durations are measured with the chains serialised on ONE stream: with the side streams on, kernels
-    # of different chains share the GPU and a launch's begin-to-end time is not that kernel's own cost
+    # ---- per-kernel HIP-event profile (separate pass, not inside the timed region; events are recorded on the streams the
+    # kernels are launched on).  Durations are measured with the chains serialised on ONE stream: with the side streams
+    # on, kernels of different chains share the GPU and a launch's begin-to-end time is not that kernel's own cost
     raw.set_option(1, 0)
     raw.set_profiling(True)
     nprof = 3
@@ -215,37 +301,52 @@ def main():
         ys = [prof.pop(k) for k in ('ypass_send', 'ypass_recv') if k in prof]
         prof['cpass_y'] = (sum(v[0] for v in ys), sum(v[1] for v in ys))
     tot_ms = sum(v[0] for v in prof.values()) or 1.0
-    dom = max((k for k in prof if kernel_alg_bytes(k, n, word)), key=lambda k: prof[k][0], default=None)
+    cab = class_alg_bytes(a.cfg, n, word, n_ypass) if default_options else {}
+    # rocprofv3 FETCH_SIZE / WRITE_SIZE of the same command, committed under profiles/ by tools/profile.sh and stamped
+    # with the hash of the sources it profiled: used only when it belongs to THIS build (else traffic = null)
+    pmc, pmc_name, stamp = None, None, source_stamp()
+    if n == 256 and a.cfg == 'cfg3' and world == 1:
+        import glob
+        suffix = '' if a.dtype == 'f64' else '_f32'
+        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_traffic_r[0-9][0-9]%s.json' % suffix)), reverse=True):
+            with open(fn) as fh:
+                cand = json.load(fh)
+            if cand.get('source_stamp') == stamp:
+                pmc, pmc_name = cand, os.path.basename(fn)
+                break
+    kernels = {}
+    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        ent = {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof, 'share': round(v[0] / tot_ms, 4)}
+        if cab.get(k):
+            gbs = cab[k] / world / (v[0] / nprof * 1e-3) / 1e9       # per GPU: a rank holds 1/world of every array
+            ent.update(alg_MB_per_eval=round(cab[k] / world / 1e6, 1), achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        if pmc and k in pmc.get('kernels', {}):
+            pk = pmc['kernels'][k]
+            ent['traffic_MB_per_eval'] = round(pk['launches'] * (pk['read_MB'] + pk['write_MB']) / pmc['evaluations'], 1)
+        kernels[k] = ent
+    dom = max((k for k in prof if cab.get(k)), key=lambda k: prof[k][0], default=None)
     roofline = None
-    kernels = {k: {'ms_per_eval': round(v[0] / nprof, 4), 'launches_per_eval': v[1] // nprof,
-                   'share': round(v[0] / tot_ms, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-    pmc = None
-    pmc_name = 'pmc_traffic_r01.json' if a.dtype == 'f64' else 'pmc_traffic_r01_f32.json'
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', pmc_name)
-    if os.path.exists(pmc_path) and n == 256 and a.cfg == 'cfg3' and world == 1:     # counters were collected on this workload
-        with open(pmc_path) as fh:
-            pmc = json.load(fh)
     if dom:
-        # per evaluation: the engine counts its whole-spectrum y passes (fractions for x-range launches), whatever the
-        # launch granularity; the split-derivative GGA chain needs 19 of them for the 23 transforms of the byte model
-        passes = n_ypass if dom == 'cpass_y' else prof[dom][1] / nprof
         launches = prof[dom][1] / nprof
         class_ms = prof[dom][0] / nprof
-        avg_ms = class_ms / launches
-        ach = kernel_alg_bytes(dom, n, word) / world * passes / (class_ms * 1e-3) / 1e9      # per GPU: a rank holds 1/world of a spectrum
-        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': (int(round((pmc['kernels'][dom]['read_MB'] + pmc['kernels'][dom]['write_MB']) * 1e6))
-                                if pmc and dom in pmc.get('kernels', {}) else None),
-                    'launches_per_eval': launches, 'spectrum_passes_per_eval': passes,
-                    'traffic_source': ('profiles/%s: ' % pmc_name + pmc['source']) if pmc else None,
-                    'avg_launch_ms': round(avg_ms, 5), 'alg_bytes_per_launch': kernel_alg_bytes(dom, n, word) / world * passes / launches,
-                    'note': 'launch durations from a profiling pass with the chains serialised on one stream (same as `OFDFT_SIDE_STREAM=0`, the setting of the committed rocprofv3 summary); the timed region overlaps independent chains on side streams'}
+        per_launch = cab[dom] / world / launches
+        ach = kernels[dom]['achieved_GBs']
+        traffic = None
+        if pmc and dom in pmc.get('kernels', {}):
+            pk = pmc['kernels'][dom]
+            traffic = int(round((pk['read_MB'] + pk['write_MB']) * 1e6))
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'launches_per_eval': launches, 'avg_launch_ms': round(class_ms / launches, 5),
+                    'alg_bytes_per_launch': per_launch,
+                    'traffic_source': ('profiles/%s (source stamp %s): %s' % (pmc_name, stamp, pmc['source'])) if traffic else None,
+                    'note': 'the class with the largest share of the evaluation among all kernel classes; launch durations '
+                            'from a profiling pass with the chains serialised on one stream (the setting of the committed '
+                            'rocprofv3 summary); the timed region overlaps independent chains on side streams'}
     alg, R, Cc = algorithmic_bytes(n, a.cfg, word)
     measured_hbm = None
     if pmc:       # rocprofv3 FETCH_SIZE / WRITE_SIZE of every kernel of the committed profile, per evaluation
-        evs = pmc['kernels'].get('chi_grad', {}).get('launches', 12)
-        measured_hbm = sum(k['launches'] * (k['read_MB'] + k['write_MB']) for k in pmc['kernels'].values()) / evs * 1e6
+        measured_hbm = sum(k['launches'] * (k['read_MB'] + k['write_MB']) for k in pmc['kernels'].values()) / pmc['evaluations'] * 1e6
     eval_gbs = alg * (a.steps / dt) / 1e9 / world  # per GPU
     # the box's own streaming ceiling beside the 8 TB/s spec figure: device-to-device copy of 512 MiB, read + write
     cp_a = torch.empty(64 * 1024 * 1024, dtype=torch.double, device=device)
@@ -260,6 +361,7 @@ def main():
     copy_gbs = 10 * 2 * cp_a.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del cp_a, cp_b
 
+    E_tot = sum(E.values())
     out = {
         'metric': 'energy+grad evals/sec', 'value': round(evals_per_s, 3), 'unit': 'evals/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 4),
@@ -273,10 +375,23 @@ def main():
         'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
                           'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'measured_copy_GBs': round(copy_gbs, 1),
                           'measured_hbm_bytes_per_eval': measured_hbm, 'ffts_executed': n_fft,
-                          'kernel_launches': n_launch, 'device_ms_last_eval': round(raw.query(3), 4)},
+                          'kernel_launches': n_launch, 'device_ms_last_eval': round(dev_ms, 4) if dev_ms is not None else None},
         'kernels': kernels,
-        'energy_Ha': sum(E.values()), 'mu': mu,
+        'energy_Ha': E_tot, 'mu': mu, 'source_stamp': stamp,
     }
+    chk = reference_check(n, a.cfg, a.dtype, E_tot, mu)
+    out['reference_check'] = chk
+    if world > 1 and rank == 0 and os.environ.get('OFDFT_BENCH_NO_PARITY') != '1':
+        # the slab-decomposed result against ONE engine on the whole grid of this rank's GPU (outside the timed region)
+        one = Engine((n, n, n), device, dtype=tdtype).set_cell(torch.as_tensor(box)).set_terms(names)
+        E1, mu1, g1 = one.energy_grad_chi(torch.as_tensor(chi_full, dtype=tdtype, device=device), n_elec,
+                                          torch.as_tensor(vext_full, dtype=tdtype, device=device))
+        gs = g1[eng.plan.x_range()]
+        out['parity_vs_single_gpu'] = {
+            'rel_dE': abs(E_tot - sum(E1.values())) / abs(sum(E1.values())), 'rel_dmu': abs(mu - mu1) / abs(mu1),
+            'grad_slab_max_rel': float((g - gs).abs().max() / gs.abs().max())}
+        one.close()
+        del g1, gs
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(a.cpu_sample_grid, n)
         if cb['full']:
@@ -298,6 +413,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and chk is not None and not chk['ok']:
+        sys.stderr.write('bench.py: energy / mu differ from the reference pin beyond %g: %r\n' % (chk['tol'], chk))
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -1,4 +1,6 @@
 """Build recipe for the HIP engine (gfx950 only).  `python -m professad_amd._build` rebuilds in-tree."""
+import contextlib
+import fcntl
 import os
 import subprocess
 import sys
@@ -33,29 +35,54 @@ def _command(extra_flags, out):
     return cmd + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', out]
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout (ranks of a multi-process job may all find the library missing at once)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build(force=False, verbose=True, extra_flags=(), out=None):
     """Compile csrc/*.hip with hipcc (cross-compiles without a GPU) into lib/libofdft_hip.so (fp64) and
     lib/libofdft_hip_f32.so (fp32 build of the same sources); the two compile side by side.
-    `extra_flags` / `out` build ONE experiment variant instead (A/B runs select it with OFDFT_LIB=<path>)."""
+    `extra_flags` / `out` build ONE experiment variant instead (A/B runs select it with OFDFT_LIB=<path>).
+    hipcc writes to a temporary name and the finished file is renamed into place under a file lock, so a concurrent
+    loader never maps a half-written library and concurrent builders do not clobber each other's output."""
     os.makedirs(LIBDIR, exist_ok=True)
     if out is not None:
-        cmd = _command(extra_flags, out)
+        tmp = '%s.tmp.%d' % (out, os.getpid())
+        cmd = _command(extra_flags, tmp)
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        os.replace(tmp, out)
         return out
-    jobs = []
-    # fp32 build: unsuffixed floating literals are fp32 too (no f64 promotion of `0.5 * x` in the fused kernels: +10 %);
-    # fp64 constants that must stay exact are spelled with long-double literals / integer operands in the sources
-    for lib, flags in ((LIB, []), (LIB_F32, ['-DOFDFT_REAL_F32', '-cl-single-precision-constant'])):
-        if force or _stale(lib):
-            cmd = _command(list(extra_flags) + flags, lib)
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in jobs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+    with _build_lock():
+        jobs = []
+        # fp32 build: unsuffixed floating literals are fp32 too (no f64 promotion of `0.5 * x` in the fused kernels: +10 %);
+        # fp64 constants that must stay exact are spelled with long-double literals / integer operands in the sources
+        for lib, flags in ((LIB, []), (LIB_F32, ['-DOFDFT_REAL_F32', '-cl-single-precision-constant'])):
+            if force or _stale(lib):          # re-checked under the lock: another process may just have built it
+                tmp = '%s.tmp.%d' % (lib, os.getpid())
+                cmd = _command(list(extra_flags) + flags, tmp)
+                if verbose:
+                    print(' '.join(cmd), flush=True)
+                jobs.append((cmd, subprocess.Popen(cmd), tmp, lib))
+        err = None
+        for cmd, p, tmp, lib in jobs:
+            if p.wait() != 0:
+                err = err or subprocess.CalledProcessError(p.returncode, cmd)
+                with contextlib.suppress(OSError):
+                    os.remove(tmp)
+            else:
+                os.replace(tmp, lib)
+        if err:
+            raise err
     return LIB
 
 

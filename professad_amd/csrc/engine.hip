@@ -64,6 +64,7 @@ struct ofdft_ctx {
     int fft_count = 0, launch_count = 0;
     double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
     float last_ms = 0.f;
+    bool ms_pending = false;    // ev1 recorded without a host wait (device-resident dist finish): elapsed time read on demand
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
@@ -133,6 +134,12 @@ int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
             return fail(ctx, OFDFT_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+
+// run the rest of the enclosing ABI function on the context's device, restoring the caller's device on return
+#define OFDFT_ON_DEVICE(ctx, dev)                                                                   \
+    DeviceScope device_scope_(dev);                                                                 \
+    if (device_scope_.err != hipSuccess)                                                            \
+        return fail(ctx, OFDFT_EHIP, "cannot select device %d: %s", (dev), hipGetErrorString(device_scope_.err))
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
 
@@ -1201,7 +1208,8 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     const double defaults[OFDFT_NPARAMS] = {kFiveSixths, kFiveSixths, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, (double)27 / 10, 1.0, 0.0, (double)40 / 27,
                                             0.0, 0.0, 0.0, 1.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
-    hipError_t e = hipSetDevice(device_id);
+    DeviceScope device_scope_(device_id);
+    hipError_t e = device_scope_.err;
     // partial-sum rows: the pointwise kernels use <= kRedBlocks blocks, the z kernels one block per row group
     c->partial_rows = kRedBlocks;
     if (c->fast && c->n2 / 2 <= 512) {
@@ -1237,7 +1245,7 @@ int ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_
 
 void ofdft_destroy(ofdft_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope device_scope_(c->device);
     graph_drop(c);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
@@ -1314,6 +1322,8 @@ int ofdft_set_terms(ofdft_ctx* c, uint32_t mask, const double* params, int npara
 
 int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, double* E_terms, void* dEdn, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (!c) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
     if (int rc = begin_call(c, st)) return rc;
     if (!den || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
@@ -1422,6 +1432,8 @@ extern "C" {
 int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, double n_electrons, double* E_terms,
                           double* mu_host, void* grad, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (!c) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
     if (int rc = begin_call(c, st)) return rc;
     if (!chi || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
@@ -1468,7 +1480,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
 int ofdft_rfftn(ofdft_ctx* c, const void* real_dev, void* spec_dev, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!c || !real_dev || !spec_dev) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     cplx* s;
     if (int rc = spec_ws(c, "io", &s)) return rc;
     if (int rc = rfftn_internal(c, (const real*)real_dev, s, st)) return rc;
@@ -1483,7 +1495,7 @@ int ofdft_rfftn(ofdft_ctx* c, const void* real_dev, void* spec_dev, void* stream
 int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!c || !real_dev || !spec_dev) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     cplx* s;
     if (int rc = spec_ws(c, "io", &s)) return rc;
     OFDFT_LAUNCH(c, st, "spec_to_internal", spec_to_internal_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0,
@@ -1499,7 +1511,7 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
 int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* local_sum, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!c || !x_local) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     if (local_sum) return device_sum(c, (const real*)x_local, square != 0, local_sum, st);
     // device-resident form: the local sum goes to scalars[15] (ofdft_dist_scalars), no host synchronisation
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
@@ -1524,6 +1536,8 @@ int ofdft_dist_scalars(ofdft_ctx* c, void** scalars_dev) {
 int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double cscale, double nel_global,
                      const void* vext_local, void* v_out_local, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (!c) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
     if (int rc = begin_call(c, st)) return rc;
     if (!src_local) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
@@ -1558,7 +1572,7 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
                      void** recvbuf) {
     hipStream_t st = (hipStream_t)stream;
     if (!c || !bytes_per_peer || !sendbuf || !recvbuf || chain < 0 || chain > 1) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     ZRun& r = zrun(c);
     if (stage != r.stage[chain] + 1 || stage < 1 || stage > 4 || (chain == 1 && r.stage[0] < 1))
         return fail(c, OFDFT_ESTATE, "stage %d of chain %d out of order", stage, chain);
@@ -1588,12 +1602,14 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
 int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!c) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     ZRun& r = zrun(c);
     if (r.stage[0] != 4 || r.stage[1] != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4 of both chains");
     int rc;
     if ((rc = zstage5(c, local_sums, st))) return rc;
     if (!local_sums) {        // device-resident form: scalars[0..10] hold the local sums, nothing waits here
+        HIP_TRY(c, hipEventRecord(c->ev1, st));
+        c->ms_pending = true;
         HIP_TRY(c, hipGetLastError());
         if (c->profiling) {   // profiling pass only: the event times are read back, which needs the stream drained
             HIP_TRY(c, hipStreamSynchronize(st));
@@ -1615,7 +1631,7 @@ int ofdft_dist_chi_grad(ofdft_ctx* c, const void* chi_local, const void* v_local
                         double mu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!c || !chi_local || !v_local || !grad_local) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi_local,
                  (const real*)v_local, (real*)grad_local, c->npts, cscale * 2.0 * c->dV,
                  cscale > 0.0 ? (const acc_t*)nullptr : (const acc_t*)c->d_scal, 2.0 * c->dV, mu);
@@ -1709,7 +1725,15 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_FFT_COUNT: *out = c->fft_count; return OFDFT_OK;
         case OFDFT_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; return OFDFT_OK;
         case OFDFT_Q_FAST_PATH: *out = c->fast ? 1.0 : 0.0; return OFDFT_OK;
-        case OFDFT_Q_KERNEL_MS: *out = c->last_ms; return OFDFT_OK;
+        case OFDFT_Q_KERNEL_MS:
+            if (c->ms_pending) {       // begin .. finish of the last slab-decomposed evaluation (this rank's stream)
+                OFDFT_ON_DEVICE(c, c->device);
+                HIP_TRY(c, hipEventSynchronize(c->ev1));
+                HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+                c->ms_pending = false;
+            }
+            *out = c->last_ms;
+            return OFDFT_OK;
         case OFDFT_Q_LAUNCH_COUNT: *out = c->launch_count; return OFDFT_OK;
         case OFDFT_Q_YPASS_COUNT: *out = c->ypass_count; return OFDFT_OK;
         case OFDFT_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; return OFDFT_OK;

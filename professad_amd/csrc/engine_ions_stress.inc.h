@@ -19,7 +19,7 @@ static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int ni
     if (nions < 1 || ntab < 2) return fail(c, OFDFT_EINVAL, "need at least one ion and two table points");
     if (pme_order != 0 && (pme_order < 2 || pme_order > kMaxPmeOrder || (pme_order & 1)))
         return fail(c, OFDFT_EINVAL, "Requires even order n >= 2 (<= %d)", kMaxPmeOrder);       // ion_utils.py:116
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     p.frac.resize(3 * (size_t)nions);
     p.cart.resize(3 * (size_t)nions);
     for (int a = 0; a < nions; ++a) {
@@ -205,6 +205,8 @@ void sym_store(double* out9, const double* c6, double diag) {
 // ion-electron entry stays zero (its potential depends on the ions: ofdft_ion_electron_stress).
 int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (!c) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
     if (int rc = begin_call(c, st)) return rc;
     if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
@@ -379,7 +381,7 @@ int ofdft_ion_ion(ofdft_ctx* c, const double* frac_host, const double* charges_h
     hipStream_t st = (hipStream_t)stream;
     if (!c || !frac_host || !charges_host || !E_host || nions < 1) return OFDFT_EINVAL;
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    HIP_TRY(c, hipSetDevice(c->device));
+    OFDFT_ON_DEVICE(c, c->device);
     const double* B = c->box;
     // interplanar spacings h_d = 1 / |row d of inv(B^T)| = vol / |cross of the other two lattice vectors|
     double h[3];

@@ -244,8 +244,23 @@ int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
     return n;
 }
 
+// sized by what the active terms send at most across one geometry boundary (the buffers only ever grow): chain 0 carries
+// {n^, (sqrt n)^} -> {vH, D_a n | grad n (3), lap} -> flux (1 | 3) -> divergence (1); chain 1 the Wang-Teter powers (1-2) and / or
+// the six WGC99 spectra
 int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * (chain == 0 ? 5 : 8);
+    const unsigned m = c->mask;
+    const bool g = m & kGgaAny, h = m & OFDFT_HARTREE, vw = m & OFDFT_VW;
+    const int ng = g ? (c->gga_split ? 1 : 3) : 0;
+    int narr;
+    if (chain == 0) {
+        narr = std::max(((h || g) ? 1 : 0) + (vw ? 1 : 0), (h ? 1 : 0) + ng + (vw ? 1 : 0));
+        narr = std::max(narr, ng);
+    } else {
+        narr = ((m & OFDFT_WT_NL) ? (c->params[OFDFT_P_WT_ALPHA] != c->params[OFDFT_P_WT_BETA] ? 2 : 1) : 0) +
+               ((m & OFDFT_WGC99_NL) ? 6 : 0);
+    }
+    if (narr < 1) narr = 1;
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
     if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
     return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
 }
@@ -748,8 +763,7 @@ ZRun& zrun(ofdft_ctx* c) {
 }
 
 int begin_call(ofdft_ctx* c, hipStream_t st) {
-    if (!c) return OFDFT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c) return OFDFT_EINVAL;      // (the ABI function that called this holds the DeviceScope)
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
     c->fft_count = 0;
     c->launch_count = 0;
@@ -761,6 +775,7 @@ int end_call(ofdft_ctx* c, hipStream_t st) {
     HIP_TRY(c, hipEventRecord(c->ev1, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    c->ms_pending = false;
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);
     return 0;

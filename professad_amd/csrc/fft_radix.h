@@ -12,6 +12,26 @@
 
 namespace ofdft {
 
+// Every C-ABI entry point works on its context's device and leaves the calling thread's current device as it found it
+// (torch keeps its own idea of the current device; an engine on another GPU must not change it behind torch's back).
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // The arithmetic type of the grid data.  The library is built once per precision (FFTW-style): the default build is
 // fp64 (the reference's precision, parity 1e-8 Ha/atom), -DOFDFT_REAL_F32 builds the fp32 variant of the same kernels
 // (BASELINE config 5).  Energy sums, their partials and every scalar derived from them are fp64 in both (acc_t).

@@ -66,7 +66,8 @@ int ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history, int de
     o->n = n_local;
     o->hist = history;
     o->device = device_id;
-    hipError_t e = hipSetDevice(device_id);
+    DeviceScope device_scope_(device_id);
+    hipError_t e = device_scope_.err;
     const size_t vb = sizeof(real) * (size_t)n_local;
     for (int i = 0; i <= history && e == hipSuccess; ++i) {
         e = hipMalloc((void**)&o->S[i], vb);
@@ -88,7 +89,7 @@ int ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history, int de
 
 void ofdft_lbfgs_destroy(ofdft_lbfgs* o) {
     if (!o) return;
-    (void)hipSetDevice(o->device);
+    DeviceScope device_scope_(o->device);
     for (int i = 0; i <= kLbfgsMaxHist; ++i) {
         if (o->S[i]) (void)hipFree(o->S[i]);
         if (o->Y[i]) (void)hipFree(o->Y[i]);
@@ -106,7 +107,8 @@ const char* ofdft_lbfgs_last_error(const ofdft_lbfgs* o) { return o ? o->err : "
 int ofdft_lbfgs_dots(ofdft_lbfgs* o, const void* g_dev, double* dots_host, int* npairs, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!o || !g_dev || !dots_host || !npairs) return OFDFT_EINVAL;
-    L_TRY(o, hipSetDevice(o->device));
+    DeviceScope device_scope_(o->device);
+    L_TRY(o, device_scope_.err);
     const int K = o->count;
     const int ns = lbfgs_nscal(K);
     const LbfgsVecs v = logical(o, K);
@@ -156,7 +158,8 @@ int ofdft_lbfgs_update(ofdft_lbfgs* o, const double* coef_s, const double* coef_
     hipStream_t st = (hipStream_t)stream;
     if (!o || !x_dev || !g_dev || !abs_step_sum || (o->count > 0 && (!coef_s || !coef_y))) return OFDFT_EINVAL;
     if (o->pending) return lfail(o, OFDFT_ESTATE, "ofdft_lbfgs_commit must follow ofdft_lbfgs_dots");
-    L_TRY(o, hipSetDevice(o->device));
+    DeviceScope device_scope_(o->device);
+    L_TRY(o, device_scope_.err);
     const int K = o->count;
     const LbfgsVecs v = logical(o, K);
     LbfgsCoef c{};

@@ -162,11 +162,15 @@ class Engine:
         (get_stress semantics, functional_tools.py:73-101); the ion-electron entry is zero (see ions.ion_electron_stress)"""
         den = self._grid_tensor(den, 'den')
         if self.dtype != torch.double:       # stress is fp64 work: widen the density and use the fp64 sibling engine
+            if self._box_key is None or self._terms_key is None:
+                raise RuntimeError('Engine.stress: set_cell and set_terms must be called first')
             sib = engine_for(self.global_shape, self.device)
-            sib._box_key, sib._terms_key = None, None
-            sib.lib.ofdft_set_cell(sib._ctx, np.frombuffer(self._box_key, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double)))
-            sib.lib.ofdft_set_terms(sib._ctx, self._terms_key[0],
-                                    np.frombuffer(self._terms_key[1], dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double)), N.NPARAMS)
+            sib._box_key, sib._terms_key = None, None          # the sibling is shared: always (re)configure it
+            sib._check(sib.lib.ofdft_set_cell(sib._ctx, np.frombuffer(self._box_key, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))),
+                       'ofdft_set_cell')
+            sib._check(sib.lib.ofdft_set_terms(sib._ctx, self._terms_key[0],
+                                               np.frombuffer(self._terms_key[1], dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double)),
+                                               N.NPARAMS), 'ofdft_set_terms')
             return sib.stress(den.double())
         buf = (C.c_double * (N.NTERMS * 9))()
         self._check(self.lib.ofdft_stress(self._ctx, C.c_void_p(den.data_ptr()), buf, self._stream()), 'ofdft_stress')

@@ -27,21 +27,28 @@ def recpot_table(raw, k_max):
     return ks, v, z
 
 
+def recpot_fields(path):
+    """(raw table values [file units], k_max [1/angstrom]) of a CASTEP-style .recpot file.
+
+    Layout after the comment block (ion_utils.py:49-73 reads the same fields): one line of two integers, one line with
+    k_max, then the table in rows of three numbers; a trailing row with fewer than three entries (the 1000 marker) is
+    not part of the table."""
+    with open(path, 'r') as fh:
+        text = fh.read()
+    head, sep, tail = text.partition('END COMMENT')
+    if not sep:
+        raise ValueError('%s: no END COMMENT marker' % path)
+    rows = [ln.split() for ln in tail.splitlines()[1:]]       # [0] is the rest of the marker line
+    rows = [r for r in rows if r]
+    k_max = float(rows[1][0])                                 # rows[0] = the two integers
+    table = [x for r in rows[2:] if len(r) == 3 for x in r]
+    return np.asarray(table, dtype=np.float64), k_max
+
+
 def read_recpot(path):
-    """Parse a CASTEP-style .recpot file -> (ks, v, z) as `recpot_table` (ion_utils.py:49-73)."""
-    vals = []
-    with open(path, 'r') as f:
-        for line in f:
-            if 'END COMMENT' in line:
-                break
-        f.readline()                                  # the '3     5' line
-        k_max = float(f.readline()) * BOHR
-        for line in f:
-            parts = line.split()
-            if len(parts) == 3:
-                vals += parts
-    raw = np.asarray(vals, dtype=np.float64) * POT_CONV
-    return recpot_table(raw, k_max)
+    """Parse a CASTEP-style .recpot file -> (ks, v, z) as `recpot_table` (units of ion_utils.py:11-13,62-66)."""
+    raw, k_max = recpot_fields(path)
+    return recpot_table(raw * POT_CONV, k_max * BOHR)
 
 
 def _f64(engine):

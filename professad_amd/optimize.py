@@ -130,8 +130,11 @@ class HipLbfgsBackend:
         self.dtype = dtype
         self.lib = N.load(N.F64 if dtype == torch.double else N.F32)      # the vectors take the library's precision
         self.device = torch.device(device)
+        # the device index is resolved exactly as Engine does: a bare 'cuda' means torch's current device
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device('cuda', idx)
         self._h = C.c_void_p(0)
-        rc = self.lib.ofdft_lbfgs_create(C.byref(self._h), int(n), int(history), self.device.index or 0)
+        rc = self.lib.ofdft_lbfgs_create(C.byref(self._h), int(n), int(history), idx)
         if rc != 0:
             raise RuntimeError('ofdft_lbfgs_create failed with code %d' % rc)
         self._buf = (C.c_double * (6 * 8 + 7))()
@@ -316,6 +319,10 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     'torch' (`FixedStepLBFGS` on torch tensors; single GPU only).
     With an fp32 engine the energies carry ~1e-6 relative round-off: choose `ntol` above that noise (the default 1e-7 eV
     suits fp64) or the loop runs to `n_maxiter`."""
+    if conv_target not in ('dE', 'dEdchi', 'euler'):
+        raise ValueError("Only 'dE', 'dEdchi' or 'euler' recognized as 'conv_target' argument")       # system.py:889-890
+    if conv_target != 'dE' and volume is None:
+        raise ValueError("conv_target=%r needs `volume` (the cell volume fixes dV)" % conv_target)
     comm = getattr(engine, 'comm', None)                    # DistEngine
     multi = comm is not None and comm.active
     if comm is not None:
@@ -371,7 +378,14 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         history.append((it, E, dE, dEdchi))
         if verbose:
             print('%5d %16.8f %12.4e %12.4e' % history[-1])
-        stop = abs(dE) if conv_target == 'dE' else dEdchi
+        if conv_target == 'euler':            # max |mu - dE/dn| at the current density (system.py:377-412)
+            c2 = n_elec / (gsum(float((chi.double() * chi.double()).sum())) / npts_global * volume)
+            den_now = (c2 * chi * chi).to(dtype)
+            _, v_now = engine.energy_potential(den_now, vext)
+            mu_now = gsum(float((v_now.double() * den_now.double()).sum())) * dV / n_elec
+            stop = gmax(float((mu_now - v_now.double()).abs().max()))
+        else:
+            stop = abs(dE) if conv_target == 'dE' else dEdchi
         if it > 5:
             conv = conv + 1 if stop < ntol else 0
         if conv == n_conv_cond_count:

@@ -83,3 +83,28 @@ def perturbed(den, box, n_elec, seed=20240601, rel=1e-3):
     out = den * (1.0 + rel * acc)
     vol = abs(np.linalg.det(box))
     return out * (n_elec / (out.mean() * vol))
+
+
+def bench_inputs(n, golden_dir=None, rank=0):
+    """Inputs of the BASELINE workload on an n^3 grid (SURVEY.md §8d option A) -> box, chi, v_ext, N_e, description.
+
+    n a multiple of 32 and the config-1 fixture present: the reference's converged fcc-Al 32^3 density tiled (n/32)^3
+    times plus the seeded low-|k| perturbation; otherwise the full-spectrum random density (option B)."""
+    import os
+    fx = os.path.join(golden_dir, 'cfg1_fccAl_32.npz') if golden_dir else None
+    if fx and os.path.exists(fx) and n % 32 == 0:
+        d = np.load(fx)
+        r = n // 32
+        box = d['box'] * r
+        n_elec = float(d['n_elec']) * r ** 3
+        den = tile_periodic(d['den'], n)
+        vext = tile_periodic(d['vext'], n)
+        den = perturbed(den, box, n_elec, seed=20240601 + rank)
+        src = 'converged fcc-Al 32^3 fixture tiled %d^3 + 1e-3 low-|k| perturbation' % r
+    else:
+        box = cubic_cell(n)
+        den = random_density((n, n, n), seed=1234 + rank)
+        vext = random_potential((n, n, n), seed=77)
+        n_elec = float(round(den.mean() * abs(np.linalg.det(box))))
+        src = 'n0(1+0.2U) random density'
+    return box, np.sqrt(den), vext, n_elec, src

@@ -1,6 +1,8 @@
-"""Worker of the multi-rank tests: `python dist_worker.py <case> <outfile>` with RANK/WORLD_SIZE/MASTER_* set.
-All ranks share cuda:0 (gloo backend, host-staged exchange) so the slab-decomposed path -- HIP kernels, pack /
-un-pack, stage sequencing, collectives -- is exercised with several ranks on a one-GPU box."""
+"""Worker of the multi-rank tests: `python dist_worker.py <case> <outfile> [f64|f32]` with RANK/WORLD_SIZE/MASTER_* set.
+Default transport: all ranks share cuda:0 (gloo backend, host-staged exchange) so the slab-decomposed path -- HIP
+kernels, pack / un-pack, stage sequencing, collectives -- is exercised with several ranks on a one-GPU box.
+OFDFT_TEST_BACKEND=nccl: one GPU per rank (cuda:LOCAL_RANK) and the product transport, RCCL all-to-alls on the engine's
+own exchange buffers (tests/test_dist_gpu.py enables that case when the box has at least two GPUs)."""
 import json
 import os
 import sys
@@ -27,9 +29,25 @@ def main():
     shape = tuple(int(x) for x in sys.argv[1].split('x'))
     out = sys.argv[2]
     dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == 'f32') else torch.double
-    dist.init_process_group('gloo')
+    backend = os.environ.get('OFDFT_TEST_BACKEND', 'gloo')
+    if backend == 'nccl':
+        dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', device_id=dev)
+    else:
+        dev = torch.device('cuda:0')
+        dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device('cuda:0')
+
+    def gather_slabs(x):
+        """every rank's slab of x -> list of host tensors"""
+        if backend == 'nccl':
+            full = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=dev)
+            dist.all_gather_into_tensor(full, x.contiguous())
+            return list(full.cpu())
+        parts = [torch.empty(tuple(x.shape), dtype=x.dtype) for _ in range(world)]
+        dist.all_gather(parts, x.cpu())
+        return parts
     box = cases.make_cell(('tri', 1.3))
     den = synth.random_density(shape, seed=41)
     vext = synth.random_potential(shape, seed=42)
@@ -44,10 +62,7 @@ def main():
         eng.set_terms(names)
         E, mu, g = eng.energy_grad_chi(t(plan.scatter(chi)), n_elec, t(plan.scatter(vext)))
         E2, v = eng.energy_potential(t(plan.scatter(den)), t(plan.scatter(vext)))
-        parts_g = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
-        parts_v = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
-        dist.all_gather(parts_g, g.cpu())
-        dist.all_gather(parts_v, v.cpu())
+        parts_g, parts_v = gather_slabs(g), gather_slabs(v)
         if rank == 0:
             ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(names)
             Er, mur, gr = ref.energy_grad_chi(t(chi), n_elec, t(vext))
@@ -91,8 +106,7 @@ def main():
         vol = abs(np.linalg.det(box))
         eng.set_terms(names)
         res = optimize_density(eng, n_elec, t(plan.scatter(vext)), volume=vol, n_maxiter=8)
-        parts = [torch.empty(plan.local_shape, dtype=dt) for _ in range(world)]
-        dist.all_gather(parts, res['chi'].cpu())
+        parts = gather_slabs(res['chi'])
         if rank == 0:
             ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(names)
             rr = optimize_density(ref, n_elec, t(vext), volume=vol, n_maxiter=8)

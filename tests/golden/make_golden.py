@@ -18,6 +18,7 @@ Fixtures written to tests/golden/:
   big_scalars.json        (--big)  64^3/128^3 scalars: E per cfg, potential probe statistics
   cfg1_fccAl_32.npz       (--cfg1) converged config-1 density, v_ext, E, iteration count
   huge_scalars.json       (--huge) 256^3 cfg3 scalars (needs ~16 GB RSS, minutes)
+  bench_scalars.json      (--bench [--bench-grid N]) the bench.py workload itself: E per term, closure E, mu, chi.grad probes
 """
 import argparse
 import json
@@ -232,9 +233,12 @@ if __name__ == '__main__':
     ap.add_argument('--small', action='store_true')
     ap.add_argument('--ions', action='store_true')
     ap.add_argument('--stress', action='store_true')
+    ap.add_argument('--recpots', action='store_true')
+    ap.add_argument('--bench', action='store_true')
+    ap.add_argument('--bench-grid', type=int, default=256)
     a = ap.parse_args()
     torch.set_num_threads(8)
-    if a.small or not (a.big or a.cfg1 or a.huge or a.ions or a.stress):
+    if a.small or not (a.big or a.cfg1 or a.huge or a.ions or a.stress or a.recpots or a.bench):
         gen_wavevecs()
         for c in cases.PER_TERM_CASES:
             gen_terms(c)
@@ -248,6 +252,15 @@ if __name__ == '__main__':
         gen_big([256], 'huge_scalars.json', ['cfg3'])
 
 
+def _recpot_table(path, IU):
+    """raw table [Ha bohr^3] and k_max [1/bohr] of a .recpot DATA file, in the units interpolate_recpot uses (before the
+    Coulomb tail is added): the product's own reader supplies the fields, the reference module the constants."""
+    from professad_amd.ions import recpot_fields
+    raw, k_max = recpot_fields(path)
+    return raw * IU.pot_conv_factor, k_max * IU.bohr
+
+
+
 def gen_ions():
     """Ionic potential fixtures (ion_utils.py:49-286, system.py:183-194): the parsed al.gga recpot table (data file of
     the reference's tests), the reference's interpolation of it, exact and PME structure factors and v_ext."""
@@ -255,18 +268,7 @@ def gen_ions():
     from professad.crystal_tools import get_cell
     os.chdir('/root/reference/tests')
     path = 'potentials/al.gga.recpot'
-    # parsed table exactly as interpolate_recpot builds it (:62-73)
-    pot = []
-    with open(path) as f:
-        for line in f:
-            if 'END COMMENT' in line:
-                break
-        f.readline()
-        k_max = float(f.readline()) * IU.bohr
-        for line in f:
-            if len(line.split()) == 3:
-                pot += line.split()
-    pot = np.asarray(pot, dtype=np.float64) * IU.pot_conv_factor
+    pot, k_max = _recpot_table(path, IU)
     out = {'recpot_raw': pot, 'recpot_kmax': np.float64(k_max), 'z': np.float64(IU.get_ion_charge(path))}
     # case A: fcc-Al conventional cell, 32^3 (config 1) -- exact and PME orders 4, 10
     box_a, frac = get_cell('fcc-c', vol_per_atom=16.8, coord_type='fractional')
@@ -366,17 +368,8 @@ def gen_recpots():
     import professad.ion_utils as IU
     out = {}
     for tag, path in (('al', '/root/reference/tests/potentials/al.gga.recpot'), ('li', '/root/reference/tests/potentials/li.gga.recpot')):
-        pot = []
-        with open(path) as f:
-            for line in f:
-                if 'END COMMENT' in line:
-                    break
-            f.readline()
-            k_max = float(f.readline()) * IU.bohr
-            for line in f:
-                if len(line.split()) == 3:
-                    pot += line.split()
-        out[tag + '_raw'] = np.asarray(pot, dtype=np.float64) * IU.pot_conv_factor
+        pot, k_max = _recpot_table(path, IU)
+        out[tag + '_raw'] = pot
         out[tag + '_kmax'] = np.float64(k_max)
     np.savez_compressed(os.path.join(HERE, 'recpots.npz'), **out)
     print('recpots.npz')
@@ -384,3 +377,47 @@ def gen_recpots():
 
 if __name__ == '__main__' and '--recpots' in sys.argv:
     gen_recpots()
+
+
+def gen_bench(n=256):
+    """Reference values of the BENCH workload itself (bench.py: synth.bench_inputs(n), cfg3 terms): per-term energies,
+    the closure's E, mu = sum(v n) dV / N_e and probe statistics of chi.grad (system.py:830-838,850-851)."""
+    box, chi, vext, n_elec, src = cases.synth.bench_inputs(n, HERE)
+    terms, _ = reference_terms(t(vext))
+    names = cases.CONFIGS['cfg3']
+    tb, tc = t(box), t(chi)
+    t0 = time.time()
+    Ec, g = closure_outputs(terms, names, tb, tc, n_elec)
+    dt = time.time() - t0
+    vol = abs(np.linalg.det(box))
+    den = (n_elec / (np.mean(chi * chi) * vol)) * chi * chi
+    td = t(den)
+
+    def fsum(b, d):
+        E = torch.zeros((1,), dtype=DT)
+        for nm in names:
+            E = E + terms[nm](b, d)
+        return E
+    v = T.get_functional_derivative(tb, td.clone(), fsum).detach().numpy()
+    mu = float(np.sum(v * den) * (vol / den.size) / n_elec)
+    per = {nm: float(terms[nm](tb, td).item()) for nm in names}
+    res = {'cfg3_%d' % n: dict(E=Ec, E_terms=per, mu=mu, grad=cases.probe_stats(g), n_elec=n_elec, density=src,
+                               input_checksum=cases.checksum(chi[:8, :8, :8], vext[:8, :8, :8]),
+                               seconds_closure_first_call=dt)}
+    fn = os.path.join(HERE, 'bench_scalars.json')
+    old = {}
+    if os.path.exists(fn):
+        with open(fn) as fh:
+            old = json.load(fh)
+    old.update(res)
+    with open(fn, 'w') as fh:
+        json.dump(old, fh, indent=1)
+    print('bench_scalars.json', n, Ec, mu, '%.1fs' % dt)
+
+
+if __name__ == '__main__' and '--bench' in sys.argv:
+    torch.set_num_threads(8)
+    _n = [int(x.split('=')[1]) for x in sys.argv if x.startswith('--bench-grid=')]
+    if '--bench-grid' in sys.argv:
+        _n = [int(sys.argv[sys.argv.index('--bench-grid') + 1])]
+    gen_bench(_n[0] if _n else 256)

@@ -17,23 +17,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world,shape,dtype', [(1, '16x16x32', 'f64'), (2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'),
-                                               (2, '64x32x128', 'f64'), (2, '32x32x32', 'f32'), (4, '16x64x32', 'f32')])
-def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
-    port = _free_port()
-    out = str(tmp_path / 'res.json')
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), shape, out, dtype], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = []
-    for p in procs:
-        o, _ = p.communicate(timeout=240)
-        logs.append(o.decode(errors='replace')[-2000:])
-    assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)
-    res = json.load(open(out))
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # does not initialise the GPU in this (parent) process
+
+
+def _check_worker_results(res, dtype):
     if dtype == 'f32':      # fp32 build: slabs against one fp32 engine differ by fp32 round-off only (tests/test_gpu_f32.py)
         for cfg, w in res.items():
             if cfg == 'opt':
@@ -53,6 +42,45 @@ def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
         assert w['dE'] < 1e-12 and w['dE2'] < 1e-12 and w['dmu'] < 1e-12, (cfg, w)
         assert w['dg'] < 1e-12 and w['dv'] < 1e-12, (cfg, w)
         assert w['ffts'] == w['ffts_ref'], (cfg, w)
+
+
+def _run_workers(world, shape, dtype, out, extra_env=None, timeout=240):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), shape, out, dtype], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:               # exactly the processes started here
+                q.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors='replace')[-2000:])
+    assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)
+    return json.load(open(out))
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason='the RCCL transport needs one GPU per rank (>= 2 GPUs on the box)')
+@pytest.mark.parametrize('shape,dtype', [('64x64x64', 'f64'), ('256x256x256', 'f64'), ('64x64x64', 'f32')])
+def test_slab_decomposed_over_rccl_matches_single_gpu(shape, dtype, tmp_path):
+    """The product transport: one process per GPU, `nccl` (= RCCL) all-to-alls on the engine's own exchange buffers
+    (raw-pointer tensors), two overlapped chains, device-resident scalars -- against one engine on rank 0's GPU.
+    Runs wherever the box has >= 2 GPUs (a one-GPU box cannot host two RCCL ranks)."""
+    world = 2 if _gpu_count() < 4 else 4
+    res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_BACKEND': 'nccl'}, timeout=600)
+    _check_worker_results(res, dtype)
+
+
+@pytest.mark.parametrize('world,shape,dtype', [(1, '16x16x32', 'f64'), (2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'),
+                                               (2, '64x32x128', 'f64'), (2, '32x32x32', 'f32'), (4, '16x64x32', 'f32')])
+def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
+    res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'))
+    _check_worker_results(res, dtype)
 
 
 @pytest.mark.parametrize('nranks,shape', [(8, (32, 64, 16)), (8, (64, 64, 64)), (8, (256, 256, 256))])

@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- pyt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o run -- python3 $REPO/bench.py --steps 8 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o run -- python3 $REPO/bench.py --steps 8 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/write.log 2>&1
 cd $REPO
-python3 tools/rocprof_summary.py $OUT/stats $OUT/fetch $OUT/write --json $OUT/pmc_traffic.json > $OUT/summary.md
+STAMP=$(python3 -c 'import bench; print(bench.source_stamp())')
+python3 tools/rocprof_summary.py $OUT/stats $OUT/fetch $OUT/write --json $OUT/pmc_traffic.json --stamp $STAMP --evaluations 12 > $OUT/summary.md
 # keep only the small artefacts (the raw traces are large)
 rm -rf $OUT/stats $OUT/fetch $OUT/write

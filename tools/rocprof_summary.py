@@ -48,10 +48,16 @@ def load_counter(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-CLASSES = [('cpass_kernel', 'cpass_y'), ('MixWgc', 'xfused_wgc'), ('MixDiv', 'xfused_div'), ('MixDensity', 'xfused_n'),
-           ('MixScale<1>', 'xfused_lap'), ('MixScale<2>', 'xfused_lind'), ('zi_combine_kernel', 'zi_combine'),
-           ('zpbe_kernel', 'zpbe'), ('zf_powers_kernel', 'zf_powers'), ('zf_density_kernel', 'zf_density'),
-           ('chi_grad_kernel', 'chi_grad'), ('sum_kernel', 'sum')]
+# kernel symbol fragment -> the engine's profiling class (the names bench.py's `kernels` table uses)
+CLASSES = [('cpass_kernel', 'cpass_y'), ('yderiv_kernel', 'yderiv'), ('ypass_xchg_kernel', 'cpass_y'),
+           ('MixWgc', 'xfused_wgc'), ('MixDiv', 'xfused_div'), ('MixDerivA', 'xfused_div'), ('MixDensity', 'xfused_n'),
+           ('MixScale<1>', 'xfused_lap'), ('MixScale<2>', 'xfused_lind'), ('xw_kernel', 'xfused_wgc'),
+           ('zi_combine_kernel', 'zi_combine'), ('zi_wgc_kernel', 'zi_wgc'), ('zpbe2_kernel', 'zpbe'), ('zpbe_kernel', 'zpbe'),
+           ('zf_powers_kernel', 'zf_powers'), ('zf_density_kernel', 'zf_density'), ('chi_grad_kernel', 'chi_grad'),
+           ('sum_kernel', 'sum'), ('wgc_table_kernel', 'wgc_table'), ('reduce_partials_kernel', 'reduce'),
+           ('closure_scale_kernel', 'reduce'), ('axpy_kernel', 'reduce')]
+# not engine kernels: runtime copies, torch's own kernels in bench.py's copy-bandwidth probe
+FOREIGN = ('__amd_rocclr', 'at::native', 'elementwise_kernel', 'vectorized_elementwise')
 
 
 def klass(name):
@@ -62,10 +68,19 @@ def klass(name):
 
 
 def main():
-    json_out = None
+    json_out = stamp = None
+    evaluations = 12
     if '--json' in sys.argv:
         i = sys.argv.index('--json')
         json_out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    if '--stamp' in sys.argv:          # hash of the native sources the profiled library was built from (bench.source_stamp)
+        i = sys.argv.index('--stamp')
+        stamp = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+    if '--evaluations' in sys.argv:    # closure evaluations the profiled command ran (warm-up + timed + profiled)
+        i = sys.argv.index('--evaluations')
+        evaluations = int(sys.argv[i + 1])
         del sys.argv[i:i + 2]
     stats = sys.argv[1]
     fetch = load_counter(sys.argv[2], 'FETCH_SIZE') if len(sys.argv) > 3 else {}
@@ -74,8 +89,14 @@ def main():
     for name, grid, ns in load_trace(stats):
         agg[(name, grid)].append(ns)
     tot = sum(sum(v) for v in agg.values())
-    print('| kernel | grid | launches | avg us | share | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | traffic GB/s |')
-    print('|---|---|---|---|---|---|---|---|')
+    # every kernel with a share above 0.5 % must belong to a class: an unclassified one would silently drop out of the
+    # per-evaluation byte sums
+    lost = [(name, 100.0 * sum(v) / tot) for (name, grid), v in agg.items()
+            if klass(name) is None and not any(f in name for f in FOREIGN) and sum(v) / tot > 0.005]
+    if lost:
+        sys.exit('rocprof_summary: unclassified kernels above 0.5 %% of the run: %r -- add them to CLASSES' % lost)
+    print('| kernel | class | grid | launches | avg us | share | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | traffic GB/s |')
+    print('|---|---|---|---|---|---|---|---|---|')
     per_class = defaultdict(lambda: [0, 0.0, 0.0, 0.0])       # launches, ns, read MB, write MB (launch-weighted sums)
     for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         avg = sum(v) / len(v)
@@ -91,11 +112,15 @@ def main():
         rd_mb = 2 * rd * 1024 / 1e6 if rd is not None else None
         wr_mb = wr * 1024 / 1e6 if wr is not None else None
         gbs = (rd_mb + wr_mb) * 1e6 / (avg * 1e-9) / 1e9 if rd_mb is not None and wr_mb is not None else None
-        print('| %s | %d | %d | %.1f | %.1f%% | %s | %s | %s |' % (
-            name, grid, len(v), avg / 1e3, 100.0 * sum(v) / tot,
+        print('| %s | %s | %d | %d | %.1f | %.1f%% | %s | %s | %s |' % (
+            name, c or '-', grid, len(v), avg / 1e3, 100.0 * sum(v) / tot,
             '%.1f' % rd_mb if rd_mb is not None else '-', '%.1f' % wr_mb if wr_mb is not None else '-',
             '%.0f' % gbs if gbs is not None else '-'))
-
+    if per_class:
+        total_mb = sum(v[2] + v[3] for v in per_class.values())
+        print()
+        print('HBM traffic of all engine kernels: %.2f GB per evaluation (%d evaluations in the run); source stamp %s'
+              % (total_mb / evaluations / 1e3, evaluations, stamp))
 
     if json_out:
         import json
@@ -103,6 +128,7 @@ def main():
                          '`OFDFT_SIDE_STREAM=0 python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline`; '
                          'reads = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM section), '
                          'writes = WRITE_SIZE KiB; per launch',
+               'source_stamp': stamp, 'evaluations': evaluations,
                'kernels': {c: {'launches': v[0], 'avg_us': round(v[1] / v[0] / 1e3, 2), 'read_MB': round(v[2] / v[0], 1),
                                'write_MB': round(v[3] / v[0], 1)} for c, v in per_class.items()}}
         with open(json_out, 'w') as fh:
