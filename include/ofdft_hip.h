@@ -120,6 +120,9 @@ int  ofdft_energy_grad_chi(ofdft_ctx* ctx, const void* chi_dev, const void* vext
 /* Validation / building-block entry points: same semantics as torch.fft.rfftn / irfftn(s=shape). */
 int  ofdft_rfftn(ofdft_ctx* ctx, const void* real_dev, void* spec_dev, void* stream);
 int  ofdft_irfftn(ofdft_ctx* ctx, const void* spec_dev, void* real_dev, void* stream);
+/* Validation of the lean transcendentals the fused kernels use (csrc/fastmath.h): out[i] = f(in[i]) for n elements of
+ * the context's precision; kind 0: 1/x, 1: log x, 2: exp x, 3: x^(-1/6), 4: x^(1/3) and 5: 1/x derived from x^(-1/6). */
+int  ofdft_debug_math(ofdft_ctx* ctx, int kind, const void* in_dev, void* out_dev, long long n, void* stream);
 
 int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
 

@@ -28,7 +28,7 @@ Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPAS
 OPT_GRAPH = 7
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
-           'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_query',
+           'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',
            'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
            'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_dots',
            'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
@@ -80,6 +80,8 @@ def load(dtype=F64):
     lib.ofdft_rfftn.restype = ip
     lib.ofdft_irfftn.argtypes = [vp, vp, vp, vp]
     lib.ofdft_irfftn.restype = ip
+    lib.ofdft_debug_math.argtypes = [vp, ip, vp, vp, C.c_longlong, vp]
+    lib.ofdft_debug_math.restype = ip
     lib.ofdft_query.argtypes = [vp, ip, dp]
     lib.ofdft_query.restype = ip
     lib.ofdft_create_dist.argtypes = [C.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]

@@ -1507,6 +1507,36 @@ int ofdft_irfftn(ofdft_ctx* c, const void* spec_dev, void* real_dev, void* strea
     return OFDFT_OK;
 }
 
+}  // extern "C"
+namespace {
+__global__ void debug_math_kernel(int kind, const real* __restrict__ in, real* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const real x = in[i];
+        real y;
+        switch (kind) {
+            case 0: y = fm::rcp(x); break;
+            case 1: y = fm::log(x); break;
+            case 2: y = fm::exp(x); break;
+            case 3: y = fm::roots(x).y; break;
+            case 4: y = fm::roots(x).n13; break;
+            default: y = fm::roots(x).inv_n; break;
+        }
+        out[i] = y;
+    }
+}
+}  // namespace
+extern "C" {
+
+int ofdft_debug_math(ofdft_ctx* c, int kind, const void* in_dev, void* out_dev, long long n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !in_dev || !out_dev || n < 1 || kind < 0 || kind > 5) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
+    OFDFT_LAUNCH(c, st, "debug_math", debug_math_kernel, dim3(grid_for(n)), dim3(256), 0, kind, (const real*)in_dev, (real*)out_dev, n);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipGetLastError());
+    return OFDFT_OK;
+}
+
 // ------------------------------------------------------------------------------ slab-decomposed (multi-GPU) API
 int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* local_sum, void* stream) {
     hipStream_t st = (hipStream_t)stream;

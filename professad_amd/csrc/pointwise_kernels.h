@@ -4,6 +4,7 @@
 #pragma once
 #include <type_traits>
 
+#include "fastmath.h"
 #include "fft_kernels.h"
 
 namespace ofdft {
@@ -13,6 +14,21 @@ namespace ofdft {
 constexpr double kPi = (double)3.14159265358979323846264338327950288L;
 constexpr double kFiveThirds = (double)5 / 3, kFiveSixths = (double)5 / 6;
 constexpr real kPiR = (real)kPi;      // pi in the grid precision (device math on `real` operands)
+// Roots and logarithms of constants, spelled out: the device compiler does NOT fold cbrt() / log() / sqrt() of a literal
+// (they are library routines there), so `cbrt(3.0 / kPiR)` inside a pointwise function was evaluated at every grid point
+// -- 4 cube roots, a logarithm, a square root and 2 quotients per PBE point, about 300 of its 650 instructions.
+constexpr real kCbrt9Pi4 = (real)9.570780000627306053141655531512398907L;      // (9 pi^4)^(1/3) = (3 pi^2)^(2/3)
+constexpr real kCbrt3OverPi = (real)0.984745021842696541178973376907781690L;   // (3 / pi)^(1/3)
+constexpr real kCrs = (real)0.620350490899400016668006812047778167L;           // (3 / (4 pi))^(1/3): rs = kCrs n^(-1/3)
+constexpr real kSqrtCrs = (real)0.787623317899743250528011536241166179L;
+constexpr real kInvSqrtCrs = (real)1.269642451250142171583074982042715431L;
+constexpr real kCbrtPiOver3 = (real)1.015491297563259267239386001491459489L;   // (pi / 3)^(1/3)
+constexpr real kPbeGamma = (real)0.031090690869654895034940863712730629L;      // (1 - ln 2) / pi^2
+constexpr real kPbeInvGamma = (real)32.16396844291482112072009037084516073L;
+constexpr real kLn2 = (real)0.693147180559945309417232121458176568L;
+constexpr real kCtf = (real)(0.3L * 9.570780000627306053141655531512398907L);  // C_TF = 0.3 (3 pi^2)^(2/3)
+constexpr real kCs2 = (real)(0.25L / 9.570780000627306053141655531512398907L); // s^2 = kCs2 |grad n|^2 / n^(8/3)
+constexpr real kCx = (real)(-0.75L * 0.984745021842696541178973376907781690L); // LDA exchange: e_x = kCx n^(4/3)
 constexpr int kRedBlocks = 1024;   // grid cap for reducing kernels (partials buffer rows)
 constexpr int kRedThreads = 256;
 constexpr int kMaxScalars = 28;    // scalars reduced by one kernel (27: the real-space stress sums)
@@ -416,46 +432,61 @@ __device__ __forceinline__ void pw92(real rs, real& eps, real& deps_drs) {
     const real dzeta = 2.0 * A * (0.5 * b1 / sr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
     deps_drs = -2.0 * A * a1 * lg + 2.0 * A * (1.0 + a1 * rs) * dzeta * izeta / (zeta + 1.0);
 }
+// the same from sr = sqrt(rs) and isr = 1 / sr, with the lean transcendentals of fastmath.h: one reciprocal (of
+// zeta (zeta + 1)) serves both quotients, log(1 + 1/zeta) = log((zeta + 1) / zeta)
+__device__ __forceinline__ void pw92_roots(real sr, real isr, real& eps, real& deps_drs) {
+    const real A = 0.0310907, a1 = 0.2137, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    const real rs = sr * sr;
+    const real zeta = 2.0 * A * (sr * (b1 + sr * (b2 + sr * (b3 + sr * b4))));
+    const real zp1 = zeta + 1.0;
+    const real iz2 = fm::rcp(zeta * zp1);            // 1 / (zeta (zeta + 1))
+    const real lg = fm::log(zp1 * zp1 * iz2);        // log((zeta + 1) / zeta)
+    const real pre = 2.0 * A * (1.0 + a1 * rs);
+    eps = -pre * lg;
+    const real dzeta = 2.0 * A * (0.5 * b1 * isr + b2 + 1.5 * b3 * sr + 2.0 * b4 * rs);
+    deps_drs = -2.0 * A * a1 * lg + pre * dzeta * iz2;
+}
 
 struct XcLocal { real ex, vx, ec, vc; };   // energy densities (per volume) and potentials
 
 // LDA exchange + one of PZ / PW / Chachiyo correlation (functionals.py:1510-1537; tools_for_tests.py:121-152)
 __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
     XcLocal r = {0.0, 0.0, 0.0, 0.0};
-    const real cx = -0.75 * cbrt(3.0 / kPiR);
-    const real n13 = cbrt(n);
+    const fm::Roots<real> q = fm::roots(n);
+    const real n13 = q.n13;
     if (mask & (1u << 6)) {
-        r.ex = cx * n13 * n;
-        r.vx = (4.0 / 3.0) * cx * n13;
+        r.ex = kCx * n13 * n;
+        r.vx = (4.0 / 3.0) * kCx * n13;
     }
     if (mask & ((1u << 7) | (1u << 8) | (1u << 9))) {
-        const real rs = cbrt(3.0 / (4.0 * kPiR * n));
+        const real rs = kCrs * q.inv13;                         // (3 / (4 pi n))^(1/3)
         if (mask & (1u << 7)) {
             const real gm = -0.1423, b1 = 1.0529, b2 = 0.3334, A = 0.0311, B = -0.048, C = 0.002, D = -0.0116;
             real eps, v;
             if (rs < 1.0) {
-                const real lr = log(rs);
+                const real lr = fm::log(rs);
                 eps = A * lr + B + C * rs * lr + D * rs;
                 v = lr * (A + (2.0 / 3.0) * C * rs) + (B - A / 3.0) + rs / 3.0 * (2.0 * D - C);
             } else {
-                const real sr = sqrt(rs), den = 1.0 + b1 * sr + b2 * rs;
-                eps = gm / den;
-                v = gm * (1.0 + (7.0 / 6.0) * b1 * sr + (4.0 / 3.0) * b2 * rs) / (den * den);
+                const real sr = kSqrtCrs * q.y, iden = fm::rcp(1.0 + b1 * sr + b2 * rs);
+                eps = gm * iden;
+                v = gm * (1.0 + (7.0 / 6.0) * b1 * sr + (4.0 / 3.0) * b2 * rs) * iden * iden;
             }
             r.ec += eps * n;
             r.vc += v;
         }
         if (mask & (1u << 8)) {
             real eps, d;
-            pw92(rs, eps, d);
+            pw92_roots(kSqrtCrs * q.y, kInvSqrtCrs * (n * q.inv13 * q.inv13 * q.y), eps, d);
             r.ec += eps * n;
             r.vc += eps - rs / 3.0 * d;
         }
         if (mask & (1u << 9)) {
-            const real a = (log(2.0) - 1.0) / (2.0 * kPiR * kPiR), b = 20.4562557;
-            const real arg = 1.0 + b / rs + b / (rs * rs);
-            const real eps = a * log(arg);
-            const real d = a / arg * (-b / (rs * rs) - 2.0 * b / (rs * rs * rs));
+            const real a = (kLn2 - 1.0) / (2.0 * kPiR * kPiR), b = 20.4562557;
+            const real irs = fm::rcp(rs);
+            const real arg = 1.0 + b * irs + b * irs * irs;
+            const real eps = a * fm::log(arg);
+            const real d = a * fm::rcp(arg) * (-b * irs * irs - 2.0 * b * irs * irs * irs);
             r.ec += eps * n;
             r.vc += eps - rs / 3.0 * d;
         }
@@ -470,17 +501,19 @@ struct GgaSel { int x, c, k, kkind; real kmu, kbeta, klambda, ksigma; };
 constexpr int kPbeScalars = 3;     // energy sums of a GGA pass: exchange, correlation, kinetic
 
 // PBE x and c: energy density f, df/dn, df/d|grad n|^2 (functionals.py:1597-1618; tools_for_tests.py:155-207)
-// (fp64 division costs ~10x a multiply on gfx950, so every quotient below goes through a shared reciprocal)
+// This is the hot pointwise function of the evaluation (the GGA mid-stage kernel is bound by fp64 vector issue): every
+// root of n comes from ONE n^(-1/6) (fm::roots), every quotient from a shared 5-instruction reciprocal, log / exp
+// from fastmath.h -- about 230 fp64 instructions per point instead of about 600 with the library functions.
 __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& sel) {
     PbePoint r = {0.0, 0.0, 0.0, 0.0, 0.0};
-    const real n13 = cbrt(n);
-    const real inv_n = 1.0 / n;
+    const fm::Roots<real> q = fm::roots(n);
+    const real n13 = q.n13;
+    const real inv_n = q.inv_n;
     const bool do_x = sel.x != 0, do_c = sel.c != 0;
+    const real n83i = inv_n * inv_n * q.inv13 * q.inv13;                // n^(-8/3)
     if (sel.k) {
         // f = tau_TF F(s^2), tau_TF = C_TF n^(5/3), s^2 = |grad n|^2 / (4 (3 pi^2)^(2/3) n^(8/3))  (functional_tools.py:230-268)
-        const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
-        const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
-        const real n83i = inv_n * inv_n * inv_n * n13;
+        const real ctf = kCtf, cs = kCs2;
         const real s2 = cs * gn2 * n83i;
         const real tau = ctf * n13 * n13 * n;
         real F, dF;                       // F and dF / d(s^2)
@@ -490,7 +523,7 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
             F = 1.0 / ch;
             dF = (s > 1e-8 && s < 100.0) ? -a * tanh(a * s) * F / (2.0 * s) : (s < 100.0 ? -0.5 * a * a : 0.0);
         } else {
-            F = exp(-sel.kmu * s2);
+            F = fm::exp(-sel.kmu * s2);
             dF = -sel.kmu * F;
         }
         r.fk = tau * F;
@@ -499,12 +532,10 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
     }
     if (do_x) {
         const real kappa = 0.804, mu = 0.066725 * kPiR * kPiR / 3.0;
-        const real cx = -0.75 * cbrt(3.0 / kPiR);
-        const real ex = cx * n13;
-        const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);     // 0.25 (3 pi^2)^(-2/3)
-        const real n83i = inv_n * inv_n * inv_n * n13;                 // n^(-8/3)
+        const real ex = kCx * n13;
+        const real cs = kCs2;                                             // 0.25 (3 pi^2)^(-2/3)
         const real s2 = cs * gn2 * n83i;
-        const real iden = 1.0 / (1.0 + (mu / kappa) * s2);
+        const real iden = fm::rcp(1.0 + (mu / kappa) * s2);
         const real Fx = 1.0 + kappa - kappa * iden;
         const real dF = mu * iden * iden;
         r.fx = Fx * ex * n;
@@ -512,29 +543,31 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
         r.dfdg += dF * cs * n83i * ex * n;
     }
     if (do_c) {
-        const real beta = 0.066725, gam = (1.0 - log(2.0)) / (kPiR * kPiR), igam = 1.0 / gam;
-        const real rs = cbrt(3.0 / (4.0 * kPiR)) * (n13 * n13 * inv_n);  // c n^(-1/3)
+        const real beta = 0.066725, gam = kPbeGamma, igam = kPbeInvGamma;
+        const real rs = kCrs * q.inv13;                                  // rs = (3 / (4 pi n))^(1/3)
+        const real sr = kSqrtCrs * q.y;                                  // sqrt(rs) = sqrt(crs) n^(-1/6)
+        const real isr = kInvSqrtCrs * (n * q.inv13 * q.inv13 * q.y);    // 1 / sqrt(rs) = n^(1/6) / sqrt(crs) = n y^5 / sqrt(crs)
         real eps, deps_drs;
-        pw92(rs, eps, deps_drs);
+        pw92_roots(sr, isr, eps, deps_drs);
         const real deps_dn = -rs * (1.0 / 3.0) * inv_n * deps_drs;
-        const real ee = exp(-eps * igam);
-        const real A = beta * igam / (ee - 1.0 + 1e-30);
+        const real ee = fm::exp(-eps * igam);
+        const real A = beta * igam * fm::rcp(ee - 1.0 + 1e-30);
         const real dAdn = A * A * (1.0 / beta) * ee * deps_dn;
-        const real ct = (1.0 / 16.0) * cbrt(kPiR / 3.0);
+        const real ct = (1.0 / 16.0) * kCbrtPiOver3;
         const real n43 = n13 * n;
-        const real in73 = 1.0 / (n43 * n + 1e-30);
+        const real in73 = fm::rcp(n43 * n + 1e-30);
         const real t2 = ct * gn2 * in73;
         const real dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 * in73 * in73;
         const real dt2dg = ct * in73;
         const real At2 = A * t2;
         const real num = 1.0 + At2, num2 = 1.0 + 2.0 * At2;
-        const real iden = 1.0 / (1.0 + At2 + At2 * At2);
+        const real iden = fm::rcp(1.0 + At2 + At2 * At2);
         const real arg = 1.0 + beta * igam * t2 * num * iden;
-        const real H = gam * log(arg);
+        const real H = gam * fm::log(arg);
         const real common = t2 * num * iden * iden * num2;
         const real dQn = (dt2dn * num2 + dAdn * t2 * t2) * iden - common * (dt2dn * A + dAdn * t2);
         const real dQg = dt2dg * num2 * iden - common * (dt2dg * A);
-        const real boa = beta / arg;
+        const real boa = beta * fm::rcp(arg);
         r.fc = (eps + H) * n;
         r.dfdn += eps + H + n * (deps_dn + boa * dQn);
         r.dfdg += n * boa * dQg;
@@ -547,8 +580,7 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
 // adds f, df/dn, df/d|grad n|^2 to p and returns df/d(lap n)
 __device__ __forceinline__ void pg_laplacian_point(real n, real gn2, real lap, const GgaSel& sel, PbePoint& p,
                                                    real& dfdl) {
-    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
-    const real cs = 0.25 / cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
+    const real ctf = kCtf, cs = kCs2;
     const real n13 = cbrt(n), inv_n = 1.0 / n;
     const real n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
     const real s2 = cs * gn2 * n83i, q = cs * lap * n53i;
@@ -735,7 +767,7 @@ __device__ __forceinline__ real combine_point(const CombineArgs& a, const Combin
 // iteration are issued together as 16-byte loads ahead of the arithmetic instead of one dependent load
 // per term behind a branch.
 __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc_t* __restrict__ partial) {
-    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);   // 0.3 (3 pi^2)^(2/3)
+    const real ctf = kCtf;   // 0.3 (3 pi^2)^(2/3)
     acc_t acc[kCombineScalars];
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;

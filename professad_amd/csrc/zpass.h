@@ -325,9 +325,10 @@ __device__ __forceinline__ void z_deriv_row(cplx (&v)[E], const ZLane<M, E>& z, 
     z_inverse_regs<M, E>(v, z, twM, twN, 0.0);
 }
 
-// x^y for x >= 0 as exp(y log x): ~2 ulp for the |y log x| = O(1..10) met here, a fraction of the instructions
-// and registers of the fully-general pow() (which the unfused pipeline keeps using as an independent check).
-__device__ __forceinline__ real pow_pos(real x, real y) { return exp(y * log(x)); }
+// x^y for x > 0 as exp(y log x) with the lean log / exp of fastmath.h: a few ulp for the |y log x| = O(1..10) met here,
+// ~52 instead of ~250 instructions of the fully-general pow() (which the unfused pipeline keeps using as an
+// independent check).
+__device__ __forceinline__ real pow_pos(real x, real y) { return fm::pow_pos(x, y); }
 
 // density of a point from the kernel's source array: n = cscale * x^2 (source = chi) or n = x (source = den)
 struct DenSrc {
@@ -406,24 +407,21 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
     cplx n[E], a[E], v[E];
     z_load_real<M, E>(n, z, ds.src);
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
+    // ONE logarithm per point serves both powers: n^e0 = exp(e0 L) now, n^e1 = exp(e1 L) for the second half (L is kept
+    // in `l`; with e0 + e1 = 5/3 the former cbrt + quotient form cost more than the second exp)
+    cplx l[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         n[q] = mkc(ds(n[q].x), ds(n[q].y));
-        a[q] = mkc(pow_pos(n[q].x, pa.e0), pow_pos(n[q].y, pa.e0));
+        l[q] = mkc(fm::log(n[q].x), fm::log(n[q].y));
+        a[q] = mkc(fm::exp(pa.e0 * l[q].x), fm::exp(pa.e0 * l[q].y));
     }
     for (int half = 0; half < 2; ++half) {
         if (half == 1) {
             if (!pa.out[3] && !pa.out[4] && !pa.out[5]) break;
 #pragma unroll
-            for (int q = 0; q < E; ++q) {
-                if (pa.sum53) {
-                    const real cx = cbrt(n[q].x), cy = cbrt(n[q].y);
-                    a[q] = mkc(n[q].x * cx * cx / a[q].x, n[q].y * cy * cy / a[q].y);
-                } else {
-                    a[q] = mkc(pow_pos(n[q].x, pa.e1), pow_pos(n[q].y, pa.e1));
-                }
-            }
+            for (int q = 0; q < E; ++q) a[q] = mkc(fm::exp(pa.e1 * l[q].x), fm::exp(pa.e1 * l[q].y));
         }
         cplx* const* o = pa.out + 3 * half;
         if (o[0]) {
@@ -637,9 +635,10 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
         t2[q].x += h0 * x0;
         t2[q].y += h1 * x1;
         // fold: e_NL = ctf n^alpha S_e ; v += ctf n^(alpha-1) (alpha S_e + n S_1); keep n^(beta-1) in t2
-        const real pb0 = pow_pos(n[q].x, a.wgc_beta - 1.0), pb1 = pow_pos(n[q].y, a.wgc_beta - 1.0);
-        const real pa0 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].x) * pb0) : pow_pos(n[q].x, a.wgc_alpha - 1.0);
-        const real pa1 = a.wgc_sum_53 ? 1.0 / (cbrt(n[q].y) * pb1) : pow_pos(n[q].y, a.wgc_alpha - 1.0);
+        // n^(beta-1) and n^(alpha-1) from ONE logarithm per point
+        const real l0 = fm::log(n[q].x), l1 = fm::log(n[q].y);
+        const real pb0 = fm::exp((a.wgc_beta - 1.0) * l0), pb1 = fm::exp((a.wgc_beta - 1.0) * l1);
+        const real pa0 = fm::exp((a.wgc_alpha - 1.0) * l0), pa1 = fm::exp((a.wgc_alpha - 1.0) * l1);
         e += ctf * (pa0 * n[q].x * t1[q].x + pa1 * n[q].y * t1[q].y);
         vacc[q].x += ctf * pa0 * (a.wgc_alpha * t1[q].x + n[q].x * t2[q].x);
         vacc[q].y += ctf * pa1 * (a.wgc_alpha * t1[q].y + n[q].y * t2[q].y);
@@ -675,7 +674,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
-    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
+    const real ctf = kCtf;
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
     // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
     // a thread only reads what it wrote).  The final reduction order is unchanged.
@@ -740,11 +739,14 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
+            __builtin_amdgcn_sched_barrier(0);
             const real x0 = w[q].x * sc, x1 = w[q].y * sc;
-            const real s0 = n[q].x != 0.0 ? sqrt(n[q].x) : 0.0, s1 = n[q].y != 0.0 ? sqrt(n[q].y) : 0.0;
-            e += -0.5 * (s0 * x0 + s1 * x1);
-            if (n[q].x != 0.0) vacc[q].x += -0.5 * x0 / s0;
-            if (n[q].y != 0.0) vacc[q].y += -0.5 * x1 / s1;
+            // sqrt(n) = n y^3 and 1 / sqrt(n) = y^3 with y = n^(-1/6) (one root, no quotient); n == 0 -> 0 (functionals.py:242-243)
+            const real y0 = n[q].x != 0.0 ? fm::roots(n[q].x).y : 0.0, y1 = n[q].y != 0.0 ? fm::roots(n[q].y).y : 0.0;
+            const real r0 = y0 * y0 * y0, r1 = y1 * y1 * y1;
+            e += -0.5 * (n[q].x * r0 * x0 + n[q].y * r1 * x1);
+            vacc[q].x += -0.5 * x0 * r0;
+            vacc[q].y += -0.5 * x1 * r1;
         }
         park[3 * 256] = e;
     }
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         for (int q = 0; q < E; ++q) {
             __builtin_amdgcn_sched_barrier(0);
             const real x0 = w[q].x * sc, x1 = w[q].y * sc;
-            pa1[q] = a.wt_is_56 ? mkc(1.0 / sqrt(cbrt(n[q].x)), 1.0 / sqrt(cbrt(n[q].y)))
+            pa1[q] = a.wt_is_56 ? mkc(fm::roots(n[q].x).y, fm::roots(n[q].y).y)
                                 : mkc(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
             e += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
             const real f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
@@ -823,15 +825,15 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         if (a.mask & 4u) {                               // TF  functionals.py:223
-            const real c0 = cbrt(n[q].x), c1 = cbrt(n[q].y);
+            const real c0 = fm::roots(n[q].x).n13, c1 = fm::roots(n[q].y).n13;
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
             vacc[q].x += (5.0 / 3.0) * ctf * c0 * c0;
             vacc[q].y += (5.0 / 3.0) * ctf * c1 * c1;
         }
         if (a.mask & (1u << 13)) {                       // vWGTF1 / 2  functionals.py:251-306
             real e0, v0, e1, v1;
-            vwgtf_point(n[q].x, cbrt(n[q].x), ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
-            vwgtf_point(n[q].y, cbrt(n[q].y), ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
+            vwgtf_point(n[q].x, fm::roots(n[q].x).n13, ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
+            vwgtf_point(n[q].y, fm::roots(n[q].y).n13, ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
             acc[9] += e0 + e1;
             vacc[q].x += v0;
             vacc[q].y += v1;
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wg
     const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     a.ds = a.ds.resolved();
     const ZLane<M, E> z(g, lds);
-    const real ctf = 0.3 * cbrt(9.0 * kPiR * kPiR * kPiR * kPiR);
+    const real ctf = kCtf;
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E>(n, z, a.ds.src);
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);

@@ -148,6 +148,16 @@ class Engine:
         self._check(self.lib.ofdft_irfftn(self._ctx, _ptr(xk), _ptr(out), self._stream()), 'ofdft_irfftn')
         return out
 
+    def debug_math(self, kind, x):
+        """the lean transcendentals of csrc/fastmath.h applied elementwise (validation only)"""
+        x = x.detach().contiguous()
+        if x.dtype != self.dtype or not x.is_cuda:
+            raise TypeError('x must be a %s device tensor' % self.dtype)
+        out = torch.empty_like(x)
+        kinds = {'rcp': 0, 'log': 1, 'exp': 2, 'rsixth': 3, 'cbrt': 4, 'inv': 5}
+        self._check(self.lib.ofdft_debug_math(self._ctx, kinds[kind], _ptr(x), _ptr(out), x.numel(), self._stream()), 'ofdft_debug_math')
+        return out
+
     def query(self, what):
         v = C.c_double(0.0)
         self._check(self.lib.ofdft_query(self._ctx, int(what), C.byref(v)), 'ofdft_query')

@@ -757,3 +757,30 @@ def test_missing_vext_is_an_error_not_a_fault():
     E, v = eng.set_option(0, 0).energy_potential(den, den, want_potential=False)      # energy only: no output array
     assert v is None and E['hartree'] > 0.0
     eng.close()
+
+
+# ------------------------------------------------------------------------------- lean transcendentals (csrc/fastmath.h)
+def test_lean_transcendentals_are_accurate_to_a_few_ulp():
+    """the 1/x, log, exp and n^(-1/6) family the fused kernels use instead of the library functions, against numpy
+    in extended precision over the ranges a density / PBE argument spans (relative error <= 2e-15)"""
+    eng = engine_for((16, 16, 16), DEV)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, 200000), 1.0 + rng.uniform(-1e-3, 1e-3, 50000),
+                        rng.uniform(0.5, 2.0, 50000), 10.0 ** rng.uniform(-300, 300, 20000)])
+    xl = x.astype(np.longdouble)
+    checks = [('rcp', x, 1.0 / xl, 2e-16 * 4), ('rsixth', x, xl ** (np.longdouble(-1) / 6), 1e-15),
+              ('cbrt', x[:300000], np.cbrt(xl[:300000]), 1e-15), ('inv', x[:300000], 1.0 / xl[:300000], 2e-15)]
+    for kind, xin, want, tol in checks:
+        got = eng.debug_math(kind, dev(xin)).cpu().numpy().astype(np.longdouble)
+        err = float(np.max(np.abs(got - want) / np.abs(want)))
+        assert err < tol, (kind, err)
+    # log: relative to max(|log x|, tiny) -- near x = 1 the result must still be relatively accurate (f = m - 1 is exact)
+    got = eng.debug_math('log', dev(x)).cpu().numpy().astype(np.longdouble)
+    want = np.log(xl)
+    err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
+    assert err < 2e-15, err
+    xe = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-1, 1, 100000), rng.uniform(-1e-8, 1e-8, 1000)])
+    got = eng.debug_math('exp', dev(xe)).cpu().numpy().astype(np.longdouble)
+    want = np.exp(xe.astype(np.longdouble))
+    err = float(np.max(np.abs(got - want) / want))
+    assert err < 2e-15, err
