@@ -232,6 +232,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      of ~25-50 kernel launches, which is what bounds grids up to ~64^3 (used by single-GPU contexts up to 2^19 points, where
                                      OFDFT_OPT_SPLIT_COMBINE is then ignored); 0: always launch kernel by kernel */
 #define OFDFT_OPT_SIDE_STREAM 1
+#define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
+                                     registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
+                                     group-parallel kernel that trades spectra through LDS */
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 
 /* Measurement support (bench.py): when on, every kernel launch of the energy calls is bracketed by HIP

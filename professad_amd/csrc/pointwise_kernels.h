@@ -418,6 +418,19 @@ struct MixWgc {
         const cplx pr = buf_load_c(t2, loff * (unsigned)(4 * sizeof(real)));
         return (O + I == 0) ? pr.x : ((O + I == 1) ? pr.y : ((O == 1) ? pr.y : pr.x));
     }
+    // wave-local x pass (xwave.h): all four entries of a k-point by two 16-byte loads, requested with the data
+    static constexpr int kTableReals = 4;
+    __device__ __forceinline__ void fetch(real (&cf)[4], long long uoff, unsigned loff, bool valid) const {
+        const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff;
+        const unsigned bo = loff * (unsigned)(4 * sizeof(real));
+        const cplx p0 = valid ? buf_load_c(t2, bo) : mkc(0.0, 0.0), p1 = valid ? buf_load_c(t2 + 1, bo) : mkc(0.0, 0.0);
+        cf[0] = p0.x; cf[1] = p0.y; cf[2] = p1.x; cf[3] = p1.y;       // w0, K1, K2, K3
+    }
+    static __device__ __forceinline__ void apply(cplx (&o)[3], const cplx (&in)[3], const real (&cf)[4]) {
+        o[0] = mkc(cf[0] * in[0].x + cf[1] * in[1].x + cf[2] * in[2].x, cf[0] * in[0].y + cf[1] * in[1].y + cf[2] * in[2].y);
+        o[1] = mkc(cf[1] * in[0].x + cf[3] * in[1].x, cf[1] * in[0].y + cf[3] * in[1].y);
+        o[2] = mkc(cf[2] * in[0].x, cf[2] * in[0].y);
+    }
 };
 
 // ---- XC pointwise math -------------------------------------------------------------------------

@@ -784,3 +784,31 @@ def test_lean_transcendentals_are_accurate_to_a_few_ulp():
     want = np.exp(xe.astype(np.longdouble))
     err = float(np.max(np.abs(got - want) / want))
     assert err < 2e-15, err
+
+
+@pytest.mark.parametrize('shape', [(8, 8, 16), (16, 32, 64), (32, 16, 32), (64, 32, 128), (128, 8, 16), (256, 64, 32), (512, 16, 32)])
+def test_wave_local_x_pass_matches_the_group_parallel_kernel(shape):
+    """the two fused x-pass kernels (xwave.h: a line of every spectrum in one wavefront, mix in registers; fft_kernels.h:
+    one wave group per spectrum, mix through LDS) on every x extent and every mix functor of configs 1-3 + GGA kinetic"""
+    box = dev(cases.make_cell(('tri', shape[0] / 16.0)))
+    den = synth.random_density(shape, seed=61)
+    vext = dev(synth.random_potential(shape, seed=62))
+    s5 = np.sqrt(5.0)
+    term_sets = [(_CFG_TERMS['cfg3'], None), (_CFG_TERMS['cfg2'], None), (['pbe'], None),
+                 (['hartree', 'tf', 'vw', 'wt_nl', 'gga_k'], {'wt_alpha': (5 + s5) / 6, 'wt_beta': (5 - s5) / 6})]     # WGC98 exponents + LKT
+    for ts, params in term_sets:
+        names = F.NativeTerms(ts).names
+        out = {}
+        for xw in (2, 1, 0):
+            for gsplit in (1, 0):
+                eng = Engine(shape, DEV).set_cell(box).set_terms(names, params)
+                eng.set_option(8, xw).set_option(6, gsplit)
+                E, v = eng.energy_potential(dev(den), vext)
+                out[(xw, gsplit)] = (E, v.cpu().numpy(), int(eng.query(0)))
+                eng.close()
+        Er, vr, nf = out[(0, 1)]
+        for key, (E, v, n) in out.items():
+            for k in Er:
+                assert abs(E[k] - Er[k]) <= 1e-12 * max(1.0, abs(Er[k])), (ts, key, k, E[k], Er[k])
+            assert relerr(v, vr) < 1e-12, (ts, key)
+            assert n == nf
