@@ -156,6 +156,44 @@ def pbe(box, n, do_x=True, do_c=True):
     return np.mean(f - n * dfdn) * np.eye(3) + t2
 
 
+def pauli_gaussian(box, n, mu=40 / 27, beta=0.25, lam=0.0, sigma=0.0):
+    """Pauli part of the Pauli-Gaussian family with the q-dependent terms (functionals.py:336-403), derived here (the
+    reference has no closed form).  For f(n, g = |grad n|^2, l = lap n) a strain at fixed electron number gives
+    n -> n/J, g -> (g - 2 eps_ij d_i n d_j n)/J^2, l -> (l - 2 eps_ij d_i d_j n)/J, hence
+        sigma_ij = delta_ij mean(f - n f_n - 2 g f_g - l f_l) - 2 mean(f_g d_i n d_j n) - 2 mean(f_l d_i d_j n)
+    with the spectral Hessian d_i d_j n = F^-1[-k_i k_j n^] (the derivative of the reference's -k^2 with respect to the cell)."""
+    g = Grid(box, n.shape)
+    kx, ky, kz, k2 = recip(box, n.shape)
+    nk = g.fwd(n)
+    d = [g.inv(1j * k * nk) for k in (kx, ky, kz)]
+    gn2 = d[0] ** 2 + d[1] ** 2 + d[2] ** 2
+    lap = g.inv(-k2 * nk)
+    cs = 0.25 * (3 * PI * PI) ** (-2 / 3)
+    s2, q = cs * gn2 / n ** (8 / 3), cs * lap / n ** (5 / 3)
+    tau = C_TF * n ** (5 / 3)
+    ex = np.exp(-mu * s2)
+    Fe = ex + beta * q * q - lam * q * s2 + sigma * s2 * s2
+    Fs, Fq = -mu * ex - lam * q + 2 * sigma * s2, 2 * beta * q - lam * s2
+    f = tau * Fe
+    f_n = (5 / 3) * tau / n * Fe + tau * (Fs * (-(8 / 3) * s2 / n) + Fq * (-(5 / 3) * q / n))
+    f_g, f_l = tau * Fs * cs / n ** (8 / 3), tau * Fq * cs / n ** (5 / 3)
+    ks = (kx, ky, kz)
+    hess = lambda i, j: g.inv(-ks[i] * ks[j] * nk)                                    # noqa: E731
+    t2 = _sym([-2 * np.mean(f_g * d[i] * d[j]) - 2 * np.mean(f_l * hess(i, j)) for i, j in PAIRS])
+    return np.mean(f - n * f_n - 2 * gn2 * f_g - lap * f_l) * np.eye(3) + t2
+
+
+def wang_teter_style(box, n, alpha=5 / 6, beta=5 / 6, kind='exp'):
+    """tools_for_tests.py:310-364: T = vW + T_TF f(X), X = T_NL / (f'(0) T_TF) -> sigma = sigma_vW + sigma_TF (f - f' X)
+    + sigma_NL f'(X) / f'(0); f enumerated as 'linear' (1 + x) or 'exp'"""
+    g = Grid(box, n.shape)
+    ev = Evaluator(g)
+    Et, En = ev.tf(n)[0], ev.wt_nl(n, alpha, beta)[0]
+    X = En / Et                                                                       # f'(0) = 1 for both choices
+    fx, dfx = (1 + X, 1.0) if kind == 'linear' else (math.exp(X), math.exp(X))
+    return vw(box, n) + tf(box, n) * (fx - dfx * X) + wt_nl(box, n, alpha, beta) * dfx
+
+
 def hermite_derivative(x, y, xs):
     """d/dxs of oracle.ions.hermite_interp (functional_tools.py:292-334)"""
     m = oi.hermite_slopes(x, y)

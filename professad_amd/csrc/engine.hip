@@ -115,10 +115,15 @@ GgaSel gga_sel(const ofdft_ctx* c) {
                   (real)c->params[OFDFT_P_GGAK_LAMBDA], (real)c->params[OFDFT_P_GGAK_SIGMA]};
 }
 
-// Pauli-Gaussian member with Laplacian-dependent terms: served by the unfused pipeline only
+// Pauli-Gaussian member with Laplacian-dependent terms (PGSL0.25 -- the reference's default --, PGSLr): one more spectrum
+// each way in the split-derivative GGA chain of the z-fused pipeline (lap n in, lap(df/dL) out); the x-fused-only and
+// the unsplit forms fall back to the unfused pipeline
 bool gga_needs_laplacian(const ofdft_ctx* c) {
     return (c->mask & OFDFT_GGA_K) && (int)c->params[OFDFT_P_GGAK_KIND] == 1 &&
            (c->params[OFDFT_P_GGAK_BETA] != 0.0 || c->params[OFDFT_P_GGAK_LAMBDA] != 0.0 || c->params[OFDFT_P_GGAK_SIGMA] != 0.0);
+}
+bool zfused_serves(const ofdft_ctx* c) {
+    return c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && (!gga_needs_laplacian(c) || c->gga_split);
 }
 
 int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
@@ -1377,7 +1382,7 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     double vn;
-    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
+    if (zfused_serves(c)) {
         double nel = 0.0;
         if (c->mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF)) {
             double nsum;
@@ -1489,7 +1494,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
     real *den, *v;
     if (int rc = real_ws(c, "v", &v)) return rc;
-    if (c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && !gga_needs_laplacian(c)) {
+    if (zfused_serves(c)) {
         // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
         // z kernels; mean(n) vol = N_e by construction; mu is formed on the device too.  One host sync per evaluation
         // (the final sums), nothing in between: the sequence is graph-capturable (closure_graph).
@@ -1621,7 +1626,8 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if ((c->mask & OFDFT_ION_ELECTRON) && !vext_local) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
-    if (gga_needs_laplacian(c)) return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members: single-GPU contexts only");
+    if (gga_needs_laplacian(c) && !c->gga_split)
+        return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members need the split-derivative GGA chain (OFDFT_OPT_GGA_SPLIT = 1)");
     ZRun& r = zrun(c);
     if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[15]; it never visits the host
         OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel_global,

@@ -211,7 +211,6 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_stress: single-GPU contexts only");
-    if (gga_needs_laplacian(c)) return fail(c, OFDFT_EINVAL, "ofdft_stress: Laplacian-dependent Pauli-Gaussian members are not covered");
     const double* den = (const double*)den_dev;
     const unsigned mask = c->mask;
     const long long npts = c->npts;
@@ -223,7 +222,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
     const double nbar = nsum * invN;                    // N_e / vol, un-rounded (functionals.py:634)
     cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
-    double *gx = nullptr, *gy = nullptr, *gz = nullptr;
+    double *gx = nullptr, *gy = nullptr, *gz = nullptr, *lapn = nullptr;
     if (int rc = spec_ws(c, "s0", &s0)) return rc;
     if (int rc = spec_ws(c, "s1", &s1)) return rc;
     if (mask & (OFDFT_HARTREE | kGgaAny)) {
@@ -240,6 +239,12 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             if (int rc = real_ws(c, "gx", &gx)) return rc;
             if (int rc = real_ws(c, "gy", &gy)) return rc;
             if (int rc = real_ws(c, "gz", &gz)) return rc;
+            if (gga_needs_laplacian(c)) {        // lap n = F^-1[-k^2 n^] (functional_tools.py:209-227)
+                if (int rc = real_ws(c, "lapn", &lapn)) return rc;
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(grid_for(c->g.total)), dim3(256), 0, s0, s1,
+                             c->kg, 0.0, 0.0);
+                if (int rc = irfftn_internal(c, s1, lapn, invN, st)) return rc;
+            }
             OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(grid_for(c->g.total)), dim3(256), 0, s0, s1, s2, s3, c->kg);
             if (int rc = irfftn_internal(c, s1, gx, invN, st)) return rc;
             if (int rc = irfftn_internal(c, s2, gy, invN, st)) return rc;
@@ -252,7 +257,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         OFDFT_LAUNCH(c, st, "stress_real", stress_real_kernel, dim3(blocks), dim3(kRedThreads), 0, den, (const double*)gx,
                      (const double*)gy, (const double*)gz, npts, mask, gga_sel(c),
                      (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nsum * c->dV) : 0.0, (int)c->params[OFDFT_P_VWGTF_KIND],
-                     c->d_partial);
+                     c->d_partial, lapn);
         if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
         const double zero6[6] = {0, 0, 0, 0, 0, 0};
         const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
@@ -270,6 +275,17 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             for (int k = 0; k < 6; ++k) c6[k] = -2.0 * o[k] * invN;
             for (int k = 0; k < 3; ++k) c6[k] += -2.0 * o[6] * invN;
             sym_store(sig + 9 * (10 + which), c6, o[7] * invN);
+        }
+        if (lapn) {       // Hessian term of the q-dependent Pauli-Gaussian members: -2 mean(f_l d_i d_j n) = (2 / N^2) sum_k w k_i k_j Re(n^ conj(f_l^))
+            if (int rc = rfftn_internal(c, lapn, s1, st)) return rc;          // lapn now holds f_l = df/d(lap n)
+            OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HESS>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)s0,
+                         (const cplx*)s1, c->kg, invN2, 0.0, c->d_partial);
+            if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+            double* o = sig + 9 * 12;
+            o[0] += 2.0 * s7[0]; o[4] += 2.0 * s7[1]; o[8] += 2.0 * s7[2];
+            o[1] += 2.0 * s7[3]; o[3] += 2.0 * s7[3];
+            o[2] += 2.0 * s7[4]; o[6] += 2.0 * s7[4];
+            o[5] += 2.0 * s7[5]; o[7] += 2.0 * s7[5];
         }
     }
     if (mask & OFDFT_VW) {

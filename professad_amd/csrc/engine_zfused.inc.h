@@ -74,20 +74,25 @@ int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, re
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
-// split-derivative GGA mid stage (zpass.h: zpbe2_kernel)
+// split-derivative GGA mid stage (zpass.h: zpbe2_kernel); L != nullptr: the Laplacian-dependent Pauli-Gaussian form
 int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const real* dzn, real* dfdn, double inv_n,
-                 int* blocks_out, hipStream_t st) {
+                 int* blocks_out, hipStream_t st, cplx* L = nullptr) {
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
-    c->fft_count += 6;    // same six 3-D transforms as the plain form (three c2r finished, three r2c started)
+    c->fft_count += L ? 8 : 6;    // same six 3-D transforms as the plain form (three c2r finished, three r2c started); + lap n, df/dL
     Bmat bm{};
     std::memcpy(bm.b, c->kg.b, sizeof(bm.b));
 #define X(M_)                                                                                                   \
     case M_: {                                                                                                  \
         *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
-        OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E>), dim3(*blocks_out), dim3(256),         \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm,  \
-                     c->g, twM, twN, c->d_partial);                                                             \
+        if (L)                                                                                                  \
+            OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E, true>), dim3(*blocks_out), dim3(256), \
+                         (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm, \
+                         c->g, twM, twN, c->d_partial, L);                                                      \
+        else                                                                                                    \
+            OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E, false>), dim3(*blocks_out), dim3(256), \
+                         (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm, \
+                         c->g, twM, twN, c->d_partial, L);                                                      \
         return 0;                                                                                               \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
@@ -212,6 +217,8 @@ struct ZRun {
     // xlist[k] = spectra of chain k that cross the next geometry boundary (= one all-to-all on several GPUs)
     std::vector<cplx*> xlist[2];
     bool gsplit = false;           // split-derivative form of the GGA chain (only D_a visits the x pass)
+    bool lapl = false;             // Laplacian-dependent Pauli-Gaussian member: lap n in, lap(df/dL) out ride the same chain
+    cplx* s_l = nullptr;
     real* dzn = nullptr;
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
@@ -251,10 +258,11 @@ int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
     const unsigned m = c->mask;
     const bool g = m & kGgaAny, h = m & OFDFT_HARTREE, vw = m & OFDFT_VW;
     const int ng = g ? (c->gga_split ? 1 : 3) : 0;
+    const int nl = (gga_needs_laplacian(c) && c->gga_split) ? 1 : 0;      // lap n back, df/dL forth
     int narr;
     if (chain == 0) {
-        narr = std::max(((h || g) ? 1 : 0) + (vw ? 1 : 0), (h ? 1 : 0) + ng + (vw ? 1 : 0));
-        narr = std::max(narr, ng);
+        narr = std::max(((h || g) ? 1 : 0) + (vw ? 1 : 0), (h ? 1 : 0) + ng + nl + (vw ? 1 : 0));
+        narr = std::max(narr, ng + nl);
     } else {
         narr = ((m & OFDFT_WT_NL) ? (c->params[OFDFT_P_WT_ALPHA] != c->params[OFDFT_P_WT_BETA] ? 2 : 1) : 0) +
                ((m & OFDFT_WGC99_NL) ? 6 : 0);
@@ -303,10 +311,13 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             if (r.s_n) both[nb++] = r.s_n;
             if (r.s_s) both[nb++] = r.s_s;
             r.gsplit = r.has_g && c->gga_split;
+            r.lapl = r.gsplit && gga_needs_laplacian(c);
+            r.s_l = nullptr;
             if (r.gsplit) {
                 if ((rc = real_ws(c, "dzn", &r.dzn))) return rc;
                 if ((rc = spec_ws(c, "zgx", &r.s_g[0]))) return rc;
                 if ((rc = spec_ws(c, "zgy", &r.s_g[1]))) return rc;
+                if (r.lapl && (rc = spec_ws(c, "zgl", &r.s_l))) return rc;
             }
             const int nch = r.gsplit ? 1 : chunks_for(c, nb, 1);
             if (nch > 1) {        // x-chunked: a chunk's spectra are y-transformed while still in the Infinity Cache
@@ -415,7 +426,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
     XfLayout lay{};
     if (dx) {
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? (r.gsplit ? 1 : 3) : 0) + (r.s_s ? 1 : 0)
+        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? (r.gsplit ? (r.lapl ? 2 : 1) : 3) : 0) + (r.s_s ? 1 : 0)
                                     : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
         lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
     }
@@ -440,6 +451,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
             }
             if (r.has_g && r.gsplit) {
                 io.out[no++] = out_of(r.s_g[0]);          // (D_a n)^ only
+                if (r.lapl) io.out[no++] = out_of(r.s_l); // -k^2 n^
             } else if (r.has_g) {
                 const char* gn[3] = {"zgx", "zgy", "zgz"};
                 for (int k = 0; k < 3; ++k) {
@@ -447,7 +459,9 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
                     io.out[no++] = out_of(r.s_g[k]);
                 }
             }
-            if (r.gsplit && r.has_h) rc = xfused<1, 2>(c, io, MixDensityA<true>{c->kg}, st, "xfused_n", lay);
+            if (r.lapl && r.has_h) rc = xfused<1, 3>(c, io, MixDensityA<true, true>{c->kg}, st, "xfused_n", lay);
+            else if (r.lapl) rc = xfused<1, 2>(c, io, MixDensityA<false, true>{c->kg}, st, "xfused_n", lay);
+            else if (r.gsplit && r.has_h) rc = xfused<1, 2>(c, io, MixDensityA<true>{c->kg}, st, "xfused_n", lay);
             else if (r.gsplit) rc = xfused<1, 1>(c, io, MixDensityA<false>{c->kg}, st, "xfused_n", lay);
             else if (r.has_h && r.has_g) rc = xfused<1, 4>(c, io, MixDensity<true, true>{c->kg}, st, "xfused_n", lay);
             else if (r.has_h) rc = xfused<1, 1>(c, io, MixDensity<true, false>{c->kg}, st, "xfused_n", lay);
@@ -523,7 +537,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     for (cplx* sp : xl) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
-        const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2];
+        const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2] || (r.s_l && sp == r.s_l);
         const bool is_w = sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2] || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
         if (is_w && r.wgc_yinv_done) {
             // already y-inverted next to the x pass
@@ -572,13 +586,18 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
     if (r.has_g && r.gsplit) {
         // split-derivative form: A = (D_a n) came back from the x pass and was y-inverted above, B = (D_b n) is local
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
-        if ((rc = launch_zpbe2(c, r.ds, r.s_g[0], r.s_g[1], r.dzn, r.dfdn, r.za.inv_n, &r.pbe_blocks, st))) return rc;
+        if ((rc = launch_zpbe2(c, r.ds, r.s_g[0], r.s_g[1], r.dzn, r.dfdn, r.za.inv_n, &r.pbe_blocks, st, r.lapl ? r.s_l : nullptr)))
+            return rc;
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
                      kPbeScalars, c->d_reduced + kCombineScalars);
         // D_b G_b in one y pass, in place (scaled like B); only G_a goes on to the x pass
         if ((rc = yderiv(c, r.s_g[1], r.s_g[1], (double)c->n0g, st))) return rc;
         if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[0], st))) return rc;
         xl.push_back(r.s_g[0]);
+        if (r.lapl) {             // (df/dL)^ goes on to the x pass beside G_a
+            if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_l, st))) return rc;
+            xl.push_back(r.s_l);
+        }
         if (dx) {
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
             if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
@@ -624,7 +643,16 @@ int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
             dio.out[0] = send;
             lay = XfLayout{c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
         }
-        if (int rc = xfused<1, 1>(c, dio, MixDerivA{c->kg}, st, "xfused_div", lay)) return rc;
+        if (r.lapl) {            // i f_a G_a^ + (k^2 / 2) (df/dL)^ -> the spectrum the combine subtracts twice
+            dio.in[1] = r.s_l;
+            if (c->nranks > 1) {
+                dio.in[1] = dio.in[0] + c->xg.arr_sz;
+                lay = XfLayout{2 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+            }
+            if (int rc = xfused<2, 1>(c, dio, MixDerivAL{c->kg}, st, "xfused_div", lay)) return rc;
+        } else if (int rc = xfused<1, 1>(c, dio, MixDerivA{c->kg}, st, "xfused_div", lay)) {
+            return rc;
+        }
         r.xlist[0].push_back(r.s_g[0]);
     } else if (chain == 0 && r.has_g) {
         XfIo dio{};

@@ -572,7 +572,8 @@ template <int LEN, int G, int NOUT> struct XfCfg {
 
 
 // Mix functor contract (all indices compile-time, so every workgroup runs straight-line code):
-//   static constexpr bool imag(int o)              coefficient of output o is i*c (else c)
+//   static constexpr bool imag(int o)              coefficient of output o is i*c (else c) ...
+//   template<int O,int I> static constexpr bool imag_oi()   ... per contribution (mixes with real AND imaginary terms in one output)
 //   template<int O,int I> static constexpr bool present()   whether input I contributes to output O
 //   template<int O,int I> real coef(x, y, kz, uoff, loff)  the real number c at that k-point; uoff + loff =
 //        element offset of the k-point in a spectrum array (uoff wave-uniform) for buffer-load table lookups
@@ -592,8 +593,13 @@ __device__ __forceinline__ void xf_mix_inputs(real& acr, real& aci, const real* 
         if constexpr (Mix::template present<O, I>()) {
             const real cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
             const real* lb = lds + (I * LPW + c.l) * STRIDE;
-            acr += cf * lb[lpad(pos)];
-            aci += cf * lb[lpad(pos + LEN / 2)];
+            if constexpr (Mix::template imag_oi<O, I>()) {       // (i c)(re + i im) = -c im + i c re
+                acr -= cf * lb[lpad(pos + LEN / 2)];
+                aci += cf * lb[lpad(pos)];
+            } else {
+                acr += cf * lb[lpad(pos)];
+                aci += cf * lb[lpad(pos + LEN / 2)];
+            }
         }
         xf_mix_inputs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
     }
@@ -619,8 +625,13 @@ __device__ __forceinline__ void xf_apply_coefs(real& acr, real& aci, const real 
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
             const real* lb = lds + (I * LPW + c.l) * STRIDE;
-            acr += cf[I] * lb[lpad(pos)];
-            aci += cf[I] * lb[lpad(pos + LEN / 2)];
+            if constexpr (Mix::template imag_oi<O, I>()) {
+                acr -= cf[I] * lb[lpad(pos + LEN / 2)];
+                aci += cf[I] * lb[lpad(pos)];
+            } else {
+                acr += cf[I] * lb[lpad(pos)];
+                aci += cf[I] * lb[lpad(pos + LEN / 2)];
+            }
         }
         xf_apply_coefs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, cf, lds, c, pos);
     }
@@ -647,7 +658,7 @@ __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const real*
             const int x = c.j + P * q;
             real acr = 0.0, aci = 0.0;
             xf_apply_coefs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, cf[qq], lds, c, x - HALF * (LEN / 2));
-            o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);
+            o[q] = mkc(acr, aci);
         }
     } else {
 #pragma unroll
@@ -656,7 +667,7 @@ __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const real*
             const int x = c.j + P * q;
             real acr = 0.0, aci = 0.0;
             xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
-            o[q] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);     // (i c)(re + i im) = -c im + i c re
+            o[q] = mkc(acr, aci);
         }
     }
 }

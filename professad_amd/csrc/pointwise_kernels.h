@@ -340,6 +340,7 @@ template <bool HAS_H, bool HAS_G> struct MixDensity {
     KGeom kg;
     static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return imag(O); }
     template <int O, int I>
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         real kx, ky, kz, k2;
@@ -352,18 +353,23 @@ template <bool HAS_H, bool HAS_G> struct MixDensity {
 
 // split-derivative form: n^ -> [v_H^], i f_a n^  with the INTEGER frequency f_a along x (the Cartesian gradient is assembled
 // from the three index derivatives in zpbe2_kernel)
-template <bool HAS_H> struct MixDensityA {
+template <bool HAS_H, bool HAS_L = false> struct MixDensityA {
     KGeom kg;
-    static __device__ __forceinline__ constexpr bool imag(int o) { return HAS_H ? o >= 1 : true; }
+    // outputs: [v_H^ (real coefficient)], i f_a n^ (imaginary), [-k^2 n^ (real): the Laplacian of n for the q-dependent
+    // Pauli-Gaussian members, functional_tools.py:271-287]
+    static __device__ __forceinline__ constexpr bool imag(int o) { return o == (HAS_H ? 1 : 0); }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return imag(O); }
     template <int O, int I>
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
-        if (HAS_H && O == 0) {
+        if constexpr (O == (HAS_H ? 1 : 0)) {
+            return ifreq(x, kg.g.n0);
+        } else {
             real kx, ky, kz, k2;
             kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
-            return (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;
+            if (HAS_H && O == 0) return (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;
+            return -k2;
         }
-        return ifreq(x, kg.g.n0);
     }
 };
 // G^ -> i f_a G^
@@ -371,8 +377,27 @@ struct MixDerivA {
     KGeom kg;
     static __device__ __forceinline__ constexpr bool imag(int) { return true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return true; }
     template <int O, int I>
     __device__ __forceinline__ real coef(int x, int, int, long long, unsigned) const { return ifreq(x, kg.g.n0); }
+};
+// (G_a^, L^) -> i f_a G_a^ + (k^2 / 2) L^ : the x part of the divergence plus the Laplacian of df/d(lap n), folded into the
+// quantity the combine kernel subtracts twice (v += df/dn - 2 div + lap(df/dL), tools_for_tests.py:86-118)
+struct MixDerivAL {
+    KGeom kg;
+    static __device__ __forceinline__ constexpr bool imag(int) { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return I == 0; }
+    template <int O, int I>
+    __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
+        if constexpr (I == 0) {
+            return ifreq(x, kg.g.n0);
+        } else {
+            real kx, ky, kz, k2;
+            kvec_xyz(kg, x, y, z, kx, ky, kz, k2);
+            return 0.5 * k2;
+        }
+    }
 };
 
 // one spectrum times a real f(k): OP as spec_scale_kernel
@@ -381,6 +406,7 @@ template <int OP> struct MixScale {
     real p0, p1;
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return imag(O); }
     template <int O, int I>
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         real kx, ky, kz, k2;
@@ -396,6 +422,7 @@ struct MixDiv {
     KGeom kg;
     static __device__ __forceinline__ constexpr bool imag(int) { return true; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return true; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return imag(O); }
     template <int O, int I>
     __device__ __forceinline__ real coef(int x, int y, int z, long long, unsigned) const {
         real kx, ky, kz, k2;
@@ -411,6 +438,7 @@ struct MixWgc {
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return O + I <= 2; }
+    template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return false; }
     template <int O, int I>
     __device__ __forceinline__ real coef(int, int, int, long long uoff, unsigned loff) const {
         // 16-byte loads of (w0,K1) or (K2,K3): identical loads of one k-point are merged by the compiler
@@ -594,11 +622,12 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
 __device__ __forceinline__ void pg_laplacian_point(real n, real gn2, real lap, const GgaSel& sel, PbePoint& p,
                                                    real& dfdl) {
     const real ctf = kCtf, cs = kCs2;
-    const real n13 = cbrt(n), inv_n = 1.0 / n;
-    const real n53i = inv_n * inv_n * n13, n83i = n53i * inv_n;
+    const fm::Roots<real> r = fm::roots(n);
+    const real n13 = r.n13, inv_n = r.inv_n;
+    const real n53i = inv_n * r.inv13 * r.inv13, n83i = n53i * inv_n;      // n^(-5/3), n^(-8/3)
     const real s2 = cs * gn2 * n83i, q = cs * lap * n53i;
     const real tau = ctf * n13 * n13 * n;
-    const real ex = exp(-sel.kmu * s2);
+    const real ex = fm::exp(-sel.kmu * s2);
     const real F = ex + sel.kbeta * q * q - sel.klambda * q * s2 + sel.ksigma * s2 * s2;
     const real Fs = -sel.kmu * ex - sel.klambda * q + 2.0 * sel.ksigma * s2;       // dF / d(s^2)
     const real Fq = 2.0 * sel.kbeta * q - sel.klambda * s2;                          // dF / dq

@@ -24,12 +24,13 @@ __device__ __forceinline__ void add_kk(double (&acc)[kStressSpecScalars], double
     acc[5] += f * ky * kz;
 }
 
-enum { STRESS_HARTREE = 0, STRESS_VW = 1, STRESS_WT = 2 };
+enum { STRESS_HARTREE = 0, STRESS_VW = 1, STRESS_WT = 2, STRESS_HESS = 3 };
 
 // a, b: UNNORMALISED spectra (b only for WT); scale = 1/N^2.
 //   HARTREE: acc_ij += w 4 pi |n~|^2 k_i k_j / k^4,              acc[6] += w 4 pi |n~|^2 / k^2        (tools_for_tests.py:212-238)
 //   VW:      acc_ij += -w |s~|^2 k_i k_j                                                              (oracle/stress.py)
 //   WT:      acc_ij += w Re(a~ b~*) aux3(eta) (k_i k_j / k^2 - delta_ij / 3),  acc[6] += w Re(a~ b~*) shape(eta)   (:262-307)
+//   HESS:    acc_ij += w Re(a~ b~*) k_i k_j     = -N^2 mean(b F^-1[-k_i k_j a~])    (Hessian term of a Laplacian-dependent GGA)
 template <int OP>
 __global__ __launch_bounds__(kRedThreads) void stress_spec_kernel(const cplx* __restrict__ a, const cplx* __restrict__ b,
                                                                   KGeom kg, double scale, double inv2kf,
@@ -49,6 +50,9 @@ __global__ __launch_bounds__(kRedThreads) void stress_spec_kernel(const cplx* __
             acc[6] += f * k2;
         } else if (OP == STRESS_VW) {
             add_kk(acc, -w * (av.x * av.x + av.y * av.y), kx, ky, kz);
+        } else if (OP == STRESS_HESS) {
+            const cplx bv = b[i];
+            add_kk(acc, w * (av.x * bv.x + av.y * bv.y), kx, ky, kz);
         } else {
             const cplx bv = b[i];
             const double re = w * (av.x * bv.x + av.y * bv.y);
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(kRedThreads) void stress_ion_kernel(const cplx* __r
 __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* __restrict__ n, const double* __restrict__ gx,
                                                                   const double* __restrict__ gy, const double* __restrict__ gz,
                                                                   long long npts, unsigned mask, GgaSel sel,
-                                                                  double gtf_inv_n0, int gtf_kind, double* __restrict__ partial) {
+                                                                  double gtf_inv_n0, int gtf_kind, double* __restrict__ partial,
+                                                                  double* __restrict__ lapn = nullptr) {
     double acc[kStressRealScalars];
 #pragma unroll
     for (int i = 0; i < kStressRealScalars; ++i) acc[i] = 0.0;
@@ -200,8 +205,23 @@ __global__ __launch_bounds__(kRedThreads) void stress_real_kernel(const double* 
             for (int which = 0; which < 3; ++which) {
                 if (which == 0 ? !do_px : (which == 1 ? !do_pc : !do_pk)) continue;
                 const GgaSel one{which == 0, which == 1, which == 2, sel.kkind, sel.kmu, 0.0, 0.0, 0.0};
-                const PbePoint p = pbe_point(d, g2, one);
+                PbePoint p = {0.0, 0.0, 0.0, 0.0, 0.0};
                 double* o = acc + 3 + 8 * which;
+                if (which == 2 && lapn) {
+                    // f(n, g, l = lap n):  sigma_ij = delta_ij mean(f - n f_n - 2 g f_g - l f_l) - 2 mean(f_g d_i n d_j n)
+                    //                                 - 2 mean(f_l d_i d_j n); the last term is reduced in k-space
+                    //                                 (stress_spec_kernel<STRESS_HESS>) from the spectrum of f_l, left in lapn
+                    GgaSel full = sel;
+                    full.x = full.c = 0;
+                    full.k = 1;
+                    double dfdl;
+                    const double l = lapn[i];
+                    pg_laplacian_point(d, g2, l, full, p, dfdl);
+                    o[7] -= l * dfdl;
+                    lapn[i] = dfdl;
+                } else {
+                    p = pbe_point(d, g2, one);
+                }
                 o[0] += a * a * p.dfdg;
                 o[1] += b * b * p.dfdg;
                 o[2] += c * c * p.dfdg;

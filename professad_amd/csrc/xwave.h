@@ -40,8 +40,13 @@ __device__ __forceinline__ void xw_accumulate(real& acr, real& aci, const cplx (
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
             const real cf = mix.template coef<O, I>(x, y, kz, uoff, loff);
-            acr += cf * in[I].x;
-            aci += cf * in[I].y;
+            if constexpr (Mix::template imag_oi<O, I>()) {       // (i c)(re + i im) = -c im + i c re
+                acr -= cf * in[I].y;
+                aci += cf * in[I].x;
+            } else {
+                acr += cf * in[I].x;
+                aci += cf * in[I].y;
+            }
         }
         xw_accumulate<NIN, NOUT, O, I + 1, Mix>(acr, aci, in, mix, x, y, kz, uoff, loff);
     }
@@ -52,7 +57,7 @@ __device__ __forceinline__ void xw_outputs(cplx (&out)[NOUT], const cplx (&in)[N
     if constexpr (O < NOUT) {
         real acr = 0.0, aci = 0.0;
         xw_accumulate<NIN, NOUT, O, 0, Mix>(acr, aci, in, mix, x, y, kz, uoff, loff);
-        out[O] = Mix::imag(O) ? mkc(-aci, acr) : mkc(acr, aci);       // (i c)(re + i im) = -c im + i c re
+        out[O] = mkc(acr, aci);
         xw_outputs<NIN, NOUT, O + 1, Mix>(out, in, mix, x, y, kz, uoff, loff);
     }
 }

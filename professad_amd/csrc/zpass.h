@@ -497,20 +497,24 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
 // D_c is formed on chip.  In: A = (D_a n)^ rows, B = (D_b n)^ rows, dzn = D_c n (real);  out: the contravariant flux
 // components G_a, G_b as spectra (in place of A, B) and df/dn - 2 D_c G_c (real) -- the whole z part of the divergence.
 struct Bmat { real b[9]; };
-template <int M, int E>
+// LAPL: the Laplacian-dependent Pauli-Gaussian members (functionals.py:336-403).  Lsp holds, on entry, the rows of
+// (lap n)^ = -k^2 n^ (x and y already back in real space); on exit the rows of the spectrum of df/d(lap n), whose
+// Laplacian joins the divergence in the next x pass (MixDerivAL).
+template <int M, int E, bool LAPL>
 __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
                                                                       const real* __restrict__ dzn,
                                                                       real* __restrict__ dfdn, real inv_n, real inv_nz,
                                                                       GgaSel sel, Bmat bm, SpecGeom g,
                                                                       const cplx* __restrict__ twM_g,
                                                                       const cplx* __restrict__ twN_g,
-                                                                      acc_t* __restrict__ partial) {
+                                                                      acc_t* __restrict__ partial, cplx* __restrict__ Lsp) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
     const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
     ds = ds.resolved();
     const ZLane<M, E> z(g, lds);
     cplx a[E], b[E], c[E], n[E];
+    cplx lp[LAPL ? E : 1];
 #if OFDFT_Z_PREFETCH
     {       // B's row is requested before A's is transformed (depth-one software pipeline, see z_issue_row)
         real nyq_a, nyq_b;
@@ -518,12 +522,20 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         z_issue_row<M, E>(b, nyq_b, z, B, g);
         z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
         z_inverse_regs<M, E>(a, z, twM, twN, nyq_a);
-        z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
+        if constexpr (LAPL) {
+            real nyq_l;
+            z_issue_row<M, E>(lp, nyq_l, z, Lsp, g);
+            z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
+            z_inverse_regs<M, E>(lp, z, twM, twN, nyq_l);
+        } else {
+            z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
+        }
     }
 #else
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
     z_load_inverse<M, E>(a, z, A, g, twM, twN);
     z_load_inverse<M, E>(b, z, B, g, twM, twN);
+    if constexpr (LAPL) z_load_inverse<M, E>(lp, z, Lsp, g, twM, twN);
 #endif
     z_load_real<M, E>(c, z, dzn);
     z_load_real<M, E>(n, z, ds.src);
@@ -539,7 +551,19 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         const real gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0, gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
         const real gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0, gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
-        if (z.valid) {
+        if constexpr (LAPL) {
+            real dl0 = 0.0, dl1 = 0.0;
+            if (z.valid) {
+                GgaSel nk = sel;
+                nk.k = 0;          // PBE parts (if any) by pbe_point, the kinetic part with its q dependence below
+                const real g20 = gx0 * gx0 + gy0 * gy0 + gz0 * gz0, g21 = gx1 * gx1 + gy1 * gy1 + gz1 * gz1;
+                p0 = pbe_point(ds(n[q].x), g20, nk);
+                p1 = pbe_point(ds(n[q].y), g21, nk);
+                pg_laplacian_point(ds(n[q].x), g20, lp[q].x * inv_n, sel, p0, dl0);
+                pg_laplacian_point(ds(n[q].y), g21, lp[q].y * inv_n, sel, p1, dl1);
+            }
+            lp[q] = mkc(dl0, dl1);
+        } else if (z.valid) {
             p0 = pbe_point(ds(n[q].x), gx0 * gx0 + gy0 * gy0 + gz0 * gz0, sel);
             p1 = pbe_point(ds(n[q].y), gx1 * gx1 + gy1 * gy1 + gz1 * gz1, sel);
         }
@@ -557,6 +581,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
     }
     z_forward_store<M, E>(a, z, A, g, twM, twN);
     z_forward_store<M, E>(b, z, B, g, twM, twN);
+    if constexpr (LAPL) z_forward_store<M, E>(lp, z, Lsp, g, twM, twN);
     z_deriv_row<M, E>(c, z, twM, twN);               // N2 x D_c G_c
 #pragma unroll
     for (int q = 0; q < E; ++q) d[q] = mkc(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);

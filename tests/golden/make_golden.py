@@ -323,7 +323,8 @@ if '--ions' in sys.argv:
     gen_ions()
 
 
-STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99', 'lkt', 'pgs', 'vwgtf1', 'vwgtf2']
+STRESS_TERMS = ['hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c', 'pbe_x', 'pbe_c', 'wgc99', 'lkt', 'pgs', 'vwgtf1', 'vwgtf2',
+                'pgsl025', 'pgslr', 'wts_exp']
 
 
 def gen_stress():

@@ -83,6 +83,38 @@ def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
     _check_worker_results(res, dtype)
 
 
+def test_eight_rank_geometry_with_the_laplacian_dependent_pauli_gaussian():
+    """PGSL0.25 + Hartree + PBE over 8 emulated slab ranks (lap n and df/dL cross the exchange beside the GGA spectra)"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    import cases
+    from local_ranks import LocalRanks
+    from professad_amd import synth
+    from professad_amd.engine import Engine
+    dev = torch.device('cuda:0')
+    shape = (64, 32, 32)
+    box = torch.as_tensor(cases.make_cell(('tri', 2.0)))
+    den = synth.smooth_density(shape, seed=41)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=dev)  # noqa: E731
+    chi = t(np.sqrt(den) * (1 + 0.05 * np.random.default_rng(43).random(shape)))
+    vext = t(synth.random_potential(shape, seed=42))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box.numpy()))) + 0.3)
+    names = ['ion_electron', 'hartree', 'vw', 'gga_k', 'pbe_x', 'pbe_c']
+    params = {'ggak_kind': 1.0, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25, 'ggak_lambda': 0.4, 'ggak_sigma': 0.2}
+    ref = Engine(shape, dev).set_cell(box).set_terms(names, params)
+    Er, mur, gr = ref.energy_grad_chi(chi, n_elec, vext)
+    ref.close()
+    for nranks in (2, 8):
+        loc = LocalRanks(shape, dev, nranks).set_cell(box).set_terms(names, params)
+        E, mu, g = loc.closure(chi, n_elec, vext)
+        loc.close()
+        for k in Er:
+            assert abs(E[k] - Er[k]) <= 1e-12 * max(1.0, abs(Er[k])), (nranks, k, E[k], Er[k])
+        assert abs(mu - mur) <= 1e-12 * max(1.0, abs(mur))
+        assert float((g - gr).abs().max()) <= 1e-12 * float(gr.abs().max())
+
+
 @pytest.mark.parametrize('nranks,shape', [(8, (32, 64, 16)), (8, (64, 64, 64)), (8, (256, 256, 256))])
 def test_eight_rank_geometry_in_one_process(nranks, shape):
     """the slab geometry of an 8-GPU job (kernels, pack / un-pack, stage order), emulated with 8 contexts on one GPU"""

@@ -534,11 +534,66 @@ def test_pauli_gaussian_members_and_all_pipelines_for_gga_kinetic():
         E, v = eng.energy_potential(dev(den))
         assert abs(sum(E.values()) - Eref) <= E_RTOL * abs(Eref), mode
         assert relerr(v.cpu().numpy(), vref) < V_RTOL, mode
-    # the Laplacian-dependent members have no stress and no slab-decomposed form: refused, not ignored
-    eng.set_terms(['vw', 'gga_k'], {'ggak_kind': 1.0, 'ggak_beta': 0.25})
-    with pytest.raises(RuntimeError):
-        eng.stress(dev(den))
     eng.close()
+
+
+@pytest.mark.parametrize('case', ['g16r', 'g16s'])
+@pytest.mark.parametrize('member', ['pgsl025', 'pgslr'])
+def test_laplacian_dependent_pauli_gaussian_through_every_pipeline(case, member):
+    """PGSL0.25 (the reference's default PauliGaussian) and PGSLr: the z-fused split-derivative chain carries lap n and
+    lap(df/dL) as one more spectrum each way; the unfused pipeline and the unsplit form (which falls back to it) agree;
+    all against the reference's goldens (tests/tools_for_tests.py:86-118 is the closed form)"""
+    gold = load('terms_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    params = {'ggak_kind': 1.0, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25}
+    if member == 'pgslr':
+        params.update(ggak_lambda=0.4, ggak_sigma=0.2)
+    Eref, vref = float(gold['E_' + member]), gold['v_' + member]
+    eng = Engine(den.shape, DEV).set_cell(dev(box)).set_terms(['vw', 'gga_k'], params)
+    counts = {}
+    for mode, gsplit in ((0, 1), (1, 1), (0, 0), (2, 1)):
+        eng.set_option(0, mode).set_option(6, gsplit)
+        E, v = eng.energy_potential(dev(den))
+        assert abs(sum(E.values()) - Eref) <= E_RTOL * abs(Eref), (mode, gsplit)
+        assert relerr(v.cpu().numpy(), vref) < V_RTOL, (mode, gsplit)
+        counts[(mode, gsplit)] = int(eng.query(4))
+    assert counts[(0, 1)] < counts[(1, 1)]            # the fused chain really ran (fewer launches than the unfused pipeline)
+    # together with PBE and Hartree in one evaluation (shared gradient chain), closure form
+    eng.set_option(0, 0).set_option(6, 1)
+    eng.set_terms(['hartree', 'vw', 'gga_k', 'pbe_x', 'pbe_c'], params)
+    E, v = eng.energy_potential(dev(den))
+    Eref2 = Eref + float(gold['E_hartree']) + float(gold['E_pbe_x']) + float(gold['E_pbe_c'])
+    vref2 = vref + gold['v_hartree'] + gold['v_pbe_x'] + gold['v_pbe_c']
+    assert abs(sum(E.values()) - Eref2) <= E_RTOL * abs(Eref2)
+    assert relerr(v.cpu().numpy(), vref2) < V_RTOL
+    eng.close()
+
+
+@pytest.mark.parametrize('case', ['g16r', 'gmix', 'g18t'])
+def test_stress_of_laplacian_dependent_pauli_gaussian_and_wt_style(case):
+    """PGSL0.25 / PGSLr (derived Hessian term, oracle/stress.py::pauli_gaussian) and the Wang-Teter style functional with
+    f = exp (tools_for_tests.py:310-364) against the reference's get_stress"""
+    g = load('stress.npz')
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    eng = Engine(den.shape, DEV).set_cell(dev(box))
+    for member, params in (('pgsl025', {'ggak_kind': 1.0, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25}),
+                           ('pgslr', {'ggak_kind': 1.0, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25, 'ggak_lambda': 0.4, 'ggak_sigma': 0.2})):
+        sig = eng.set_terms(['vw', 'gga_k'], params).stress(dev(den))
+        tot = sig['vw'] + sig['gga_k']
+        ref = g['%s_%s' % (case, member)]
+        assert np.abs(tot - ref).max() <= 2e-10 * np.abs(ref).max(), (member, np.abs(tot - ref).max(), np.abs(ref).max())
+    eng.close()
+
+    def get_stress(f):        # the reference's recipe, functional_tools.py:94-99
+        b = dev(box).clone().requires_grad_(True)
+        vol = torch.abs(torch.linalg.det(b))
+        E = f(b, dev(den) * vol.detach() / vol)
+        dEdcell = torch.autograd.grad(E, b)[0].T
+        return (dEdcell @ b.detach() / vol.detach()).cpu().numpy()
+    for f, key in ((F.WangTeterStyleFunctional((5 / 6, 5 / 6, torch.exp)), 'wts_exp'), (F.PauliGaussian(), 'pgsl025')):
+        s = get_stress(f)
+        ref = g['%s_%s' % (case, key)]
+        assert np.abs(s - ref).max() <= 2e-10 * np.abs(ref).max(), key
 
 
 def test_generic_extent_paths_agree():

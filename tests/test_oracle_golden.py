@@ -133,7 +133,10 @@ def test_stress_oracle():
                'lda_x': st.lda(box, den, 'lda_x'), 'pz_c': st.lda(box, den, 'pz_c'), 'pw_c': st.lda(box, den, 'pw_c'),
                'chachiyo_c': st.lda(box, den, 'chachiyo_c'), 'pbe_x': st.pbe(box, den, True, False),
                'pbe_c': st.pbe(box, den, False, True),
-               'wgc99': st.tf(box, den) + st.vw(box, den) + st.wgc99_nl(box, den)}
+               'wgc99': st.tf(box, den) + st.vw(box, den) + st.wgc99_nl(box, den),
+               'pgsl025': st.vw(box, den) + st.pauli_gaussian(box, den),
+               'pgslr': st.vw(box, den) + st.pauli_gaussian(box, den, 40 / 27, 0.25, 0.4, 0.2),
+               'wts_exp': st.wang_teter_style(box, den)}
         for k, v in got.items():
             ref = g['%s_%s' % (case, k)]
             assert np.abs(v - ref).max() <= 1e-11 * np.abs(ref).max(), (case, k)
