@@ -85,10 +85,14 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_P_GGAK_KIND   6   /* 0 = LKT (default), 1 = Pauli-Gaussian exp(-mu s^2) */
 #define OFDFT_P_GGAK_MU     7   /* default 40/27 (PGS); 1.0 = PG1 */
 #define OFDFT_P_GGAK_BETA   8   /* Pauli-Gaussian coefficients of q^2, -q s^2, s^4 (functionals.py:336-403); any non-zero one */
-#define OFDFT_P_GGAK_LAMBDA 9   /* makes the term depend on the reduced Laplacian q: evaluated by the unfused single-GPU     */
-#define OFDFT_P_GGAK_SIGMA  10  /* pipeline (one more c2r and r2c); not available slab-decomposed or for the stress          */
+#define OFDFT_P_GGAK_LAMBDA 9   /* makes the term depend on the reduced Laplacian q (PGSL0.25 = the reference's default,    */
+#define OFDFT_P_GGAK_SIGMA  10  /* PGSLr): one more spectrum each way in the GGA chain; every pipeline, slabs and stress     */
 #define OFDFT_P_VWGTF_KIND  11  /* 1 = vWGTF1 (default), 2 = vWGTF2 */
-#define OFDFT_NPARAMS       12
+#define OFDFT_P_WTS_KIND    12  /* Pauli-positivity stabilisation of WangTeterStyleFunctional (functionals.py:728-782) for a term
+                                   set with OFDFT_TF and OFDFT_WT_NL: T = T_TF f(X), X = T_NL / (f'(0) T_TF).  0 (default): f(x) = 1 + x,
+                                   i.e. the plain sum T_TF + T_NL; 1: f(x) = exp(x).  Then E_terms[TF] reports T_TF f(X), E_terms[WT_NL]
+                                   zero, the potential and the stress carry the weights f - f' X and f'(X) / f'(0).  Single-GPU contexts. */
+#define OFDFT_NPARAMS       13
 
 /* ofdft_query selectors */
 #define OFDFT_Q_FFT_COUNT        0  /* 3-D FFTs executed by the last energy call              */

@@ -23,7 +23,7 @@ TERM_BITS = {
 TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x', 'pz_c', 'pw_c', 'chachiyo_c',
               'pbe_x', 'pbe_c', 'gga_k', 'vwgtf']
 NTERMS = 14
-NPARAMS = 12
+NPARAMS = 13
 Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPASS_COUNT, Q_GRAPH_REPLAYS = 0, 1, 2, 3, 4, 5, 6
 OPT_GRAPH = 7
 OPT_XWAVE = 8

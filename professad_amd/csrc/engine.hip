@@ -122,6 +122,11 @@ bool gga_needs_laplacian(const ofdft_ctx* c) {
     return (c->mask & OFDFT_GGA_K) && (int)c->params[OFDFT_P_GGAK_KIND] == 1 &&
            (c->params[OFDFT_P_GGAK_BETA] != 0.0 || c->params[OFDFT_P_GGAK_LAMBDA] != 0.0 || c->params[OFDFT_P_GGAK_SIGMA] != 0.0);
 }
+// Pauli-positivity stabilised Wang-Teter style functional (functionals.py:728-782) with f = exp: two combine passes (energies
+// first, then the potential with the weights f - f' X, f' they determine)
+bool wts_active(const ofdft_ctx* c) {
+    return (int)c->params[OFDFT_P_WTS_KIND] == 1 && (c->mask & OFDFT_TF) && (c->mask & OFDFT_WT_NL);
+}
 bool zfused_serves(const ofdft_ctx* c) {
     return c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && (!gga_needs_laplacian(c) || c->gga_split);
 }
@@ -853,9 +858,24 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
     if (!cb.conv_b) cb.conv_b = d;
     if (!cb.u0) cb.u0 = cb.u1 = cb.u2 = cb.gA = cb.gB = cb.gC = d;
     if (!cb.dfdn) cb.dfdn = cb.div = d;
-    OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, cb, c->d_partial);
     double sums[kCombineScalars];
+    double wts_f = 1.0;
+    if (wts_active(c)) {      // first pass: energies only -> X = T_NL / T_TF -> weights of the two potentials
+        CombineArgs c1 = cb;
+        c1.v_out = nullptr;
+        OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, c1, c->d_partial);
+        if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
+        const double X = sums[4] / sums[2];
+        wts_f = std::exp(X);
+        cb.w_tf = (real)(wts_f * (1.0 - X));
+        cb.w_nl = (real)wts_f;
+    }
+    OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, cb, c->d_partial);
     if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
+    if (wts_active(c)) {
+        sums[2] *= wts_f;
+        sums[4] = 0.0;
+    }
     const double dV = c->dV;
     if (mask & OFDFT_ION_ELECTRON) E_terms[0] = sums[0] * dV;
     if (mask & OFDFT_HARTREE) E_terms[1] = sums[1] * dV;
@@ -1259,7 +1279,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
     const double s5 = std::sqrt(5.0);
     const double defaults[OFDFT_NPARAMS] = {kFiveSixths, kFiveSixths, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, (double)27 / 10, 1.0, 0.0, (double)40 / 27,
-                                            0.0, 0.0, 0.0, 1.0};
+                                            0.0, 0.0, 0.0, 1.0, 0.0};
     std::memcpy(c->params, defaults, sizeof(defaults));
     DeviceScope device_scope_(device_id);
     hipError_t e = device_scope_.err;
@@ -1271,7 +1291,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * c->partial_rows * kMaxScalars);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_reduced, sizeof(double) * kMaxScalars);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_scal, sizeof(double) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_scal, sizeof(double) * 8);    // [0] closure scale, [2] split WGC99 energy, [4..6] WT-style weights
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -1628,6 +1648,8 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     if (!(c->fast && c->n2 / 2 <= 512)) return fail(c, OFDFT_EINVAL, "staged path needs the power-of-two fast path");
     if (gga_needs_laplacian(c) && !c->gga_split)
         return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members need the split-derivative GGA chain (OFDFT_OPT_GGA_SPLIT = 1)");
+    if (wts_active(c) && c->nranks > 1)
+        return fail(c, OFDFT_EINVAL, "the stabilised Wang-Teter style functional (OFDFT_P_WTS_KIND) is served by single-GPU contexts");
     ZRun& r = zrun(c);
     if (from_chi == 2) {      // closure scale from the (all-reduced) sum of chi^2 in scalars[15]; it never visits the host
         OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel_global,

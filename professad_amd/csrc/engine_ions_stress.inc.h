@@ -320,6 +320,16 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         for (int k = 0; k < 6; ++k) c6[k] = pref * s7[k];
         sym_store(sig + 9 * 4, c6, -2.0 / 3.0 * pref * s7[6]);                                  // -2/3 T_NL / vol
     }
+    if (wts_active(c)) {      // T = T_TF f(X): sigma = sigma_TF (f - f' X) + sigma_NL f'(X) / f'(0)   (tools_for_tests.py:310-364), f = exp
+        // both stresses carry -2/3 E / vol on their diagonals: T_TF / vol = -3/2 sig_TF[0] exactly; T_NL / vol from the trace
+        // of the Wang-Teter tensor (its k-dependent part is traceless)
+        const double tf_over_vol = -1.5 * sig[9 * 2], nl_over_vol = -0.5 * (sig[9 * 4] + sig[9 * 4 + 4] + sig[9 * 4 + 8]);
+        const double X = nl_over_vol / tf_over_vol, fx = std::exp(X);
+        for (int k = 0; k < 9; ++k) {
+            sig[9 * 2 + k] *= fx * (1.0 - X);
+            sig[9 * 4 + k] *= fx;
+        }
+    }
     if (mask & OFDFT_WGC99_NL) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
         const long long nel_r = std::llround(nsum * c->dV);                                      // functionals.py:952

@@ -243,6 +243,7 @@ ZRun& zrun(ofdft_ctx* c);
 // Every chunk must be whole workgroups of every z kernel (at most 256 rows each) -> powers of two that divide n0.
 int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
     if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which)) return 1;
+    if (which == 8 && wts_active(c)) return 1;        // the two-pass combine of the stabilised WT-style functional is not chunked
     // automatic: about 100 MB of spectra per chunk (measured best at 256^3: 8 chunks for the six WGC99 spectra)
     int want = c->xchunks > 1 ? (c->xchunks * narr + 5) / 6
                               : (int)std::min<double>(64.0, (double)narr * sizeof(cplx) * (double)c->g.total / 100e6);
@@ -711,6 +712,17 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
         HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
     }
+    const bool wts = wts_active(c);
+    r.za.wts_w = nullptr;
+    if (wts) {            // energies-only pass -> device-resident weights f - f' X, f' (no host round trip: graph-capturable)
+        ZCombineArgs z1 = r.za;
+        z1.v_out = nullptr;
+        if ((rc = launch_zi_combine(c, z1, &r.combine_blocks, st))) return rc;
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
+                     r.combine_blocks, kCombineScalars, c->d_reduced);
+        OFDFT_LAUNCH(c, st, "reduce", wts_weights_kernel, dim3(1), dim3(64), 0, (const acc_t*)c->d_reduced, c->d_scal + 4);
+        r.za.wts_w = c->d_scal + 4;
+    }
     if (chunked) {        // y-inverse of a chunk of every result spectrum, then the combine kernel on the same x planes
         const int narr = (int)r.deferred.size();
         const int nch = chunks_for(c, narr + 2, 8);       // + the real rows (chi, v_ext, df/dn, v) the kernel touches
@@ -725,6 +737,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
     }
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
+    if (wts) OFDFT_LAUNCH(c, st, "reduce", wts_finalize_kernel, dim3(1), dim3(64), 0, c->d_reduced, (const acc_t*)(c->d_scal + 4));
     if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
     r.stage[0] = r.stage[1] = 5;
     if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself

@@ -714,6 +714,7 @@ struct CombineArgs {
     int gtf_kind;        // 1 = vWGTF1, 2 = vWGTF2
     int wt_is_56;        // alpha = beta = 5/6: n^(-1/6) = 1/sqrt(cbrt n), no pow
     int wgc_sum_53;      // alpha + beta = 5/3: n^(alpha-1) = 1/(cbrt(n) n^(beta-1)), one pow instead of two
+    real w_tf = 1.0, w_nl = 1.0;   // weights of the TF / Wang-Teter potentials (stabilised WT-style functional, OFDFT_P_WTS_KIND)
 };
 // partial scalars: 0 ion-electron, 1 hartree, 2 tf, 3 vw, 4 wt-nl, 5 wgc-nl, 6 lda-x, 7 local-c, 8 sum(v*n), 9 vWGTF
 constexpr int kCombineScalars = 10;
@@ -761,7 +762,7 @@ __device__ __forceinline__ real combine_point(const CombineArgs& a, const Combin
     if (a.mask & 4u) {                                  // TF  functionals.py:223; tools_for_tests.py:19-20
         const real n23 = n13 * n13;
         acc[2] += ctf * n23 * n;
-        v += (5.0 / 3.0) * ctf * n23;
+        v += a.w_tf * (5.0 / 3.0) * ctf * n23;
     }
     if (a.mask & 8u) {                                  // vW  functionals.py:245; tools_for_tests.py:23-26
         const real s = (n != 0.0) ? sqrt(n) : 0.0;
@@ -773,9 +774,9 @@ __device__ __forceinline__ real combine_point(const CombineArgs& a, const Combin
         acc[4] += ctf * (pa1 * n - a.wt_nbar_pa) * p.cb;
         if (a.conv_a) {
             const real pb1 = pow(n, a.wt_beta - 1.0);
-            v += ctf * (a.wt_alpha * pa1 * p.cb + a.wt_beta * pb1 * p.cva);
+            v += a.w_nl * ctf * (a.wt_alpha * pa1 * p.cb + a.wt_beta * pb1 * p.cva);
         } else {
-            v += ctf * 2.0 * a.wt_alpha * pa1 * p.cb;
+            v += a.w_nl * ctf * 2.0 * a.wt_alpha * pa1 * p.cb;
         }
     }
     if (a.mask & 32u) {                                 // WGC99 NL  SURVEY §8a-8
@@ -848,6 +849,24 @@ __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long lon
 __global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc_t* __restrict__ cscale, acc_t n_elec,
                                      acc_t vol_over_npts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
+}
+
+// Stabilised Wang-Teter style functional T_TF f(X), X = T_NL / T_TF, f = exp (functionals.py:771-782): weights of the two
+// potentials from the reduced sums of a first (energy-only) combine pass ...
+__global__ void wts_weights_kernel(const acc_t* __restrict__ sums, acc_t* __restrict__ w) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const acc_t X = sums[4] / sums[2], fx = ::exp(X);
+        w[0] = fx * (1.0 - X);      // f - f' X
+        w[1] = fx;                  // f' / f'(0)
+        w[2] = fx;
+    }
+}
+// ... and the reported sums after the second pass: [2] <- T_TF f(X), [4] <- 0
+__global__ void wts_finalize_kernel(acc_t* __restrict__ sums, const acc_t* __restrict__ w) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sums[2] *= w[2];
+        sums[4] = 0.0;
+    }
 }
 
 __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,

@@ -614,6 +614,7 @@ struct ZCombineArgs {
     real gtf_inv_n0;
     int gtf_kind;
     int wt_is_56, wgc_sum_53;
+    const acc_t* wts_w;     // device weights (w_tf, w_nl) of the stabilised WT-style functional, or null
 };
 
 // WGC99 nonlocal part of one row (SURVEY §8a-8 closed form): adds the potential to vacc, returns the thread's energy sum
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         vacc[q] = mkc(0.0, 0.0);
     }
     const real sc = a.inv_n;
+    const real w_tf = a.wts_w ? (real)a.wts_w[0] : (real)1.0, w_nl = a.wts_w ? (real)a.wts_w[1] : (real)1.0;
     // Depth-one software pipeline over the spectra this kernel consumes (lean instantiation): chain[i] = the i-th
     // spectrum or null; a section takes its row from the registers filled one section earlier and requests the next
     // present one before transforming its own (z_issue_row).
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
             pa1[q] = a.wt_is_56 ? mkc(fm::roots(n[q].x).y, fm::roots(n[q].y).y)
                                 : mkc(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
             e += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
-            const real f = a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha;
+            const real f = w_nl * (a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha);
             vacc[q].x += ctf * f * pa1[q].x * x0;
             vacc[q].y += ctf * f * pa1[q].y * x1;
         }
@@ -795,8 +797,8 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
             take_row(std::integral_constant<int, 3>{}, a.conv_a);
 #pragma unroll
             for (int q = 0; q < E; ++q) {
-                vacc[q].x += ctf * a.wt_beta * pow_pos(n[q].x, a.wt_beta - 1.0) * w[q].x * sc;
-                vacc[q].y += ctf * a.wt_beta * pow_pos(n[q].y, a.wt_beta - 1.0) * w[q].y * sc;
+                vacc[q].x += w_nl * ctf * a.wt_beta * pow_pos(n[q].x, a.wt_beta - 1.0) * w[q].x * sc;
+                vacc[q].y += w_nl * ctf * a.wt_beta * pow_pos(n[q].y, a.wt_beta - 1.0) * w[q].y * sc;
             }
         }
     }
@@ -852,8 +854,8 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         if (a.mask & 4u) {                               // TF  functionals.py:223
             const real c0 = fm::roots(n[q].x).n13, c1 = fm::roots(n[q].y).n13;
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
-            vacc[q].x += (5.0 / 3.0) * ctf * c0 * c0;
-            vacc[q].y += (5.0 / 3.0) * ctf * c1 * c1;
+            vacc[q].x += w_tf * (5.0 / 3.0) * ctf * c0 * c0;
+            vacc[q].y += w_tf * (5.0 / 3.0) * ctf * c1 * c1;
         }
         if (a.mask & (1u << 13)) {                       // vWGTF1 / 2  functionals.py:251-306
             real e0, v0, e1, v1;

@@ -93,14 +93,15 @@ class Engine:
 
     def set_terms(self, names, params=None):
         """names: iterable of keys of _native.TERM_BITS; params: dict slot->value
-        (wt_alpha, wt_beta, wgc_alpha, wgc_beta, wgc_gamma, wgc_kappa, ggak_kind, ggak_mu, ggak_beta, ggak_lambda, ggak_sigma, vwgtf_kind)."""
+        (wt_alpha, wt_beta, wgc_alpha, wgc_beta, wgc_gamma, wgc_kappa, ggak_kind, ggak_mu, ggak_beta, ggak_lambda, ggak_sigma, vwgtf_kind,
+        wts_kind)."""
         mask = 0
         for nm in names:
             mask |= N.TERM_BITS[nm]
         slots = ['wt_alpha', 'wt_beta', 'wgc_alpha', 'wgc_beta', 'wgc_gamma', 'wgc_kappa', 'ggak_kind', 'ggak_mu', 'ggak_beta',
-                 'ggak_lambda', 'ggak_sigma', 'vwgtf_kind']
+                 'ggak_lambda', 'ggak_sigma', 'vwgtf_kind', 'wts_kind']
         s5 = np.sqrt(5.0)
-        vals = np.array([5 / 6, 5 / 6, (5 + s5) / 6, (5 - s5) / 6, 2.7, 1.0, 0.0, 40 / 27, 0.0, 0.0, 0.0, 1.0], dtype=np.float64)
+        vals = np.array([5 / 6, 5 / 6, (5 + s5) / 6, (5 - s5) / 6, 2.7, 1.0, 0.0, 40 / 27, 0.0, 0.0, 0.0, 1.0, 0.0], dtype=np.float64)
         for k, v in (params or {}).items():
             vals[slots.index(k)] = float(v)
         key = (mask, vals.tobytes())

@@ -285,8 +285,13 @@ class PauliGaussian:
 
 class WangTeterStyleFunctional:
     """functionals.py:728-782: T = vW + T_TF f(T_NL / (f'(0) T_TF)) with a Pauli-positivity stabilisation function f
-    (f(0) = 1; default f(x) = 1 + x, i.e. a plain Wang-Teter style functional).  The three energies come from the engine;
-    f acts on the scalars in torch, so its derivative reaches the native potentials through autograd."""
+    (f(0) = 1; default f(x) = 1 + x, i.e. a plain Wang-Teter style functional).
+
+    The two stabilisation functions the reference's papers and tests use are served by ONE engine evaluation
+    (``OFDFT_P_WTS_KIND``): f(x) = 1 + x is the plain sum T_TF + T_NL, f = exp runs the combine stage twice (energies, then
+    the potential with the weights f - f' X and f'(X) / f'(0) they determine); the stress carries the same weights
+    (tests/tools_for_tests.py:310-364).  Any other callable f -- a user lambda cannot cross the C ABI -- composes the three
+    native energies in torch, its derivative reaching the native potentials and stresses through autograd."""
 
     def __init__(self, init_args=None):
         self.alpha, self.beta, self.f = (5 / 6, 5 / 6, (lambda t: 1 + t)) if init_args is None else init_args
@@ -294,9 +299,19 @@ class WangTeterStyleFunctional:
         if float(self.f(zero).detach()) != 1.0:
             raise ValueError('Requires f(0) = 1')
         self.fprime0 = float(torch.autograd.grad(self.f(zero), zero)[0])
+        probe = torch.tensor([-0.7, 0.25, 1.0], dtype=torch.double)
+        got = self.f(probe)
+        self._kind = None
+        if torch.allclose(got, 1 + probe, rtol=1e-14, atol=0):
+            self._kind = 0.0
+        elif torch.allclose(got, torch.exp(probe), rtol=1e-14, atol=0):
+            self._kind = 1.0
         self.__name__ = self.__qualname__ = 'WangTeterStyleFunctional'
 
     def forward(self, box_vecs, den):
+        if self._kind is not None:
+            return _evaluate(box_vecs, den, ('tf', 'vw', 'wt_nl'),
+                             (('wt_alpha', float(self.alpha)), ('wt_beta', float(self.beta)), ('wts_kind', self._kind)))
         vW, TF = Weizsaecker(box_vecs, den), ThomasFermi(box_vecs, den)
         T_NL = non_local_KEF(box_vecs, den, float(self.alpha), float(self.beta)) / self.fprime0
         return vW + TF * self.f(T_NL / TF)

@@ -257,7 +257,13 @@ def _recpot_table(path, IU):
     Coulomb tail is added): the product's own reader supplies the fields, the reference module the constants."""
     from professad_amd.ions import recpot_fields
     raw, k_max = recpot_fields(path)
-    return raw * IU.pot_conv_factor, k_max * IU.bohr
+    raw, k_max = raw * IU.pot_conv_factor, k_max * IU.bohr
+    # pin the reader to the REFERENCE's own parse of the same file: interpolate_recpot evaluated at the table's own nodes
+    # returns the table (the Coulomb tail it adds for the interpolation is subtracted again, ion_utils.py:66-80)
+    ks = np.linspace(0.0, k_max, raw.size)
+    back = IU.interpolate_recpot(path, torch.as_tensor(ks)).numpy()
+    assert raw.size > 1000 and np.allclose(back, raw, rtol=1e-9, atol=1e-9 * np.abs(raw).max()), 'reader differs from the reference parse'
+    return raw, k_max
 
 
 

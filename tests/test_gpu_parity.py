@@ -582,6 +582,10 @@ def test_stress_of_laplacian_dependent_pauli_gaussian_and_wt_style(case):
         tot = sig['vw'] + sig['gga_k']
         ref = g['%s_%s' % (case, member)]
         assert np.abs(tot - ref).max() <= 2e-10 * np.abs(ref).max(), (member, np.abs(tot - ref).max(), np.abs(ref).max())
+    sig = eng.set_terms(['tf', 'vw', 'wt_nl'], {'wts_kind': 1.0}).stress(dev(den))      # native weights f - f' X, f'
+    ref = g['%s_wts_exp' % case]
+    tot = sig['tf'] + sig['vw'] + sig['wt_nl']
+    assert np.abs(tot - ref).max() <= 2e-10 * np.abs(ref).max(), np.abs(tot - ref).max()
     eng.close()
 
     def get_stress(f):        # the reference's recipe, functional_tools.py:94-99
@@ -867,3 +871,43 @@ def test_wave_local_x_pass_matches_the_group_parallel_kernel(shape):
                 assert abs(E[k] - Er[k]) <= 1e-12 * max(1.0, abs(Er[k])), (ts, key, k, E[k], Er[k])
             assert relerr(v, vr) < 1e-12, (ts, key)
             assert n == nf
+
+
+@pytest.mark.parametrize('case', ['g16r', 'g17r', 'g18t'])
+def test_stabilised_wang_teter_style_functional_in_one_engine_call(case):
+    """WangTeterStyleFunctional with f = exp (functionals.py:728-782) as ONE native evaluation (two combine passes) through
+    every pipeline -- g17r / g18t are non power-of-two grids (unfused pipeline) -- against the reference's golden, the
+    closure form against the same potential, and a custom f (torch composition) against the native form"""
+    gold = load('terms_%s.npz' % case)
+    box, den, vext, chi, n_elec = cases.make_inputs(case)
+    Eref, vref = float(gold['E_wts_exp']), gold['v_wts_exp']
+    eng = Engine(den.shape, DEV).set_cell(dev(box)).set_terms(['tf', 'vw', 'wt_nl'], {'wts_kind': 1.0})
+    for mode in (0, 1, 2):
+        eng.set_option(0, mode)
+        E, v = eng.energy_potential(dev(den))
+        assert abs(sum(E.values()) - Eref) <= E_RTOL * abs(Eref), mode
+        assert relerr(v.cpu().numpy(), vref) < V_RTOL, mode
+        assert E['wt_nl'] == 0.0 and E['tf'] > 0.0
+    eng.set_option(0, 0)
+    # closure: n = N_e chi^2 / int chi^2; the gradient is 2 c chi (v - mu) dV with THIS functional's potential
+    vol = abs(np.linalg.det(box))
+    c = n_elec / (np.mean(chi * chi) * vol)
+    Ed, vd = eng.energy_potential(dev(c * chi * chi))
+    Ec, mu, g = eng.energy_grad_chi(dev(chi), n_elec)
+    assert abs(sum(Ec.values()) - sum(Ed.values())) <= 1e-12 * abs(sum(Ed.values()))
+    vdn = vd.cpu().numpy()
+    mu_ref = float(np.sum(vdn * c * chi * chi) * vol / chi.size / n_elec)
+    gref = 2 * c * chi * (vdn - mu_ref) * vol / chi.size
+    assert abs(mu - mu_ref) <= 1e-11 * abs(mu_ref) and relerr(g.cpu().numpy(), gref) < 1e-10
+    eng.close()
+    # the drop-in class: enumerated f -> native single call; anything else -> torch composition of native energies
+    f_native = F.WangTeterStyleFunctional((5 / 6, 5 / 6, torch.exp))
+    f_custom = F.WangTeterStyleFunctional((5 / 6, 5 / 6, lambda x: torch.exp(x * 1.0000000001) ** 1.0))
+    assert f_native._kind == 1.0 and F.WangTeterStyleFunctional()._kind == 0.0
+    tb = dev(box)
+    for f in (f_native, f_custom):
+        E = float(f(tb, dev(den)))
+        v = F.get_functional_derivative(tb, dev(den), f).cpu().numpy()
+        tol = 1e-8 if f is f_custom else 1.0
+        assert abs(E - Eref) <= max(E_RTOL, 1e-9 if f is f_custom else 0) * abs(Eref) * (10 if f is f_custom else 1)
+        assert relerr(v, vref) < (1e-8 if f is f_custom else V_RTOL), tol
