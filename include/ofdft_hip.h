@@ -130,6 +130,20 @@ int  ofdft_debug_math(ofdft_ctx* ctx, int kind, const void* in_dev, void* out_de
 
 int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
 
+/* ---- collectives for the slab-decomposed per-geometry-step routines --------------------------------------------
+ * The hot path (ofdft_dist_*) is staged so that the HOST issues its all-to-alls between stages.  The routines that run
+ * once per geometry step (ofdft_stress, ofdft_ionic_potential, ofdft_ion_electron_forces, ofdft_ion_electron_stress)
+ * need several distributed transforms and reductions in one call; on a slab-decomposed context they call back into the
+ * host's communication layer (torch.distributed over RCCL in professad_amd.distributed; anything with these semantics):
+ *   all_to_all(user, send_dev, recv_dev, bytes_per_peer, stream): equal-split all-to-all of device buffers (peer p's chunk
+ *       at offset p * bytes_per_peer), ordered after the work already enqueued on `stream`; work enqueued on `stream`
+ *       after the call returns is ordered after the exchange.
+ *   all_reduce(user, host_buf, count): in-place sum over the ranks of `count` doubles in HOST memory.
+ * Both return 0 on success.  Every rank must make the same sequence of calls (they are collective). */
+typedef int (*ofdft_all_to_all_fn)(void* user, void* send_dev, void* recv_dev, unsigned long long bytes_per_peer, void* stream);
+typedef int (*ofdft_all_reduce_fn)(void* user, double* host_buf, int count);
+int  ofdft_set_collectives(ofdft_ctx* ctx, ofdft_all_to_all_fn all_to_all, ofdft_all_reduce_fn all_reduce, void* user);
+
 /* ---- slab-decomposed evaluation over several GPUs (one process per GPU) --------------------
  * Rank r of P owns the real-space x-slab [n0/P][n1][n2].  The evaluation is cut at the four points where the
  * spectra change between the x-slab geometry (z, y passes) and the y-slab geometry (x pass); at each one the

@@ -32,7 +32,12 @@ EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell'
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',
            'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
            'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_dots',
-           'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
+           'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_collectives', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
+
+
+# callback types of ofdft_set_collectives (include/ofdft_hip.h)
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 
 class NativeLibraryError(RuntimeError):
@@ -125,6 +130,8 @@ def load(dtype=F64):
     lib.ofdft_lbfgs_commit.restype = ip
     lib.ofdft_lbfgs_update.argtypes = [vp, dp, dp, C.c_double, C.c_double, vp, vp, dp, vp]
     lib.ofdft_lbfgs_update.restype = ip
+    lib.ofdft_set_collectives.argtypes = [vp, A2A_FN, ALLREDUCE_FN, vp]
+    lib.ofdft_set_collectives.restype = ip
     lib.ofdft_set_option.argtypes = [vp, ip, C.c_double]
     lib.ofdft_set_option.restype = ip
     lib.ofdft_set_profiling.argtypes = [vp, ip]

@@ -100,6 +100,10 @@ struct ofdft_ctx {
     bool use_graph = true;
     long long graph_replays = 0;
     hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
+    // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
+    ofdft_all_to_all_fn a2a = nullptr;
+    ofdft_all_reduce_fn allreduce = nullptr;
+    void* coll_user = nullptr;
     char err[512] = "";
 };
 
@@ -509,9 +513,44 @@ int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const 
 
 bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
 
+// ---- slab-decomposed 3-D transforms for the per-geometry-step routines (stress, ionic potential, forces): a real x-slab
+// [n0/P][n1][n2] <-> the y-slab of the half spectrum in the block-8 layout of the x-pass geometry (c->gx: all of x, n1/P of
+// y), which is what every k-space kernel of those routines indexes (kvec / spec_decode with kg.g = gx, kg.y0).  One
+// all-to-all per transform through the host's collective (ofdft_set_collectives); the y pass reads / writes the exchange
+// layout directly, a small kernel converts between it and the block-8 y-slab array.
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv);
+__global__ void xchg_unpack_kernel(const cplx* __restrict__ buf, cplx* __restrict__ spec, SpecGeom gx, XchgGeom xg, int pack) {
+    // record of x: [ main (b, yl, kin) | planes (plane, yl) ], one array per record
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < gx.total; i += (long long)gridDim.x * blockDim.x) {
+        int x, yl, kz;
+        spec_decode(gx, i, x, yl, kz);
+        const long long r = (long long)x * xg.arr_sz +
+                            (kz < gx.nzm ? (((long long)(kz >> 3) * xg.nyl + yl) * 8 + (kz & 7))
+                                         : ((long long)xg.nb * xg.nyl * 8 + (long long)(kz - gx.nzm) * xg.nyl + yl));
+        if (pack) const_cast<cplx*>(buf)[r] = spec[i];
+        else spec[i] = buf[r];
+    }
+}
+int dist_exchange(ofdft_ctx* c, cplx* send, cplx* recv, hipStream_t st) {
+    if (!c->a2a) return fail(c, OFDFT_ESTATE, "slab-decomposed context without collectives: call ofdft_set_collectives first");
+    const unsigned long long bytes = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz);
+    if (int rc = c->a2a(c->coll_user, send, recv, bytes, (void*)st)) return fail(c, OFDFT_EHIP, "all-to-all callback failed (%d)", rc);
+    return 0;
+}
+// in-place sum over the ranks of host numbers (no-op on one rank)
+int global_sums(ofdft_ctx* c, double* v, int n) {
+    if (c->nranks == 1) return 0;
+    if (!c->allreduce) return fail(c, OFDFT_ESTATE, "slab-decomposed context without collectives: call ofdft_set_collectives first");
+    if (int rc = c->allreduce(c->coll_user, v, n)) return fail(c, OFDFT_EHIP, "all-reduce callback failed (%d)", rc);
+    return 0;
+}
+int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
+int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
+
 // real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
+    if (c->nranks > 1) return dist_rfftn(c, in, spec, st);
     if (c->fast) {
         int rc;
         switch (c->n2 / 2) {
@@ -549,6 +588,7 @@ int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
 // internal half spectrum (destroyed) -> real, scaled by `scale` (1/N for irfftn semantics)
 int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
     c->fft_count++;
+    if (c->nranks > 1) return dist_irfftn(c, spec, out, scale, st);
     if (c->fast) {
         int rc;
         if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;
@@ -616,6 +656,53 @@ int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
         case 256: return launch_zinv_t<256>(c, spec, out, scale, st);
         case 512: return launch_zinv_t<512>(c, spec, out, scale, st);
         case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
+    }
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+    cplx *send, *recv, *tmp;
+    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
+    int rc;
+    switch (c->n2 / 2) {          // z-forward of the local rows into the x-slab layout
+        case 8: rc = launch_zfwd_t<8>(c, in, tmp, st); break;
+        case 16: rc = launch_zfwd_t<16>(c, in, tmp, st); break;
+        case 32: rc = launch_zfwd_t<32>(c, in, tmp, st); break;
+        case 64: rc = launch_zfwd_t<64>(c, in, tmp, st); break;
+        case 128: rc = launch_zfwd_t<128>(c, in, tmp, st); break;
+        case 256: rc = launch_zfwd_t<256>(c, in, tmp, st); break;
+        case 512: rc = launch_zfwd_t<512>(c, in, tmp, st); break;
+        default: rc = fail(c, OFDFT_EINVAL, "bad n2");
+    }
+    if (rc) return rc;
+    if ((rc = ypass_xchg<false>(c, {tmp}, send, st))) return rc;           // y-forward, written in the exchange layout
+    if ((rc = dist_exchange(c, send, recv, st))) return rc;
+    XchgGeom xg = c->xg;
+    xg.rec = xg.arr_sz;
+    OFDFT_LAUNCH(c, st, "xchg_unpack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)recv, spec, c->gx, xg, 0);
+    return fast_axis_pass<false>(c, 0, spec, st);                           // x-forward on the y-slab
+}
+
+int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
+    cplx *send, *recv, *tmp;
+    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
+    int rc;
+    if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;             // x-inverse on the y-slab
+    XchgGeom xg = c->xg;
+    xg.rec = xg.arr_sz;
+    OFDFT_LAUNCH(c, st, "xchg_pack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)send, spec, c->gx, xg, 1);
+    if ((rc = dist_exchange(c, send, recv, st))) return rc;
+    if ((rc = ypass_xchg<true>(c, {tmp}, recv, st))) return rc;             // y-inverse out of the exchange layout
+    switch (c->n2 / 2) {
+        case 8: return launch_zinv_t<8>(c, tmp, out, scale, st);
+        case 16: return launch_zinv_t<16>(c, tmp, out, scale, st);
+        case 32: return launch_zinv_t<32>(c, tmp, out, scale, st);
+        case 64: return launch_zinv_t<64>(c, tmp, out, scale, st);
+        case 128: return launch_zinv_t<128>(c, tmp, out, scale, st);
+        case 256: return launch_zinv_t<256>(c, tmp, out, scale, st);
+        case 512: return launch_zinv_t<512>(c, tmp, out, scale, st);
     }
     return fail(c, OFDFT_EINVAL, "bad n2");
 }
@@ -1769,6 +1856,14 @@ int ofdft_ion_ion(ofdft_ctx* c, const double*, const double*, int, double, doubl
 }
 }
 #endif
+
+int ofdft_set_collectives(ofdft_ctx* c, ofdft_all_to_all_fn all_to_all, ofdft_all_reduce_fn all_reduce, void* user) {
+    if (!c) return OFDFT_EINVAL;
+    c->a2a = all_to_all;
+    c->allreduce = all_reduce;
+    c->coll_user = user;
+    return OFDFT_OK;
+}
 
 int ofdft_set_option(ofdft_ctx* c, int option, double value) {
     if (!c) return OFDFT_EINVAL;

@@ -15,7 +15,8 @@ struct IonPrep {
 static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int nions, const double* tab_k,
                        const double* tab_v, int ntab, double z_ion, int pme_order, hipStream_t st) {
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
-    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ionic-potential entry points: single-GPU contexts only");
+    if (c->nranks > 1 && !(c->a2a && c->allreduce))
+        return fail(c, OFDFT_ESTATE, "slab-decomposed context: the ionic-potential entry points need ofdft_set_collectives");
     if (nions < 1 || ntab < 2) return fail(c, OFDFT_EINVAL, "need at least one ion and two table points");
     if (pme_order != 0 && (pme_order < 2 || pme_order > kMaxPmeOrder || (pme_order & 1)))
         return fail(c, OFDFT_EINVAL, "Requires even order n >= 2 (<= %d)", kMaxPmeOrder);       // ion_utils.py:116
@@ -61,7 +62,7 @@ static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int ni
             for (int i = n - 1; i >= 1; --i) M[i] = (i * M[i] + (double)(n - i) * M[i - 1]) / (n - 1);
             M[0] = 0.0;
         }
-        const int cnt[3] = {c->n0, c->n1, c->g.nzc}, Ns[3] = {c->n0, c->n1, c->n2};
+        const int cnt[3] = {c->n0g, c->n1g, c->g.nzc}, Ns[3] = {c->n0g, c->n1g, c->n2};      // global extents
         p.hb.resize((size_t)cnt[0] + cnt[1] + cnt[2]);
         size_t off = 0;
         for (int d = 0; d < 3; ++d) {
@@ -82,7 +83,7 @@ static int ion_prepare(ofdft_ctx* c, IonPrep& p, const double* frac_host, int ni
         if (int rc = get_ws(c, "i:b", sizeof(cplx) * p.hb.size(), (void**)&d_b)) return rc;
         HIP_TRY(c, hipMemcpyAsync(d_b, p.hb.data(), sizeof(cplx) * p.hb.size(), hipMemcpyHostToDevice, st));
         p.d_b0 = d_b;
-        p.d_b1 = d_b + cnt[0];
+        p.d_b1 = d_b + cnt[0] + c->kg.y0;      // the k-space kernels index b1 by the LOCAL y of the y-slab
         p.d_b2 = d_b + cnt[0] + cnt[1];
     }
     return 0;
@@ -107,7 +108,7 @@ int ofdft_ionic_potential(ofdft_ctx* c, const double* frac_host, int nions, cons
         if (int rc = spec_ws(c, "i:Q", &sQ)) return rc;
         HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
         OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, tmp, c->n0, c->n1, c->n2);
+                     pme_order, tmp, c->n0g, c->n1g, c->n2, c->rank * c->n0, c->n0);
         if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
         OFDFT_LAUNCH(c, st, "ion_spec", ion_potential_spec_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)sQ, sF, c->kg,
                      (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, (const double*)nullptr, nions, p.tab,
@@ -149,6 +150,7 @@ int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* f
                 for (int b = 0; b < kb; ++b) t += h[((size_t)a * kb + b) * 3 + s3];
                 forces_host[3 * a + s3] = pref * (double)t;
             }
+        if (int rc = global_sums(c, forces_host, 3 * nions)) return rc;      // each rank summed its own k-points
     } else {
         double *theta, *d_G;
         std::vector<double> G(3 * (size_t)nions);
@@ -159,9 +161,10 @@ int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* f
                      c->kg, (const cplx*)p.d_b0, (const cplx*)p.d_b1, (const cplx*)p.d_b2, p.tab, 1.0 / c->vol);
         if (int rc = irfftn_internal(c, sT, theta, 1.0, st)) return rc;
         OFDFT_LAUNCH(c, st, "pme_gather", pme_gather_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, (const double*)theta, c->n0, c->n1, c->n2, d_G);
+                     pme_order, (const double*)theta, c->n0g, c->n1g, c->n2, d_G, c->rank * c->n0, c->n0);
         HIP_TRY(c, hipMemcpyAsync(G.data(), d_G, sizeof(double) * G.size(), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        if (int rc = global_sums(c, G.data(), (int)G.size())) return rc;     // each rank gathered over its own planes
         // dU/dR_j = dV sum_d G_d N_d d(frac_d)/d(cart_j),  frac = cart @ inv(box)  ->  d frac_d / d cart_j = inv(box)[j][d]
         const double* a9 = c->box;
         const double det = a9[0] * (a9[4] * a9[8] - a9[5] * a9[7]) - a9[1] * (a9[3] * a9[8] - a9[5] * a9[6]) +
@@ -176,7 +179,7 @@ int ofdft_ion_electron_forces(ofdft_ctx* c, const void* den_dev, const double* f
         inv[6] = (a9[3] * a9[7] - a9[4] * a9[6]) / det;
         inv[7] = (a9[1] * a9[6] - a9[0] * a9[7]) / det;
         inv[8] = (a9[0] * a9[4] - a9[1] * a9[3]) / det;
-        const int Ns[3] = {c->n0, c->n1, c->n2};
+        const int Ns[3] = {c->n0g, c->n1g, c->n2};
         for (int a = 0; a < nions; ++a)
             for (int j = 0; j < 3; ++j) {
                 double t = 0.0;
@@ -210,16 +213,22 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
     if (int rc = begin_call(c, st)) return rc;
     if (!den_dev || !sig) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
-    if (c->nranks > 1) return fail(c, OFDFT_EINVAL, "ofdft_stress: single-GPU contexts only");
+    if (c->nranks > 1 && !(c->a2a && c->allreduce))
+        return fail(c, OFDFT_ESTATE, "slab-decomposed context: ofdft_stress needs ofdft_set_collectives");
+    if (wts_active(c) && c->nranks > 1)
+        return fail(c, OFDFT_EINVAL, "the stabilised Wang-Teter style functional (OFDFT_P_WTS_KIND) is served by single-GPU contexts");
     const double* den = (const double*)den_dev;
     const unsigned mask = c->mask;
     const long long npts = c->npts;
-    const double invN = 1.0 / (double)npts, invN2 = invN * invN;
+    // slab-decomposed contexts: npts = this rank's points (kernel extents); every normalisation uses the GLOBAL grid, every
+    // reduced number is summed over the ranks (global_sums: the host's all-reduce) before it is used
+    const double invN = 1.0 / (double)c->npts_g, invN2 = invN * invN;
     for (int i = 0; i < OFDFT_NTERMS * 9; ++i) sig[i] = 0.0;
     const int sp_blocks = grid_for(c->g.total, kRedThreads, kRedBlocks), pw_grid = grid_for(npts / 2 + 1);
     double s7[kStressSpecScalars];
     double nsum;
     if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
+    if (int rc = global_sums(c, &nsum, 1)) return rc;
     const double nbar = nsum * invN;                    // N_e / vol, un-rounded (functionals.py:634)
     cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
     double *gx = nullptr, *gy = nullptr, *gz = nullptr, *lapn = nullptr;
@@ -231,6 +240,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HARTREE>), dim3(sp_blocks), dim3(kRedThreads), 0,
                          (const cplx*)s0, (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
             if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+            if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
             sym_store(sig + 9 * 1, s7, -0.5 * s7[6]);                 // -E_H / vol on the diagonal
         }
         if (mask & kGgaAny) {
@@ -259,6 +269,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
                      (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nsum * c->dV) : 0.0, (int)c->params[OFDFT_P_VWGTF_KIND],
                      c->d_partial, lapn);
         if (int rc = fetch_partials(c, blocks, kStressRealScalars, r, st)) return rc;
+        if (int rc = global_sums(c, r, kStressRealScalars)) return rc;
         const double zero6[6] = {0, 0, 0, 0, 0, 0};
         const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
         if (mask & OFDFT_TF) sym_store(sig + 9 * 2, zero6, -2.0 / 3.0 * ctf * r[0] * invN);      // tools_for_tests.py:241-243
@@ -281,6 +292,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
             OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_HESS>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)s0,
                          (const cplx*)s1, c->kg, invN2, 0.0, c->d_partial);
             if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+            if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
             double* o = sig + 9 * 12;
             o[0] += 2.0 * s7[0]; o[4] += 2.0 * s7[1]; o[8] += 2.0 * s7[2];
             o[1] += 2.0 * s7[3]; o[3] += 2.0 * s7[3];
@@ -296,6 +308,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_VW>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)s0,
                      (const cplx*)nullptr, c->kg, invN2, 0.0, c->d_partial);
         if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
         sym_store(sig + 9 * 3, s7, 0.0);
     }
     if (mask & OFDFT_WT_NL) {
@@ -316,6 +329,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         OFDFT_LAUNCH(c, st, "stress_spec", (stress_spec_kernel<STRESS_WT>), dim3(sp_blocks), dim3(kRedThreads), 0, (const cplx*)sa,
                      (const cplx*)s0, c->kg, invN2, 1.0 / (2.0 * kf), c->d_partial);
         if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
         double c6[6];
         for (int k = 0; k < 6; ++k) c6[k] = pref * s7[k];
         sym_store(sig + 9 * 4, c6, -2.0 / 3.0 * pref * s7[6]);                                  // -2/3 T_NL / vol
@@ -355,6 +369,7 @@ int ofdft_stress(ofdft_ctx* c, const void* den_dev, double* sig, void* stream) {
         OFDFT_LAUNCH(c, st, "stress_wgc", stress_wgc_kernel, dim3(sp_blocks), dim3(kRedThreads), 0, sp, c->kg, ser, invN2,
                      c->d_partial);
         if (int rc = fetch_partials(c, sp_blocks, kStressSpecScalars, s7, st)) return rc;
+        if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
         const double ctf = 0.3 * std::pow(3.0 * kPi * kPi, 2.0 / 3.0);
         double c6[6];
         for (int k = 0; k < 6; ++k) c6[k] = ctf * s7[k];
@@ -380,7 +395,7 @@ int ofdft_ion_electron_stress(ofdft_ctx* c, const void* den_dev, const double* f
         if (int rc = real_ws(c, "i:tmp", &tmp)) return rc;
         HIP_TRY(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)c->npts, st));
         OFDFT_LAUNCH(c, st, "pme_spread", pme_spread_kernel, dim3(nions), dim3(256), 0, (const double*)p.d_frac, nions,
-                     pme_order, tmp, c->n0, c->n1, c->n2);
+                     pme_order, tmp, c->n0g, c->n1g, c->n2, c->rank * c->n0, c->n0);
         if (int rc = rfftn_internal(c, tmp, sQ, st)) return rc;
     }
     const int blocks = grid_for(c->g.total, kRedThreads, kRedBlocks);
@@ -389,7 +404,8 @@ int ofdft_ion_electron_stress(ofdft_ctx* c, const void* den_dev, const double* f
                  pme_order == 0 ? (const double*)p.d_cart : (const double*)nullptr, nions, p.tab, c->d_partial);
     double s7[kStressSpecScalars];
     if (int rc = fetch_partials(c, blocks, kStressSpecScalars, s7, st)) return rc;
-    const double invN = 1.0 / (double)c->npts;
+    if (int rc = global_sums(c, s7, kStressSpecScalars)) return rc;
+    const double invN = 1.0 / (double)c->npts_g;
     double c6[6];
     for (int k = 0; k < 6; ++k) c6[k] = -s7[k] * invN / c->vol;
     sym_store(sigma_host, c6, -s7[6] * invN / c->vol);

@@ -20,8 +20,10 @@ __device__ __forceinline__ void bspline_values(double x, int order, double* M) {
 }
 
 // Q(l0,l1,l2) += M0 M1 M2 with periodic wrap (ion_utils.py:249-273); one workgroup per ion
+// slab-decomposed contexts: Q is this rank's x-slab (planes x0 .. x0 + nxl of the n0 global ones); every rank walks all
+// ions and keeps the stencil points that fall on its planes -- no halo exchange, no communication
 __global__ __launch_bounds__(256) void pme_spread_kernel(const double* __restrict__ frac, int nion, int order,
-                                                         double* __restrict__ Q, int n0, int n1, int n2) {
+                                                         double* __restrict__ Q, int n0, int n1, int n2, int x0, int nxl) {
     __shared__ double M[3][kMaxPmeOrder];
     __shared__ int L[3][kMaxPmeOrder];
     const int a = blockIdx.x;
@@ -41,7 +43,9 @@ __global__ __launch_bounds__(256) void pme_spread_kernel(const double* __restric
     const int tot = order * order * order;
     for (int t = threadIdx.x; t < tot; t += blockDim.x) {
         const int i2 = t % order, i1 = (t / order) % order, i0 = t / (order * order);
-        atomicAdd(&Q[((long long)L[0][i0] * n1 + L[1][i1]) * n2 + L[2][i2]], M[0][i0] * M[1][i1] * M[2][i2]);
+        const int xl = L[0][i0] - x0;
+        if (xl < 0 || xl >= nxl) continue;
+        atomicAdd(&Q[((long long)xl * n1 + L[1][i1]) * n2 + L[2][i2]], M[0][i0] * M[1][i1] * M[2][i2]);
     }
 }
 
@@ -162,9 +166,10 @@ __global__ void pme_theta_spec_kernel(const cplx* __restrict__ nk, cplx* __restr
 }
 
 // G[a][d] = sum over the ion's B-spline stencil of theta(l) * d/du_d (M0 M1 M2); one workgroup per ion
+// (slab-decomposed contexts: theta is this rank's x-slab; G then holds the partial sums over its planes)
 __global__ __launch_bounds__(256) void pme_gather_kernel(const double* __restrict__ frac, int nion, int order,
                                                          const double* __restrict__ theta, int n0, int n1, int n2,
-                                                         double* __restrict__ G) {
+                                                         double* __restrict__ G, int x0, int nxl) {
     __shared__ double M[3][kMaxPmeOrder], D[3][kMaxPmeOrder];
     __shared__ int L[3][kMaxPmeOrder];
     __shared__ double red[4][3];
@@ -195,7 +200,9 @@ __global__ __launch_bounds__(256) void pme_gather_kernel(const double* __restric
     const int tot = order * order * order;
     for (int t = threadIdx.x; t < tot; t += blockDim.x) {
         const int i2 = t % order, i1 = (t / order) % order, i0 = t / (order * order);
-        const double th = theta[((long long)L[0][i0] * n1 + L[1][i1]) * n2 + L[2][i2]];
+        const int xl = L[0][i0] - x0;
+        if (xl < 0 || xl >= nxl) continue;
+        const double th = theta[((long long)xl * n1 + L[1][i1]) * n2 + L[2][i2]];
         acc[0] += th * D[0][i0] * M[1][i1] * M[2][i2];
         acc[1] += th * M[0][i0] * D[1][i1] * M[2][i2];
         acc[2] += th * M[0][i0] * M[1][i1] * D[2][i2];

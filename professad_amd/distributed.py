@@ -131,6 +131,45 @@ class HipStages(Engine):
         self.device_scalars = torch.as_tensor(_RawDeviceBuffer(p.value, 16, '<f8'), device=self.device)
         self._xbuf = {}
 
+    def enable_collectives(self, comm):
+        """Hand the engine the two collectives its per-geometry-step routines (stress, ionic potential, ion-electron forces
+        and stress) call back into on a slab-decomposed context (``ofdft_set_collectives``): an equal-split all-to-all of
+        engine-owned device buffers and an in-place sum of a small host vector -- both through `comm` (RCCL under the
+        nccl backend; host-staged under gloo).  The callbacks run on the calling thread, whose current torch stream is
+        the stream the engine call was given, so the collective is ordered with the engine's kernels on it."""
+        if not comm.active:
+            return self
+
+        def a2a(user, send, recv, nbytes, stream):
+            try:
+                tot = int(nbytes) * comm.nranks
+                key = (int(send), int(recv), tot)
+                ex = self._xbuf.get(key)
+                if ex is None:
+                    ex = self._xbuf[key] = (torch.as_tensor(_RawDeviceBuffer(send, tot), device=self.device),
+                                            torch.as_tensor(_RawDeviceBuffer(recv, tot), device=self.device))
+                w = comm.all_to_all(ex[0], ex[1])
+                if w is not None:
+                    w.wait()
+                return 0
+            except Exception as e:  # noqa: BLE001  (nothing may propagate across the C ABI)
+                self._cb_error = e
+                return 1
+
+        def allreduce(user, buf, count):
+            try:
+                v = np.ctypeslib.as_array(buf, shape=(int(count),))
+                v[:] = comm.all_reduce_sum(v.copy(), self.device)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self._cb_error = e
+                return 1
+
+        self._cb_error = None
+        self._callbacks = (N.A2A_FN(a2a), N.ALLREDUCE_FN(allreduce))       # keep the thunks alive as long as the context
+        self._check(self.lib.ofdft_set_collectives(self._ctx, self._callbacks[0], self._callbacks[1], None), 'ofdft_set_collectives')
+        return self
+
     def sumsq(self, x, square=True, on_device=False):
         """local sum of x^2 (or x): returned as a float, or left in device_scalars[15] without a host sync"""
         x = self._grid_tensor(x, 'x')
@@ -275,6 +314,7 @@ class DistEngine:
         stress and ion forces are then formed by the fp64 routines from the gathered density."""
         self.comm = Comm(group)
         self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
+        self.stages.enable_collectives(self.comm)
         self.plan = self.stages.plan
         self.npts_global = int(np.prod(self.plan.shape))
         self._vol = None
@@ -303,12 +343,23 @@ class DistEngine:
     def query(self, what):
         return self.stages.query(what)
 
-    # ---- once-per-geometry-step quantities (stress, ion forces): not slab-decomposed.  The density is all-gathered
-    # (one grid-sized message per step, against 23 spectra per energy evaluation) and every rank runs the single-GPU
-    # routines on the full grid -- redundant work, no further communication, identical results on all ranks.
+    # ---- once-per-geometry-step quantities (stress, ionic potential, ion-electron forces and stress): slab-decomposed like
+    # the hot path.  Each rank works on its x-slab (PME spreading / gathering on its own planes, real-space sums over its
+    # points) and on its y-slab of every spectrum; the transforms go through one all-to-all each, the reduced numbers
+    # through one small all-reduce each (the engine calls back into `Comm`, see HipStages.enable_collectives).  These
+    # routines are fp64 work: an fp32 engine hands them to an fp64 slab engine of the same decomposition.
+    def _f64_stages(self):
+        if self.stages.dtype == torch.double:
+            return self.stages
+        if getattr(self, '_f64', None) is None:
+            self._f64 = HipStages(self.plan.shape, self.stages.device, nranks=self.comm.nranks, rank=self.comm.rank,
+                                  dtype=torch.double).enable_collectives(self.comm)
+        self._f64.set_cell(self._box_np.reshape(3, 3))
+        return self._f64
+
     def gather(self, slab):
-        """this rank's x-slab -> the full grid on every rank"""
-        slab = self.stages._grid_tensor(slab, 'slab').double()      # the per-geometry-step routines are fp64
+        """this rank's x-slab -> the full grid on every rank (diagnostics; the routines below do not need it)"""
+        slab = self.stages._grid_tensor(slab, 'slab')
         if not self.comm.active:
             return slab
         if self.comm.backend == 'nccl':
@@ -319,33 +370,30 @@ class DistEngine:
         dist.all_gather(parts, slab.cpu(), group=self.comm.group)
         return torch.cat(parts).to(slab.device)
 
-    def _full_engine(self):
-        if getattr(self, '_full', None) is None:
-            self._full = Engine(self.plan.shape, self.stages.device)
-        self._full._box_key = None
-        self._full.lib.ofdft_set_cell(self._full._ctx, self._box_c)
-        return self._full
-
     def stress(self, den_slab, names, params=None):
         """per-term stress tensors of the full system (see Engine.stress) from this rank's density slab"""
-        return self._full_engine().set_terms(names, params).stress(self.gather(den_slab))
+        eng = self._f64_stages()
+        den = self.stages._grid_tensor(den_slab, 'den').double()
+        return eng.set_terms(names, params).stress(den)
 
     def ion_electron_forces(self, den_slab, species, pme_order=None):
         """ion-electron forces of the full system (see ions.ion_electron_forces) from this rank's density slab"""
         from .ions import ion_electron_forces
-        return ion_electron_forces(self._full_engine(), self._box_np.reshape(3, 3), self.gather(den_slab), species, pme_order)
+        den = self.stages._grid_tensor(den_slab, 'den').double()
+        return ion_electron_forces(self._f64_stages(), self._box_np.reshape(3, 3), den, species, pme_order)
 
     def ion_electron_stress(self, den_slab, species, pme_order=None):
         from .ions import ion_electron_stress
-        return ion_electron_stress(self._full_engine(), self._box_np.reshape(3, 3), self.gather(den_slab), species, pme_order)
+        den = self.stages._grid_tensor(den_slab, 'den').double()
+        return ion_electron_stress(self._f64_stages(), self._box_np.reshape(3, 3), den, species, pme_order)
 
     def ionic_potential(self, species, pme_order=None):
-        """this rank's x-slab of v_ext built from the ions (every rank builds the full potential: one small FFT per step)"""
+        """this rank's x-slab of v_ext built from the ions (PME: each rank spreads onto its own planes)"""
         from .ions import ionic_potential
-        return ionic_potential(self._full_engine(), self._box_np.reshape(3, 3), species,
-                               pme_order)[self.plan.x_range()].to(self.stages.dtype).contiguous()
+        return ionic_potential(self._f64_stages(), self._box_np.reshape(3, 3), species,
+                               pme_order).to(self.stages.dtype).contiguous()
 
     def close(self):
         self.stages.close()
-        if getattr(self, '_full', None) is not None:
-            self._full.close()
+        if getattr(self, '_f64', None) is not None:
+            self._f64.close()

@@ -76,29 +76,37 @@ def main():
                 dv=float(np.abs(vfull - vr.cpu().numpy()).max() / np.abs(vr.cpu().numpy()).max()),
                 ffts=eng.query(0), ffts_ref=ref.query(0))
             ref.close()
-    # stress from a density slab (all-gather + full-grid routine on every rank) vs one GPU
-    bits = NativeTerms(['hartree', 'wgc99', 'pbe']).names
-    sd = eng.stress(t(plan.scatter(den)), bits)
-    if rank == 0:
-        ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(bits)
-        sr = ref.stress(t(den))
-        worst['stress'] = dict(dE=max(float(np.abs(sd[k] - sr[k]).max()) for k in sr), dE2=0.0, dmu=0.0, dg=0.0, dv=0.0,
-                               ffts=0, ffts_ref=0)
-        ref.close()
+    # stress from a density slab -- slab-decomposed (distributed transforms through the engine's collective callbacks,
+    # per-rank partial sums + small all-reduces; no gathered grid) -- vs one GPU; two term sets so that every stress
+    # kernel family runs on slabs (Hartree, WGC99, PBE | vW, Wang-Teter, TF, LDA, the q-dependent Pauli-Gaussian)
+    worst['stress'] = dict(dE=0.0, dE2=0.0, dmu=0.0, dg=0.0, dv=0.0, ffts=0, ffts_ref=0)
+    for bits, params in ((NativeTerms(['hartree', 'wgc99', 'pbe']).names, None),
+                         (('tf', 'vw', 'wt_nl', 'lda_x', 'pz_c', 'gga_k'), {'ggak_kind': 1.0, 'ggak_beta': 0.25, 'ggak_lambda': 0.4})):
+        sd = eng.stress(t(plan.scatter(den)), bits, params)
+        if rank == 0:
+            ref = Engine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box)).set_terms(bits, params)
+            sr = ref.stress(t(den))
+            worst['stress']['dE'] = max(worst['stress']['dE'], max(float(np.abs(sd[k] - sr[k]).max()) for k in sr))
+            ref.close()
     # ionic potential slab and ion-electron forces through the slab-decomposed engine vs one GPU
     from professad_amd.ions import ion_electron_forces, ionic_potential
     ks = np.linspace(0.0, 12.0, 400)
     tab = (ks, -4 * np.pi * 3.0 / (ks ** 2 + 1.5) * np.exp(-0.05 * ks ** 2) + np.where(ks > 0, 4 * np.pi * 3.0 / np.where(ks > 0, ks, 1.0) ** 2, 0.0) * 0 , 3)
     frac = np.array([[0.1, 0.2, 0.3], [0.6, 0.55, 0.8]])
-    vs = eng.ionic_potential([(frac, tab)], pme_order=4)
-    Fs = eng.ion_electron_forces(t(plan.scatter(den)), [(frac, tab)], pme_order=4)[0]
-    if rank == 0:
-        ref = Engine(shape, dev)
-        vr = ionic_potential(ref, box, [(frac, tab)], pme_order=4)
-        Fr = ion_electron_forces(ref, box, t(den).double(), [(frac, tab)], pme_order=4)[0]
-        worst['ions'] = dict(dE=float((vs - vr[plan.x_range()]).abs().max() / vr.abs().max()), dE2=float(np.abs(Fs - Fr).max()),
-                             dmu=0.0, dg=0.0, dv=0.0, ffts=0, ffts_ref=0)
-        ref.close()
+    from professad_amd.ions import ion_electron_stress
+    worst['ions'] = dict(dE=0.0, dE2=0.0, dmu=0.0, dg=0.0, dv=0.0, ffts=0, ffts_ref=0)
+    for order in (4, None):          # particle-mesh Ewald (each rank spreads / gathers on its own planes) and the exact sum
+        vs = eng.ionic_potential([(frac, tab)], pme_order=order)
+        Fs = eng.ion_electron_forces(t(plan.scatter(den)), [(frac, tab)], pme_order=order)[0]
+        Ss = eng.ion_electron_stress(t(plan.scatter(den)), [(frac, tab)], pme_order=order)
+        if rank == 0:
+            ref = Engine(shape, dev)
+            vr = ionic_potential(ref, box, [(frac, tab)], pme_order=order)
+            Fr = ion_electron_forces(ref, box, t(den).double(), [(frac, tab)], pme_order=order)[0]
+            Sr = ion_electron_stress(ref, box, t(den).double(), [(frac, tab)], pme_order=order)
+            worst['ions']['dE'] = max(worst['ions']['dE'], float((vs.double() - vr[plan.x_range()]).abs().max() / vr.abs().max()))
+            worst['ions']['dE2'] = max(worst['ions']['dE2'], float(np.abs(Fs - Fr).max()), float(np.abs(Ss - Sr).max()))
+            ref.close()
     # density optimisation over slabs (fused L-BFGS sweeps on each rank's slab, all-reduced scalars) vs one GPU
     if shape == (32, 32, 32):
         from professad_amd.optimize import optimize_density
