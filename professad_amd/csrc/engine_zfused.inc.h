@@ -6,6 +6,10 @@
 #define OFDFT_EZ 4
 #endif
 constexpr int EZ = OFDFT_EZ;   // points per lane wanted by the register-hungry fused z kernels
+#ifndef OFDFT_EZ_POWERS
+#define OFDFT_EZ_POWERS OFDFT_EZ
+#endif
+constexpr int EZP = OFDFT_EZ_POWERS;   // ... and by zf_powers (one input row, up to six output spectra)
 
 int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
     if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;
@@ -42,10 +46,10 @@ int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipSt
     SpecGeom gz = c->g;
 #define X(M_)                                                                                                      \
     case M_: {                                                                                                     \
-        const int nb = z_blocks<M_, ZPick<M_, EZ>::E>(c) / nchunks;                                                \
+        const int nb = z_blocks<M_, ZPick<M_, EZP>::E>(c) / nchunks;                                                \
         gz.blk0 = chunk * nb;                                                                                      \
-        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),           \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, pa, gz, twM, twN);                                       \
+        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZP>::E>), dim3(nb), dim3(256),           \
+                     (ZW<M_, ZPick<M_, EZP>::E>::LDS), ds, pa, gz, twM, twN);                                       \
         return 0;                                                                                                  \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }

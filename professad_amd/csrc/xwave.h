@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw
         for (int q = 0; q < E; ++q) a[I][q] = valid ? buf_load_c_aux<OFDFT_XW_LD_AUX>(ub + q * qstep, voff) : mkc(0.0, 0.0);
     });
     // table-driven mixes: the k-point entries are requested with the data (one batch in flight), not one by one later
-    constexpr int NC = mix_coef_count<Mix>::N;
+#ifndef OFDFT_XW_PREFETCH
+#define OFDFT_XW_PREFETCH 1
+#endif
+    constexpr int NC = OFDFT_XW_PREFETCH ? mix_coef_count<Mix>::N : 0;
     real cfs[E][NC > 0 ? NC : 1];
     if constexpr (NC > 0) {
 #pragma unroll

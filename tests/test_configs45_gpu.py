@@ -106,3 +106,45 @@ def test_config5_whole_1024_grid_fp32_is_the_tiled_fp64_32_cube(terms):
     scale = float(pot32.abs().max())
     for sl in ((slice(0, base),) * 3, (slice(n - base, n), slice(base, 2 * base), slice(n - base, n))):
         assert float((potN[sl].double() - pot32).abs().max()) <= 5e-4 * scale
+
+
+def _al_table():
+    """the al.gga recpot table (DATA of the reference's tests, committed as tests/golden/recpots.npz)"""
+    import os
+    import cases
+    from professad_amd.ions import recpot_table
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), 'recpots.npz'))
+    return recpot_table(g['al_raw'], float(g['al_kmax']))
+
+
+@pytest.mark.parametrize('n', [256, 1024])
+def test_config5_pme_potential_and_forces_at_scale_by_periodic_tiling(n):
+    """Particle-mesh Ewald with the ion count of config 5: the fcc-Al conventional cell (4 ions, 32^3 grid) repeated
+    (n/32)^3 times -- 131 072 ions on the 1024^3 grid.  The tiled system is exactly periodic, so its ionic potential is the
+    tiled 32^3 potential and every ion feels the force of its image in the small cell: PME spreading (atomics), the
+    b-factor multiply, both transforms and the force gather at full size, pinned without a reference run."""
+    from professad_amd.ions import ion_electron_forces, ionic_potential
+    base, order = 32, 10
+    r = n // base
+    tab = _al_table()
+    frac32 = np.array([[0.0, 0.0, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5], [0.5, 0.5, 0.0]]) + 0.013      # off the grid points
+    box32 = synth.cubic_cell(base)
+    small = Engine((base,) * 3, DEV)
+    v32 = ionic_potential(small, box32, [(frac32, tab)], pme_order=order)
+    den32 = torch.as_tensor(synth.smooth_density((base,) * 3, seed=9, n0=0.03, amp=0.4), device=DEV)
+    F32_ = ion_electron_forces(small, box32, den32, [(frac32, tab)], pme_order=order)[0]
+    small.close()
+    shifts = np.stack(np.meshgrid(np.arange(r), np.arange(r), np.arange(r), indexing='ij'), -1).reshape(-1, 1, 3)
+    frac = ((frac32[None, :, :] + shifts) / r).reshape(-1, 3)
+    assert frac.shape[0] == 4 * r ** 3
+    big = Engine((n,) * 3, DEV)
+    boxN = synth.cubic_cell(n)
+    vN = ionic_potential(big, boxN, [(frac, tab)], pme_order=order)
+    scale = float(v32.abs().max())
+    for sl in ((slice(0, base),) * 3, (slice(n - base, n), slice(base, 2 * base), slice(n - base, n))):
+        assert float((vN[sl] - v32).abs().max()) <= 1e-9 * scale
+    del vN
+    denN = den32.repeat(r, r, r)
+    FN = ion_electron_forces(big, boxN, denN, [(frac, tab)], pme_order=order)[0].reshape(-1, 4, 3)
+    big.close()
+    assert np.abs(FN - F32_[None]).max() <= 1e-9 * max(np.abs(F32_).max(), 1e-3)
