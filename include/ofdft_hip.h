@@ -250,6 +250,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      of ~25-50 kernel launches, which is what bounds grids up to ~64^3 (used by single-GPU contexts up to 2^19 points, where
                                      OFDFT_OPT_SPLIT_COMBINE is then ignored); 0: always launch kernel by kernel */
 #define OFDFT_OPT_SIDE_STREAM 1
+#define OFDFT_OPT_MIXED_RADIX 9   /* 1 (default): extents with factors 3 and 5 that have a line-transform plan (48, 96, 120, 144, 160, 192, 240, 250, 270,
+                                     288, 320, 384, 480) run the register / LDS transforms and the fused pipelines like the powers of two;
+                                     0: they take the chirp-z transforms + the unfused pipeline like any other extent (validation, A/B) */
 #define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
                                      registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
                                      group-parallel kernel that trades spectra through LDS */

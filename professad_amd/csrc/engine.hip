@@ -177,6 +177,27 @@ void prof_end(ofdft_ctx* c, hipStream_t st);
 
 bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// Extents served by the register / LDS line transforms (fft_radix.h plans) -- and with them by the fused pipelines:
+// powers of two, and the 2^a 3^b 5^c extents listed here (any other extent: chirp-z line transforms + the unfused pipeline).
+// OFDFT_MIXED_LINES: x / y extents; OFDFT_MIXED_ROWS: the half lengths n2 / 2 of the z rows for the same extents.
+// (the fp32 build keeps the powers of two only: its other extents take the chirp-z path)
+#ifndef OFDFT_REAL_F32
+#define OFDFT_MIXED_LINES(X) X(48) X(96) X(120) X(144) X(160) X(192) X(240) X(250) X(270) X(288) X(320) X(384) X(480)
+#define OFDFT_MIXED_ROWS(X) X(24) X(48) X(60) X(72) X(80) X(96) X(120) X(125) X(135) X(144) X(160) X(192) X(240)
+#else
+#define OFDFT_MIXED_LINES(X)
+#define OFDFT_MIXED_ROWS(X)
+#endif
+bool mixed_line(int n) {
+#define X(L) if (n == L) return true;
+    OFDFT_MIXED_LINES(X)
+#undef X
+    return false;
+}
+bool line_extent_ok(int n) { return (is_pow2(n) && n >= 8 && n <= 1024) || mixed_line(n); }
+bool row_extent_ok(int n2) { return (is_pow2(n2) && n2 >= 16 && n2 <= 2048) || mixed_line(n2); }
+bool all_pow2(const ofdft_ctx* c) { return is_pow2(c->n0g) && is_pow2(c->n1g) && is_pow2(c->n2); }
+
 int grid_for(long long n, int tpb = 256, int cap = 2048) {
     long long b = (n + tpb - 1) / tpb;
     if (b > cap) b = cap;
@@ -340,6 +361,7 @@ int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, h
     switch (len) {
         OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
         OFDFT_CASE(1024)
+        OFDFT_MIXED_LINES(OFDFT_CASE)
     }
 #undef OFDFT_CASE
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
@@ -387,10 +409,17 @@ int launch_zfwd_t(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = get_twiddle(c, M, &twM)) return rc;
     if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
-    using Cfg = ZCfg<M>;
-    const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
-    OFDFT_LAUNCH(c, st, "zfwd", (zfwd_kernel<M, PreIdentity>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, in, spec, c->g, twM,
-                       twN, PreIdentity());
+    if constexpr ((M & (M - 1)) == 0) {
+        using Cfg = ZCfg<M>;
+        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_kernel<M, PreIdentity>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, in, spec, c->g, twM,
+                           twN, PreIdentity());
+    } else {          // rows with factors 3 / 5: the wave-local z pass (zpass.h)
+        using W = ZW<M, ZPick<M, 8>::E>;
+        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
+        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, in, spec, c->g, (const cplx*)twM,
+                     (const cplx*)twN);
+    }
     return 0;
 }
 template <int M>
@@ -398,12 +427,38 @@ int launch_zinv_t(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipSt
     cplx *twM, *twN;
     if (int rc = get_twiddle(c, M, &twM)) return rc;
     if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
-    using Cfg = ZCfg<M>;
-    const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
-    PostScale post{(real)scale};
-    OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
-                       twN, post);
+    if constexpr ((M & (M - 1)) == 0) {
+        using Cfg = ZCfg<M>;
+        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+        PostScale post{(real)scale};
+        OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
+                           twN, post);
+    } else {
+        using W = ZW<M, ZPick<M, 8>::E>;
+        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
+        OFDFT_LAUNCH(c, st, "zinv", (zinv_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, spec, out, c->g, (const cplx*)twM,
+                     (const cplx*)twN, (real)scale);
+    }
     return 0;
+}
+// dispatch on the half length of the z rows
+int zfwd_any(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+#define X(M_) case M_: return launch_zfwd_t<M_>(c, in, spec, st);
+    switch (c->n2 / 2) {
+        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+        OFDFT_MIXED_ROWS(X)
+    }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+int zinv_any(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
+#define X(M_) case M_: return launch_zinv_t<M_>(c, spec, out, scale, st);
+    switch (c->n2 / 2) {
+        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+        OFDFT_MIXED_ROWS(X)
+    }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
 }
 
 int gen_axis(ofdft_ctx* c, int axis, int inv, cplx*& cur, cplx*& other, hipStream_t st) {
@@ -552,18 +607,7 @@ int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
     if (c->nranks > 1) return dist_rfftn(c, in, spec, st);
     if (c->fast) {
-        int rc;
-        switch (c->n2 / 2) {
-            case 8: rc = launch_zfwd_t<8>(c, in, spec, st); break;
-            case 16: rc = launch_zfwd_t<16>(c, in, spec, st); break;
-            case 32: rc = launch_zfwd_t<32>(c, in, spec, st); break;
-            case 64: rc = launch_zfwd_t<64>(c, in, spec, st); break;
-            case 128: rc = launch_zfwd_t<128>(c, in, spec, st); break;
-            case 256: rc = launch_zfwd_t<256>(c, in, spec, st); break;
-            case 512: rc = launch_zfwd_t<512>(c, in, spec, st); break;
-            case 1024: rc = launch_zfwd_t<1024>(c, in, spec, st); break;
-            default: rc = fail(c, OFDFT_EINVAL, "bad n2");
-        }
+        int rc = zfwd_any(c, in, spec, st);
         if (rc) return rc;
         if ((rc = fast_axis_pass<false>(c, 1, spec, st))) return rc;
         return fast_axis_pass<false>(c, 0, spec, st);
@@ -593,17 +637,7 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream
         int rc;
         if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;
         if ((rc = fast_axis_pass<true>(c, 1, spec, st))) return rc;
-        switch (c->n2 / 2) {
-            case 8: return launch_zinv_t<8>(c, spec, out, scale, st);
-            case 16: return launch_zinv_t<16>(c, spec, out, scale, st);
-            case 32: return launch_zinv_t<32>(c, spec, out, scale, st);
-            case 64: return launch_zinv_t<64>(c, spec, out, scale, st);
-            case 128: return launch_zinv_t<128>(c, spec, out, scale, st);
-            case 256: return launch_zinv_t<256>(c, spec, out, scale, st);
-            case 512: return launch_zinv_t<512>(c, spec, out, scale, st);
-            case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
-        }
-        return fail(c, OFDFT_EINVAL, "bad n2");
+        return zinv_any(c, spec, out, scale, st);
     }
     if (bluestein_ok(c)) {
         if (int rc = bluestein_pass(c, 0, 0, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
@@ -627,18 +661,7 @@ int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream
 // z-forward + y-forward (the x transform is left to the fused x pass)
 int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     c->fft_count++;
-    int rc;
-    switch (c->n2 / 2) {
-        case 8: rc = launch_zfwd_t<8>(c, in, spec, st); break;
-        case 16: rc = launch_zfwd_t<16>(c, in, spec, st); break;
-        case 32: rc = launch_zfwd_t<32>(c, in, spec, st); break;
-        case 64: rc = launch_zfwd_t<64>(c, in, spec, st); break;
-        case 128: rc = launch_zfwd_t<128>(c, in, spec, st); break;
-        case 256: rc = launch_zfwd_t<256>(c, in, spec, st); break;
-        case 512: rc = launch_zfwd_t<512>(c, in, spec, st); break;
-        case 1024: rc = launch_zfwd_t<1024>(c, in, spec, st); break;
-        default: rc = fail(c, OFDFT_EINVAL, "bad n2");
-    }
+    int rc = zfwd_any(c, in, spec, st);
     if (rc) return rc;
     return fast_axis_pass<false>(c, 1, spec, st);
 }
@@ -647,34 +670,14 @@ int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
 int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
     c->fft_count++;
     if (int rc = fast_axis_pass<true>(c, 1, spec, st)) return rc;
-    switch (c->n2 / 2) {
-        case 8: return launch_zinv_t<8>(c, spec, out, scale, st);
-        case 16: return launch_zinv_t<16>(c, spec, out, scale, st);
-        case 32: return launch_zinv_t<32>(c, spec, out, scale, st);
-        case 64: return launch_zinv_t<64>(c, spec, out, scale, st);
-        case 128: return launch_zinv_t<128>(c, spec, out, scale, st);
-        case 256: return launch_zinv_t<256>(c, spec, out, scale, st);
-        case 512: return launch_zinv_t<512>(c, spec, out, scale, st);
-        case 1024: return launch_zinv_t<1024>(c, spec, out, scale, st);
-    }
-    return fail(c, OFDFT_EINVAL, "bad n2");
+    return zinv_any(c, spec, out, scale, st);
 }
 
 int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
     cplx *send, *recv, *tmp;
     if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
     if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
-    int rc;
-    switch (c->n2 / 2) {          // z-forward of the local rows into the x-slab layout
-        case 8: rc = launch_zfwd_t<8>(c, in, tmp, st); break;
-        case 16: rc = launch_zfwd_t<16>(c, in, tmp, st); break;
-        case 32: rc = launch_zfwd_t<32>(c, in, tmp, st); break;
-        case 64: rc = launch_zfwd_t<64>(c, in, tmp, st); break;
-        case 128: rc = launch_zfwd_t<128>(c, in, tmp, st); break;
-        case 256: rc = launch_zfwd_t<256>(c, in, tmp, st); break;
-        case 512: rc = launch_zfwd_t<512>(c, in, tmp, st); break;
-        default: rc = fail(c, OFDFT_EINVAL, "bad n2");
-    }
+    int rc = zfwd_any(c, in, tmp, st);          // z-forward of the local rows into the x-slab layout
     if (rc) return rc;
     if ((rc = ypass_xchg<false>(c, {tmp}, send, st))) return rc;           // y-forward, written in the exchange layout
     if ((rc = dist_exchange(c, send, recv, st))) return rc;
@@ -695,16 +698,7 @@ int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t s
     OFDFT_LAUNCH(c, st, "xchg_pack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)send, spec, c->gx, xg, 1);
     if ((rc = dist_exchange(c, send, recv, st))) return rc;
     if ((rc = ypass_xchg<true>(c, {tmp}, recv, st))) return rc;             // y-inverse out of the exchange layout
-    switch (c->n2 / 2) {
-        case 8: return launch_zinv_t<8>(c, tmp, out, scale, st);
-        case 16: return launch_zinv_t<16>(c, tmp, out, scale, st);
-        case 32: return launch_zinv_t<32>(c, tmp, out, scale, st);
-        case 64: return launch_zinv_t<64>(c, tmp, out, scale, st);
-        case 128: return launch_zinv_t<128>(c, tmp, out, scale, st);
-        case 256: return launch_zinv_t<256>(c, tmp, out, scale, st);
-        case 512: return launch_zinv_t<512>(c, tmp, out, scale, st);
-    }
-    return fail(c, OFDFT_EINVAL, "bad n2");
+    return zinv_any(c, tmp, out, scale, st);
 }
 
 // where the x pass finds its spectra: {} = y-slab arrays in the block-8 layout (one GPU); otherwise the exchange
@@ -803,6 +797,9 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
         case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
         case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
         case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+#define X(L) case L: return launch_xfused_t<L, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        OFDFT_MIXED_LINES(X)
+#undef X
     }
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
 }
@@ -1354,9 +1351,9 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     c->gx = g;
     c->gx.n0 = n0g;
     c->gx.n1 = n1g / nranks;        // same nrows / totals as g
-    c->fast = is_pow2(n0g) && is_pow2(n1g) && is_pow2(n2) && is_pow2(nranks) && n0g >= 8 && n0g <= 1024 && n1g >= 8 &&
-              n1g <= 1024 && n2 >= 16 && n2 <= 2048;
-    if (nranks > 1 && !(c->fast && n2 / 2 <= 512 && c->gx.n1 >= 1)) {
+    // register / LDS line transforms (and with them the fused pipelines) for powers of two and the listed 2^a 3^b 5^c extents
+    c->fast = line_extent_ok(n0g) && line_extent_ok(n1g) && row_extent_ok(n2) && is_pow2(nranks);
+    if (nranks > 1 && !(c->fast && all_pow2(c) && n2 / 2 <= 512 && c->gx.n1 >= 1)) {
         delete c;
         return fail(nullptr, OFDFT_EINVAL, "the slab-decomposed path needs power-of-two extents (n2 <= 1024)");
     }
@@ -1894,6 +1891,10 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             return OFDFT_OK;
         case OFDFT_OPT_XCHUNK_MASK:
             c->xchunk_mask = (int)value & 31;
+            return OFDFT_OK;
+        case OFDFT_OPT_MIXED_RADIX:
+            c->fast = line_extent_ok(c->n0g) && line_extent_ok(c->n1g) && row_extent_ok(c->n2) && is_pow2(c->nranks) &&
+                      (value != 0.0 || all_pow2(c));
             return OFDFT_OK;
         case OFDFT_OPT_XWAVE:
             c->use_xwave = (int)value;

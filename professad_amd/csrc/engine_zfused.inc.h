@@ -1,7 +1,7 @@
 // The z-fused pipeline of the engine (five stages, two chains; single- and multi-GPU) and the launchers of the z
 // kernels.  Included once by engine.hip inside its anonymous namespace (one translation unit).
 // ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
-#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512)
+#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) OFDFT_MIXED_ROWS(X)
 #ifndef OFDFT_EZ
 #define OFDFT_EZ 4
 #endif
@@ -27,10 +27,10 @@ int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, 
     SpecGeom gz = c->g;
 #define X(M_)                                                                                                       \
     case M_: {                                                                                                      \
-        const int nb = z_blocks<M_, 8>(c) / nchunks;                                                                \
+        const int nb = z_blocks<M_, ZPick<M_, 8>::E>(c) / nchunks;                                                  \
         gz.blk0 = chunk * nb;                                                                                       \
-        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, 8>), dim3(nb), dim3(256), (ZW<M_, 8>::LDS), ds,    \
-                     out_n, out_s, gz, twM, twN, dzn);                                                              \
+        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, ZPick<M_, 8>::E>), dim3(nb), dim3(256),            \
+                     (ZW<M_, ZPick<M_, 8>::E>::LDS), ds, out_n, out_s, gz, twM, twN, dzn);                          \
         return 0;                                                                                                   \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }
@@ -127,6 +127,9 @@ int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st
         case 256: return launch_yderiv_t<256>(c, in, out, scale, st);
         case 512: return launch_yderiv_t<512>(c, in, out, scale, st);
         case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st);
+#define X(L) case L: return launch_yderiv_t<L>(c, in, out, scale, st);
+        OFDFT_MIXED_LINES(X)
+#undef X
     }
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
 }
@@ -246,7 +249,7 @@ ZRun& zrun(ofdft_ctx* c);
 // spectra -> proportionally more chunks, so that a chunk's working set stays the same share of the Infinity Cache.
 // Every chunk must be whole workgroups of every z kernel (at most 256 rows each) -> powers of two that divide n0.
 int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
-    if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which)) return 1;
+    if (c->nranks > 1 || c->xchunks == 1 || !(c->xchunk_mask & which) || !all_pow2(c)) return 1;
     if (which == 8 && wts_active(c)) return 1;        // the two-pass combine of the stabilised WT-style functional is not chunked
     // automatic: about 100 MB of spectra per chunk (measured best at 256^3: 8 chunks for the six WGC99 spectra)
     int want = c->xchunks > 1 ? (c->xchunks * narr + 5) / 6

@@ -136,19 +136,45 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
     const long long b0 = uniform64(line_base(m, L0));
     cplx* ub = data + b0;                                   // wave-uniform
     const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
-    const long long qstep = uniform64((long long)P * m.se); // uniform element stride between a thread's points
+    const long long se_u = uniform64(m.se);                 // uniform element stride; slot q holds element j + cin(q) / j + cout(q)
+    using PL = Plan<LEN>;
     cplx v[E];
-    if (valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + q * qstep, voff);
-    } else {
-#pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
-    }
+    for (int q = 0; q < E; ++q)
+        v[q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + PL::cin(q) * se_u, voff)
+                                                               : mkc(0.0, 0.0);
     line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + q * qstep, voff, v[q]);
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(j, q)) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + PL::cout(q) * se_u, voff, v[q]);
+    }
+}
+
+// Register slots from the exit pattern of a transform (element j + cout(q)) to its entry pattern (element j + cin(q)),
+// through the line buffer: needed between a forward and an inverse transform of the same line when the plan is not EXACT
+// (extents with factors 3 / 5; for the power-of-two plans the two patterns coincide and this is a no-op).
+template <class PL, bool WAVE>
+__device__ __forceinline__ void repattern_out_to_in(cplx (&v)[PL::E], int j, real* line) {
+    if constexpr (!PL::EXACT) {
+        constexpr int E = PL::E;
+        real re[E];
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpad(j + PL::cout(q))] = v[q].x;
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int q = 0; q < E; ++q) re[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? line[lpad(j + PL::cin(q))] : (real)0.0;
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpad(j + PL::cout(q))] = v[q].y;
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            v[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? mkc(re[q], line[lpad(j + PL::cin(q))]) : mkc(0.0, 0.0);
+        exchange_sync<WAVE>();
     }
 }
 
@@ -175,23 +201,27 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* _
     const bool valid = L < m.nlines;
     const long long b0 = uniform64(line_base(m, L0));
     const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
-    const long long qstep = uniform64((long long)P * m.se);
+    const long long se_u = uniform64(m.se);
+    using PL = Plan<LEN>;
     cplx v[E];
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = valid ? buf_load_c(in + roff + b0 + q * qstep, voff) : mkc(0.0, 0.0);
+    for (int q = 0; q < E; ++q)
+        v[q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c(in + roff + b0 + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
     real* mine = lds + l * LineBuf<LEN>::STRIDE;
     line_fft<LEN, false>(v, j, mine, tw);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const int e = j + P * q;
+        const int e = j + PL::cout(q);
         const real f = scale * (real)(e <= LEN / 2 ? e : e - LEN);
         v[q] = mkc(-f * v[q].y, f * v[q].x);
     }
     __syncthreads();
+    repattern_out_to_in<PL, false>(v, j, mine);
     line_fft<LEN, true>(v, j, mine, tw);
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(out + roff + b0 + q * qstep, voff, v[q]);
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(j, q)) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(out + roff + b0 + PL::cout(q) * se_u, voff, v[q]);
     }
 }
 
@@ -567,7 +597,13 @@ template <int LEN, int G, int NOUT> struct XfCfg {
     static constexpr int WANT = ((OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8) * (16 / (int)sizeof(cplx));
     static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
     static constexpr int TPB = G * LPW * P;
-    static constexpr size_t LDS = sizeof(real) * G * LPW * LineBuf<LEN>::STRIDE;
+    // the mix trades the spectra through the line buffers in two halves of the register slots: real parts of a half at
+    // positions j + P qq (qq < EH), imaginary parts RGN further on; 2 RGN = LEN for the power-of-two plans
+    static constexpr int EH = (E + 1) / 2;
+    static constexpr int RGN = P * EH;
+    static constexpr int STRIDE = (2 * RGN + ((2 * RGN) >> 4) + 2 > LineBuf<LEN>::STRIDE) ? 2 * RGN + ((2 * RGN) >> 4) + 2
+                                                                                         : LineBuf<LEN>::STRIDE;
+    static constexpr size_t LDS = sizeof(real) * G * LPW * STRIDE;
 };
 
 
@@ -579,29 +615,28 @@ template <int LEN, int G, int NOUT> struct XfCfg {
 //        element offset of the k-point in a spectrum array (uoff wave-uniform) for buffer-load table lookups
 template <int LEN, int LPW_> struct XfMixCtx {
     int j, l, y, kz;
-    long long b0, qstep;
+    long long b0, tse;  // uniform offset of the tile and uniform element stride of the k-point tables along the line
     unsigned loff;      // per-lane element offset of the thread's first point (table lookups)
 };
 
 // (re, im) += coef<O,I>(k) * input_I, for I = I0..NIN-1 (compile-time recursion; absent terms vanish).  Both parts
-// of the inputs are in LDS at once (re at pos, im at pos + LEN/2), so every coefficient is fetched ONCE.
-template <int LEN, int LPW, int NIN, int O, int I, class Mix>
+// of the inputs are in LDS at once (re at pos, im at pos + RGN), so every coefficient is fetched ONCE.
+template <int LEN, int LPW, int STRIDE, int RGN, int NIN, int O, int I, class Mix>
 __device__ __forceinline__ void xf_mix_inputs(real& acr, real& aci, const real* lds, const XfMixCtx<LEN, LPW>& c,
                                               const Mix& mix, int q, int x, int pos) {
-    constexpr int STRIDE = LineBuf<LEN>::STRIDE;
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
-            const real cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
+            const real cf = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + Plan<LEN>::cout(q) * c.tse, c.loff);
             const real* lb = lds + (I * LPW + c.l) * STRIDE;
             if constexpr (Mix::template imag_oi<O, I>()) {       // (i c)(re + i im) = -c im + i c re
-                acr -= cf * lb[lpad(pos + LEN / 2)];
+                acr -= cf * lb[lpad(pos + RGN)];
                 aci += cf * lb[lpad(pos)];
             } else {
                 acr += cf * lb[lpad(pos)];
-                aci += cf * lb[lpad(pos + LEN / 2)];
+                aci += cf * lb[lpad(pos + RGN)];
             }
         }
-        xf_mix_inputs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
+        xf_mix_inputs<LEN, LPW, STRIDE, RGN, NIN, O, I + 1, Mix>(acr, aci, lds, c, mix, q, x, pos);
     }
 }
 
@@ -613,73 +648,75 @@ template <class Mix> struct mix_has_tables<Mix, std::void_t<decltype(Mix::kTable
 template <int LEN, int LPW, int NIN, int O, int I, class Mix>
 __device__ __forceinline__ void xf_fetch_coefs(real (&cf)[NIN], const XfMixCtx<LEN, LPW>& c, const Mix& mix, int q, int x) {
     if constexpr (I < NIN) {
-        if constexpr (Mix::template present<O, I>()) cf[I] = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + q * c.qstep, c.loff);
+        if constexpr (Mix::template present<O, I>()) cf[I] = mix.template coef<O, I>(x, c.y, c.kz, c.b0 + Plan<LEN>::cout(q) * c.tse, c.loff);
         else cf[I] = 0.0;
         xf_fetch_coefs<LEN, LPW, NIN, O, I + 1, Mix>(cf, c, mix, q, x);
     }
 }
-template <int LEN, int LPW, int NIN, int O, int I, class Mix>
+template <int LEN, int LPW, int STRIDE, int RGN, int NIN, int O, int I, class Mix>
 __device__ __forceinline__ void xf_apply_coefs(real& acr, real& aci, const real (&cf)[NIN], const real* lds,
                                                const XfMixCtx<LEN, LPW>& c, int pos) {
-    constexpr int STRIDE = LineBuf<LEN>::STRIDE;
     if constexpr (I < NIN) {
         if constexpr (Mix::template present<O, I>()) {
             const real* lb = lds + (I * LPW + c.l) * STRIDE;
             if constexpr (Mix::template imag_oi<O, I>()) {
-                acr -= cf[I] * lb[lpad(pos + LEN / 2)];
+                acr -= cf[I] * lb[lpad(pos + RGN)];
                 aci += cf[I] * lb[lpad(pos)];
             } else {
                 acr += cf[I] * lb[lpad(pos)];
-                aci += cf[I] * lb[lpad(pos + LEN / 2)];
+                aci += cf[I] * lb[lpad(pos + RGN)];
             }
         }
-        xf_apply_coefs<LEN, LPW, NIN, O, I + 1, Mix>(acr, aci, cf, lds, c, pos);
+        xf_apply_coefs<LEN, LPW, STRIDE, RGN, NIN, O, I + 1, Mix>(acr, aci, cf, lds, c, pos);
     }
 }
 
-// one output (compile-time O) from all inputs for the half of the thread's points with index HALF
-template <int LEN, int LPW, int NIN, int O, class Mix, int HALF>
+// one output (compile-time O) from all inputs for the half of the thread's register slots with index HALF
+template <int LEN, int LPW, int STRIDE, int NIN, int O, class Mix, int HALF>
 __device__ __forceinline__ void xf_mix_part(cplx (&o)[Plan<LEN>::E], const real* lds, const XfMixCtx<LEN, LPW>& c,
                                             const Mix& mix) {
-    constexpr int P = Plan<LEN>::P, E = Plan<LEN>::E;
+    using PL = Plan<LEN>;
+    constexpr int P = PL::P, E = PL::E, EH = (E + 1) / 2, RGN = P * EH;
     if constexpr (mix_has_tables<Mix>::value && OFDFT_XF_BATCH_TABLES) {
         // Left to the compiler, the table loads came one at a time, each waited for before the next was issued: ~24
         // dependent HBM / L2 round trips per thread, i.e. the workgroup's whole lifetime.
-        real cf[E / 2][NIN];
+        real cf[EH][NIN];
 #pragma unroll
-        for (int qq = 0; qq < E / 2; ++qq) {
-            const int q = qq + HALF * (E / 2);
-            xf_fetch_coefs<LEN, LPW, NIN, O, 0, Mix>(cf[qq], c, mix, q, c.j + P * q);
+        for (int qq = 0; qq < EH; ++qq) {
+            const int q = qq + HALF * EH;
+            if (q < E && PL::slot_out(q)) xf_fetch_coefs<LEN, LPW, NIN, O, 0, Mix>(cf[qq], c, mix, q, c.j + PL::cout(q));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qq = 0; qq < E / 2; ++qq) {
-            const int q = qq + HALF * (E / 2);
-            const int x = c.j + P * q;
-            real acr = 0.0, aci = 0.0;
-            xf_apply_coefs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, cf[qq], lds, c, x - HALF * (LEN / 2));
-            o[q] = mkc(acr, aci);
+        for (int qq = 0; qq < EH; ++qq) {
+            const int q = qq + HALF * EH;
+            if (q < E && PL::slot_out(q)) {
+                real acr = 0.0, aci = 0.0;
+                xf_apply_coefs<LEN, LPW, STRIDE, RGN, NIN, O, 0, Mix>(acr, aci, cf[qq], lds, c, c.j + P * qq);
+                o[q] = mkc(acr, aci);
+            }
         }
     } else {
 #pragma unroll
-        for (int qq = 0; qq < E / 2; ++qq) {
-            const int q = qq + HALF * (E / 2);
-            const int x = c.j + P * q;
-            real acr = 0.0, aci = 0.0;
-            xf_mix_inputs<LEN, LPW, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, x, x - HALF * (LEN / 2));
-            o[q] = mkc(acr, aci);
+        for (int qq = 0; qq < EH; ++qq) {
+            const int q = qq + HALF * EH;
+            if (q < E && PL::slot_out(q)) {
+                real acr = 0.0, aci = 0.0;
+                xf_mix_inputs<LEN, LPW, STRIDE, RGN, NIN, O, 0, Mix>(acr, aci, lds, c, mix, q, c.j + PL::cout(q), c.j + P * qq);
+                o[q] = mkc(acr, aci);
+            }
         }
     }
 }
 
-template <int LEN, int LPW, int NIN, int NOUT, class Mix, int IMPART>
+template <int LEN, int LPW, int STRIDE, int NIN, int NOUT, class Mix, int IMPART>
 __device__ __forceinline__ void xf_mix_dispatch(int grp, cplx (&o)[Plan<LEN>::E], const real* lds,
                                                 const XfMixCtx<LEN, LPW>& c, const Mix& mix) {
     // grp is wave-uniform: a scalar branch into straight-line code specialised per output
-    if (grp == 0) xf_mix_part<LEN, LPW, NIN, 0, Mix, IMPART>(o, lds, c, mix);
-    if constexpr (NOUT > 1) { if (grp == 1) xf_mix_part<LEN, LPW, NIN, 1, Mix, IMPART>(o, lds, c, mix); }
-    if constexpr (NOUT > 2) { if (grp == 2) xf_mix_part<LEN, LPW, NIN, 2, Mix, IMPART>(o, lds, c, mix); }
-    if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, LPW, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
+    if (grp == 0) xf_mix_part<LEN, LPW, STRIDE, NIN, 0, Mix, IMPART>(o, lds, c, mix);
+    if constexpr (NOUT > 1) { if (grp == 1) xf_mix_part<LEN, LPW, STRIDE, NIN, 1, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 2) { if (grp == 2) xf_mix_part<LEN, LPW, STRIDE, NIN, 2, Mix, IMPART>(o, lds, c, mix); }
+    if constexpr (NOUT > 3) { if (grp == 3) xf_mix_part<LEN, LPW, STRIDE, NIN, 3, Mix, IMPART>(o, lds, c, mix); }
 }
 
 #ifndef OFDFT_XF_MINWAVES
@@ -695,7 +732,8 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     XfStride xs) {
     constexpr int G = NIN > NOUT ? NIN : NOUT;
     using Cfg = XfCfg<LEN, G, NOUT>;
-    constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = LineBuf<LEN>::STRIDE;
+    using PL = Plan<LEN>;
+    constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, STRIDE = Cfg::STRIDE, EH = Cfg::EH, RGN = Cfg::RGN;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     static_assert((LPW * P) % 64 == 0, "a thread group must be whole waves");
@@ -730,18 +768,18 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     const long long L0 = (long long)bid * LPW;
     const long long b0 = uniform64(region + line_base(m, L0));                 // wave-uniform
     const unsigned voff = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * m.se) * kCB) : 0u;
-    const long long qstep = uniform64((long long)P * m.se);
-    const long long se_o = xs.se_out ? xs.se_out : m.se, se_t = xs.tse ? xs.tse : m.se;
+    const long long se_u = uniform64(m.se);
+    const long long se_o = uniform64(xs.se_out ? xs.se_out : m.se), se_t = uniform64(xs.tse ? xs.tse : m.se);
     const unsigned voff_o = valid ? (unsigned)((base - line_base(m, L0) + (long long)j * se_o) * kCB) : 0u;
     const unsigned tloff = valid ? (unsigned)(base - line_base(m, L0) + (long long)j * se_t) : 0u;
-    const long long qstep_o = uniform64((long long)P * se_o), tqstep = uniform64((long long)P * se_t);
     cplx v[E];
     if (valid && grp < NIN) {
         // the group index is wave-uniform only when a group is a whole number of waves; select the pointer
         // with scalar-friendly code: each wave belongs to exactly one group when LPW*P % 64 == 0
         const cplx* ub = xf_pick(io.in, grp) + b0;
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = buf_load_c_aux<OFDFT_XF_LD_AUX>(ub + q * qstep, voff);
+        for (int q = 0; q < E; ++q)
+            v[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? buf_load_c_aux<OFDFT_XF_LD_AUX>(ub + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
     } else {
 #pragma unroll
         for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
@@ -752,34 +790,40 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     cplx o[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) o[q] = mkc(0.0, 0.0);
-    XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, tqstep, tloff};
-    // ---- mix in two halves of the k-points (x < LEN/2, then the rest): the line buffer holds the real parts of a
-    // half at [0, LEN/2) and the imaginary parts at [LEN/2, LEN)
-    static_assert(E % 2 == 0, "points per thread must be even");
+    XfMixCtx<LEN, LPW> mc{j, l, y, kz, b0, se_t, tloff};
+    // ---- mix in two halves of the register slots (the k-points x = j + cout(q)): the line buffer holds the real parts of
+    // a half at positions j + P qq and the imaginary parts RGN further on
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < E / 2; ++q) {
-        mine[lpad(j + P * q)] = v[q].x;
-        mine[lpad(j + P * q + LEN / 2)] = v[q].y;
+    for (int qq = 0; qq < EH; ++qq) {
+        mine[lpad(j + P * qq)] = v[qq].x;
+        mine[lpad(j + P * qq + RGN)] = v[qq].y;
     }
     __syncthreads();
-    xf_mix_dispatch<LEN, LPW, NIN, NOUT, Mix, 0>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, LPW, STRIDE, NIN, NOUT, Mix, 0>(grp, o, lds, mc, mix);
     __syncthreads();
 #pragma unroll
-    for (int q = E / 2; q < E; ++q) {
-        mine[lpad(j + P * q - LEN / 2)] = v[q].x;
-        mine[lpad(j + P * q)] = v[q].y;
+    for (int qq = 0; qq < EH; ++qq) {
+        if (qq + EH < E) {
+            mine[lpad(j + P * qq)] = v[qq + EH].x;
+            mine[lpad(j + P * qq + RGN)] = v[qq + EH].y;
+        }
     }
     __syncthreads();
-    xf_mix_dispatch<LEN, LPW, NIN, NOUT, Mix, 1>(grp, o, lds, mc, mix);
+    xf_mix_dispatch<LEN, LPW, STRIDE, NIN, NOUT, Mix, 1>(grp, o, lds, mc, mix);
+    if constexpr (!PL::EXACT) {      // k-space results sit in the exit pattern of the forward transform
+        __syncthreads();
+        repattern_out_to_in<PL, false>(o, j, mine);
+    }
     line_fft<LEN, true>(o, j, mine, tw);
     if (valid && grp < NOUT) {
         cplx* ub = xf_pick(io.out, grp) + b0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
+            if (!(PL::slot_out(q) && PL::lane_out(j, q))) continue;
             // nt stores pay in the block-8 layout (one GPU); in the exchange layout (x stride = a whole record) they cost 16 %
-            if (xs.se_out) buf_store_c(ub + q * qstep_o, voff_o, o[q]);
-            else buf_store_c_aux<OFDFT_XF_ST_AUX>(ub + q * qstep_o, voff_o, o[q]);
+            if (xs.se_out) buf_store_c(ub + PL::cout(q) * se_o, voff_o, o[q]);
+            else buf_store_c_aux<OFDFT_XF_ST_AUX>(ub + PL::cout(q) * se_o, voff_o, o[q]);
         }
     }
 }

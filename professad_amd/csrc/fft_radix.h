@@ -190,15 +190,160 @@ template <int R, bool INV> struct Dft {
     }
 };
 
-// ---- per-length plan: stage radices, points per thread E, threads per line P = LEN / E
+// ---- odd and mixed radices (grids whose extents are 2^a 3^b 5^c): cos / sin of 2 pi m / N as literals
+template <int N> struct UnitRoots;
+template <> struct UnitRoots<3> {
+    static constexpr double c[3] = {1.0, -0.5000000000000000000000000, -0.5000000000000000000000000};
+    static constexpr double s[3] = {0.0, 0.8660254037844385965883021, -0.8660254037844385965883021};
+};
+template <> struct UnitRoots<5> {
+    static constexpr double c[5] = {1.0, 0.3090169943749474512628694, -0.8090169943749474512628694, -0.8090169943749474512628694, 0.3090169943749474512628694};
+    static constexpr double s[5] = {0.0, 0.9510565162951535311819384, 0.5877852522924731371034568, -0.5877852522924731371034568, -0.9510565162951535311819384};
+};
+template <> struct UnitRoots<6> {
+    static constexpr double c[6] = {1.0, 0.5000000000000000000000000, -0.5000000000000000000000000, -1.0, -0.5000000000000000000000000, 0.5000000000000000000000000};
+    static constexpr double s[6] = {0.0, 0.8660254037844385965883021, 0.8660254037844385965883021, 0.0, -0.8660254037844385965883021, -0.8660254037844385965883021};
+};
+template <> struct UnitRoots<9> {
+    static constexpr double c[9] = {1.0, 0.7660444431189780134516809, 0.1736481776669303589422100, -0.5000000000000000000000000, -0.9396926207859084279050421, -0.9396926207859084279050421, -0.5000000000000000000000000, 0.1736481776669303589422100, 0.7660444431189780134516809};
+    static constexpr double s[9] = {0.0, 0.6427876096865393629187224, 0.9848077530122080203156543, 0.8660254037844385965883021, 0.3420201433256687129080831, -0.3420201433256687129080831, -0.8660254037844385965883021, -0.9848077530122080203156543, -0.6427876096865393629187224};
+};
+template <> struct UnitRoots<10> {
+    static constexpr double c[10] = {1.0, 0.8090169943749474512628694, 0.3090169943749474512628694, -0.3090169943749474512628694, -0.8090169943749474512628694, -1.0, -0.8090169943749474512628694, -0.3090169943749474512628694, 0.3090169943749474512628694, 0.8090169943749474512628694};
+    static constexpr double s[10] = {0.0, 0.5877852522924731371034568, 0.9510565162951535311819384, 0.9510565162951535311819384, 0.5877852522924731371034568, 0.0, -0.5877852522924731371034568, -0.9510565162951535311819384, -0.9510565162951535311819384, -0.5877852522924731371034568};
+};
+template <> struct UnitRoots<12> {
+    static constexpr double c[12] = {1.0, 0.8660254037844385965883021, 0.5000000000000000000000000, 0.0, -0.5000000000000000000000000, -0.8660254037844385965883021, -1.0, -0.8660254037844385965883021, -0.5000000000000000000000000, 0.0, 0.5000000000000000000000000, 0.8660254037844385965883021};
+    static constexpr double s[12] = {0.0, 0.5000000000000000000000000, 0.8660254037844385965883021, 1.0, 0.8660254037844385965883021, 0.5000000000000000000000000, 0.0, -0.5000000000000000000000000, -0.8660254037844385965883021, -1.0, -0.8660254037844385965883021, -0.5000000000000000000000000};
+};
+template <> struct UnitRoots<15> {
+    static constexpr double c[15] = {1.0, 0.9135454576426008665990253, 0.6691306063588582375700753, 0.3090169943749474512628694, -0.1045284632676534708473071, -0.5000000000000000000000000, -0.8090169943749474512628694, -0.9781476007338056888329447, -0.9781476007338056888329447, -0.8090169943749474512628694, -0.5000000000000000000000000, -0.1045284632676534708473071, 0.3090169943749474512628694, 0.6691306063588582375700753, 0.9135454576426008665990253};
+    static constexpr double s[15] = {0.0, 0.4067366430758002082690439, 0.7431448254773942441175905, 0.9510565162951535311819384, 0.9945218953682732898613494, 0.8660254037844385965883021, 0.5877852522924731371034568, 0.2079116908177593425754992, -0.2079116908177593425754992, -0.5877852522924731371034568, -0.8660254037844385965883021, -0.9945218953682732898613494, -0.9510565162951535311819384, -0.7431448254773942441175905, -0.4067366430758002082690439};
+};
+
+// a * W_N^K, W_N = exp(-2 pi i / N) (forward; conjugate for the inverse), K compile-time
+template <int N, int K, bool INV> __device__ __forceinline__ cplx mul_root(cplx a) {
+    constexpr int k = ((K % N) + N) % N;
+    if constexpr (k == 0) {
+        return a;
+    } else if constexpr (2 * k == N) {
+        return mkc(-a.x, -a.y);
+    } else if constexpr (4 * k == N) {
+        return mul_mi<INV>(a);
+    } else if constexpr (4 * k == 3 * N) {
+        return mul_mi<!INV>(a);
+    } else {
+        constexpr real c = (real)UnitRoots<N>::c[k];
+        constexpr real sn = (real)(INV ? UnitRoots<N>::s[k] : -UnitRoots<N>::s[k]);
+        return mkc(a.x * c - a.y * sn, a.x * sn + a.y * c);
+    }
+}
+template <bool INV> struct Dft<3, INV> {
+    static __device__ __forceinline__ void run(cplx* a) {
+        constexpr real s = (real)UnitRoots<3>::s[1];
+        const cplx t1 = cadd(a[1], a[2]);
+        const cplx t2 = mkc(a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y);
+        const cplx d = csub(a[1], a[2]);
+        const cplx t3 = INV ? mkc(-s * d.y, s * d.x) : mkc(s * d.y, -s * d.x);      // -+ i s (a1 - a2)
+        a[0] = cadd(a[0], t1);
+        a[1] = cadd(t2, t3);
+        a[2] = csub(t2, t3);
+    }
+};
+template <bool INV> struct Dft<5, INV> {
+    static __device__ __forceinline__ void run(cplx* a) {
+        constexpr real c1 = (real)UnitRoots<5>::c[1], c2 = (real)UnitRoots<5>::c[2];
+        constexpr real s1 = (real)UnitRoots<5>::s[1], s2 = (real)UnitRoots<5>::s[2];
+        const cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+        const cplx m1 = mkc(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+        const cplx m2 = mkc(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+        const cplx n1 = mkc(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        const cplx n2 = mkc(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2; inverse: signs swapped
+        const cplx in1 = INV ? mkc(-n1.y, n1.x) : mkc(n1.y, -n1.x);
+        const cplx in2 = INV ? mkc(-n2.y, n2.x) : mkc(n2.y, -n2.x);
+        a[0] = mkc(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
+        a[1] = cadd(m1, in1);
+        a[4] = csub(m1, in1);
+        a[2] = cadd(m2, in2);
+        a[3] = csub(m2, in2);
+    }
+};
+// R = R1 R2 by one Cooley-Tukey step in registers: sub-sequences x[n2 + R2 n1] -> DFT_R1 -> times W_R^(n2 k1) -> DFT_R2 over n2
+template <int R1, int R2, bool INV> struct DftCT {
+    static constexpr int R = R1 * R2;
+    template <int N2, int K1> static __device__ __forceinline__ void twiddle_row(cplx (&y)[R2][R1]) {
+        if constexpr (K1 < R1) {
+            y[N2][K1] = mul_root<R, N2 * K1, INV>(y[N2][K1]);
+            twiddle_row<N2, K1 + 1>(y);
+        }
+    }
+    template <int N2> static __device__ __forceinline__ void twiddle_all(cplx (&y)[R2][R1]) {
+        if constexpr (N2 < R2) {
+            twiddle_row<N2, 1>(y);
+            twiddle_all<N2 + 1>(y);
+        }
+    }
+    static __device__ __forceinline__ void run(cplx* a) {
+        cplx y[R2][R1];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) y[n2][n1] = a[n2 + R2 * n1];
+            Dft<R1, INV>::run(y[n2]);
+        }
+        twiddle_all<1>(y);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            cplx z[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) z[n2] = y[n2][k1];
+            Dft<R2, INV>::run(z);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) a[k1 + R1 * k2] = z[k2];
+        }
+    }
+};
+template <bool INV> struct Dft<6, INV> { static __device__ __forceinline__ void run(cplx* a) { DftCT<3, 2, INV>::run(a); } };
+template <bool INV> struct Dft<9, INV> { static __device__ __forceinline__ void run(cplx* a) { DftCT<3, 3, INV>::run(a); } };
+template <bool INV> struct Dft<10, INV> { static __device__ __forceinline__ void run(cplx* a) { DftCT<5, 2, INV>::run(a); } };
+template <bool INV> struct Dft<12, INV> { static __device__ __forceinline__ void run(cplx* a) { DftCT<3, 4, INV>::run(a); } };
+template <bool INV> struct Dft<15, INV> { static __device__ __forceinline__ void run(cplx* a) { DftCT<3, 5, INV>::run(a); } };
+
+// ---- per-length plan: stage radices, threads per line P, register slots per thread E.
+// Stage s has LEN / R_s butterflies, dealt round-robin over the P threads of the line: thread j takes butterflies
+// j, j + P, ... (NB_s = ceil(LEN / (R_s P)) of them; when LEN / R_s is not a multiple of P some lanes idle in the last
+// round -- that is how extents with factors 3 and 5 keep P a power of two, i.e. tiles of whole wavefronts).  Butterfly
+// beta of the FIRST stage takes x[beta + t LEN/R_0], t < R_0; butterfly beta of the LAST stage leaves
+// X[beta + u LEN/R_last]: a thread's q-th register slot therefore holds element j + cin(q) on entry and j + cout(q) on
+// exit (for the power-of-two plans both are P q and every slot is used: loads and stores with consecutive j coalesce
+// and no reordering pass exists).
+template <int LEN_, int P_, int NST_, int R0_, int R1_, int R2_, int R3_> struct PlanBase {
+    static constexpr int LEN = LEN_;
+    static constexpr int NST = NST_;
+    static constexpr int P = P_;
+    static __host__ __device__ constexpr int radix(int s) { return s == 0 ? R0_ : (s == 1 ? R1_ : (s == 2 ? R2_ : R3_)); }
+    static __host__ __device__ constexpr int nbf(int s) { return LEN_ / radix(s); }                  // butterflies of stage s
+    static __host__ __device__ constexpr int nb(int s) { return (nbf(s) + P_ - 1) / P_; }            // ... per thread
+    static __host__ __device__ constexpr int slots(int s) { return radix(s) * nb(s); }
+    static __host__ __device__ constexpr int emax(int s) { return s >= NST_ ? 0 : (slots(s) > emax(s + 1) ? slots(s) : emax(s + 1)); }
+    static constexpr int E = emax(0);
+    static_assert(R0_ * (NST_ > 1 ? R1_ : 1) * (NST_ > 2 ? R2_ : 1) * (NST_ > 3 ? R3_ : 1) == LEN_, "radices must multiply to LEN");
+    // element offsets of register slot q relative to the thread index j, on entry / on exit, and whether the slot is used
+    static __host__ __device__ constexpr int cin(int q) { return (q % nb(0)) * P_ + (q / nb(0)) * nbf(0); }
+    static __host__ __device__ constexpr int cout(int q) { return (q % nb(NST_ - 1)) * P_ + (q / nb(NST_ - 1)) * nbf(NST_ - 1); }
+    static __host__ __device__ constexpr bool slot_in(int q) { return q < slots(0); }
+    static __host__ __device__ constexpr bool slot_out(int q) { return q < slots(NST_ - 1); }
+    static constexpr bool FULL_IN = nbf(0) % P_ == 0, FULL_OUT = nbf(NST_ - 1) % P_ == 0;
+    static __device__ __forceinline__ bool lane_in(int j, int q) { return FULL_IN || j + (q % nb(0)) * P_ < nbf(0); }
+    static __device__ __forceinline__ bool lane_out(int j, int q) { return FULL_OUT || j + (q % nb(NST_ - 1)) * P_ < nbf(NST_ - 1); }
+    // every slot used on both sides, element j + P q in slot q: the layout the power-of-two kernels were written for
+    static constexpr bool EXACT = FULL_IN && FULL_OUT && slots(0) == E && slots(NST_ - 1) == E && P_ * E == LEN_;
+};
 template <int LEN> struct Plan;
-#define OFDFT_PLAN(LEN_, NST_, R0_, R1_, R2_, E_)                                   \
-    template <> struct Plan<LEN_> {                                                \
-        static constexpr int LEN = LEN_;                                           \
-        static constexpr int NST = NST_;                                           \
-        static constexpr int E = E_;                                               \
-        static constexpr int P = LEN_ / E_;                                        \
-        static __host__ __device__ constexpr int radix(int s) { return s == 0 ? R0_ : (s == 1 ? R1_ : R2_); } \
+#define OFDFT_PLAN(LEN_, NST_, R0_, R1_, R2_, E_)                                                                     \
+    template <> struct Plan<LEN_> : PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, 1> {                              \
+        static_assert(PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, 1>::E == E_ && PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, 1>::EXACT, "plan"); \
     };
 OFDFT_PLAN(8, 1, 8, 1, 1, 8)
 OFDFT_PLAN(16, 1, 16, 1, 1, 16)
@@ -209,6 +354,22 @@ OFDFT_PLAN(256, 2, 16, 16, 1, 16)
 OFDFT_PLAN(512, 3, 8, 8, 8, 8)
 OFDFT_PLAN(1024, 3, 16, 8, 8, 16)
 #undef OFDFT_PLAN
+// extents with factors 3 and 5 (OFDFT_MIXED_SIZES lists them for the dispatch switches): LEN, P, stages, radices
+#define OFDFT_GPLAN(LEN_, P_, NST_, R0_, R1_, R2_) template <> struct Plan<LEN_> : PlanBase<LEN_, P_, NST_, R0_, R1_, R2_, 1> {};
+OFDFT_GPLAN(48, 8, 2, 6, 8, 1)          // 8 + 6 butterflies over 8 threads: E = 8
+OFDFT_GPLAN(96, 8, 2, 8, 12, 1)         // E = 16
+OFDFT_GPLAN(120, 16, 2, 8, 15, 1)       // 15 / 8 butterflies: E = 15
+OFDFT_GPLAN(144, 16, 2, 16, 9, 1)       // 9 / 16: E = 16
+OFDFT_GPLAN(160, 16, 2, 16, 10, 1)      // 10 / 16: E = 16
+OFDFT_GPLAN(192, 16, 2, 12, 16, 1)      // 16 / 12: E = 16
+OFDFT_GPLAN(240, 16, 2, 16, 15, 1)      // 15 / 16: E = 16
+OFDFT_GPLAN(250, 32, 3, 5, 5, 10)       // 50 / 50 / 25: E = 10
+OFDFT_GPLAN(270, 32, 3, 6, 9, 5)        // 45 / 30 / 54: E = 12
+OFDFT_GPLAN(288, 32, 3, 6, 6, 8)        // 48 / 48 / 36: E = 16
+OFDFT_GPLAN(320, 32, 3, 8, 8, 5)        // 40 / 40 / 64: E = 16
+OFDFT_GPLAN(384, 32, 3, 8, 8, 6)        // 48 / 48 / 64: E = 16
+OFDFT_GPLAN(480, 32, 3, 16, 6, 5)       // 30 / 80 / 96: E = 18
+#undef OFDFT_GPLAN
 
 // padded position inside an LDS line buffer (breaks the power-of-two strides of the exchange)
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
@@ -234,37 +395,44 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
     static constexpr int R = PL::radix(S);
     static constexpr int E = PL::E;
     static constexpr int P = PL::P;
-    static constexpr int NB = E / R;       // butterflies per thread in this stage (also register stride)
+    static constexpr int NBF = PL::nbf(S);     // butterflies of this stage (LEN / R)
+    static constexpr int NB = PL::nb(S);       // ... per thread (also the register stride of a butterfly's inputs)
+    static constexpr bool FULL = NBF % P == 0; // every lane busy in every round
 
     static __device__ __forceinline__ void run(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {
         // ---- twiddle + butterflies
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            cplx a[R];
+            if (FULL || j + b * P < NBF) {
+                cplx a[R];
 #pragma unroll
-            for (int t = 0; t < R; ++t) a[t] = v[b + t * NB];
-            if constexpr (NS > 1) {
-                // twiddles W^(t k), t = 1..R-1: ONE table load (W^k) and a depth-<=4 product tree for the
-                // powers (<= ~5 ulp), instead of R-1 loads whose prefetch would pin 4(R-1) VGPRs
-                const int k = (j + b * P) % NS;
-                constexpr int TSTEP = LEN / (NS * R);
-                cplx w[R];
-                w[1] = tw[k * TSTEP];
-                if (INV) w[1].y = -w[1].y;
+                for (int t = 0; t < R; ++t) a[t] = v[b + t * NB];
+                if constexpr (NS > 1) {
+                    // twiddles W^(t k), t = 1..R-1: ONE table load (W^k) and a depth-<=4 product tree for the
+                    // powers (<= ~5 ulp), instead of R-1 loads whose prefetch would pin 4(R-1) VGPRs
+                    const int k = (j + b * P) % NS;
+                    constexpr int TSTEP = LEN / (NS * R);
+                    cplx w[R];
+                    w[1] = tw[k * TSTEP];
+                    if (INV) w[1].y = -w[1].y;
 #pragma unroll
-                for (int t = 2; t < R; ++t) {
-                    const int hi = (t >= 8) ? 8 : ((t >= 4) ? 4 : 2);   // largest power of two <= t
-                    w[t] = (t == hi) ? cmul(w[t / 2], w[t / 2]) : cmul(w[hi], w[t - hi]);
+                    for (int t = 2; t < R; ++t) {
+                        const int hi = (t >= 8) ? 8 : ((t >= 4) ? 4 : 2);   // largest power of two <= t
+                        w[t] = (t == hi) ? cmul(w[t / 2], w[t / 2]) : cmul(w[hi], w[t - hi]);
+                    }
+#pragma unroll
+                    for (int t = 1; t < R; ++t) a[t] = cmul(a[t], w[t]);
                 }
+                Dft<R, INV>::run(a);
 #pragma unroll
-                for (int t = 1; t < R; ++t) a[t] = cmul(a[t], w[t]);
+                for (int t = 0; t < R; ++t) v[b + t * NB] = a[t];
             }
-            Dft<R, INV>::run(a);
-#pragma unroll
-            for (int t = 0; t < R; ++t) v[b + t * NB] = a[t];
         }
-        // ---- exchange through LDS (not after the last stage)
+        // ---- exchange through LDS (not after the last stage): this stage's outputs at their Stockham positions, the next
+        // stage's butterfly inputs (element beta + t LEN/R') back into its register slots
         if constexpr (S + 1 < PL::NST) {
+            constexpr int R2 = PL::radix(S + 1), NBF2 = PL::nbf(S + 1), NB2 = PL::nb(S + 1);
+            constexpr bool FULL2 = NBF2 % P == 0;
             int base[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -274,20 +442,32 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
             exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB; ++b)
+                if (FULL || j + b * P < NBF) {
 #pragma unroll
-                for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
+                    for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
+                }
             exchange_sync<WAVE>();
             real re[E];
 #pragma unroll
-            for (int q = 0; q < E; ++q) re[q] = line[lpad(j + P * q)];
+            for (int b = 0; b < NB2; ++b)
+                if (FULL2 || j + b * P < NBF2) {
+#pragma unroll
+                    for (int t = 0; t < R2; ++t) re[b + t * NB2] = line[lpad(j + b * P + t * NBF2)];
+                }
             exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB; ++b)
+                if (FULL || j + b * P < NBF) {
 #pragma unroll
-                for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
+                    for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
+                }
             exchange_sync<WAVE>();
 #pragma unroll
-            for (int q = 0; q < E; ++q) v[q] = mkc(re[q], line[lpad(j + P * q)]);
+            for (int b = 0; b < NB2; ++b)
+                if (FULL2 || j + b * P < NBF2) {
+#pragma unroll
+                    for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpad(j + b * P + t * NBF2)]);
+                }
             StageP<PL, S + 1, NS * R, INV, WAVE>::run(v, j, line, tw);
         }
     }
@@ -305,15 +485,9 @@ __device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, real* l
 // threads are lanes of one wave, so the exchanges need no barrier (extra stages only cost LDS traffic), and
 // the small register footprint leaves room for fused pointwise math.
 template <int LEN_, int E_> struct ZPlan;
-#define OFDFT_ZPLAN(LEN_, E_, NST_, R0_, R1_, R2_, R3_)                             \
-    template <> struct ZPlan<LEN_, E_> {                                           \
-        static constexpr int LEN = LEN_;                                           \
-        static constexpr int NST = NST_;                                           \
-        static constexpr int E = E_;                                               \
-        static constexpr int P = LEN_ / E_;                                        \
-        static __host__ __device__ constexpr int radix(int s) {                    \
-            return s == 0 ? R0_ : (s == 1 ? R1_ : (s == 2 ? R2_ : R3_));           \
-        }                                                                          \
+#define OFDFT_ZPLAN(LEN_, E_, NST_, R0_, R1_, R2_, R3_)                                              \
+    template <> struct ZPlan<LEN_, E_> : PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_> {     \
+        static_assert(PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::E == E_ && PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::EXACT, "plan"); \
     };
 OFDFT_ZPLAN(8, 8, 1, 8, 1, 1, 1)
 OFDFT_ZPLAN(16, 8, 2, 8, 2, 1, 1)
@@ -332,6 +506,26 @@ OFDFT_ZPLAN(256, 4, 4, 4, 4, 4, 4)
 
 // E to use for a z kernel that wants `want` points per lane: lines longer than 64*want need more
 template <int M, int WANT> struct ZPick { static constexpr int E = (M / WANT <= 64) ? WANT : 8; };
+// rows whose half length M = n2 / 2 has factors 3 and 5: one plan per M (P a power of two <= 64, E as small as the
+// factorisation allows), whatever lane width the kernel asked for
+#define OFDFT_ZGPLAN(M_, P_, NST_, R0_, R1_, R2_, R3_)                                                               \
+    template <> struct ZPlan<M_, PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E> : PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_> {}; \
+    template <> struct ZPick<M_, 4> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };   \
+    template <> struct ZPick<M_, 8> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };
+OFDFT_ZGPLAN(24, 8, 2, 6, 4, 1, 1)        // E = 6
+OFDFT_ZGPLAN(48, 16, 3, 4, 4, 3, 1)       // E = 4
+OFDFT_ZGPLAN(60, 16, 3, 4, 5, 3, 1)       // E = 6
+OFDFT_ZGPLAN(72, 32, 3, 4, 6, 3, 1)       // E = 6
+OFDFT_ZGPLAN(80, 32, 3, 4, 4, 5, 1)       // E = 5
+OFDFT_ZGPLAN(96, 32, 3, 4, 4, 6, 1)       // E = 6
+OFDFT_ZGPLAN(120, 32, 3, 4, 5, 6, 1)      // E = 6
+OFDFT_ZGPLAN(125, 32, 3, 5, 5, 5, 1)      // E = 5
+OFDFT_ZGPLAN(135, 32, 3, 3, 9, 5, 1)      // E = 9
+OFDFT_ZGPLAN(144, 64, 3, 4, 6, 6, 1)      // E = 6
+OFDFT_ZGPLAN(160, 32, 3, 4, 8, 5, 1)      // E = 8
+OFDFT_ZGPLAN(192, 64, 4, 4, 4, 4, 3)      // E = 4
+OFDFT_ZGPLAN(240, 64, 4, 4, 4, 3, 5)      // E = 6
+#undef OFDFT_ZGPLAN
 
 template <int LEN, int E, bool INV>
 __device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {

@@ -46,6 +46,10 @@ template <int M, int E_> struct ZW {
     static constexpr int N2 = 2 * M;
 };
 
+// waves per SIMD the fused z kernels are compiled for: the power-of-two rows up to 512 keep 4 points per lane (two or three
+// waves); rows of 1024 (8 points) and rows with factors 3 / 5 (5..9 points per lane) need a whole SIMD's registers
+template <int M, int E> constexpr int z_waves(int want) { return (M >= 512 || E > 4) ? (want > 2 ? 2 : 1) : want; }
+
 // lane geometry of the z kernels
 template <int M, int E> struct ZLane {
     int j;            // lane's position inside its row group
@@ -111,24 +115,43 @@ __device__ __forceinline__ void z_tw_commit(real* lds, const ZTwReq<M, E>& r, co
 #endif
 }
 
-// ---- real rows: lane holds (a[2(j+Pq)], a[2(j+Pq)+1]) for q = 0..7
-template <int M, int E>
+// ---- real rows: a register slot holds the pair (a[2 e], a[2 e + 1]) of element e = j + cin(q) -- rows that go INTO a
+// forward transform -- or e = j + cout(q) -- rows combined with what comes OUT of an inverse transform (the two patterns
+// coincide, e = j + P q, for the power-of-two plans)
+template <int M, int E, bool OUT = false>
 __device__ __forceinline__ void z_load_real(cplx (&v)[E], const ZLane<M, E>& z, const real* __restrict__ a) {
     using W = ZW<M, E>;
+    using PL = typename W::PL;
     const cplx* ub = reinterpret_cast<const cplx*>(a + z.row_u * W::N2);
     const unsigned voff = (unsigned)((z.rw * M + z.j) * kCB);
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = z.valid ? buf_load_c_aux<OFDFT_ZR_LD_AUX>(ub + q * W::P, voff) : mkc(0.0, 0.0);
+    for (int q = 0; q < E; ++q) {
+        const bool on = OUT ? (PL::slot_out(q) && PL::lane_out(z.j, q)) : (PL::slot_in(q) && PL::lane_in(z.j, q));
+        v[q] = (z.valid && on) ? buf_load_c_aux<OFDFT_ZR_LD_AUX>(ub + (OUT ? PL::cout(q) : PL::cin(q)), voff) : mkc(0.0, 0.0);
+    }
 }
 template <int M, int E>
 __device__ __forceinline__ void z_store_real(const cplx (&v)[E], const ZLane<M, E>& z, real* __restrict__ a) {
     using W = ZW<M, E>;
+    using PL = typename W::PL;
     cplx* ub = reinterpret_cast<cplx*>(a + z.row_u * W::N2);
     const unsigned voff = (unsigned)((z.rw * M + z.j) * kCB);
     if (z.valid) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf_store_c_aux<OFDFT_ZR_ST_AUX>(ub + q * W::P, voff, v[q]);
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(z.j, q)) buf_store_c_aux<OFDFT_ZR_ST_AUX>(ub + PL::cout(q), voff, v[q]);
     }
+}
+
+// element offset of coefficient kz of row `row` in the block-8 layout (general form; the power-of-two rows use the split
+// uniform / per-lane form below)
+__device__ __forceinline__ long long z_spec_off(const SpecGeom& g, long long row, int kz) {
+    return kz < g.nzm ? (((long long)(kz >> 3)) * g.nrows + row) * 8 + (kz & 7) : g.main_count + (long long)(kz - g.nzm) * g.nrows + row;
+}
+// partner index of the split r2c / c2r post-processing
+template <int M> __device__ __forceinline__ int z_mirror(int k) {
+    if constexpr ((M & (M - 1)) == 0) return (M - k) & (M - 1);
+    else return k == 0 ? 0 : M - k;
 }
 
 // spectrum element k = j + P q of row `row` lives at ((k>>3)*nrows + row)*8 + (k&7); the (P q)>>3 part of
@@ -148,122 +171,112 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
                                                 const SpecGeom& g, const cplx* __restrict__ twM,
                                                 const cplx* __restrict__ twN) {
     using W = ZW<M, E>;
+    using PL = typename W::PL;
     constexpr int P = W::P;
     wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
+    if constexpr (PL::EXACT) {
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+        exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
-    c0r = z.mine[0];
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+        c0r = z.mine[0];
+        exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
-    exchange_sync<true>();
-    const unsigned voff = z_spec_voff<M, E>(z, g);
-    static_for<E>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        const int k = z.j + P * q;
-        const real ci_m = z.mine[lpad((M - k) & (M - 1))];
-        const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
-        const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
-        const cplx X = cadd(ev, cmul(twN[k], od));
-        if (z.valid) buf_store_c_aux<OFDFT_ZS_ST_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
-    });
-    if (z.j == 0 && z.valid) {
-        const real c0i = z.mine[0];
-        spec[g.main_count + z.row] = mkc(c0r - c0i, 0.0);
-    }
-    exchange_sync<true>();
-}
-
-// inverse: half-spectrum row of `spec` -> unscaled real pairs in v (imaginary parts of kz = 0 / Nyquist ignored)
-template <int M, int E>
-__device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ spec,
-                                               const SpecGeom& g, const cplx* __restrict__ twM,
-                                               const cplx* __restrict__ twN) {
-    using W = ZW<M, E>;
-    constexpr int P = W::P;
-    // keep this row's loads below the previous array's work: hoisting the loads of ALL arrays to the kernel top
-    // (the compiler's default) costs 16 VGPRs per array and collapses the occupancy that hides their latency
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned voff = z_spec_voff<M, E>(z, g);
-    static_for<E>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : mkc(0.0, 0.0);
-    });
-    const real nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
-    real xr_m[E];
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+        exchange_sync<true>();
+        const unsigned voff = z_spec_voff<M, E>(z, g);
+        static_for<E>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int k = z.j + P * q;
+            const real ci_m = z.mine[lpad((M - k) & (M - 1))];
+            const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+            const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+            const cplx X = cadd(ev, cmul(twN[k], od));
+            if (z.valid) buf_store_c_aux<OFDFT_ZS_ST_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff, X);
+        });
+    } else {          // rows with factors 3 / 5: slot q holds coefficient k = j + cout(q); general addressing
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].x;
+        exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) xr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
+        c0r = z.mine[0];
+        exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
-    exchange_sync<true>();
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].y;
+        exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const int k = z.j + P * q;
-        const real xi_m = z.mine[lpad((M - k) & (M - 1))];
-        const cplx x = v[q];
-        if (k == 0) {
-            v[q] = mkc(x.x + nyq, x.x - nyq);
-        } else {
-            const cplx ev = mkc(x.x + xr_m[q], x.y - xi_m);
-            const cplx d = mkc(x.x - xr_m[q], x.y + xi_m);
-            const cplx od = cmul(d, cconj(twN[k]));
-            v[q] = mkc(ev.x - od.y, ev.y + od.x);
+        for (int q = 0; q < E; ++q) {
+            if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;
+            const int k = z.j + PL::cout(q);
+            const real ci_m = z.mine[lpad(z_mirror<M>(k))];
+            const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
+            const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
+            const cplx X = cadd(ev, cmul(twN[k], od));
+            if (z.valid) spec[z_spec_off(g, z.row, k)] = X;
         }
     }
-    exchange_sync<true>();
-    wave_line_fft<M, E, true>(v, z.j, z.mine, twM);
+    if (z.j == 0 && z.valid) {
+        const real c0i = z.mine[0];
+        spec[z_spec_off(g, z.row, M)] = mkc(c0r - c0i, 0.0);
+    }
     exchange_sync<true>();
 }
 
-// the loads of z_load_inverse on their own: issue them one array AHEAD of the transform that consumes them (software
-// pipeline of depth one: E more complex registers buy a second row of HBM requests in flight per wave)
+// the loads of an inverse row transform: coefficient k = j + cin(q) of row `row` into slot q, the Nyquist coefficient (lane
+// j == 0) into nyq.  Issued one array AHEAD of the transform that consumes them by the fused kernels (software pipeline of
+// depth one: E more complex registers buy a second row of HBM requests in flight per wave)
 template <int M, int E>
 __device__ __forceinline__ void z_issue_row(cplx (&v)[E], real& nyq, const ZLane<M, E>& z, const cplx* __restrict__ spec,
                                             const SpecGeom& g) {
-    const unsigned voff = z_spec_voff<M, E>(z, g);
-    static_for<E>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : mkc(0.0, 0.0);
-    });
-    nyq = (z.valid && z.j == 0) ? spec[g.main_count + z.row].x : 0.0;
+    using PL = typename ZW<M, E>::PL;
+    if constexpr (PL::EXACT) {
+        const unsigned voff = z_spec_voff<M, E>(z, g);
+        static_for<E>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            v[q] = z.valid ? buf_load_c_aux<OFDFT_ZS_LD_AUX>(spec + z_spec_ubase<M, E, q>(z, g), voff) : mkc(0.0, 0.0);
+        });
+    } else {
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            v[q] = (z.valid && PL::slot_in(q) && PL::lane_in(z.j, q)) ? spec[z_spec_off(g, z.row, z.j + PL::cin(q))] : mkc(0.0, 0.0);
+    }
+    nyq = (z.valid && z.j == 0) ? spec[z_spec_off(g, z.row, M)].x : 0.0;
 }
 
 // ---- row transforms that stay on chip (the spectrum lives in registers) -----------------------------------------
-// forward: real pairs in v -> v[q] = coefficient k = j + P q (k < M) of the row's half spectrum; nyq (lane j == 0) =
-// coefficient M (real)
+// forward: real pairs in v (entry pattern) -> v[q] = coefficient k = j + cout(q) (k < M) of the row's half spectrum; nyq
+// (lane j == 0) = coefficient M (real)
 template <int M, int E>
 __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                                const cplx* __restrict__ twN, real& nyq) {
     using W = ZW<M, E>;
-    constexpr int P = W::P;
+    using PL = typename W::PL;
     wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    for (int q = 0; q < E; ++q)
+        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].x;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
     c0r = z.mine[0];
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    for (int q = 0; q < E; ++q)
+        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].y;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const int k = z.j + P * q;
-        const real ci_m = z.mine[lpad((M - k) & (M - 1))];
+        if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;
+        const int k = z.j + PL::cout(q);
+        const real ci_m = z.mine[lpad(z_mirror<M>(k))];
         const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
         const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
         v[q] = cadd(ev, cmul(twN[k], od));
@@ -272,27 +285,31 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
 }
 
-// inverse of the above: v[q] = coefficient k = j + P q, nyq = coefficient M -> unscaled real pairs
+// inverse of the above: v[q] = coefficient k = j + cin(q), nyq = coefficient M -> unscaled real pairs (exit pattern);
+// imaginary parts of the kz = 0 / Nyquist coefficients are ignored, as irfftn does
 template <int M, int E>
 __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                                const cplx* __restrict__ twN, real nyq) {
     using W = ZW<M, E>;
-    constexpr int P = W::P;
+    using PL = typename W::PL;
     real xr_m[E];
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+    for (int q = 0; q < E; ++q)
+        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpad(z.j + PL::cin(q))] = v[q].x;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) xr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+    for (int q = 0; q < E; ++q) xr_m[q] = (PL::slot_in(q) && PL::lane_in(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cin(q)))] : (real)0.0;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+    for (int q = 0; q < E; ++q)
+        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpad(z.j + PL::cin(q))] = v[q].y;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const int k = z.j + P * q;
-        const real xi_m = z.mine[lpad((M - k) & (M - 1))];
+        if (!(PL::slot_in(q) && PL::lane_in(z.j, q))) continue;
+        const int k = z.j + PL::cin(q);
+        const real xi_m = z.mine[lpad(z_mirror<M>(k))];
         const cplx x = v[q];
         if (k == 0) {
             v[q] = mkc(x.x + nyq, x.x - nyq);
@@ -306,22 +323,42 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
     wave_line_fft<M, E, true>(v, z.j, z.mine, twM);
     exchange_sync<true>();
+    if constexpr (!PL::EXACT) {      // slots no butterfly of the last stage wrote: keep them out of every sum downstream
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) v[q] = mkc(0.0, 0.0);
+    }
+}
+
+// inverse: half-spectrum row of `spec` -> unscaled real pairs in v (imaginary parts of kz = 0 / Nyquist ignored)
+template <int M, int E>
+__device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ spec,
+                                               const SpecGeom& g, const cplx* __restrict__ twM,
+                                               const cplx* __restrict__ twN) {
+    // keep this row's loads below the previous array's work: hoisting the loads of ALL arrays to the kernel top
+    // (the compiler's default) costs 16 VGPRs per array and collapses the occupancy that hides their latency
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    real nyq;
+    z_issue_row<M, E>(v, nyq, z, spec, g);
+    z_inverse_regs<M, E>(v, z, twM, twN, nyq);
 }
 
 // index derivative along the row, D_c f = F^-1[i f_c F[f]] with the integer frequency f_c = k (rfftfreq,
-// functional_tools.py:155): real pairs in -> N2 x (derivative) out.  The k = 0 and Nyquist terms are purely imaginary
-// after the multiplication and drop out of the real inverse, as they do in the reference's irfftn.
+// functional_tools.py:155): real pairs in (entry pattern) -> N2 x (derivative) out (exit pattern).  The k = 0 and Nyquist
+// terms are purely imaginary after the multiplication and drop out of the real inverse, as they do in the reference's irfftn.
 template <int M, int E>
 __device__ __forceinline__ void z_deriv_row(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                             const cplx* __restrict__ twN) {
-    constexpr int P = ZW<M, E>::P;
+    using PL = typename ZW<M, E>::PL;
     real nyq;
     z_forward_regs<M, E>(v, z, twM, twN, nyq);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        const real k = (real)(z.j + P * q);
+        const real k = (real)(z.j + PL::cout(q));
         v[q] = mkc(-k * v[q].y, k * v[q].x);
     }
+    repattern_out_to_in<PL, true>(v, z.j, z.mine);
     z_inverse_regs<M, E>(v, z, twM, twN, 0.0);
 }
 
@@ -351,9 +388,39 @@ struct DenSrc {
 };
 
 // ------------------------------------------------------------------------------------------------
+// plain z passes in the wave-local form (rows whose half length has factors 3 / 5; the power-of-two rows use
+// zfwd_kernel / zinv_kernel of fft_kernels.h): real rows -> half spectrum, half spectrum -> real rows times `scale`
+template <int M, int E>
+__global__ __launch_bounds__(256) void zfwd_w_kernel(const real* __restrict__ in, cplx* __restrict__ spec, SpecGeom g,
+                                                     const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
+    const ZLane<M, E> z(g, lds);
+    cplx v[E];
+    z_load_real<M, E>(v, z, in);
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
+    z_forward_store<M, E>(v, z, spec, g, twM, twN);
+}
+template <int M, int E>
+__global__ __launch_bounds__(256) void zinv_w_kernel(const cplx* __restrict__ spec, real* __restrict__ out, SpecGeom g,
+                                                     const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g, real scale) {
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    const cplx *twM, *twN;
+    const ZTwReq<M, E> twq = z_tw_request<M, E>(twM_g, twN_g);
+    const ZLane<M, E> z(g, lds);
+    cplx v[E];
+    z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
+    z_load_inverse<M, E>(v, z, spec, g, twM, twN);
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = mkc(v[q].x * scale, v[q].y * scale);
+    z_store_real<M, E>(v, z, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // chi|n -> n^ and (sqrt n)^      (functionals.py:65 rfftn(den); :245 laplacian(k2, sqrt_den))
 template <int M, int E>
-__global__ __launch_bounds__(256, 3) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
+__global__ __launch_bounds__(256, (ZW<M, E>::PL::EXACT ? 3 : 2)) void zf_density_kernel(DenSrc ds, cplx* __restrict__ out_n, cplx* __restrict__ out_s,
                                                          SpecGeom g, const cplx* __restrict__ twM_g,
                                                          const cplx* __restrict__ twN_g, real* __restrict__ dzn = nullptr) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
@@ -397,7 +464,7 @@ struct PowersArgs {
     int sum53;       // e0 + e1 == 5/3: n^e1 = n^(5/3) / n^e0
 };
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
+__global__ __launch_bounds__(256, (z_waves<M, E>(3))) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
                                                         const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
@@ -450,7 +517,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 2 : 3)) void zf_powers_kernel(DenS
 // flux_j = df/d|grad n|^2 * d_j n -> spectra again, in place.  (functionals.py:1597-1618;
 // tests/tools_for_tests.py:155-207)
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
+__global__ __launch_bounds__(256, (z_waves<M, E>(OFDFT_ZPBE_WAVES))) void zpbe_kernel(DenSrc ds, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                                    cplx* __restrict__ gz, real* __restrict__ dfdn, real inv_n,
                                                    GgaSel sel, SpecGeom g, const cplx* __restrict__ twM_g,
                                                    const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
@@ -464,7 +531,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
     z_load_inverse<M, E>(a, z, gx, g, twM, twN);
     z_load_inverse<M, E>(b, z, gy, g, twM, twN);
     z_load_inverse<M, E>(c, z, gz, g, twM, twN);
-    z_load_real<M, E>(n, z, ds.src);
+    z_load_real<M, E, true>(n, z, ds.src);
     acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
 #pragma unroll
@@ -473,7 +540,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
         const real ax = a[q].x * inv_n, bx = b[q].x * inv_n, cx = c[q].x * inv_n;
         const real ay = a[q].y * inv_n, by = b[q].y * inv_n, cy = c[q].y * inv_n;
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
-        if (z.valid) {
+        if (z.valid && ZW<M, E>::PL::slot_out(q) && ZW<M, E>::PL::lane_out(z.j, q)) {
             p0 = pbe_point(ds(n[q].x), ax * ax + bx * bx + cx * cx, sel);
             p1 = pbe_point(ds(n[q].y), ay * ay + by * by + cy * cy, sel);
         }
@@ -486,8 +553,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZPBE_WAVES)) void zpbe_k
         c[q] = mkc(p0.dfdg * cx, p1.dfdg * cy);
     }
     z_store_real<M, E>(d, z, dfdn);
+    using PL = typename ZW<M, E>::PL;      // (rows with factors 3 / 5: results of an inverse sit in the exit pattern)
+    repattern_out_to_in<PL, true>(a, z.j, z.mine);
     z_forward_store<M, E>(a, z, gx, g, twM, twN);
+    repattern_out_to_in<PL, true>(b, z.j, z.mine);
     z_forward_store<M, E>(b, z, gy, g, twM, twN);
+    repattern_out_to_in<PL, true>(c, z.j, z.mine);
     z_forward_store<M, E>(c, z, gz, g, twM, twN);
     block_reduce_store<kPbeScalars>(acc, partial + (long long)g.blk0 * kPbeScalars);
 }
@@ -501,7 +572,7 @@ struct Bmat { real b[9]; };
 // (lap n)^ = -k^2 n^ (x and y already back in real space); on exit the rows of the spectrum of df/d(lap n), whose
 // Laplacian joins the divergence in the next x pass (MixDerivAL).
 template <int M, int E, bool LAPL>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
+__global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
                                                                       const real* __restrict__ dzn,
                                                                       real* __restrict__ dfdn, real inv_n, real inv_nz,
                                                                       GgaSel sel, Bmat bm, SpecGeom g,
@@ -537,8 +608,8 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
     z_load_inverse<M, E>(b, z, B, g, twM, twN);
     if constexpr (LAPL) z_load_inverse<M, E>(lp, z, Lsp, g, twM, twN);
 #endif
-    z_load_real<M, E>(c, z, dzn);
-    z_load_real<M, E>(n, z, ds.src);
+    z_load_real<M, E, true>(c, z, dzn);
+    z_load_real<M, E, true>(n, z, ds.src);
     acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
 #pragma unroll
@@ -553,7 +624,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
         if constexpr (LAPL) {
             real dl0 = 0.0, dl1 = 0.0;
-            if (z.valid) {
+            if (z.valid && ZW<M, E>::PL::slot_out(q) && ZW<M, E>::PL::lane_out(z.j, q)) {
                 GgaSel nk = sel;
                 nk.k = 0;          // PBE parts (if any) by pbe_point, the kinetic part with its q dependence below
                 const real g20 = gx0 * gx0 + gy0 * gy0 + gz0 * gz0, g21 = gx1 * gx1 + gy1 * gy1 + gz1 * gz1;
@@ -563,7 +634,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
                 pg_laplacian_point(ds(n[q].y), g21, lp[q].y * inv_n, sel, p1, dl1);
             }
             lp[q] = mkc(dl0, dl1);
-        } else if (z.valid) {
+        } else if (z.valid && ZW<M, E>::PL::slot_out(q) && ZW<M, E>::PL::lane_out(z.j, q)) {
             p0 = pbe_point(ds(n[q].x), gx0 * gx0 + gy0 * gy0 + gz0 * gz0, sel);
             p1 = pbe_point(ds(n[q].y), gx1 * gx1 + gy1 * gy1 + gz1 * gz1, sel);
         }
@@ -579,9 +650,16 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zpbe2_kernel(DenSrc d
         c[q] = mkc(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
                             p1.dfdg * (bm.b[6] * gx1 + bm.b[7] * gy1 + bm.b[8] * gz1));
     }
+    using PL = typename ZW<M, E>::PL;      // (rows with factors 3 / 5: pointwise results sit in the exit pattern of the inverses)
+    repattern_out_to_in<PL, true>(a, z.j, z.mine);
     z_forward_store<M, E>(a, z, A, g, twM, twN);
+    repattern_out_to_in<PL, true>(b, z.j, z.mine);
     z_forward_store<M, E>(b, z, B, g, twM, twN);
-    if constexpr (LAPL) z_forward_store<M, E>(lp, z, Lsp, g, twM, twN);
+    if constexpr (LAPL) {
+        repattern_out_to_in<PL, true>(lp, z.j, z.mine);
+        z_forward_store<M, E>(lp, z, Lsp, g, twM, twN);
+    }
+    repattern_out_to_in<PL, true>(c, z.j, z.mine);
     z_deriv_row<M, E>(c, z, twM, twN);               // N2 x D_c G_c
 #pragma unroll
     for (int q = 0; q < E; ++q) d[q] = mkc(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);
@@ -693,7 +771,7 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
 }
 
 template <int M, int E, bool WGC_INLINE>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM_g,
+__global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM_g,
                                                          const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
@@ -708,11 +786,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 #pragma unroll
     for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];
-    z_load_real<M, E>(n, z, a.ds.src);
+    z_load_real<M, E, true>(n, z, a.ds.src);
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
+    using PL = typename ZW<M, E>::PL;
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
+        n[q] = (z.valid && PL::slot_out(q) && PL::lane_out(z.j, q)) ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
         vacc[q] = mkc(0.0, 0.0);
     }
     const real sc = a.inv_n;
@@ -806,7 +885,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
         if (WGC_INLINE) {
             park[5 * 256] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, sc, ctf);
         } else {                                         // computed by zi_wgc_kernel on the nonlocal chain's stream
-            z_load_real<M, E>(w, z, a.v_part);
+            z_load_real<M, E, true>(w, z, a.v_part);
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 vacc[q].x += w[q].x;
@@ -817,7 +896,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     if (a.mask & (7u << 10)) {                           // PBE / GGA kinetic: v += df/dn - 2 div  (tools_for_tests.py:168-170)
         take_row(std::integral_constant<int, 4>{}, a.div);
         cplx d[E];
-        z_load_real<M, E>(d, z, a.dfdn);
+        z_load_real<M, E, true>(d, z, a.dfdn);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             vacc[q].x += d[q].x - 2.0 * w[q].x * sc;
@@ -835,7 +914,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
     // ---- local terms and the sum of v n
     if (a.mask & 1u) {
         cplx ve[E];
-        z_load_real<M, E>(ve, z, a.vext);
+        z_load_real<M, E, true>(ve, z, a.vext);
         real e = 0.0;
 #pragma unroll
         for (int q = 0; q < E; ++q) {
@@ -851,6 +930,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
+        if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;      // (rows with factors 3 / 5: slots without a grid point)
         if (a.mask & 4u) {                               // TF  functionals.py:223
             const real c0 = fm::roots(n[q].x).n13, c1 = fm::roots(n[q].y).n13;
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
@@ -890,7 +970,7 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : 2)) void zi_combine_kernel(ZCo
 // The WGC99 part of the combine on its own (split form): chi|n row + the six result spectra -> v_part rows and the
 // energy partial sums (one per workgroup).  Runs on the nonlocal chain's stream while the other chain still works.
 template <int M, int E>
-__global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wgc_kernel(ZCombineArgs a, real* __restrict__ v_part, SpecGeom g,
+__global__ __launch_bounds__(256, (z_waves<M, E>(OFDFT_ZIWGC_WAVES))) void zi_wgc_kernel(ZCombineArgs a, real* __restrict__ v_part, SpecGeom g,
                                                        const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g,
                                                        acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
@@ -900,11 +980,12 @@ __global__ __launch_bounds__(256, (M >= 512 ? 1 : OFDFT_ZIWGC_WAVES)) void zi_wg
     const ZLane<M, E> z(g, lds);
     const real ctf = kCtf;
     cplx n[E], vacc[E], w[E];
-    z_load_real<M, E>(n, z, a.ds.src);
+    z_load_real<M, E, true>(n, z, a.ds.src);
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
+    using PL = typename ZW<M, E>::PL;
 #pragma unroll
     for (int q = 0; q < E; ++q) {
-        n[q] = z.valid ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
+        n[q] = (z.valid && PL::slot_out(q) && PL::lane_out(z.j, q)) ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
         vacc[q] = mkc(0.0, 0.0);
     }
     acc_t acc[1];

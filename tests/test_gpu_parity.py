@@ -39,7 +39,11 @@ def load(name):
 # ------------------------------------------------------------------------------- FFT building block
 FFT_SHAPES = [(8, 8, 16), (16, 16, 16), (16, 32, 64), (64, 64, 64), (32, 16, 128), (8, 128, 32), (256, 8, 32),
               (128, 128, 128), (512, 8, 16), (8, 1024, 16), (8, 8, 1024), (8, 8, 2048),
-              (17, 17, 17), (18, 20, 16), (5, 6, 7), (20, 20, 20), (9, 8, 12)]
+              (17, 17, 17), (18, 20, 16), (5, 6, 7), (20, 20, 20), (9, 8, 12),
+              # extents with factors 3 and 5 served by mixed-radix plans (fft_radix.h), every x / y / z plan at least once
+              (48, 96, 120), (120, 48, 96), (144, 160, 48), (96, 144, 160), (192, 240, 250), (250, 192, 240), (240, 250, 192),
+              (270, 288, 144), (288, 270, 320), (320, 48, 270), (384, 48, 288), (48, 384, 384), (480, 96, 320), (96, 480, 480),
+              (64, 240, 48), (250, 16, 270)]
 
 
 @pytest.mark.parametrize('shape', FFT_SHAPES)
@@ -55,7 +59,8 @@ def test_rfftn_irfftn_match_numpy(shape):
     got_r = eng.irfftn(torch.as_tensor(yk, device=DEV)).cpu().numpy()
     ref_r = np.fft.irfftn(yk, s=shape, axes=(0, 1, 2))
     assert relerr(got_r, ref_r) < 1e-13
-    assert eng.fast_path == all((s & (s - 1)) == 0 for s in shape)
+    mixed = (48, 96, 120, 144, 160, 192, 240, 250, 270, 288, 320, 384, 480)          # extents with a mixed-radix plan
+    assert eng.fast_path == all((s & (s - 1)) == 0 or s in mixed for s in shape)
     eng.close()
 
 
@@ -911,3 +916,61 @@ def test_stabilised_wang_teter_style_functional_in_one_engine_call(case):
         tol = 1e-8 if f is f_custom else 1.0
         assert abs(E - Eref) <= max(E_RTOL, 1e-9 if f is f_custom else 0) * abs(Eref) * (10 if f is f_custom else 1)
         assert relerr(v, vref) < (1e-8 if f is f_custom else V_RTOL), tol
+
+
+@pytest.mark.parametrize('shape', [(48, 96, 120), (96, 120, 48), (144, 160, 192), (240, 250, 270), (270, 240, 250), (250, 270, 240),
+                                   (288, 48, 320), (320, 384, 96), (480, 96, 144), (96, 48, 480), (64, 240, 256), (256, 128, 250)])
+def test_mixed_radix_extents_run_the_fused_pipelines(shape):
+    """grids whose extents have factors 3 and 5 (the reference's ecut2shape never returns a power of two): the
+    mixed-radix line transforms put them on the z-fused pipeline.  Checked against the chirp-z + unfused path (option 9 off:
+    independent transforms AND independent pipeline), with the x-fused-only and unfused pipelines on the same
+    transforms in between, energy_potential and closure forms, configs 1-3 + the q-dependent Pauli-Gaussian."""
+    box = cases.make_cell(('tri', shape[0] / 24.0))
+    den = synth.random_density(shape, seed=71)
+    vext = synth.random_potential(shape, seed=72)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(73).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
+    eng = Engine(shape, DEV).set_cell(dev(box))
+    assert eng.fast_path
+    sets = [(F.NativeTerms(names).names, None) for names in _CFG_TERMS.values()]
+    sets.append((('hartree', 'vw', 'gga_k', 'pbe_x', 'pbe_c'), {'ggak_kind': 1.0, 'ggak_beta': 0.25, 'ggak_lambda': 0.4, 'ggak_sigma': 0.2}))
+    for names, params in sets:
+        eng.set_terms(names, params)
+        res = {}
+        for key, (mixed, mode) in {'ref': (0, 0), 'zf': (1, 0), 'xf': (1, 2), 'un': (1, 1)}.items():
+            eng.set_option(9, mixed).set_option(0, mode)
+            assert eng.fast_path == bool(mixed)
+            E, v = eng.energy_potential(dev(den), dev(vext))
+            Ec, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+            res[key] = (E, v.cpu().numpy(), Ec, mu, g.cpu().numpy(), int(eng.query(4)))
+        ref = res['ref']
+        for key in ('zf', 'xf', 'un'):
+            r = res[key]
+            for k in ref[0]:
+                assert abs(r[0][k] - ref[0][k]) <= 1e-11 * max(1.0, abs(ref[0][k])), (names, key, k, r[0][k], ref[0][k])
+                assert abs(r[2][k] - ref[2][k]) <= 1e-11 * max(1.0, abs(ref[2][k])), (names, key, k)
+            assert relerr(r[1], ref[1]) < 1e-10, (names, key, relerr(r[1], ref[1]))
+            assert relerr(r[4], ref[4]) < 1e-10, (names, key)
+            assert abs(r[3] - ref[3]) < 1e-11 * max(1.0, abs(ref[3]))
+        assert res['zf'][5] < res['un'][5]               # the fused pipeline really ran (fewer launches)
+    eng.set_option(9, 1).set_option(0, 0)
+    eng.close()
+
+
+def test_mixed_radix_grid_matches_the_oracle():
+    """config 3 on a 48 x 96 x 120 triclinic grid against the pinned CPU oracle (closed forms on numpy FFTs)"""
+    shape = (48, 96, 120)
+    box = cases.make_cell(('tri', 2.0))
+    den = synth.random_density(shape, seed=81)
+    vext = synth.random_potential(shape, seed=82)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(83).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
+    ev = cf.Evaluator(cf.Grid(box, shape))
+    Eo, go, muo = ev.closure(['ion_electron', 'hartree', 'wgc99', 'pbe_x', 'pbe_c'], chi, n_elec, vext)
+    eng = Engine(shape, DEV).set_cell(dev(box)).set_terms(F.NativeTerms(_CFG_TERMS['cfg3']).names)
+    assert eng.fast_path
+    E, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+    assert abs(sum(E.values()) - Eo) <= E_RTOL * abs(Eo)
+    assert abs(mu - muo) <= 1e-9 * max(1.0, abs(muo))
+    assert relerr(g.cpu().numpy(), go) < V_RTOL
+    eng.close()
