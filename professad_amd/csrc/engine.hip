@@ -1,139 +1,16 @@
 // C-ABI implementation of the OFDFT energy/gradient engine (include/ofdft_hip.h).  gfx950 only.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/ofdft_hip.h"
-#include "bluestein.h"
+// Core translation unit: context, workspaces, pipelines, entry points (engine_ctx.h lists the other sources).
+#include "engine_ctx.h"
 #ifndef OFDFT_REAL_F32
 #include "ion_kernels.h"
 #include "stress_kernels.h"
 #endif
-#include "zpass.h"
-#include "xwave.h"
-
-using namespace ofdft;
 
 namespace {
-
 thread_local char g_create_error[512] = "";
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
 }  // namespace
 
-struct ofdft_ctx {
-    int n0 = 0, n1 = 0, n2 = 0, device = 0;     // LOCAL real-space extents (x-slab: n0 = n0g / nranks)
-    int n0g = 0, n1g = 0, nranks = 1, rank = 0; // global extents and slab decomposition
-    SpecGeom g{};      // spectrum geometry of the z and y passes (x-slab: n0 local, n1 global)
-    SpecGeom gx{};     // spectrum geometry of the x pass (y-slab: n0 global, n1 local); == g on one GPU
-    KGeom kg{};        // k-vectors in the x-pass geometry
-    XchgGeom xg{};     // exchange-buffer layout of the slab-decomposed path (rec / chunk filled per stage)
-    long long npts = 0;      // local points
-    long long npts_g = 0;    // global points (normalisation, dV)
-    bool fast = false, cell_set = false, force_unfused = false;
-    int pipeline = 0;   // 0 = z-fused (default on power-of-two grids), 1 = unfused, 2 = x-fused only
-    double box[9] = {0}, vol = 0.0, dV = 0.0;
-    unsigned mask = 0;
-    double params[OFDFT_NPARAMS];
-    // twiddle tables by length
-    std::map<int, cplx*> tw;
-    // named workspaces
-    std::map<std::string, DevBuf> ws;
-    size_t ws_bytes = 0;
-    // reduction partials (device) + pinned host mirror
-    double* d_partial = nullptr;
-    double* d_reduced = nullptr;     // second-level sums [kMaxScalars]
-    double* d_scal = nullptr;        // device-resident scalars: [0] = closure scale c
-    double* h_partial = nullptr;
-    long long partial_rows = 0;
-    // WGC tables
-    double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
-    long long wgc_key_nel = -1;
-    bool wgc_valid = false;
-    // stats
-    int fft_count = 0, launch_count = 0;
-    double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
-    float last_ms = 0.f;
-    bool ms_pending = false;    // ev1 recorded without a host wait (device-resident dist finish): elapsed time read on demand
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
-    hipStream_t side_stream = nullptr, side_stream2 = nullptr;
-    bool use_side_stream = true;
-    bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
-    bool gga_split = true;       // GGA chain in split-derivative form: only the x index-derivative visits the x pass
-    bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
-    int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
-    int use_xwave = 1;   // fused x pass: 1 = wave-local kernel (xwave.h) where it measured faster (passes over >= 3 spectra, x extents <= 512), 2 = wherever it exists, 0 = group-parallel kernel only
-    int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
-    // optional per-kernel-class profiling (HIP events around every launch)
-    bool profiling = false;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    struct Pending { const char* name; size_t a, b; };
-    std::vector<Pending> pending;
-    struct Acc { double ms = 0.0; long long launches = 0; };
-    std::map<std::string, Acc> prof;
-    struct ofdft_zrun_holder* zr = nullptr;
-    // hipGraph replay of the closure evaluation (ofdft_energy_grad_chi): one entry per argument set
-    struct GraphEntry {
-        const void *chi = nullptr, *vext = nullptr, *grad = nullptr;
-        double nel = 0.0;
-        unsigned long long version = 0;      // configuration the graph was captured under
-        int seen = 0;                        // calls with these arguments so far (the first one runs uncaptured: it allocates)
-        hipGraphExec_t exec = nullptr;
-        bool wgc_split = false;
-        int fft_count = 0, launch_count = 0;
-        double ypass_count = 0.0;
-    };
-    std::vector<GraphEntry> graphs;
-    unsigned long long version = 1;          // bumped by set_cell / set_terms / set_option
-    bool use_graph = true;
-    long long graph_replays = 0;
-    hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
-    // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
-    ofdft_all_to_all_fn a2a = nullptr;
-    ofdft_all_reduce_fn allreduce = nullptr;
-    void* coll_user = nullptr;
-    char err[512] = "";
-};
-
-namespace {
-
-constexpr unsigned kGgaAny = OFDFT_PBE_X | OFDFT_PBE_C | OFDFT_GGA_K;   // terms served by the gradient / divergence machinery
-constexpr int kNSums = kCombineScalars + kPbeScalars;                  // local sums of an evaluation (12)
-constexpr int kSumsqSlot = 15;                                         // d_reduced slot of sum chi^2 (closure form)
-
-GgaSel gga_sel(const ofdft_ctx* c) {
-    return GgaSel{(c->mask & OFDFT_PBE_X) ? 1 : 0, (c->mask & OFDFT_PBE_C) ? 1 : 0, (c->mask & OFDFT_GGA_K) ? 1 : 0,
-                  (int)c->params[OFDFT_P_GGAK_KIND], (real)c->params[OFDFT_P_GGAK_MU], (real)c->params[OFDFT_P_GGAK_BETA],
-                  (real)c->params[OFDFT_P_GGAK_LAMBDA], (real)c->params[OFDFT_P_GGAK_SIGMA]};
-}
-
-// Pauli-Gaussian member with Laplacian-dependent terms (PGSL0.25 -- the reference's default --, PGSLr): one more spectrum
-// each way in the split-derivative GGA chain of the z-fused pipeline (lap n in, lap(df/dL) out); the x-fused-only and
-// the unsplit forms fall back to the unfused pipeline
-bool gga_needs_laplacian(const ofdft_ctx* c) {
-    return (c->mask & OFDFT_GGA_K) && (int)c->params[OFDFT_P_GGAK_KIND] == 1 &&
-           (c->params[OFDFT_P_GGAK_BETA] != 0.0 || c->params[OFDFT_P_GGAK_LAMBDA] != 0.0 || c->params[OFDFT_P_GGAK_SIGMA] != 0.0);
-}
-// Pauli-positivity stabilised Wang-Teter style functional (functionals.py:728-782) with f = exp: two combine passes (energies
-// first, then the potential with the weights f - f' X, f' they determine)
-bool wts_active(const ofdft_ctx* c) {
-    return (int)c->params[OFDFT_P_WTS_KIND] == 1 && (c->mask & OFDFT_TF) && (c->mask & OFDFT_WT_NL);
-}
-bool zfused_serves(const ofdft_ctx* c) {
-    return c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && (!gga_needs_laplacian(c) || c->gga_split);
-}
+namespace eng {
 
 int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
     va_list ap;
@@ -141,68 +18,6 @@ int fail(ofdft_ctx* c, int code, const char* fmt, ...) {
     vsnprintf(c ? c->err : g_create_error, 512, fmt, ap);
     va_end(ap);
     return code;
-}
-
-#define HIP_TRY(ctx, call)                                                                         \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(ctx, OFDFT_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-
-// run the rest of the enclosing ABI function on the context's device, restoring the caller's device on return
-#define OFDFT_ON_DEVICE(ctx, dev)                                                                   \
-    DeviceScope device_scope_(dev);                                                                 \
-    if (device_scope_.err != hipSuccess)                                                            \
-        return fail(ctx, OFDFT_EHIP, "cannot select device %d: %s", (dev), hipGetErrorString(device_scope_.err))
-
-struct ProfRec { const char* name; hipEvent_t a, b; };
-
-void graph_drop(ofdft_ctx* c);
-// hipGraph replay serves the launch-bound regime only (single-GPU contexts up to 2^19 points, e.g. 64 x 64 x 128; above
-// that launches are hidden behind the kernels and the measured gain is nil).  There the WGC99 part of the combine stays inside the combine kernel: the forked + split stream topology
-// crashes this ROCm's stream capture, and fewer launches is the better trade on small grids anyway.
-bool graph_eligible(const ofdft_ctx* c) { return c->use_graph && c->nranks == 1 && c->npts <= (1LL << 19); }
-void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name);
-void prof_end(ofdft_ctx* c, hipStream_t st);
-
-#define OFDFT_LAUNCH(c, st, name, kern, grid, block, lds, ...)            \
-    do {                                                                  \
-        prof_begin(c, st, name);                                          \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);      \
-        prof_end(c, st);                                                  \
-        (c)->launch_count++;                                              \
-    } while (0)
-
-bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-
-// Extents served by the register / LDS line transforms (fft_radix.h plans) -- and with them by the fused pipelines:
-// powers of two, and the 2^a 3^b 5^c extents listed here (any other extent: chirp-z line transforms + the unfused pipeline).
-// OFDFT_MIXED_LINES: x / y extents; OFDFT_MIXED_ROWS: the half lengths n2 / 2 of the z rows for the same extents.
-// (the fp32 build keeps the powers of two only: its other extents take the chirp-z path)
-#ifndef OFDFT_REAL_F32
-#define OFDFT_MIXED_LINES(X) X(48) X(96) X(120) X(144) X(160) X(192) X(240) X(250) X(270) X(288) X(320) X(384) X(480)
-#define OFDFT_MIXED_ROWS(X) X(24) X(48) X(60) X(72) X(80) X(96) X(120) X(125) X(135) X(144) X(160) X(192) X(240)
-#else
-#define OFDFT_MIXED_LINES(X)
-#define OFDFT_MIXED_ROWS(X)
-#endif
-bool mixed_line(int n) {
-#define X(L) if (n == L) return true;
-    OFDFT_MIXED_LINES(X)
-#undef X
-    return false;
-}
-bool line_extent_ok(int n) { return (is_pow2(n) && n >= 8 && n <= 1024) || mixed_line(n); }
-bool row_extent_ok(int n2) { return (is_pow2(n2) && n2 >= 16 && n2 <= 2048) || mixed_line(n2); }
-bool all_pow2(const ofdft_ctx* c) { return is_pow2(c->n0g) && is_pow2(c->n1g) && is_pow2(c->n2); }
-
-int grid_for(long long n, int tpb = 256, int cap = 2048) {
-    long long b = (n + tpb - 1) / tpb;
-    if (b > cap) b = cap;
-    if (b < 1) b = 1;
-    return (int)b;
 }
 
 int get_twiddle(ofdft_ctx* c, int n, cplx** out) {
@@ -293,299 +108,30 @@ void prof_collect(ofdft_ctx* c) {
     c->ev_used = 0;
 }
 
-// ---------------------------------------------------------------------------------- FFT drivers
-template <int LEN, bool INV>
-int launch_cpass_t(ofdft_ctx* c, const ArrList& arrs, int narr, const LineMap& main, const LineMap& rem, hipStream_t st,
-                   const char* nm) {
-    cplx* tw;
-    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
-    using Cfg = PassCfg<LEN>;
-    LineMap mm = main;
-    mm.blk0 = main.blk0 / Cfg::LPW;                     // line offset -> workgroup offset
-    const int mb = (main.nlines - main.blk0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, mm, rem, mb,
-                 c->g.main_count, tw);
-    return 0;
-}
 
-// line maps of the block-8 layout (see fft_kernels.h)
-void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
-    const SpecGeom& g = axis == 0 ? c->gx : c->g;
-    const int nb = g.nzm / 8, nrem = g.nzc - g.nzm;
-    if (axis == 0) {   // x lines: base = b*n0*n1*8 + (y*8+kin), stride n1*8
-        main.d = g.n1 * 8; main.sb = (long long)g.n0 * g.n1 * 8; main.sl = 1; main.se = (long long)g.n1 * 8;
-        main.nlines = nb * g.n1 * 8; main.lf = 0;  // lf filled by caller (LPW)
-        rem.d = g.n1; rem.sb = (long long)g.n0 * g.n1; rem.sl = 1; rem.se = g.n1; rem.nlines = nrem * g.n1; rem.lf = 0;
-    } else {           // y lines: base = (b*n0+x)*n1*8 + kin, stride 8
-        main.d = 8; main.sb = (long long)g.n1 * 8; main.sl = 1; main.se = 8; main.nlines = nb * g.n0 * 8; main.lf = 8;
-        rem.d = 1; rem.sb = g.n1; rem.sl = 0; rem.se = 1; rem.nlines = nrem * g.n0; rem.lf = 1;
-    }
-    if (main.nlines == 0) { main.d = 1; main.lf = 1; }
-    if (rem.nlines == 0) { rem.d = 1; rem.lf = 1; }
-}
-
-// line pass over `narr` spectra in ONE launch; cx > 0 restricts a y pass to the x planes [x0, x0 + cx)
-// kb1 > kb0 restricts a y pass to the kz blocks [kb0, kb1) (the remainder planes ride with the last range)
-template <bool INV>
-int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0,
-                         int kb0 = 0, int kb1 = 0) {
-    LineMap main, rem;
-    pass_maps(c, axis, main, rem);
-    if (kb1 > kb0 && axis == 1) {
-        const int per_block = c->g.n0 * 8;              // lines per kz block
-        main.blk0 = kb0 * per_block;                    // converted to workgroups below
-        main.nlines = kb1 * per_block;
-        if (kb1 != c->g.nzm / 8) rem.nlines = 0;
-    }
-    if (cx > 0 && axis == 1) {
-        main.gc = rem.gc = cx;
-        main.gn = rem.gn = c->g.n0;
-        main.g0 = rem.g0 = x0;
-        main.nlines = (c->g.nzm / 8) * cx * 8;
-        rem.nlines = (c->g.nzc - c->g.nzm) * cx;
-    }
-    ArrList arrs{};
-    for (int a = 0; a < narr; ++a) arrs.p[a] = specs[a];
-    if (axis == 1) {
-        double frac = 1.0;
-        if (cx > 0) frac *= (double)cx / c->g.n0;
-        if (kb1 > kb0) frac *= (double)(kb1 - kb0) * 8.0 / c->g.nzc;
-        c->ypass_count += narr * frac;
-    }
-    const int len = axis == 0 ? c->n0g : c->n1;
-    const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
-#define OFDFT_CASE(L)                                                   \
-    case L:                                                             \
-        if (axis == 0) main.lf = rem.lf = PassCfg<L>::LPW;              \
-        return launch_cpass_t<L, INV>(c, arrs, narr, main, rem, st, nm);
-    switch (len) {
-        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
-        OFDFT_CASE(1024)
-        OFDFT_MIXED_LINES(OFDFT_CASE)
-    }
-#undef OFDFT_CASE
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
-}
-
-template <bool INV>
-int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
-    return fast_axis_pass_multi<INV>(c, axis, &spec, 1, st);
-}
-// y pass of `narr` x-slab spectra straight into (forward) / out of (inverse) an all-to-all buffer
-template <int LEN, bool INV>
-int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st) {
-    cplx* tw;
-    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
-    using Cfg = PassCfg<LEN>;
-    LineMap main, rem;
-    pass_maps(c, 1, main, rem);
-    XchgGeom xg = c->xg;
-    xg.rec = narr * xg.arr_sz;
-    xg.chunk = xg.nxl * xg.rec;
-    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, INV ? "ypass_recv" : "ypass_send", (ypass_xchg_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB),
-                 Cfg::LDS, arrs, buf, xg, main, rem, mb, c->g.main_count, tw);
-    return 0;
-}
-template <bool INV>
-int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st) {
-    const int narr = (int)list.size();
-    if (narr == 0) return 0;
-    if (narr > 16) return fail(c, OFDFT_EINVAL, "too many spectra in one exchange (%d)", narr);
-    ArrList arrs{};
-    for (int a = 0; a < narr; ++a) arrs.p[a] = list[a];
-    c->ypass_count += narr;
-#define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st);
-    switch (c->n1) {
-        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
-        OFDFT_CASE(1024)
-    }
-#undef OFDFT_CASE
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
-}
-
-template <int M>
-int launch_zfwd_t(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
-    cplx *twM, *twN;
-    if (int rc = get_twiddle(c, M, &twM)) return rc;
-    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
-    if constexpr ((M & (M - 1)) == 0) {
-        using Cfg = ZCfg<M>;
-        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
-        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_kernel<M, PreIdentity>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, in, spec, c->g, twM,
-                           twN, PreIdentity());
-    } else {          // rows with factors 3 / 5: the wave-local z pass (zpass.h)
-        using W = ZW<M, ZPick<M, 8>::E>;
-        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
-        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, in, spec, c->g, (const cplx*)twM,
-                     (const cplx*)twN);
-    }
-    return 0;
-}
-template <int M>
-int launch_zinv_t(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
-    cplx *twM, *twN;
-    if (int rc = get_twiddle(c, M, &twM)) return rc;
-    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
-    if constexpr ((M & (M - 1)) == 0) {
-        using Cfg = ZCfg<M>;
-        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
-        PostScale post{(real)scale};
-        OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
-                           twN, post);
+// sized by what the active terms send at most across one geometry boundary (the buffers only ever grow): chain 0 carries
+// {n^, (sqrt n)^} -> {vH, D_a n | grad n (3), lap} -> flux (1 | 3) -> divergence (1); chain 1 the Wang-Teter powers (1-2) and / or
+// the six WGC99 spectra
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
+    const unsigned m = c->mask;
+    const bool g = m & kGgaAny, h = m & OFDFT_HARTREE, vw = m & OFDFT_VW;
+    const int ng = g ? (c->gga_split ? 1 : 3) : 0;
+    const int nl = (gga_needs_laplacian(c) && c->gga_split) ? 1 : 0;      // lap n back, df/dL forth
+    int narr;
+    if (chain == 0) {
+        narr = std::max(((h || g) ? 1 : 0) + (vw ? 1 : 0), (h ? 1 : 0) + ng + nl + (vw ? 1 : 0));
+        narr = std::max(narr, ng + nl);
     } else {
-        using W = ZW<M, ZPick<M, 8>::E>;
-        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
-        OFDFT_LAUNCH(c, st, "zinv", (zinv_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, spec, out, c->g, (const cplx*)twM,
-                     (const cplx*)twN, (real)scale);
+        narr = ((m & OFDFT_WT_NL) ? (c->params[OFDFT_P_WT_ALPHA] != c->params[OFDFT_P_WT_BETA] ? 2 : 1) : 0) +
+               ((m & OFDFT_WGC99_NL) ? 6 : 0);
     }
-    return 0;
-}
-// dispatch on the half length of the z rows
-int zfwd_any(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
-#define X(M_) case M_: return launch_zfwd_t<M_>(c, in, spec, st);
-    switch (c->n2 / 2) {
-        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
-        OFDFT_MIXED_ROWS(X)
-    }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-int zinv_any(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
-#define X(M_) case M_: return launch_zinv_t<M_>(c, spec, out, scale, st);
-    switch (c->n2 / 2) {
-        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
-        OFDFT_MIXED_ROWS(X)
-    }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
+    if (narr < 1) narr = 1;
+    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
+    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
+    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
 }
 
-int gen_axis(ofdft_ctx* c, int axis, int inv, cplx*& cur, cplx*& other, hipStream_t st) {
-    cplx* tw;
-    if (int rc = get_twiddle(c, axis == 0 ? c->n0 : c->n1, &tw)) return rc;
-    OFDFT_LAUNCH(c, st, "gen_c2c", gen_c2c_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, cur, other, c->g,
-                       axis, inv, tw);
-    std::swap(cur, other);
-    return 0;
-}
 
-// ---- Bluestein tables (bluestein.h): chirp w_n = exp(-i pi n^2 / N) and the filter spectrum FFT_M(conj w, wrapped) / M
-struct BsTables { cplx *chirp = nullptr, *filt = nullptr; int M = 0; };
-
-int bluestein_pad(int N) {
-    int M = 8;
-    while (M < 2 * N - 1) M *= 2;
-    return M;
-}
-
-int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
-    const std::string key = "bs:" + std::to_string(N);
-    const int M = bluestein_pad(N);
-    out->M = M;
-    auto it = c->ws.find(key);
-    if (it != c->ws.end()) {
-        out->chirp = (cplx*)it->second.p;
-        out->filt = out->chirp + N;
-        return 0;
-    }
-    const long double pi = 3.14159265358979323846264338327950288L;
-    std::vector<cplx> h((size_t)N + M);
-    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
-    for (int n = 0; n < N; ++n) {
-        const long long r = ((long long)n * n) % (2LL * N);          // n^2 mod 2N keeps the angle small and exact
-        const long double ph = -pi * (long double)r / (long double)N;
-        const long double cr = cosl(ph), ci = sinl(ph);
-        h[n] = mkc((double)cr, (double)ci);
-        br[n] = cr;
-        bi[n] = -ci;                                                   // b_n = conj(w_n), b_{-n} = b_n
-        if (n) {
-            br[M - n] = cr;
-            bi[M - n] = -ci;
-        }
-    }
-    // FFT_M(b) / M by a direct O(M^2) sum in extended precision (once per length; M <= 1024)
-    std::vector<long double> cs(M), sn(M);
-    for (int m = 0; m < M; ++m) {
-        cs[m] = cosl(-2.0L * pi * m / M);
-        sn[m] = sinl(-2.0L * pi * m / M);
-    }
-    for (int k = 0; k < M; ++k) {
-        long double sr = 0.0L, si = 0.0L;
-        for (int n = 0; n < M; ++n) {
-            if (br[n] == 0.0L && bi[n] == 0.0L) continue;
-            const int t = (int)(((long long)k * n) % M);
-            sr += br[n] * cs[t] - bi[n] * sn[t];
-            si += br[n] * sn[t] + bi[n] * cs[t];
-        }
-        h[N + k] = mkc((double)(sr / M), (double)(si / M));
-    }
-    cplx* d;
-    if (int rc = get_ws(c, key.c_str(), sizeof(cplx) * h.size(), (void**)&d)) return rc;
-    HIP_TRY(c, hipMemcpy(d, h.data(), sizeof(cplx) * h.size(), hipMemcpyHostToDevice));
-    out->chirp = d;
-    out->filt = d + N;
-    return 0;
-}
-
-template <int M>
-int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const real* rin, real* rout, const BsArgs& b, const BsTables& t,
-                       hipStream_t st) {
-    cplx* tw;
-    if (int rc = get_twiddle(c, M, &tw)) return rc;
-    using Cfg = PassCfg<M>;
-    const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
-    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, rin, rout, c->g, b,
-                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
-    return 0;
-}
-
-// one generic-length pass: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
-int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const real* rin, real* rout, double scale,
-                   hipStream_t st) {
-    const int N = mode == 0 ? (axis == 0 ? c->n0 : c->n1) : c->n2;
-    BsTables t;
-    if (int rc = get_bluestein(c, N, &t)) return rc;
-    BsArgs b{};
-    b.N = N;
-    b.mode = mode;
-    b.axis = axis;
-    b.inv = inv;
-    b.scale = scale;
-    b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : c->g.nrows;
-    switch (t.M) {
-        case 8: return launch_bluestein_t<8>(c, spec, rin, rout, b, t, st);
-        case 16: return launch_bluestein_t<16>(c, spec, rin, rout, b, t, st);
-        case 32: return launch_bluestein_t<32>(c, spec, rin, rout, b, t, st);
-        case 64: return launch_bluestein_t<64>(c, spec, rin, rout, b, t, st);
-        case 128: return launch_bluestein_t<128>(c, spec, rin, rout, b, t, st);
-        case 256: return launch_bluestein_t<256>(c, spec, rin, rout, b, t, st);
-        case 512: return launch_bluestein_t<512>(c, spec, rin, rout, b, t, st);
-        case 1024: return launch_bluestein_t<1024>(c, spec, rin, rout, b, t, st);
-    }
-    return fail(c, OFDFT_EINVAL, "no Bluestein plan for length %d", N);
-}
-
-bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
-
-// ---- slab-decomposed 3-D transforms for the per-geometry-step routines (stress, ionic potential, forces): a real x-slab
-// [n0/P][n1][n2] <-> the y-slab of the half spectrum in the block-8 layout of the x-pass geometry (c->gx: all of x, n1/P of
-// y), which is what every k-space kernel of those routines indexes (kvec / spec_decode with kg.g = gx, kg.y0).  One
-// all-to-all per transform through the host's collective (ofdft_set_collectives); the y pass reads / writes the exchange
-// layout directly, a small kernel converts between it and the block-8 y-slab array.
-int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv);
-__global__ void xchg_unpack_kernel(const cplx* __restrict__ buf, cplx* __restrict__ spec, SpecGeom gx, XchgGeom xg, int pack) {
-    // record of x: [ main (b, yl, kin) | planes (plane, yl) ], one array per record
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < gx.total; i += (long long)gridDim.x * blockDim.x) {
-        int x, yl, kz;
-        spec_decode(gx, i, x, yl, kz);
-        const long long r = (long long)x * xg.arr_sz +
-                            (kz < gx.nzm ? (((long long)(kz >> 3) * xg.nyl + yl) * 8 + (kz & 7))
-                                         : ((long long)xg.nb * xg.nyl * 8 + (long long)(kz - gx.nzm) * xg.nyl + yl));
-        if (pack) const_cast<cplx*>(buf)[r] = spec[i];
-        else spec[i] = buf[r];
-    }
-}
 int dist_exchange(ofdft_ctx* c, cplx* send, cplx* recv, hipStream_t st) {
     if (!c->a2a) return fail(c, OFDFT_ESTATE, "slab-decomposed context without collectives: call ofdft_set_collectives first");
     const unsigned long long bytes = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz);
@@ -599,210 +145,15 @@ int global_sums(ofdft_ctx* c, double* v, int n) {
     if (int rc = c->allreduce(c->coll_user, v, n)) return fail(c, OFDFT_EHIP, "all-reduce callback failed (%d)", rc);
     return 0;
 }
-int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
-int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
 
-// real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
-int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
-    c->fft_count++;
-    if (c->nranks > 1) return dist_rfftn(c, in, spec, st);
-    if (c->fast) {
-        int rc = zfwd_any(c, in, spec, st);
-        if (rc) return rc;
-        if ((rc = fast_axis_pass<false>(c, 1, spec, st))) return rc;
-        return fast_axis_pass<false>(c, 0, spec, st);
-    }
-    if (bluestein_ok(c)) {        // arbitrary extents: chirp-z line transforms, in place
-        if (int rc = bluestein_pass(c, 1, 2, 0, spec, in, nullptr, 1.0, st)) return rc;
-        if (int rc = bluestein_pass(c, 0, 1, 0, spec, nullptr, nullptr, 1.0, st)) return rc;
-        return bluestein_pass(c, 0, 0, 0, spec, nullptr, nullptr, 1.0, st);
-    }
-    cplx *tw2, *tmp;
-    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
-    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
-    // z into tmp, y: tmp -> spec, x: spec -> tmp, then copy back (two swaps leave the result in tmp)
-    OFDFT_LAUNCH(c, st, "gen_r2c_z", gen_r2c_z_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, in, spec, c->g, tw2);
-    cplx *cur = spec, *other = tmp;
-    if (int rc = gen_axis(c, 1, 0, cur, other, st)) return rc;
-    if (int rc = gen_axis(c, 0, 0, cur, other, st)) return rc;
-    if (cur != spec) HIP_TRY(c, hipMemcpyAsync(spec, cur, sizeof(cplx) * c->g.total, hipMemcpyDeviceToDevice, st));
-    return 0;
-}
+}  // namespace eng
 
-// internal half spectrum (destroyed) -> real, scaled by `scale` (1/N for irfftn semantics)
-int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
-    c->fft_count++;
-    if (c->nranks > 1) return dist_irfftn(c, spec, out, scale, st);
-    if (c->fast) {
-        int rc;
-        if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;
-        if ((rc = fast_axis_pass<true>(c, 1, spec, st))) return rc;
-        return zinv_any(c, spec, out, scale, st);
-    }
-    if (bluestein_ok(c)) {
-        if (int rc = bluestein_pass(c, 0, 0, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
-        if (int rc = bluestein_pass(c, 0, 1, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
-        return bluestein_pass(c, 2, 2, 1, spec, nullptr, out, scale, st);
-    }
-    cplx *tw2, *tmp;
-    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
-    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
-    cplx *cur = spec, *other = tmp;
-    if (int rc = gen_axis(c, 0, 1, cur, other, st)) return rc;
-    if (int rc = gen_axis(c, 1, 1, cur, other, st)) return rc;
-    PostScale post{(real)scale};
-    OFDFT_LAUNCH(c, st, "gen_c2r_z", (gen_c2r_z_kernel<PostScale>), dim3((unsigned)((c->npts + 255) / 256)), dim3(256), 0, cur, out,
-                       c->g, tw2, post);
-    return 0;
-}
+using namespace eng;
 
+namespace {
 
-// ---------------------------------------------------------------------------------- fused-pipeline pieces
-// z-forward + y-forward (the x transform is left to the fused x pass)
-int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
-    c->fft_count++;
-    int rc = zfwd_any(c, in, spec, st);
-    if (rc) return rc;
-    return fast_axis_pass<false>(c, 1, spec, st);
-}
-
-// y-inverse + z-inverse (c2r) of a spectrum whose x axis is already back in real space
-int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
-    c->fft_count++;
-    if (int rc = fast_axis_pass<true>(c, 1, spec, st)) return rc;
-    return zinv_any(c, spec, out, scale, st);
-}
-
-int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
-    cplx *send, *recv, *tmp;
-    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
-    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
-    int rc = zfwd_any(c, in, tmp, st);          // z-forward of the local rows into the x-slab layout
-    if (rc) return rc;
-    if ((rc = ypass_xchg<false>(c, {tmp}, send, st))) return rc;           // y-forward, written in the exchange layout
-    if ((rc = dist_exchange(c, send, recv, st))) return rc;
-    XchgGeom xg = c->xg;
-    xg.rec = xg.arr_sz;
-    OFDFT_LAUNCH(c, st, "xchg_unpack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)recv, spec, c->gx, xg, 0);
-    return fast_axis_pass<false>(c, 0, spec, st);                           // x-forward on the y-slab
-}
-
-int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
-    cplx *send, *recv, *tmp;
-    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
-    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
-    int rc;
-    if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;             // x-inverse on the y-slab
-    XchgGeom xg = c->xg;
-    xg.rec = xg.arr_sz;
-    OFDFT_LAUNCH(c, st, "xchg_pack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)send, spec, c->gx, xg, 1);
-    if ((rc = dist_exchange(c, send, recv, st))) return rc;
-    if ((rc = ypass_xchg<true>(c, {tmp}, recv, st))) return rc;             // y-inverse out of the exchange layout
-    return zinv_any(c, tmp, out, scale, st);
-}
-
-// where the x pass finds its spectra: {} = y-slab arrays in the block-8 layout (one GPU); otherwise the exchange
-// buffers of the slab-decomposed path (x-major records, see XchgGeom): element strides along x of the inputs, the
-// outputs and the k-point tables
-struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; int kb0 = 0, kb1 = 0; };   // kb1 > kb0: kz blocks [kb0, kb1) only
-
-template <int LEN, int NIN, int NOUT, class Mix>
-int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
-    constexpr int G = NIN > NOUT ? NIN : NOUT;
-    using Cfg = XfCfg<LEN, G, NOUT>;
-    cplx* tw;
-    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
-    LineMap main, rem;
-    SpecGeom gk = c->gx;
-    if (lay.se_in) {
-        const int nyl = c->xg.nyl;
-        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
-        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
-        if (main.nlines == 0) main.d = 1;
-        if (rem.nlines == 0) rem.d = 1;
-        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
-    } else {
-        pass_maps(c, 0, main, rem);
-    }
-    main.lf = rem.lf = Cfg::LPW;
-    int line0 = 0;
-    if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
-        const int per_block = c->gx.n1 * 8;
-        line0 = lay.kb0 * per_block;
-        main.nlines = lay.kb1 * per_block;
-        if (lay.kb1 != c->gx.nzm / 8) rem.nlines = 0;
-    }
-    main.blk0 = line0 / Cfg::LPW;
-    const int mb = (main.nlines - line0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
-                 gk, tw, mix, XfStride{lay.se_out, lay.tse});
-    return 0;
-}
-
-// the wave-local form of the same pass (xwave.h): a line of every spectrum in the lanes of one wave, mix in registers
-template <int LEN, int NIN, int NOUT, class Mix>
-int launch_xw_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
-    using Cfg = XwCfg<LEN>;
-    cplx* tw;
-    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
-    LineMap main, rem;
-    SpecGeom gk = c->gx;
-    if (lay.se_in) {
-        const int nyl = c->xg.nyl;
-        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
-        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
-        if (main.nlines == 0) main.d = 1;
-        if (rem.nlines == 0) rem.d = 1;
-        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
-    } else {
-        pass_maps(c, 0, main, rem);
-    }
-    main.lf = rem.lf = Cfg::LPB;
-    int line0 = 0;
-    if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
-        const int per_block = c->gx.n1 * 8;
-        if (per_block % Cfg::LPB) return fail(c, OFDFT_EINVAL, "kz-range x pass needs whole workgroups per kz block");
-        line0 = lay.kb0 * per_block;
-        main.nlines = lay.kb1 * per_block;
-        if (lay.kb1 != c->gx.nzm / 8) rem.nlines = 0;
-    }
-    main.blk0 = line0 / Cfg::LPB;
-    const int mb = (main.nlines - line0 + Cfg::LPB - 1) / Cfg::LPB, rb = (rem.nlines + Cfg::LPB - 1) / Cfg::LPB;
-    OFDFT_LAUNCH(c, st, nm, (xw_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb, gk,
-                 (const cplx*)tw, mix, XfStride{lay.se_out, lay.tse});
-    return 0;
-}
-
-// forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
-template <int NIN, int NOUT, class Mix>
-int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{}) {
-    // measured at 256^3 (A/B on one box): 3 -> 3 (WGC99) 0.55 -> 0.53 ms, 1 -> 2 0.112 -> 0.097 ms, but 1 -> 1 0.062 -> 0.079 ms
-    if (c->use_xwave == 2 || (c->use_xwave == 1 && NIN + NOUT >= 3)) {
-        switch (c->n0g) {
-            case 8: return launch_xw_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 16: return launch_xw_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 32: return launch_xw_t<32, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 64: return launch_xw_t<64, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 128: return launch_xw_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 256: return launch_xw_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-            case 512: return launch_xw_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        }
-    }
-    switch (c->n0g) {
-        case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 64: return launch_xfused_t<64, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 128: return launch_xfused_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-#define X(L) case L: return launch_xfused_t<L, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
-        OFDFT_MIXED_LINES(X)
-#undef X
-    }
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
-}
+struct ProfRec { const char* name; hipEvent_t a, b; };
+void graph_drop(ofdft_ctx* c);
 
 // ---------------------------------------------------------------------------------- reductions
 // copy `rows` x `ns` partials to the host and sum them in a fixed order

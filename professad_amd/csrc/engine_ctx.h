@@ -1,0 +1,243 @@
+// Shared declarations of the engine's translation units (gfx950 only).
+//
+// The library is built from several separately compiled sources so that a change recompiles only its own kernels:
+//   engine.hip    C ABI, pipelines (unfused, x-fused, z-fused stages), ion / stress / L-BFGS entry points and their kernels
+//   lines.hip     line-transform drivers: y / x passes, plain z passes, chirp-z and plain-DFT paths, the slab-decomposed
+//                 3-D transforms of the per-geometry-step routines
+//   xpass_a.hip   fused x passes (forward-x, k-space mix, inverse-x): table-driven and single-spectrum mixes
+//   xpass_b.hip   fused x passes: density / gradient / divergence mixes
+//   zfused.hip    launchers of the wave-local z kernels with fused real-space physics (zpass.h)
+// Kernels are templates in the headers (instantiated where they are launched) or `static` (one copy per source that uses them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ofdft_hip.h"
+#include "bluestein.h"
+#include "zpass.h"
+#include "xwave.h"
+
+using namespace ofdft;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ofdft_ctx {
+    int n0 = 0, n1 = 0, n2 = 0, device = 0;     // LOCAL real-space extents (x-slab: n0 = n0g / nranks)
+    int n0g = 0, n1g = 0, nranks = 1, rank = 0; // global extents and slab decomposition
+    SpecGeom g{};      // spectrum geometry of the z and y passes (x-slab: n0 local, n1 global)
+    SpecGeom gx{};     // spectrum geometry of the x pass (y-slab: n0 global, n1 local); == g on one GPU
+    KGeom kg{};        // k-vectors in the x-pass geometry
+    XchgGeom xg{};     // exchange-buffer layout of the slab-decomposed path (rec / chunk filled per stage)
+    long long npts = 0;      // local points
+    long long npts_g = 0;    // global points (normalisation, dV)
+    bool fast = false, cell_set = false, force_unfused = false;
+    int pipeline = 0;   // 0 = z-fused (default on power-of-two grids), 1 = unfused, 2 = x-fused only
+    double box[9] = {0}, vol = 0.0, dV = 0.0;
+    unsigned mask = 0;
+    double params[OFDFT_NPARAMS];
+    // twiddle tables by length
+    std::map<int, cplx*> tw;
+    // named workspaces
+    std::map<std::string, DevBuf> ws;
+    size_t ws_bytes = 0;
+    // reduction partials (device) + pinned host mirror
+    double* d_partial = nullptr;
+    double* d_reduced = nullptr;     // second-level sums [kMaxScalars]
+    double* d_scal = nullptr;        // device-resident scalars: [0] = closure scale c
+    double* h_partial = nullptr;
+    long long partial_rows = 0;
+    // WGC tables
+    double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
+    long long wgc_key_nel = -1;
+    bool wgc_valid = false;
+    // stats
+    int fft_count = 0, launch_count = 0;
+    double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
+    float last_ms = 0.f;
+    bool ms_pending = false;    // ev1 recorded without a host wait (device-resident dist finish): elapsed time read on demand
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+    bool use_side_stream = true;
+    bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
+    bool gga_split = true;       // GGA chain in split-derivative form: only the x index-derivative visits the x pass
+    bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
+    int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
+    int use_xwave = 1;   // fused x pass: 1 = wave-local kernel (xwave.h) where it measured faster (passes over >= 3 spectra, x extents <= 512), 2 = wherever it exists, 0 = group-parallel kernel only
+    int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
+    // optional per-kernel-class profiling (HIP events around every launch)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Pending { const char* name; size_t a, b; };
+    std::vector<Pending> pending;
+    struct Acc { double ms = 0.0; long long launches = 0; };
+    std::map<std::string, Acc> prof;
+    struct ofdft_zrun_holder* zr = nullptr;
+    // hipGraph replay of the closure evaluation (ofdft_energy_grad_chi): one entry per argument set
+    struct GraphEntry {
+        const void *chi = nullptr, *vext = nullptr, *grad = nullptr;
+        double nel = 0.0;
+        unsigned long long version = 0;      // configuration the graph was captured under
+        int seen = 0;                        // calls with these arguments so far (the first one runs uncaptured: it allocates)
+        hipGraphExec_t exec = nullptr;
+        bool wgc_split = false;
+        int fft_count = 0, launch_count = 0;
+        double ypass_count = 0.0;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long version = 1;          // bumped by set_cell / set_terms / set_option
+    bool use_graph = true;
+    long long graph_replays = 0;
+    hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
+    // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
+    ofdft_all_to_all_fn a2a = nullptr;
+    ofdft_all_reduce_fn allreduce = nullptr;
+    void* coll_user = nullptr;
+    char err[512] = "";
+};
+
+
+namespace eng {
+
+constexpr unsigned kGgaAny = OFDFT_PBE_X | OFDFT_PBE_C | OFDFT_GGA_K;   // terms served by the gradient / divergence machinery
+constexpr int kNSums = kCombineScalars + kPbeScalars;                  // local sums of an evaluation (12)
+constexpr int kSumsqSlot = 15;                                         // d_reduced slot of sum chi^2 (closure form)
+
+inline GgaSel gga_sel(const ofdft_ctx* c) {
+    return GgaSel{(c->mask & OFDFT_PBE_X) ? 1 : 0, (c->mask & OFDFT_PBE_C) ? 1 : 0, (c->mask & OFDFT_GGA_K) ? 1 : 0,
+                  (int)c->params[OFDFT_P_GGAK_KIND], (real)c->params[OFDFT_P_GGAK_MU], (real)c->params[OFDFT_P_GGAK_BETA],
+                  (real)c->params[OFDFT_P_GGAK_LAMBDA], (real)c->params[OFDFT_P_GGAK_SIGMA]};
+}
+
+// Pauli-Gaussian member with Laplacian-dependent terms (PGSL0.25 -- the reference's default --, PGSLr): one more spectrum
+// each way in the split-derivative GGA chain of the z-fused pipeline (lap n in, lap(df/dL) out); the x-fused-only and
+// the unsplit forms fall back to the unfused pipeline
+inline bool gga_needs_laplacian(const ofdft_ctx* c) {
+    return (c->mask & OFDFT_GGA_K) && (int)c->params[OFDFT_P_GGAK_KIND] == 1 &&
+           (c->params[OFDFT_P_GGAK_BETA] != 0.0 || c->params[OFDFT_P_GGAK_LAMBDA] != 0.0 || c->params[OFDFT_P_GGAK_SIGMA] != 0.0);
+}
+// Pauli-positivity stabilised Wang-Teter style functional (functionals.py:728-782) with f = exp: two combine passes (energies
+// first, then the potential with the weights f - f' X, f' they determine)
+inline bool wts_active(const ofdft_ctx* c) {
+    return (int)c->params[OFDFT_P_WTS_KIND] == 1 && (c->mask & OFDFT_TF) && (c->mask & OFDFT_WT_NL);
+}
+inline bool zfused_serves(const ofdft_ctx* c) {
+    return c->fast && c->pipeline == 0 && c->n2 / 2 <= 512 && (!gga_needs_laplacian(c) || c->gga_split);
+}
+
+int fail(ofdft_ctx* c, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, OFDFT_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+
+// run the rest of the enclosing ABI function on the context's device, restoring the caller's device on return
+#define OFDFT_ON_DEVICE(ctx, dev)                                                                   \
+    DeviceScope device_scope_(dev);                                                                 \
+    if (device_scope_.err != hipSuccess)                                                            \
+        return fail(ctx, OFDFT_EHIP, "cannot select device %d: %s", (dev), hipGetErrorString(device_scope_.err))
+
+// hipGraph replay serves the launch-bound regime only (single-GPU contexts up to 2^19 points, e.g. 64 x 64 x 128; above
+// that launches are hidden behind the kernels and the measured gain is nil).  There the WGC99 part of the combine stays inside the combine kernel: the forked + split stream topology
+// crashes this ROCm's stream capture, and fewer launches is the better trade on small grids anyway.
+inline bool graph_eligible(const ofdft_ctx* c) { return c->use_graph && c->nranks == 1 && c->npts <= (1LL << 19); }
+void prof_begin(ofdft_ctx* c, hipStream_t st, const char* name);
+void prof_end(ofdft_ctx* c, hipStream_t st);
+void prof_collect(ofdft_ctx* c);
+
+#define OFDFT_LAUNCH(c, st, name, kern, grid, block, lds, ...)            \
+    do {                                                                  \
+        prof_begin(c, st, name);                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);      \
+        prof_end(c, st);                                                  \
+        (c)->launch_count++;                                              \
+    } while (0)
+
+inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// Extents served by the register / LDS line transforms (fft_radix.h plans) -- and with them by the fused pipelines:
+// powers of two, and the 2^a 3^b 5^c extents listed here (any other extent: chirp-z line transforms + the unfused pipeline).
+// OFDFT_MIXED_LINES: x / y extents; OFDFT_MIXED_ROWS: the half lengths n2 / 2 of the z rows for the same extents.
+// (the fp32 build keeps the powers of two only: its other extents take the chirp-z path)
+#ifndef OFDFT_REAL_F32
+#define OFDFT_MIXED_LINES(X) X(48) X(96) X(120) X(144) X(160) X(192) X(240) X(250) X(270) X(288) X(320) X(384) X(480)
+#define OFDFT_MIXED_ROWS(X) X(24) X(48) X(60) X(72) X(80) X(96) X(120) X(125) X(135) X(144) X(160) X(192) X(240)
+#else
+#define OFDFT_MIXED_LINES(X)
+#define OFDFT_MIXED_ROWS(X)
+#endif
+inline bool mixed_line(int n) {
+#define X(L) if (n == L) return true;
+    OFDFT_MIXED_LINES(X)
+#undef X
+    return false;
+}
+inline bool line_extent_ok(int n) { return (is_pow2(n) && n >= 8 && n <= 1024) || mixed_line(n); }
+inline bool row_extent_ok(int n2) { return (is_pow2(n2) && n2 >= 16 && n2 <= 2048) || mixed_line(n2); }
+inline bool all_pow2(const ofdft_ctx* c) { return is_pow2(c->n0g) && is_pow2(c->n1g) && is_pow2(c->n2); }
+
+inline int grid_for(long long n, int tpb = 256, int cap = 2048) {
+    long long b = (n + tpb - 1) / tpb;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+
+// ---- workspaces and tables (engine.hip)
+int get_twiddle(ofdft_ctx* c, int n, cplx** out);
+int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out);
+int real_ws(ofdft_ctx* c, const char* name, real** out);
+int spec_ws(ofdft_ctx* c, const char* name, cplx** out);
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv);
+int dist_exchange(ofdft_ctx* c, cplx* send, cplx* recv, hipStream_t st);
+int global_sums(ofdft_ctx* c, double* v, int n);
+
+// ---- line-transform drivers (lines.hip)
+void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem);
+template <bool INV>
+int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0,
+                         int kb0 = 0, int kb1 = 0);
+template <bool INV> int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st);
+template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st);
+int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st);
+int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
+int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
+int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
+int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
+
+// ---- fused x passes (xpass_a.hip, xpass_b.hip; xpass_impl.h).  Where the x pass finds its spectra: {} = y-slab arrays in
+// the block-8 layout (one GPU); otherwise the exchange buffers of the slab-decomposed path (x-major records, see XchgGeom):
+// element strides along x of the inputs, the outputs and the k-point tables
+struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; int kb0 = 0, kb1 = 0; };   // kb1 > kb0: kz blocks [kb0, kb1) only
+template <int NIN, int NOUT, class Mix>
+int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{});
+
+// ---- launchers of the fused z kernels (zfused.hip).  (chunk, nchunks): the launch covers that share of the rows, i.e. the
+// x planes [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
+int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0, int nchunks = 1,
+                      real* dzn = nullptr);
+int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1);
+int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, real* dfdn, double inv_n, int* blocks_out,
+                hipStream_t st, int chunk = 0, int nchunks = 1);
+int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const real* dzn, real* dfdn, double inv_n, int* blocks_out,
+                 hipStream_t st, cplx* L = nullptr);
+int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1);
+int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, real* v_part, double* partial, int* blocks_out, hipStream_t st);
+
+}  // namespace eng

@@ -1,180 +1,6 @@
 // The z-fused pipeline of the engine (five stages, two chains; single- and multi-GPU) and the launchers of the z
 // kernels.  Included once by engine.hip inside its anonymous namespace (one translation unit).
 // ---------------------------------------------------------------------------------- z-fused pipeline (zpass.h)
-#define OFDFT_ZCASES(X) X(8) X(16) X(32) X(64) X(128) X(256) X(512) OFDFT_MIXED_ROWS(X)
-#ifndef OFDFT_EZ
-#define OFDFT_EZ 4
-#endif
-constexpr int EZ = OFDFT_EZ;   // points per lane wanted by the register-hungry fused z kernels
-#ifndef OFDFT_EZ_POWERS
-#define OFDFT_EZ_POWERS OFDFT_EZ
-#endif
-constexpr int EZP = OFDFT_EZ_POWERS;   // ... and by zf_powers (one input row, up to six output spectra)
-
-int z_tables(ofdft_ctx* c, cplx** twM, cplx** twN) {
-    if (int rc = get_twiddle(c, c->n2 / 2, twM)) return rc;
-    return get_twiddle(c, c->n2, twN);
-}
-template <int M, int E> int z_blocks(const ofdft_ctx* c) { return (int)((c->g.nrows + ZW<M, E>::RPB - 1) / ZW<M, E>::RPB); }
-
-// The z launchers take (chunk, nchunks): the launch covers that share of the rows, i.e. the x planes
-// [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
-int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0,
-                      int nchunks = 1, real* dzn = nullptr) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0) c->fft_count += (out_n ? 1 : 0) + (out_s ? 1 : 0);
-    SpecGeom gz = c->g;
-#define X(M_)                                                                                                       \
-    case M_: {                                                                                                      \
-        const int nb = z_blocks<M_, ZPick<M_, 8>::E>(c) / nchunks;                                                  \
-        gz.blk0 = chunk * nb;                                                                                       \
-        OFDFT_LAUNCH(c, st, "zf_density", (zf_density_kernel<M_, ZPick<M_, 8>::E>), dim3(nb), dim3(256),            \
-                     (ZW<M_, ZPick<M_, 8>::E>::LDS), ds, out_n, out_s, gz, twM, twN, dzn);                          \
-        return 0;                                                                                                   \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0)
-        for (int i = 0; i < 6; ++i) c->fft_count += pa.out[i] ? 1 : 0;
-    SpecGeom gz = c->g;
-#define X(M_)                                                                                                      \
-    case M_: {                                                                                                     \
-        const int nb = z_blocks<M_, ZPick<M_, EZP>::E>(c) / nchunks;                                                \
-        gz.blk0 = chunk * nb;                                                                                      \
-        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZP>::E>), dim3(nb), dim3(256),           \
-                     (ZW<M_, ZPick<M_, EZP>::E>::LDS), ds, pa, gz, twM, twN);                                       \
-        return 0;                                                                                                  \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, real* dfdn, double inv_n,
-                int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    if (chunk == 0) c->fft_count += 6;    // three c2r finished + three r2c started on chip
-    SpecGeom gq = c->g;
-#define X(M_)                                                                                                   \
-    case M_: {                                                                                                  \
-        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
-        const int nb = *blocks_out / nchunks;                                                                   \
-        gq.blk0 = chunk * nb;                                                                                   \
-        OFDFT_LAUNCH(c, st, "zpbe", (zpbe_kernel<M_, ZPick<M_, EZ>::E>), dim3(nb), dim3(256),                   \
-                     (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, gx, gy, gz, dfdn, inv_n, gga_sel(c), gq, twM, twN,   \
-                     c->d_partial);                                                                             \
-        return 0;                                                                                               \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-// split-derivative GGA mid stage (zpass.h: zpbe2_kernel); L != nullptr: the Laplacian-dependent Pauli-Gaussian form
-int launch_zpbe2(ofdft_ctx* c, const DenSrc& ds, cplx* A, cplx* B, const real* dzn, real* dfdn, double inv_n,
-                 int* blocks_out, hipStream_t st, cplx* L = nullptr) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    c->fft_count += L ? 8 : 6;    // same six 3-D transforms as the plain form (three c2r finished, three r2c started); + lap n, df/dL
-    Bmat bm{};
-    std::memcpy(bm.b, c->kg.b, sizeof(bm.b));
-#define X(M_)                                                                                                   \
-    case M_: {                                                                                                  \
-        *blocks_out = z_blocks<M_, ZPick<M_, EZ>::E>(c);                                                        \
-        if (L)                                                                                                  \
-            OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E, true>), dim3(*blocks_out), dim3(256), \
-                         (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm, \
-                         c->g, twM, twN, c->d_partial, L);                                                      \
-        else                                                                                                    \
-            OFDFT_LAUNCH(c, st, "zpbe", (zpbe2_kernel<M_, ZPick<M_, EZ>::E, false>), dim3(*blocks_out), dim3(256), \
-                         (ZW<M_, ZPick<M_, EZ>::E>::LDS), ds, A, B, dzn, dfdn, inv_n, 1.0 / (double)c->n2, gga_sel(c), bm, \
-                         c->g, twM, twN, c->d_partial, L);                                                      \
-        return 0;                                                                                               \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-// index derivative along y of an x-slab spectrum in (kz; y, x) form, in one pass (fft_kernels.h: yderiv_kernel)
-template <int LEN>
-int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
-    cplx* tw;
-    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
-    using Cfg = PassCfg<LEN>;
-    LineMap main, rem;
-    pass_maps(c, 1, main, rem);
-    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, "yderiv", (yderiv_kernel<LEN>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, in, out, main, rem, mb,
-                 c->g.main_count, (const cplx*)tw, scale);
-    return 0;
-}
-int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
-    switch (c->n1) {
-        case 8: return launch_yderiv_t<8>(c, in, out, scale, st);
-        case 16: return launch_yderiv_t<16>(c, in, out, scale, st);
-        case 32: return launch_yderiv_t<32>(c, in, out, scale, st);
-        case 64: return launch_yderiv_t<64>(c, in, out, scale, st);
-        case 128: return launch_yderiv_t<128>(c, in, out, scale, st);
-        case 256: return launch_yderiv_t<256>(c, in, out, scale, st);
-        case 512: return launch_yderiv_t<512>(c, in, out, scale, st);
-        case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st);
-#define X(L) case L: return launch_yderiv_t<L>(c, in, out, scale, st);
-        OFDFT_MIXED_LINES(X)
-#undef X
-    }
-    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
-}
-
-int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipStream_t st, int chunk = 0, int nchunks = 1) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-    SpecGeom gq = c->g;
-    const size_t park = sizeof(double) * 256 * kCombineScalars;
-#define X(M_)                                                                                                     \
-    case M_: {                                                                                                    \
-        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
-        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
-        const int nb = *blocks_out / nchunks;                                                                     \
-        gq.blk0 = chunk * nb;                                                                                     \
-        if (a.v_part || !(a.mask & OFDFT_WGC99_NL))   /* no inline WGC99 section needed: the lean instantiation */  \
-            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, false>), dim3(nb), dim3(256),          \
-                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
-        else                                                                                                      \
-            OFDFT_LAUNCH(c, st, "zi_combine", (zi_combine_kernel<M_, W::E, true>), dim3(nb), dim3(256),           \
-                         (W::LDS + park), a, gq, twM, twN, c->d_partial);                                         \
-        return 0;                                                                                                 \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
-// split form: the WGC99 part of the combine on the nonlocal chain's stream -> v_part rows + one energy partial per block
-int launch_zi_wgc(ofdft_ctx* c, const ZCombineArgs& a, real* v_part, double* partial, int* blocks_out, hipStream_t st) {
-    cplx *twM, *twN;
-    if (int rc = z_tables(c, &twM, &twN)) return rc;
-#define X(M_)                                                                                                     \
-    case M_: {                                                                                                    \
-        using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \
-        *blocks_out = z_blocks<M_, W::E>(c);                                                                      \
-        OFDFT_LAUNCH(c, st, "zi_wgc", (zi_wgc_kernel<M_, W::E>), dim3(*blocks_out), dim3(256), (W::LDS), a, v_part, \
-                     c->g, twM, twN, partial);                                                                    \
-        return 0;                                                                                                 \
-    }
-    switch (c->n2 / 2) { OFDFT_ZCASES(X) }
-#undef X
-    return fail(c, OFDFT_EINVAL, "bad n2");
-}
-
 void energies_from_sums(const ofdft_ctx* c, const double* sums, const double* pbe_sums, double* E_terms, double* vn_int) {
     const unsigned mask = c->mask;
     const double dV = c->dV;
@@ -257,28 +83,6 @@ int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
     int n = 1;
     while (n * 2 <= want && c->n0 % (n * 2) == 0 && ((long long)(c->n0 / (n * 2)) * c->n1) % 256 == 0) n *= 2;
     return n;
-}
-
-// sized by what the active terms send at most across one geometry boundary (the buffers only ever grow): chain 0 carries
-// {n^, (sqrt n)^} -> {vH, D_a n | grad n (3), lap} -> flux (1 | 3) -> divergence (1); chain 1 the Wang-Teter powers (1-2) and / or
-// the six WGC99 spectra
-int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
-    const unsigned m = c->mask;
-    const bool g = m & kGgaAny, h = m & OFDFT_HARTREE, vw = m & OFDFT_VW;
-    const int ng = g ? (c->gga_split ? 1 : 3) : 0;
-    const int nl = (gga_needs_laplacian(c) && c->gga_split) ? 1 : 0;      // lap n back, df/dL forth
-    int narr;
-    if (chain == 0) {
-        narr = std::max(((h || g) ? 1 : 0) + (vw ? 1 : 0), (h ? 1 : 0) + ng + nl + (vw ? 1 : 0));
-        narr = std::max(narr, ng + nl);
-    } else {
-        narr = ((m & OFDFT_WT_NL) ? (c->params[OFDFT_P_WT_ALPHA] != c->params[OFDFT_P_WT_BETA] ? 2 : 1) : 0) +
-               ((m & OFDFT_WGC99_NL) ? 6 : 0);
-    }
-    if (narr < 1) narr = 1;
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
-    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
-    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
 }
 
 // Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(ZCfg<M>::TPB) void zinv_kernel(const cplx* __restri
 
 // ----------------------------------------------------------------------------------------------
 // generic (any extent) naive DFT kernels -- correctness path for non power-of-two grids
-__global__ void gen_r2c_z_kernel(const real* __restrict__ in, cplx* __restrict__ spec, SpecGeom g,
+static __global__ void gen_r2c_z_kernel(const real* __restrict__ in, cplx* __restrict__ spec, SpecGeom g,
                                  const cplx* __restrict__ tw2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.total) return;
@@ -495,7 +495,7 @@ __global__ void gen_r2c_z_kernel(const real* __restrict__ in, cplx* __restrict__
 }
 
 // out-of-place complex DFT along axis 0 (x) or 1 (y)
-__global__ void gen_c2c_kernel(const cplx* __restrict__ in, cplx* __restrict__ out, SpecGeom g, int axis, int inv,
+static __global__ void gen_c2c_kernel(const cplx* __restrict__ in, cplx* __restrict__ out, SpecGeom g, int axis, int inv,
                                const cplx* __restrict__ tw) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.total) return;
@@ -541,14 +541,14 @@ __global__ void gen_c2r_z_kernel(const cplx* __restrict__ spec, real* __restrict
 }
 
 // standard [n0][n1][nzc] <-> internal layout
-__global__ void spec_to_internal_kernel(const cplx* __restrict__ stdl, cplx* __restrict__ intl, SpecGeom g) {
+static __global__ void spec_to_internal_kernel(const cplx* __restrict__ stdl, cplx* __restrict__ intl, SpecGeom g) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.total) return;
     int x, y, kz;
     spec_decode(g, i, x, y, kz);
     intl[i] = stdl[((long long)x * g.n1 + y) * g.nzc + kz];
 }
-__global__ void spec_to_standard_kernel(const cplx* __restrict__ intl, cplx* __restrict__ stdl, SpecGeom g) {
+static __global__ void spec_to_standard_kernel(const cplx* __restrict__ intl, cplx* __restrict__ stdl, SpecGeom g) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.total) return;
     int x, y, kz;

@@ -1,0 +1,439 @@
+// Line-transform drivers of the engine (see engine_ctx.h for the split of the sources).  gfx950 only.
+#include "engine_ctx.h"
+
+namespace eng {
+
+// ---------------------------------------------------------------------------------- FFT drivers
+template <int LEN, bool INV>
+int launch_cpass_t(ofdft_ctx* c, const ArrList& arrs, int narr, const LineMap& main, const LineMap& rem, hipStream_t st,
+                   const char* nm) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    LineMap mm = main;
+    mm.blk0 = main.blk0 / Cfg::LPW;                     // line offset -> workgroup offset
+    const int mb = (main.nlines - main.blk0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, mm, rem, mb,
+                 c->g.main_count, tw);
+    return 0;
+}
+
+// line maps of the block-8 layout (see fft_kernels.h)
+void pass_maps(const ofdft_ctx* c, int axis, LineMap& main, LineMap& rem) {
+    const SpecGeom& g = axis == 0 ? c->gx : c->g;
+    const int nb = g.nzm / 8, nrem = g.nzc - g.nzm;
+    if (axis == 0) {   // x lines: base = b*n0*n1*8 + (y*8+kin), stride n1*8
+        main.d = g.n1 * 8; main.sb = (long long)g.n0 * g.n1 * 8; main.sl = 1; main.se = (long long)g.n1 * 8;
+        main.nlines = nb * g.n1 * 8; main.lf = 0;  // lf filled by caller (LPW)
+        rem.d = g.n1; rem.sb = (long long)g.n0 * g.n1; rem.sl = 1; rem.se = g.n1; rem.nlines = nrem * g.n1; rem.lf = 0;
+    } else {           // y lines: base = (b*n0+x)*n1*8 + kin, stride 8
+        main.d = 8; main.sb = (long long)g.n1 * 8; main.sl = 1; main.se = 8; main.nlines = nb * g.n0 * 8; main.lf = 8;
+        rem.d = 1; rem.sb = g.n1; rem.sl = 0; rem.se = 1; rem.nlines = nrem * g.n0; rem.lf = 1;
+    }
+    if (main.nlines == 0) { main.d = 1; main.lf = 1; }
+    if (rem.nlines == 0) { rem.d = 1; rem.lf = 1; }
+}
+
+// line pass over `narr` spectra in ONE launch; cx > 0 restricts a y pass to the x planes [x0, x0 + cx)
+// kb1 > kb0 restricts a y pass to the kz blocks [kb0, kb1) (the remainder planes ride with the last range)
+template <bool INV>
+int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0, int cx,
+                         int kb0, int kb1) {
+    LineMap main, rem;
+    pass_maps(c, axis, main, rem);
+    if (kb1 > kb0 && axis == 1) {
+        const int per_block = c->g.n0 * 8;              // lines per kz block
+        main.blk0 = kb0 * per_block;                    // converted to workgroups below
+        main.nlines = kb1 * per_block;
+        if (kb1 != c->g.nzm / 8) rem.nlines = 0;
+    }
+    if (cx > 0 && axis == 1) {
+        main.gc = rem.gc = cx;
+        main.gn = rem.gn = c->g.n0;
+        main.g0 = rem.g0 = x0;
+        main.nlines = (c->g.nzm / 8) * cx * 8;
+        rem.nlines = (c->g.nzc - c->g.nzm) * cx;
+    }
+    ArrList arrs{};
+    for (int a = 0; a < narr; ++a) arrs.p[a] = specs[a];
+    if (axis == 1) {
+        double frac = 1.0;
+        if (cx > 0) frac *= (double)cx / c->g.n0;
+        if (kb1 > kb0) frac *= (double)(kb1 - kb0) * 8.0 / c->g.nzc;
+        c->ypass_count += narr * frac;
+    }
+    const int len = axis == 0 ? c->n0g : c->n1;
+    const char* nm = axis == 0 ? "cpass_x" : "cpass_y";
+#define OFDFT_CASE(L)                                                   \
+    case L:                                                             \
+        if (axis == 0) main.lf = rem.lf = PassCfg<L>::LPW;              \
+        return launch_cpass_t<L, INV>(c, arrs, narr, main, rem, st, nm);
+    switch (len) {
+        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
+        OFDFT_CASE(1024)
+        OFDFT_MIXED_LINES(OFDFT_CASE)
+    }
+#undef OFDFT_CASE
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", len);
+}
+
+template <bool INV>
+int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
+    return fast_axis_pass_multi<INV>(c, axis, &spec, 1, st);
+}
+// y pass of `narr` x-slab spectra straight into (forward) / out of (inverse) an all-to-all buffer
+template <int LEN, bool INV>
+int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    LineMap main, rem;
+    pass_maps(c, 1, main, rem);
+    XchgGeom xg = c->xg;
+    xg.rec = narr * xg.arr_sz;
+    xg.chunk = xg.nxl * xg.rec;
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, INV ? "ypass_recv" : "ypass_send", (ypass_xchg_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB),
+                 Cfg::LDS, arrs, buf, xg, main, rem, mb, c->g.main_count, tw);
+    return 0;
+}
+template <bool INV>
+int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st) {
+    const int narr = (int)list.size();
+    if (narr == 0) return 0;
+    if (narr > 16) return fail(c, OFDFT_EINVAL, "too many spectra in one exchange (%d)", narr);
+    ArrList arrs{};
+    for (int a = 0; a < narr; ++a) arrs.p[a] = list[a];
+    c->ypass_count += narr;
+#define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st);
+    switch (c->n1) {
+        OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
+        OFDFT_CASE(1024)
+    }
+#undef OFDFT_CASE
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
+}
+
+template <int M>
+int launch_zfwd_t(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = get_twiddle(c, M, &twM)) return rc;
+    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
+    if constexpr ((M & (M - 1)) == 0) {
+        using Cfg = ZCfg<M>;
+        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_kernel<M, PreIdentity>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, in, spec, c->g, twM,
+                           twN, PreIdentity());
+    } else {          // rows with factors 3 / 5: the wave-local z pass (zpass.h)
+        using W = ZW<M, ZPick<M, 8>::E>;
+        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
+        OFDFT_LAUNCH(c, st, "zfwd", (zfwd_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, in, spec, c->g, (const cplx*)twM,
+                     (const cplx*)twN);
+    }
+    return 0;
+}
+template <int M>
+int launch_zinv_t(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = get_twiddle(c, M, &twM)) return rc;
+    if (int rc = get_twiddle(c, 2 * M, &twN)) return rc;
+    if constexpr ((M & (M - 1)) == 0) {
+        using Cfg = ZCfg<M>;
+        const int blocks = (int)((c->g.nrows + Cfg::RPW - 1) / Cfg::RPW);
+        PostScale post{(real)scale};
+        OFDFT_LAUNCH(c, st, "zinv", (zinv_kernel<M, PostScale>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, out, c->g, twM,
+                           twN, post);
+    } else {
+        using W = ZW<M, ZPick<M, 8>::E>;
+        const int blocks = (int)((c->g.nrows + W::RPB - 1) / W::RPB);
+        OFDFT_LAUNCH(c, st, "zinv", (zinv_w_kernel<M, W::E>), dim3(blocks), dim3(256), W::LDS, spec, out, c->g, (const cplx*)twM,
+                     (const cplx*)twN, (real)scale);
+    }
+    return 0;
+}
+// dispatch on the half length of the z rows
+int zfwd_any(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+#define X(M_) case M_: return launch_zfwd_t<M_>(c, in, spec, st);
+    switch (c->n2 / 2) {
+        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+        OFDFT_MIXED_ROWS(X)
+    }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+int zinv_any(ofdft_ctx* c, const cplx* spec, real* out, double scale, hipStream_t st) {
+#define X(M_) case M_: return launch_zinv_t<M_>(c, spec, out, scale, st);
+    switch (c->n2 / 2) {
+        X(8) X(16) X(32) X(64) X(128) X(256) X(512) X(1024)
+        OFDFT_MIXED_ROWS(X)
+    }
+#undef X
+    return fail(c, OFDFT_EINVAL, "bad n2");
+}
+
+int gen_axis(ofdft_ctx* c, int axis, int inv, cplx*& cur, cplx*& other, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, axis == 0 ? c->n0 : c->n1, &tw)) return rc;
+    OFDFT_LAUNCH(c, st, "gen_c2c", gen_c2c_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, cur, other, c->g,
+                       axis, inv, tw);
+    std::swap(cur, other);
+    return 0;
+}
+
+// ---- Bluestein tables (bluestein.h): chirp w_n = exp(-i pi n^2 / N) and the filter spectrum FFT_M(conj w, wrapped) / M
+struct BsTables { cplx *chirp = nullptr, *filt = nullptr; int M = 0; };
+
+int bluestein_pad(int N) {
+    int M = 8;
+    while (M < 2 * N - 1) M *= 2;
+    return M;
+}
+
+int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
+    const std::string key = "bs:" + std::to_string(N);
+    const int M = bluestein_pad(N);
+    out->M = M;
+    auto it = c->ws.find(key);
+    if (it != c->ws.end()) {
+        out->chirp = (cplx*)it->second.p;
+        out->filt = out->chirp + N;
+        return 0;
+    }
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<cplx> h((size_t)N + M);
+    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+    for (int n = 0; n < N; ++n) {
+        const long long r = ((long long)n * n) % (2LL * N);          // n^2 mod 2N keeps the angle small and exact
+        const long double ph = -pi * (long double)r / (long double)N;
+        const long double cr = cosl(ph), ci = sinl(ph);
+        h[n] = mkc((double)cr, (double)ci);
+        br[n] = cr;
+        bi[n] = -ci;                                                   // b_n = conj(w_n), b_{-n} = b_n
+        if (n) {
+            br[M - n] = cr;
+            bi[M - n] = -ci;
+        }
+    }
+    // FFT_M(b) / M by a direct O(M^2) sum in extended precision (once per length; M <= 1024)
+    std::vector<long double> cs(M), sn(M);
+    for (int m = 0; m < M; ++m) {
+        cs[m] = cosl(-2.0L * pi * m / M);
+        sn[m] = sinl(-2.0L * pi * m / M);
+    }
+    for (int k = 0; k < M; ++k) {
+        long double sr = 0.0L, si = 0.0L;
+        for (int n = 0; n < M; ++n) {
+            if (br[n] == 0.0L && bi[n] == 0.0L) continue;
+            const int t = (int)(((long long)k * n) % M);
+            sr += br[n] * cs[t] - bi[n] * sn[t];
+            si += br[n] * sn[t] + bi[n] * cs[t];
+        }
+        h[N + k] = mkc((double)(sr / M), (double)(si / M));
+    }
+    cplx* d;
+    if (int rc = get_ws(c, key.c_str(), sizeof(cplx) * h.size(), (void**)&d)) return rc;
+    HIP_TRY(c, hipMemcpy(d, h.data(), sizeof(cplx) * h.size(), hipMemcpyHostToDevice));
+    out->chirp = d;
+    out->filt = d + N;
+    return 0;
+}
+
+template <int M>
+int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const real* rin, real* rout, const BsArgs& b, const BsTables& t,
+                       hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, M, &tw)) return rc;
+    using Cfg = PassCfg<M>;
+    const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
+    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, rin, rout, c->g, b,
+                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
+    return 0;
+}
+
+// one generic-length pass: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
+int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const real* rin, real* rout, double scale,
+                   hipStream_t st) {
+    const int N = mode == 0 ? (axis == 0 ? c->n0 : c->n1) : c->n2;
+    BsTables t;
+    if (int rc = get_bluestein(c, N, &t)) return rc;
+    BsArgs b{};
+    b.N = N;
+    b.mode = mode;
+    b.axis = axis;
+    b.inv = inv;
+    b.scale = scale;
+    b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : c->g.nrows;
+    switch (t.M) {
+        case 8: return launch_bluestein_t<8>(c, spec, rin, rout, b, t, st);
+        case 16: return launch_bluestein_t<16>(c, spec, rin, rout, b, t, st);
+        case 32: return launch_bluestein_t<32>(c, spec, rin, rout, b, t, st);
+        case 64: return launch_bluestein_t<64>(c, spec, rin, rout, b, t, st);
+        case 128: return launch_bluestein_t<128>(c, spec, rin, rout, b, t, st);
+        case 256: return launch_bluestein_t<256>(c, spec, rin, rout, b, t, st);
+        case 512: return launch_bluestein_t<512>(c, spec, rin, rout, b, t, st);
+        case 1024: return launch_bluestein_t<1024>(c, spec, rin, rout, b, t, st);
+    }
+    return fail(c, OFDFT_EINVAL, "no Bluestein plan for length %d", N);
+}
+
+bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
+
+// ---- slab-decomposed 3-D transforms for the per-geometry-step routines (stress, ionic potential, forces): a real x-slab
+// [n0/P][n1][n2] <-> the y-slab of the half spectrum in the block-8 layout of the x-pass geometry (c->gx: all of x, n1/P of
+// y), which is what every k-space kernel of those routines indexes (kvec / spec_decode with kg.g = gx, kg.y0).  One
+// all-to-all per transform through the host's collective (ofdft_set_collectives); the y pass reads / writes the exchange
+// layout directly, a small kernel converts between it and the block-8 y-slab array.
+static __global__ void xchg_unpack_kernel(const cplx* __restrict__ buf, cplx* __restrict__ spec, SpecGeom gx, XchgGeom xg, int pack) {
+    // record of x: [ main (b, yl, kin) | planes (plane, yl) ], one array per record
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < gx.total; i += (long long)gridDim.x * blockDim.x) {
+        int x, yl, kz;
+        spec_decode(gx, i, x, yl, kz);
+        const long long r = (long long)x * xg.arr_sz +
+                            (kz < gx.nzm ? (((long long)(kz >> 3) * xg.nyl + yl) * 8 + (kz & 7))
+                                         : ((long long)xg.nb * xg.nyl * 8 + (long long)(kz - gx.nzm) * xg.nyl + yl));
+        if (pack) const_cast<cplx*>(buf)[r] = spec[i];
+        else spec[i] = buf[r];
+    }
+}
+static int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
+static int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
+
+// real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
+int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+    c->fft_count++;
+    if (c->nranks > 1) return dist_rfftn(c, in, spec, st);
+    if (c->fast) {
+        int rc = zfwd_any(c, in, spec, st);
+        if (rc) return rc;
+        if ((rc = fast_axis_pass<false>(c, 1, spec, st))) return rc;
+        return fast_axis_pass<false>(c, 0, spec, st);
+    }
+    if (bluestein_ok(c)) {        // arbitrary extents: chirp-z line transforms, in place
+        if (int rc = bluestein_pass(c, 1, 2, 0, spec, in, nullptr, 1.0, st)) return rc;
+        if (int rc = bluestein_pass(c, 0, 1, 0, spec, nullptr, nullptr, 1.0, st)) return rc;
+        return bluestein_pass(c, 0, 0, 0, spec, nullptr, nullptr, 1.0, st);
+    }
+    cplx *tw2, *tmp;
+    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
+    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
+    // z into tmp, y: tmp -> spec, x: spec -> tmp, then copy back (two swaps leave the result in tmp)
+    OFDFT_LAUNCH(c, st, "gen_r2c_z", gen_r2c_z_kernel, dim3((unsigned)((c->g.total + 255) / 256)), dim3(256), 0, in, spec, c->g, tw2);
+    cplx *cur = spec, *other = tmp;
+    if (int rc = gen_axis(c, 1, 0, cur, other, st)) return rc;
+    if (int rc = gen_axis(c, 0, 0, cur, other, st)) return rc;
+    if (cur != spec) HIP_TRY(c, hipMemcpyAsync(spec, cur, sizeof(cplx) * c->g.total, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// internal half spectrum (destroyed) -> real, scaled by `scale` (1/N for irfftn semantics)
+int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
+    c->fft_count++;
+    if (c->nranks > 1) return dist_irfftn(c, spec, out, scale, st);
+    if (c->fast) {
+        int rc;
+        if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;
+        if ((rc = fast_axis_pass<true>(c, 1, spec, st))) return rc;
+        return zinv_any(c, spec, out, scale, st);
+    }
+    if (bluestein_ok(c)) {
+        if (int rc = bluestein_pass(c, 0, 0, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
+        if (int rc = bluestein_pass(c, 0, 1, 1, spec, nullptr, nullptr, 1.0, st)) return rc;
+        return bluestein_pass(c, 2, 2, 1, spec, nullptr, out, scale, st);
+    }
+    cplx *tw2, *tmp;
+    if (int rc = get_twiddle(c, c->n2, &tw2)) return rc;
+    if (int rc = spec_ws(c, "gen_tmp", &tmp)) return rc;
+    cplx *cur = spec, *other = tmp;
+    if (int rc = gen_axis(c, 0, 1, cur, other, st)) return rc;
+    if (int rc = gen_axis(c, 1, 1, cur, other, st)) return rc;
+    PostScale post{(real)scale};
+    OFDFT_LAUNCH(c, st, "gen_c2r_z", (gen_c2r_z_kernel<PostScale>), dim3((unsigned)((c->npts + 255) / 256)), dim3(256), 0, cur, out,
+                       c->g, tw2, post);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------- fused-pipeline pieces
+// z-forward + y-forward (the x transform is left to the fused x pass)
+int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+    c->fft_count++;
+    int rc = zfwd_any(c, in, spec, st);
+    if (rc) return rc;
+    return fast_axis_pass<false>(c, 1, spec, st);
+}
+
+// y-inverse + z-inverse (c2r) of a spectrum whose x axis is already back in real space
+int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
+    c->fft_count++;
+    if (int rc = fast_axis_pass<true>(c, 1, spec, st)) return rc;
+    return zinv_any(c, spec, out, scale, st);
+}
+
+static int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
+    cplx *send, *recv, *tmp;
+    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
+    int rc = zfwd_any(c, in, tmp, st);          // z-forward of the local rows into the x-slab layout
+    if (rc) return rc;
+    if ((rc = ypass_xchg<false>(c, {tmp}, send, st))) return rc;           // y-forward, written in the exchange layout
+    if ((rc = dist_exchange(c, send, recv, st))) return rc;
+    XchgGeom xg = c->xg;
+    xg.rec = xg.arr_sz;
+    OFDFT_LAUNCH(c, st, "xchg_unpack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)recv, spec, c->gx, xg, 0);
+    return fast_axis_pass<false>(c, 0, spec, st);                           // x-forward on the y-slab
+}
+
+static int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st) {
+    cplx *send, *recv, *tmp;
+    if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
+    if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
+    int rc;
+    if ((rc = fast_axis_pass<true>(c, 0, spec, st))) return rc;             // x-inverse on the y-slab
+    XchgGeom xg = c->xg;
+    xg.rec = xg.arr_sz;
+    OFDFT_LAUNCH(c, st, "xchg_pack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)send, spec, c->gx, xg, 1);
+    if ((rc = dist_exchange(c, send, recv, st))) return rc;
+    if ((rc = ypass_xchg<true>(c, {tmp}, recv, st))) return rc;             // y-inverse out of the exchange layout
+    return zinv_any(c, tmp, out, scale, st);
+}
+
+
+// index derivative along y of an x-slab spectrum in (kz; y, x) form, in one pass (fft_kernels.h: yderiv_kernel)
+template <int LEN>
+int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    using Cfg = PassCfg<LEN>;
+    LineMap main, rem;
+    pass_maps(c, 1, main, rem);
+    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, "yderiv", (yderiv_kernel<LEN>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, in, out, main, rem, mb,
+                 c->g.main_count, (const cplx*)tw, scale);
+    return 0;
+}
+int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+    switch (c->n1) {
+        case 8: return launch_yderiv_t<8>(c, in, out, scale, st);
+        case 16: return launch_yderiv_t<16>(c, in, out, scale, st);
+        case 32: return launch_yderiv_t<32>(c, in, out, scale, st);
+        case 64: return launch_yderiv_t<64>(c, in, out, scale, st);
+        case 128: return launch_yderiv_t<128>(c, in, out, scale, st);
+        case 256: return launch_yderiv_t<256>(c, in, out, scale, st);
+        case 512: return launch_yderiv_t<512>(c, in, out, scale, st);
+        case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st);
+#define X(L) case L: return launch_yderiv_t<L>(c, in, out, scale, st);
+        OFDFT_MIXED_LINES(X)
+#undef X
+    }
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);
+}
+
+
+template int fast_axis_pass_multi<false>(ofdft_ctx*, int, cplx* const*, int, hipStream_t, int, int, int, int);
+template int fast_axis_pass_multi<true>(ofdft_ctx*, int, cplx* const*, int, hipStream_t, int, int, int, int);
+template int fast_axis_pass<false>(ofdft_ctx*, int, cplx*, hipStream_t);
+template int fast_axis_pass<true>(ofdft_ctx*, int, cplx*, hipStream_t);
+template int ypass_xchg<false>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t);
+template int ypass_xchg<true>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t);
+
+}  // namespace eng

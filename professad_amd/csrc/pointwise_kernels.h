@@ -62,7 +62,7 @@ __device__ __forceinline__ void block_reduce_store(acc_t (&acc)[NS], acc_t* __re
 }
 
 // second level: partial[rows][ns] -> out[ns], fixed summation order (bitwise reproducible)
-__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const acc_t* __restrict__ partial, int rows, int ns,
+static __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const acc_t* __restrict__ partial, int rows, int ns,
                                                                       acc_t* __restrict__ out) {
     const int s = blockIdx.x;
     acc_t acc[1] = {0.0};
@@ -110,7 +110,7 @@ __global__ void map_kernel(const real* __restrict__ a, real* __restrict__ out, l
 }
 
 // WGC99 real-space inputs: A = n^e, B = A theta, C = A theta^2 / 2 (functionals.py:974-981)
-__global__ void wgc_prep_kernel(const real* __restrict__ n, real* __restrict__ A, real* __restrict__ B,
+static __global__ void wgc_prep_kernel(const real* __restrict__ n, real* __restrict__ A, real* __restrict__ B,
                                 real* __restrict__ C, long long npts, real expo, real nref) {
     const long long n2 = npts >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
@@ -176,7 +176,7 @@ __global__ void spec_scale_kernel(const cplx* __restrict__ in, cplx* __restrict_
 }
 
 // acc += f * k^2 * in   (adds -f * Laplacian in reciprocal space)
-__global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restrict__ acc, KGeom kg, real f) {
+static __global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restrict__ acc, KGeom kg, real f) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
         real kx, ky, kz, k2;
         kvec(kg, i, kx, ky, kz, k2);
@@ -186,7 +186,7 @@ __global__ void spec_add_lap_kernel(const cplx* __restrict__ in, cplx* __restric
 }
 
 // g_j = i k_j * in (functional_tools.py:183)
-__global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__ gx, cplx* __restrict__ gy,
+static __global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__ gx, cplx* __restrict__ gy,
                                  cplx* __restrict__ gz, KGeom kg) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
         real kx, ky, kz, k2;
@@ -199,7 +199,7 @@ __global__ void spec_grad_kernel(const cplx* __restrict__ in, cplx* __restrict__
 }
 
 // out = sum_j i k_j f_j
-__global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* __restrict__ fy, const cplx* __restrict__ fz,
+static __global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* __restrict__ fy, const cplx* __restrict__ fz,
                                 cplx* __restrict__ out, KGeom kg) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < kg.g.total; i += (long long)gridDim.x * blockDim.x) {
         real kx, ky, kz, k2;
@@ -210,7 +210,7 @@ __global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* __restr
 }
 
 // WGC99 spectral mixing, in place: (A,B,C) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A)   SURVEY §8a-8
-__global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, cplx* __restrict__ C,
+static __global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, cplx* __restrict__ C,
                                     const real* __restrict__ w0, const real* __restrict__ K1,
                                     const real* __restrict__ K2, const real* __restrict__ K3, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, doubl
     w3 = THIRD ? H3 + P3 / (eta * eta * eta) : 0.0;
 }
 
-__global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict__ K1o, real* __restrict__ K2o,
+static __global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict__ K1o, real* __restrict__ K2o,
                                  real* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
     for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < kg.g.total; ii += (long long)gridDim.x * blockDim.x) {
         real kx, ky, kz, k2;
@@ -638,7 +638,7 @@ __device__ __forceinline__ void pg_laplacian_point(real n, real gn2, real lap, c
 }
 
 // PBE mid stage: grad n -> energy partials (x, c), df/dn, flux_j = df/dg * grad_j n (in place)
-__global__ __launch_bounds__(kRedThreads) void pbe_kernel(const real* __restrict__ n, real* __restrict__ gx,
+static __global__ __launch_bounds__(kRedThreads) void pbe_kernel(const real* __restrict__ n, real* __restrict__ gx,
                                                           real* __restrict__ gy, real* __restrict__ gz,
                                                           real* __restrict__ dfdn, long long npts, GgaSel sel,
                                                           acc_t* __restrict__ partial, real* __restrict__ lapn = nullptr) {
@@ -809,7 +809,7 @@ __device__ __forceinline__ real combine_point(const CombineArgs& a, const Combin
 // Every array pointer in CombineArgs is valid (the host points unused ones at `n`), so all loads of an
 // iteration are issued together as 16-byte loads ahead of the arithmetic instead of one dependent load
 // per term behind a branch.
-__global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc_t* __restrict__ partial) {
+static __global__ __launch_bounds__(kRedThreads) void combine_kernel(CombineArgs a, acc_t* __restrict__ partial) {
     const real ctf = kCtf;   // 0.3 (3 pi^2)^(2/3)
     acc_t acc[kCombineScalars];
 #pragma unroll
@@ -846,14 +846,14 @@ __global__ void axpy_kernel(const T* __restrict__ x, T* __restrict__ y, long lon
 
 // chi.grad = c * 2 chi (v - mu) dV   (system.py:850-853)
 // c = N_e / (mean(chi^2) vol) from the reduced sum of chi^2, left on the device (system.py:833-834)
-__global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc_t* __restrict__ cscale, acc_t n_elec,
+static __global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc_t* __restrict__ cscale, acc_t n_elec,
                                      acc_t vol_over_npts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
 }
 
 // Stabilised Wang-Teter style functional T_TF f(X), X = T_NL / T_TF, f = exp (functionals.py:771-782): weights of the two
 // potentials from the reduced sums of a first (energy-only) combine pass ...
-__global__ void wts_weights_kernel(const acc_t* __restrict__ sums, acc_t* __restrict__ w) {
+static __global__ void wts_weights_kernel(const acc_t* __restrict__ sums, acc_t* __restrict__ w) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const acc_t X = sums[4] / sums[2], fx = ::exp(X);
         w[0] = fx * (1.0 - X);      // f - f' X
@@ -862,14 +862,14 @@ __global__ void wts_weights_kernel(const acc_t* __restrict__ sums, acc_t* __rest
     }
 }
 // ... and the reported sums after the second pass: [2] <- T_TF f(X), [4] <- 0
-__global__ void wts_finalize_kernel(acc_t* __restrict__ sums, const acc_t* __restrict__ w) {
+static __global__ void wts_finalize_kernel(acc_t* __restrict__ sums, const acc_t* __restrict__ w) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         sums[2] *= w[2];
         sums[4] = 0.0;
     }
 }
 
-__global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
+static __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
                                 long long npts, real c2dV_host, const acc_t* __restrict__ cscale_dev, real two_dV,
                                 real mu_host, const acc_t* __restrict__ vn_dev = nullptr, acc_t dV = 0.0, acc_t n_elec = 1.0) {
     const real c2dV = cscale_dev ? (real)(cscale_dev[0] * two_dV) : c2dV_host;

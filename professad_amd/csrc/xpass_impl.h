@@ -1,0 +1,107 @@
+// Launchers of the fused x passes (xfused_kernel in fft_kernels.h, xw_kernel in xwave.h): included by xpass_a.hip and
+// xpass_b.hip, which instantiate them for the mix functors of the pipelines.
+#pragma once
+#include "engine_ctx.h"
+
+namespace eng {
+
+template <int LEN, int NIN, int NOUT, class Mix>
+int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
+    constexpr int G = NIN > NOUT ? NIN : NOUT;
+    using Cfg = XfCfg<LEN, G, NOUT>;
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    LineMap main, rem;
+    SpecGeom gk = c->gx;
+    if (lay.se_in) {
+        const int nyl = c->xg.nyl;
+        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
+        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
+        if (main.nlines == 0) main.d = 1;
+        if (rem.nlines == 0) rem.d = 1;
+        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
+    } else {
+        pass_maps(c, 0, main, rem);
+    }
+    main.lf = rem.lf = Cfg::LPW;
+    int line0 = 0;
+    if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
+        const int per_block = c->gx.n1 * 8;
+        line0 = lay.kb0 * per_block;
+        main.nlines = lay.kb1 * per_block;
+        if (lay.kb1 != c->gx.nzm / 8) rem.nlines = 0;
+    }
+    main.blk0 = line0 / Cfg::LPW;
+    const int mb = (main.nlines - line0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (xfused_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb,
+                 gk, tw, mix, XfStride{lay.se_out, lay.tse});
+    return 0;
+}
+
+// the wave-local form of the same pass (xwave.h): a line of every spectrum in the lanes of one wave, mix in registers
+template <int LEN, int NIN, int NOUT, class Mix>
+int launch_xw_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& lay, hipStream_t st, const char* nm) {
+    using Cfg = XwCfg<LEN>;
+    cplx* tw;
+    if (int rc = get_twiddle(c, LEN, &tw)) return rc;
+    LineMap main, rem;
+    SpecGeom gk = c->gx;
+    if (lay.se_in) {
+        const int nyl = c->xg.nyl;
+        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
+        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
+        if (main.nlines == 0) main.d = 1;
+        if (rem.nlines == 0) rem.d = 1;
+        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
+    } else {
+        pass_maps(c, 0, main, rem);
+    }
+    main.lf = rem.lf = Cfg::LPB;
+    int line0 = 0;
+    if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
+        const int per_block = c->gx.n1 * 8;
+        if (per_block % Cfg::LPB) return fail(c, OFDFT_EINVAL, "kz-range x pass needs whole workgroups per kz block");
+        line0 = lay.kb0 * per_block;
+        main.nlines = lay.kb1 * per_block;
+        if (lay.kb1 != c->gx.nzm / 8) rem.nlines = 0;
+    }
+    main.blk0 = line0 / Cfg::LPB;
+    const int mb = (main.nlines - line0 + Cfg::LPB - 1) / Cfg::LPB, rb = (rem.nlines + Cfg::LPB - 1) / Cfg::LPB;
+    OFDFT_LAUNCH(c, st, nm, (xw_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb, gk,
+                 (const cplx*)tw, mix, XfStride{lay.se_out, lay.tse});
+    return 0;
+}
+
+// forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
+template <int NIN, int NOUT, class Mix>
+int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay) {
+    // measured at 256^3 (A/B on one box): 3 -> 3 (WGC99) 0.55 -> 0.53 ms, 1 -> 2 0.112 -> 0.097 ms, but 1 -> 1 0.062 -> 0.079 ms
+    if (c->use_xwave == 2 || (c->use_xwave == 1 && NIN + NOUT >= 3)) {
+        switch (c->n0g) {
+            case 8: return launch_xw_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 16: return launch_xw_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 32: return launch_xw_t<32, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 64: return launch_xw_t<64, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 128: return launch_xw_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 256: return launch_xw_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            case 512: return launch_xw_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        }
+    }
+    switch (c->n0g) {
+        case 8: return launch_xfused_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 16: return launch_xfused_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 32: return launch_xfused_t<32, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 64: return launch_xfused_t<64, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 128: return launch_xfused_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 256: return launch_xfused_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 512: return launch_xfused_t<512, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        case 1024: return launch_xfused_t<1024, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+#define X(L) case L: return launch_xfused_t<L, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        OFDFT_MIXED_LINES(X)
+#undef X
+    }
+    return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
+}
+
+
+}  // namespace eng
