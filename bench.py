@@ -239,7 +239,9 @@ def main():
     box, chi_full, vext_full, n_elec, src = make_inputs(n, 0)
     chi_h, vext_h = chi_full, vext_full
     if world > 1:
-        eng = DistEngine((n, n, n), device, dtype=tdtype).set_cell(torch.as_tensor(box)).set_terms(names)
+        # OFDFT_BENCH_TRANSPORT=ipc: the library's own peer-copy exchange instead of host-issued RCCL all-to-alls
+        transport = os.environ.get('OFDFT_BENCH_TRANSPORT', 'collective')
+        eng = DistEngine((n, n, n), device, dtype=tdtype, transport=transport).set_cell(torch.as_tensor(box)).set_terms(names)
         xs = eng.plan.x_range()
         chi_h, vext_h = np.ascontiguousarray(chi_h[xs]), np.ascontiguousarray(vext_h[xs])
         raw = eng.stages
@@ -370,7 +372,9 @@ def main():
                    if a.cfg == 'cfg3' else '%d^3 grid, %s, IonElectron+Hartree+WT(+TF+vW)+PZ-LDA closure' % (n, a.dtype),
                    'grid': [n, n, n], 'terms': names, 'density': src,
                    'parallelism': 'single GPU' if world == 1 else
-                   'x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world},
+                   ('x-slab decomposition over %d GPUs, 6 RCCL all-to-alls (two overlapped chains) + 2 small all-reduces per evaluation' % world)
+                   if os.environ.get('OFDFT_BENCH_TRANSPORT', 'collective') == 'collective' else
+                   ('x-slab decomposition over %d GPUs, library-issued peer copies over hipIpc mappings (6 exchanges, two overlapped chains) + 2 mailbox reductions per evaluation, no collective call' % world)},
         'roofline': roofline,
         'eval_roofline': {'alg_bytes_per_eval': alg, 'achieved_GBs_per_gpu': round(eval_gbs, 1),
                           'frac_of_peak': round(eval_gbs / HBM_PEAK_GBS, 4), 'measured_copy_GBs': round(copy_gbs, 1),

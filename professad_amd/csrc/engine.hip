@@ -128,7 +128,9 @@ int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
     if (narr < 1) narr = 1;
     const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
     if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
-    return get_ws(c, chain == 0 ? "x:recv0" : "x:recv1", bytes, (void**)recv);
+    // (the ipc transport alternates between two receive buffers per chain: peers deliver stage k + 1 while stage k is still read)
+    const char* rn[2][2] = {{"x:recv0", "x:recv0b"}, {"x:recv1", "x:recv1b"}};
+    return get_ws(c, rn[chain][c->recv_parity[chain]], bytes, (void**)recv);
 }
 
 
@@ -154,6 +156,7 @@ namespace {
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
 void graph_drop(ofdft_ctx* c);
+void ipc_release(ofdft_ctx* c);
 
 // ---------------------------------------------------------------------------------- reductions
 // copy `rows` x `ns` partials to the host and sum them in a fixed order
@@ -755,6 +758,7 @@ void ofdft_destroy(ofdft_ctx* c) {
     if (!c) return;
     DeviceScope device_scope_(c->device);
     graph_drop(c);
+    ipc_release(c);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->ws)
@@ -1044,6 +1048,8 @@ int ofdft_debug_math(ofdft_ctx* c, int kind, const void* in_dev, void* out_dev, 
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
+
+#include "ipc_exchange.inc.h"
 
 // ------------------------------------------------------------------------------ slab-decomposed (multi-GPU) API
 int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* local_sum, void* stream) {

@@ -101,6 +101,9 @@ struct ofdft_ctx {
     long long graph_replays = 0;
     hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
     // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
+    // direct peer-store exchange (ofdft_ipc_*): peers' receive buffers / mailboxes mapped through hipIpc, no host in the loop
+    struct ofdft_ipc_state* ipc = nullptr;
+    int recv_parity[2] = {0, 0};       // which of a chain's two receive buffers the next stage reads (0 unless the ipc transport flips it)
     ofdft_all_to_all_fn a2a = nullptr;
     ofdft_all_reduce_fn allreduce = nullptr;
     void* coll_user = nullptr;

@@ -1,0 +1,295 @@
+// Direct peer-store exchange of the slab-decomposed hot path (included by engine.hip inside its extern "C" block).
+//
+// The staged API (ofdft_dist_begin / _stage / _finish) leaves the all-to-alls to the host: six collectives and a dozen
+// ctypes calls per evaluation from Python.  Here the library does the whole evaluation in ONE call and moves the data
+// itself over the fully connected xGMI mesh of an MI355X node: every rank maps every peer's receive buffers and mailbox
+// through hipIpc (handles travel once, at set-up, through whatever the host has: ofdft_ipc_export / ofdft_ipc_attach), then
+//   * a stage's spectra go straight from the local send buffer into chunk [me] of each peer's receive buffer by
+//     device-to-device copies enqueued on the chain's stream (peer p's copy runs over the direct link me <-> p);
+//   * behind its copies a rank stamps the evaluation's epoch into word [chain][me] of each peer's mailbox;
+//   * the consumer's stream runs a one-wave kernel that waits (bounded) until every peer's word has reached the epoch.
+// Two receive buffers per chain alternate, so a peer may deliver stage k + 1 while stage k is still being read.  The two
+// small all-reduces (sum chi^2; the 13 energy sums) use the same mailboxes: every rank posts its numbers to every peer and
+// sums the P contributions in rank order -- bitwise the same on all ranks.  One host synchronisation per evaluation.
+// Nothing here is specific to separate GPUs: ranks sharing one GPU (tests) map each other's buffers the same way.
+}  // extern "C"
+
+struct ofdft_ipc_state {
+    int P = 0, me = 0;
+    // exported / attached objects: 0..3 = receive buffers (chain 0 a / b, chain 1 a / b), 4 = mailbox
+    void* peer[5][16] = {};            // peer[w][p]: rank p's object w in THIS process' address space (p == me: the local pointer)
+    bool opened[5][16] = {};
+    size_t bytes[5] = {};              // size the exported buffers had (re-export when a set_terms grows them)
+    // mailbox layout (this rank's copy): flags [3 kinds][16 ranks] u32 | sums [2 kinds][16 ranks][16] f64
+    unsigned* flags = nullptr;
+    double* sums = nullptr;
+    unsigned epoch[3] = {0, 0, 0};     // per kind: chain 0, chain 1, all-reduce
+    unsigned* d_stamp = nullptr;       // device scratch: the epoch values the flag copies read
+    int* d_err = nullptr;              // set by a wait that ran out of patience
+    int* h_err = nullptr;
+    hipStream_t side = nullptr;        // chain 1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+namespace {
+
+constexpr size_t kIpcFlagWords = 3 * 16, kIpcSumDoubles = 2 * 16 * 16;
+constexpr size_t kIpcMailboxBytes = kIpcFlagWords * sizeof(unsigned) + 64 + kIpcSumDoubles * sizeof(double);
+
+void ipc_release(ofdft_ctx* c) {
+    ofdft_ipc_state* s = c->ipc;
+    if (!s) return;
+    for (int w = 0; w < 5; ++w)
+        for (int p = 0; p < 16; ++p)
+            if (s->opened[w][p] && s->peer[w][p]) (void)hipIpcCloseMemHandle(s->peer[w][p]);
+    if (s->flags) (void)hipFree(s->flags);
+    if (s->d_stamp) (void)hipFree(s->d_stamp);
+    if (s->d_err) (void)hipFree(s->d_err);
+    if (s->h_err) (void)hipHostFree(s->h_err);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    delete s;
+    c->ipc = nullptr;
+}
+
+// one wave: lane p waits until rank p's word has reached `epoch` (relaxed system-scope loads: the words are written by
+// other ranks' copy engines / kernels); every lane leaves after ~4 s at the latest and reports through err
+__global__ void ipc_wait_kernel(const unsigned* flags, int P, int me, unsigned epoch, int* err) {
+    const int p = threadIdx.x;
+    if (p >= P || p == me) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+    while ((int)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ULL) {
+            *err = 1 + p;
+            return;
+        }
+    }
+}
+__global__ void ipc_stamp_kernel(unsigned* stamp, unsigned e0, unsigned e1, unsigned e2) {
+    if (threadIdx.x == 0) {
+        stamp[0] = e0;
+        stamp[1] = e1;
+        stamp[2] = e2;
+    }
+}
+// out[i] = sum over ranks (in rank order) of slots[p][i]
+__global__ void ipc_sum_kernel(const double* slots, int P, int n, double* out) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    double t = 0.0;
+    for (int p = 0; p < P; ++p) t += slots[p * 16 + i];
+    out[i] = t;
+}
+
+int ipc_state(ofdft_ctx* c, ofdft_ipc_state** out) {
+    if (!c->ipc) {
+        ofdft_ipc_state* s = new (std::nothrow) ofdft_ipc_state();
+        if (!s) return fail(c, OFDFT_ENOMEM, "out of host memory");
+        s->P = c->nranks;
+        s->me = c->rank;
+        c->ipc = s;
+        void* mb = nullptr;
+        HIP_TRY(c, hipMalloc(&mb, kIpcMailboxBytes));
+        HIP_TRY(c, hipMemset(mb, 0, kIpcMailboxBytes));
+        s->flags = (unsigned*)mb;
+        s->sums = (double*)((char*)mb + kIpcFlagWords * sizeof(unsigned) + 64);
+        HIP_TRY(c, hipMalloc((void**)&s->d_stamp, 64));
+        HIP_TRY(c, hipMalloc((void**)&s->d_err, sizeof(int)));
+        HIP_TRY(c, hipMemset(s->d_err, 0, sizeof(int)));
+        HIP_TRY(c, hipHostMalloc((void**)&s->h_err, sizeof(int)));
+        HIP_TRY(c, hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        s->peer[4][s->me] = mb;
+    }
+    *out = c->ipc;
+    return 0;
+}
+
+// the local object `what` (allocating the exchange buffers at the size the active terms need)
+int ipc_local(ofdft_ctx* c, int what, void** ptr, size_t* bytes) {
+    ofdft_ipc_state* s;
+    if (int rc = ipc_state(c, &s)) return rc;
+    if (what == 4) {
+        *ptr = s->peer[4][s->me];
+        *bytes = kIpcMailboxBytes;
+        return 0;
+    }
+    const int chain = what / 2, par = what % 2;
+    const int keep = c->recv_parity[chain];
+    cplx *send, *recv;
+    c->recv_parity[chain] = par;
+    const int rc = dist_buffers(c, chain, &send, &recv);
+    c->recv_parity[chain] = keep;
+    if (rc) return rc;
+    *ptr = recv;
+    *bytes = c->ws[std::string(chain == 0 ? (par ? "x:recv0b" : "x:recv0") : (par ? "x:recv1b" : "x:recv1"))].bytes;
+    s->peer[what][s->me] = recv;
+    s->bytes[what] = *bytes;
+    return 0;
+}
+
+// spectra of one stage: send buffer -> chunk [me] of every rank's receive buffer of the OTHER parity, epoch stamps behind
+// them, then the bounded wait for every peer's stamp; flips the chain's parity (the next stage reads what was delivered)
+int ipc_exchange(ofdft_ctx* c, int chain, cplx* send, size_t bytes_per_peer, hipStream_t st) {
+    ofdft_ipc_state* s = c->ipc;
+    const int next = c->recv_parity[chain] ^ 1, w = 2 * chain + next;
+    for (int p = 0; p < s->P; ++p) {
+        if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: receive buffer %d of rank %d is not attached", w, p);
+        HIP_TRY(c, hipMemcpyAsync((char*)s->peer[w][p] + (size_t)s->me * bytes_per_peer, (const char*)send + (size_t)p * bytes_per_peer,
+                                  bytes_per_peer, hipMemcpyDeviceToDevice, st));
+    }
+    const unsigned e = ++s->epoch[chain];
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, s->d_stamp + 4 * chain, e, e, e);
+    for (int p = 0; p < s->P; ++p)
+        if (p != s->me)
+            HIP_TRY(c, hipMemcpyAsync((unsigned*)s->peer[4][p] + chain * 16 + s->me, s->d_stamp + 4 * chain, sizeof(unsigned),
+                                      hipMemcpyDeviceToDevice, st));
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + chain * 16), s->P, s->me, e,
+                 s->d_err);
+    c->recv_parity[chain] = next;
+    return 0;
+}
+
+// all ranks' `n` doubles at `src` (device) summed in rank order into `dst` (device); kind 0 / 1 = the two reductions
+int ipc_allreduce(ofdft_ctx* c, int kind, const double* src, int n, double* dst, hipStream_t st) {
+    ofdft_ipc_state* s = c->ipc;
+    const size_t off = kIpcFlagWords * sizeof(unsigned) + 64 + sizeof(double) * ((size_t)kind * 256 + (size_t)s->me * 16);
+    for (int p = 0; p < s->P; ++p)
+        HIP_TRY(c, hipMemcpyAsync((char*)s->peer[4][p] + off, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    const unsigned e = ++s->epoch[2];
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, s->d_stamp + 8, e, e, e);
+    for (int p = 0; p < s->P; ++p)
+        if (p != s->me)
+            HIP_TRY(c, hipMemcpyAsync((unsigned*)s->peer[4][p] + 2 * 16 + s->me, s->d_stamp + 8, sizeof(unsigned),
+                                      hipMemcpyDeviceToDevice, st));
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + 2 * 16), s->P, s->me, e, s->d_err);
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_sum_kernel, dim3(1), dim3(64), 0, (const double*)(s->sums + (size_t)kind * 256), s->P, n, dst);
+    return 0;
+}
+
+}  // namespace
+extern "C" {
+
+// hipIpc handle (64 bytes) of this rank's object `what`: 0..3 = receive buffers (chain 0 a / b, chain 1 a / b), 4 = mailbox.
+// Call after ofdft_set_terms (the buffers are sized by the active terms); export again when ofdft_set_terms changes them.
+int ofdft_ipc_export(ofdft_ctx* c, int what, void* handle64) {
+    if (!c || !handle64 || what < 0 || what > 4) return OFDFT_EINVAL;
+    if (c->nranks < 2 || c->nranks > 16) return fail(c, OFDFT_EINVAL, "the ipc transport serves 2..16 ranks");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    OFDFT_ON_DEVICE(c, c->device);
+    void* ptr;
+    size_t bytes;
+    if (int rc = ipc_local(c, what, &ptr, &bytes)) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    HIP_TRY(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, ptr));
+    return OFDFT_OK;
+}
+
+// map rank `peer`'s object `what` from the handle that rank exported
+int ofdft_ipc_attach(ofdft_ctx* c, int peer, int what, const void* handle64) {
+    if (!c || !handle64 || what < 0 || what > 4 || peer < 0 || peer >= c->nranks) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
+    ofdft_ipc_state* s;
+    if (int rc = ipc_state(c, &s)) return rc;
+    if (peer == s->me) return OFDFT_OK;
+    if (s->opened[what][peer] && s->peer[what][peer]) {
+        (void)hipIpcCloseMemHandle(s->peer[what][peer]);
+        s->peer[what][peer] = nullptr;
+        s->opened[what][peer] = false;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof(h));
+    void* ptr = nullptr;
+    HIP_TRY(c, hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    s->peer[what][peer] = ptr;
+    s->opened[what][peer] = true;
+    return OFDFT_OK;
+}
+
+// The closure chi -> (E, mu, chi.grad) on this rank's slab with the exchange done by the library (see the head of this
+// file): every rank calls it with the same n_electrons.  Same results as the staged path (same kernels, same order).
+int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_local, double n_electrons, double* E_terms,
+                       double* mu_host, void* grad_local, void* v_work_local, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
+    if (int rc = begin_call(c, st)) return rc;
+    if (!chi_local || !E_terms || !grad_local || !v_work_local) return fail(c, OFDFT_EINVAL, "null argument");
+    if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
+    if (c->nranks < 2 || !c->ipc) return fail(c, OFDFT_ESTATE, "ofdft_dist_closure needs a slab-decomposed context with the ipc transport attached");
+    if ((c->mask & OFDFT_ION_ELECTRON) && !vext_local) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    if (gga_needs_laplacian(c) && !c->gga_split) return fail(c, OFDFT_EINVAL, "Laplacian-dependent Pauli-Gaussian members need OFDFT_OPT_GGA_SPLIT = 1");
+    if (wts_active(c)) return fail(c, OFDFT_EINVAL, "the stabilised Wang-Teter style functional is served by single-GPU contexts");
+    ofdft_ipc_state* s = c->ipc;
+    for (int w = 0; w < 5; ++w)
+        for (int p = 0; p < s->P; ++p)
+            if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: object %d of rank %d is not attached", w, p);
+    for (int w = 0; w < 4; ++w) {       // a set_terms that grew the buffers after the export invalidates the peers' mappings
+        void* ptr;
+        size_t bytes;
+        if (int rc = ipc_local(c, w, &ptr, &bytes)) return rc;
+        if (bytes != s->bytes[w] || ptr != s->peer[w][s->me]) return fail(c, OFDFT_ESTATE, "ipc transport: exchange buffers changed since ofdft_ipc_export");
+    }
+    const real* chi = (const real*)chi_local;
+    // ---- sum chi^2 over all ranks -> closure scale on the device
+    const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+    OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
+    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1, c->d_reduced + kSumsqSlot);
+    if (int rc = ipc_allreduce(c, 0, c->d_reduced + kSumsqSlot, 1, c->d_reduced + kSumsqSlot, st)) return rc;
+    OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, n_electrons,
+                 c->vol / (double)c->npts_g);
+    ZRun& r = zrun(c);
+    r.ds = DenSrc{chi, 0.0, 1, c->d_scal};
+    r.nel = n_electrons;
+    r.vext = (const real*)vext_local;
+    r.v_out = (real*)v_work_local;
+    r.stage[0] = r.stage[1] = 0;
+    r.deferred.clear();
+    r.forked = false;
+    r.xlist[0].clear();
+    r.xlist[1].clear();
+    // ---- the two chains on their own streams; a stage's exchange is enqueued right behind its kernels
+    HIP_TRY(c, hipEventRecord(s->ev_fork, st));
+    HIP_TRY(c, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    for (int stage = 1; stage <= 4; ++stage)
+        for (int chain = 0; chain < 2; ++chain) {
+            hipStream_t cs = chain == 0 ? st : s->side;
+            int rc;
+            switch (stage) {
+                case 1: rc = zstage1(c, cs, chain); break;
+                case 2: rc = zstage2(c, cs, chain); break;
+                case 3: rc = zstage3(c, cs, chain); break;
+                default: rc = zstage4(c, cs, chain); break;
+            }
+            if (rc) return rc;
+            if (!r.xlist[chain].empty()) {
+                cplx *send, *recv;
+                if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+                const size_t bytes = sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist[chain].size();
+                if ((rc = ipc_exchange(c, chain, send, bytes, cs))) return rc;
+            }
+        }
+    HIP_TRY(c, hipEventRecord(s->ev_join, s->side));
+    HIP_TRY(c, hipStreamWaitEvent(st, s->ev_join, 0));
+    if (int rc = zstage5(c, nullptr, st)) return rc;               // local sums -> d_reduced[0..12]
+    if (int rc = ipc_allreduce(c, 1, c->d_reduced, kNSums + 1, c->d_reduced, st)) return rc;
+    OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v_work_local,
+                 (real*)grad_local, c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV,
+                 n_electrons);
+    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kNSums + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(s->h_err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (int rc = end_call(c, st)) return rc;
+    if (*s->h_err) {
+        const int who = *s->h_err - 1;
+        (void)hipMemset(s->d_err, 0, sizeof(int));
+        return fail(c, OFDFT_EHIP, "ipc transport: no delivery from rank %d within the wait limit", who);
+    }
+    double vn;
+    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+    energies_from_sums(c, c->h_partial, c->h_partial + kCombineScalars, E_terms, &vn);
+    if (mu_host) *mu_host = vn / n_electrons;
+    return OFDFT_OK;
+}

@@ -170,6 +170,41 @@ class HipStages(Engine):
         self._check(self.lib.ofdft_set_collectives(self._ctx, self._callbacks[0], self._callbacks[1], None), 'ofdft_set_collectives')
         return self
 
+    def attach_ipc(self, comm):
+        """Set up the library's own exchange (``ofdft_ipc_*``): export this rank's receive buffers and mailbox, pass the 64-byte
+        hipIpc handles around with ONE all-gather, map every peer's.  Afterwards `closure_ipc` runs an evaluation without
+        any torch / RCCL call.  To be repeated after a `set_terms` that changes the exchange buffers."""
+        if not comm.active:
+            return False
+        mine = np.zeros((5, 64), dtype=np.uint8)
+        for w in range(5):
+            self._check(self.lib.ofdft_ipc_export(self._ctx, w, mine[w].ctypes.data_as(C.c_void_p)), 'ofdft_ipc_export')
+        t = torch.from_numpy(mine.reshape(-1).copy())
+        dev = self.device if comm.backend == 'nccl' else 'cpu'
+        allh = [torch.empty_like(t, device=dev) for _ in range(comm.nranks)]
+        dist.all_gather(allh, t.to(dev), group=comm.group)
+        for p, h in enumerate(allh):
+            if p == comm.rank:
+                continue
+            hh = np.ascontiguousarray(h.cpu().numpy().reshape(5, 64))
+            for w in range(5):
+                self._check(self.lib.ofdft_ipc_attach(self._ctx, p, w, hh[w].ctypes.data_as(C.c_void_p)), 'ofdft_ipc_attach')
+        if comm.backend == 'nccl':
+            torch.cuda.synchronize(self.device)
+        dist.barrier(group=comm.group)                # nobody starts writing before everybody has mapped
+        self._ipc_terms = self._terms_key
+        return True
+
+    def closure_ipc(self, chi, n_elec, vext):
+        """chi -> (E_terms, mu, chi.grad) on this rank's slab, the exchange done inside the library (ofdft_dist_closure)"""
+        out, v = torch.empty_like(chi), torch.empty_like(chi)
+        E = (C.c_double * N.NTERMS)()
+        mu = C.c_double(0.0)
+        self._check(self.lib.ofdft_dist_closure(self._ctx, C.c_void_p(chi.data_ptr()), C.c_void_p(vext.data_ptr() if vext is not None else 0),
+                                                float(n_elec), E, C.byref(mu), C.c_void_p(out.data_ptr()), C.c_void_p(v.data_ptr()),
+                                                self._stream()), 'ofdft_dist_closure')
+        return {nm: E[i] for i, nm in enumerate(N.TERM_ORDER)}, mu.value, out
+
     def sumsq(self, x, square=True, on_device=False):
         """local sum of x^2 (or x): returned as a float, or left in device_scalars[15] without a host sync"""
         x = self._grid_tensor(x, 'x')
@@ -309,9 +344,14 @@ class DistEngine:
     """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
     as `Engine`, on this rank's slab."""
 
-    def __init__(self, shape, device, group=None, dtype=torch.double):
+    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective'):
         """dtype=torch.float32 runs the slab-decomposed hot path on the fp32 build (half the bytes on every link);
-        stress and ion forces are then formed by the fp64 routines from the gathered density."""
+        stress and ion forces are then formed by the fp64 routines on fp64 slabs.
+        transport: 'collective' = the host issues an all-to-all per stage through torch.distributed (RCCL under nccl);
+        'ipc' = the library maps the peers' buffers (hipIpc) and moves the spectra itself, one call per evaluation."""
+        if transport not in ('collective', 'ipc'):
+            raise ValueError("transport must be 'collective' or 'ipc'")
+        self.transport = transport
         self.comm = Comm(group)
         self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
         self.stages.enable_collectives(self.comm)
@@ -333,6 +373,10 @@ class DistEngine:
     def energy_grad_chi(self, chi, n_elec, vext=None):
         chi = self.stages._grid_tensor(chi, 'chi')
         vext = self.stages._grid_tensor(vext, 'v_ext')
+        if self.transport == 'ipc' and self.comm.active:
+            if getattr(self.stages, '_ipc_terms', None) != self.stages._terms_key:
+                self.stages.attach_ipc(self.comm)          # first use, or the term set (hence the buffers) changed
+            return self.stages.closure_ipc(chi, n_elec, vext)
         return run_closure(self.stages, self.comm, chi, n_elec, vext, self._vol, self.npts_global, torch.empty_like)
 
     def energy_potential(self, den, vext=None):

@@ -54,7 +54,7 @@ def main():
     chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(43).random(shape))
     n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
-    eng = DistEngine(shape, dev, dtype=dt).set_cell(torch.as_tensor(box))
+    eng = DistEngine(shape, dev, dtype=dt, transport=os.environ.get('OFDFT_TEST_TRANSPORT', 'collective')).set_cell(torch.as_tensor(box))
     plan = eng.plan
     worst = {}
     for cfg in ('cfg1', 'cfg2', 'cfg3'):

@@ -72,7 +72,18 @@ def test_slab_decomposed_over_rccl_matches_single_gpu(shape, dtype, tmp_path):
     (raw-pointer tensors), two overlapped chains, device-resident scalars -- against one engine on rank 0's GPU.
     Runs wherever the box has >= 2 GPUs (a one-GPU box cannot host two RCCL ranks)."""
     world = 2 if _gpu_count() < 4 else 4
-    res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_BACKEND': 'nccl'}, timeout=600)
+    for transport in ('collective', 'ipc'):          # RCCL all-to-alls issued by the host; peer copies issued by the library
+        res = _run_workers(world, shape, dtype, str(tmp_path / ('res_%s.json' % transport)),
+                           {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_TEST_TRANSPORT': transport}, timeout=600)
+        _check_worker_results(res, dtype)
+
+
+@pytest.mark.parametrize('world,shape,dtype', [(2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'), (2, '64x32x128', 'f64'), (4, '32x32x32', 'f32')])
+def test_slab_decomposed_with_the_library_own_exchange(world, shape, dtype, tmp_path):
+    """transport='ipc': the ranks map each other's receive buffers and mailboxes through hipIpc and the library moves the
+    spectra itself (peer copies + epoch stamps + bounded waits), one C call per evaluation and no collective in it -- here with
+    the ranks sharing one GPU, which exercises the very same mappings, copies and flags as separate GPUs do"""
+    res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_TRANSPORT': 'ipc'})
     _check_worker_results(res, dtype)
 
 
