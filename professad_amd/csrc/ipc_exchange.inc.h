@@ -4,9 +4,10 @@
 // ctypes calls per evaluation from Python.  Here the library does the whole evaluation in ONE call and moves the data
 // itself over the fully connected xGMI mesh of an MI355X node: every rank maps every peer's receive buffers and mailbox
 // through hipIpc (handles travel once, at set-up, through whatever the host has: ofdft_ipc_export / ofdft_ipc_attach), then
-//   * a stage's spectra go straight from the local send buffer into chunk [me] of each peer's receive buffer by
-//     device-to-device copies enqueued on the chain's stream (peer p's copy runs over the direct link me <-> p);
-//   * behind its copies a rank stamps the evaluation's epoch into word [chain][me] of each peer's mailbox;
+//   * a stage's spectra go straight from the local send buffer into chunk [me] of each peer's receive buffer by ONE
+//     kernel on the chain's stream whose workgroups store to all peers at once (blockIdx.y = peer: every direct link
+//     me <-> p is driven concurrently -- P - 1 stream-ordered copies would use one link at a time);
+//   * behind it a one-wave kernel stamps the evaluation's epoch into word [chain][me] of each peer's mailbox;
 //   * the consumer's stream runs a one-wave kernel that waits (bounded) until every peer's word has reached the epoch.
 // Two receive buffers per chain alternate, so a peer may deliver stage k + 1 while stage k is still being read.  The two
 // small all-reduces (sum chi^2; the 13 energy sums) use the same mailboxes: every rank posts its numbers to every peer and
@@ -67,12 +68,24 @@ __global__ void ipc_wait_kernel(const unsigned* flags, int P, int me, unsigned e
         }
     }
 }
-__global__ void ipc_stamp_kernel(unsigned* stamp, unsigned e0, unsigned e1, unsigned e2) {
-    if (threadIdx.x == 0) {
-        stamp[0] = e0;
-        stamp[1] = e1;
-        stamp[2] = e2;
-    }
+struct IpcPeers { void* p[16]; };
+// chunk [peer] of the local send buffer -> chunk [me] of rank peer's receive buffer (16-byte accesses; blockIdx.y = peer)
+__global__ __launch_bounds__(256) void ipc_scatter_kernel(const u32x4* __restrict__ send, IpcPeers recv, int me, long long vec_per_peer) {
+    const int peer = blockIdx.y;
+    const u32x4* src = send + (long long)peer * vec_per_peer;
+    u32x4* dst = reinterpret_cast<u32x4*>(recv.p[peer]) + (long long)me * vec_per_peer;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_peer; i += (long long)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+// lane p: epoch -> word `word` of rank p's mailbox (system scope: another agent polls it)
+__global__ void ipc_stamp_kernel(IpcPeers mailbox, int P, int me, int word, unsigned epoch) {
+    const int p = threadIdx.x;
+    if (p < P && p != me) __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox.p[p]) + word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// lane (p, i): this rank's i-th number -> its slot in rank p's mailbox
+__global__ void ipc_post_kernel(IpcPeers mailbox, int P, size_t byte_off, const double* __restrict__ src, int n) {
+    const int p = threadIdx.x / 16, i = threadIdx.x % 16;
+    if (p < P && i < n) reinterpret_cast<double*>(reinterpret_cast<char*>(mailbox.p[p]) + byte_off)[i] = src[i];
 }
 // out[i] = sum over ranks (in rank order) of slots[p][i]
 __global__ void ipc_sum_kernel(const double* slots, int P, int n, double* out) {
@@ -136,17 +149,18 @@ int ipc_local(ofdft_ctx* c, int what, void** ptr, size_t* bytes) {
 int ipc_exchange(ofdft_ctx* c, int chain, cplx* send, size_t bytes_per_peer, hipStream_t st) {
     ofdft_ipc_state* s = c->ipc;
     const int next = c->recv_parity[chain] ^ 1, w = 2 * chain + next;
+    IpcPeers recv{}, mail{};
     for (int p = 0; p < s->P; ++p) {
         if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: receive buffer %d of rank %d is not attached", w, p);
-        HIP_TRY(c, hipMemcpyAsync((char*)s->peer[w][p] + (size_t)s->me * bytes_per_peer, (const char*)send + (size_t)p * bytes_per_peer,
-                                  bytes_per_peer, hipMemcpyDeviceToDevice, st));
+        recv.p[p] = s->peer[w][p];
+        mail.p[p] = s->peer[4][p];
     }
+    if (bytes_per_peer % 16) return fail(c, OFDFT_EINVAL, "ipc transport: message size not a multiple of 16 bytes");
+    const long long vec = (long long)(bytes_per_peer / 16);
+    const int bx = (int)std::min<long long>(2048 / s->P + 1, (vec + 255) / 256);
+    OFDFT_LAUNCH(c, st, "ipc_scatter", ipc_scatter_kernel, dim3(bx, s->P), dim3(256), 0, (const u32x4*)send, recv, s->me, vec);
     const unsigned e = ++s->epoch[chain];
-    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, s->d_stamp + 4 * chain, e, e, e);
-    for (int p = 0; p < s->P; ++p)
-        if (p != s->me)
-            HIP_TRY(c, hipMemcpyAsync((unsigned*)s->peer[4][p] + chain * 16 + s->me, s->d_stamp + 4 * chain, sizeof(unsigned),
-                                      hipMemcpyDeviceToDevice, st));
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, mail, s->P, s->me, chain * 16 + s->me, e);
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + chain * 16), s->P, s->me, e,
                  s->d_err);
     c->recv_parity[chain] = next;
@@ -157,14 +171,11 @@ int ipc_exchange(ofdft_ctx* c, int chain, cplx* send, size_t bytes_per_peer, hip
 int ipc_allreduce(ofdft_ctx* c, int kind, const double* src, int n, double* dst, hipStream_t st) {
     ofdft_ipc_state* s = c->ipc;
     const size_t off = kIpcFlagWords * sizeof(unsigned) + 64 + sizeof(double) * ((size_t)kind * 256 + (size_t)s->me * 16);
-    for (int p = 0; p < s->P; ++p)
-        HIP_TRY(c, hipMemcpyAsync((char*)s->peer[4][p] + off, src, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    IpcPeers mail{};
+    for (int p = 0; p < s->P; ++p) mail.p[p] = s->peer[4][p];
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_post_kernel, dim3(1), dim3(256), 0, mail, s->P, off, src, n);
     const unsigned e = ++s->epoch[2];
-    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, s->d_stamp + 8, e, e, e);
-    for (int p = 0; p < s->P; ++p)
-        if (p != s->me)
-            HIP_TRY(c, hipMemcpyAsync((unsigned*)s->peer[4][p] + 2 * 16 + s->me, s->d_stamp + 8, sizeof(unsigned),
-                                      hipMemcpyDeviceToDevice, st));
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, mail, s->P, s->me, 2 * 16 + s->me, e);
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + 2 * 16), s->P, s->me, e, s->d_err);
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_sum_kernel, dim3(1), dim3(64), 0, (const double*)(s->sums + (size_t)kind * 256), s->P, n, dst);
     return 0;
