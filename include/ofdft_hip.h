@@ -136,11 +136,11 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
  * to device into chunk [rank] of each peer's buffer on the chain's stream (one direct xGMI link per peer pair), stamps an
  * epoch behind them and waits (bounded, ~4 s) for the peers' stamps in a one-wave kernel; the two small reductions use
  * the same mailboxes and add the ranks' numbers in rank order.  Set-up, once per (context, term set): every rank exports
- * the handles of objects 0..4 (0..3: the two receive buffers of each chain, 4: the mailbox), the host passes them around
- * (64 bytes each, any transport) and every rank attaches every peer's.  No torch / RCCL call per evaluation; results are
+ * the handle of its arena -- ONE allocation that holds the two receive buffers of each chain and the mailbox -- with the
+ * five objects' byte offsets, the host passes them around (64 + 40 bytes, any transport) and every rank attaches every peer's.  No torch / RCCL call per evaluation; results are
  * those of the staged path (same kernels in the same order).  v_work_local_dev: a slab-sized work array for dE/dn. */
-int  ofdft_ipc_export(ofdft_ctx* ctx, int what, void* handle64);
-int  ofdft_ipc_attach(ofdft_ctx* ctx, int peer_rank, int what, const void* handle64);
+int  ofdft_ipc_export(ofdft_ctx* ctx, void* handle64, unsigned long long* offsets5);
+int  ofdft_ipc_attach(ofdft_ctx* ctx, int peer_rank, const void* handle64, const unsigned long long* offsets5);
 int  ofdft_dist_closure(ofdft_ctx* ctx, const void* chi_local_dev, const void* vext_local_dev, double n_electrons_global,
                         double* E_terms_host, double* mu_host, void* grad_local_dev, void* v_work_local_dev, void* stream);
 

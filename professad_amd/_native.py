@@ -107,9 +107,9 @@ def load(dtype=F64):
     lib.ofdft_dist_energies.restype = ip
     lib.ofdft_dist_chi_grad.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp]
     lib.ofdft_dist_chi_grad.restype = ip
-    lib.ofdft_ipc_export.argtypes = [vp, ip, vp]
+    lib.ofdft_ipc_export.argtypes = [vp, vp, C.POINTER(C.c_ulonglong)]
     lib.ofdft_ipc_export.restype = ip
-    lib.ofdft_ipc_attach.argtypes = [vp, ip, ip, vp]
+    lib.ofdft_ipc_attach.argtypes = [vp, ip, vp, C.POINTER(C.c_ulonglong)]
     lib.ofdft_ipc_attach.restype = ip
     lib.ofdft_dist_closure.argtypes = [vp, vp, vp, C.c_double, dp, dp, vp, vp, vp]
     lib.ofdft_dist_closure.restype = ip

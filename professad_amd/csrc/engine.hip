@@ -51,11 +51,12 @@ int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out) {
     DevBuf& b = c->ws[name];
     if (b.bytes < bytes) {
         if (b.p) {
-            HIP_TRY(c, hipFree(b.p));
+            if (!b.borrowed) HIP_TRY(c, hipFree(b.p));
             c->ws_bytes -= b.bytes;
         }
         b.p = nullptr;
         b.bytes = 0;
+        b.borrowed = false;
         HIP_TRY(c, hipMalloc(&b.p, bytes));
         b.bytes = bytes;
         c->ws_bytes += bytes;
@@ -112,7 +113,7 @@ void prof_collect(ofdft_ctx* c) {
 // sized by what the active terms send at most across one geometry boundary (the buffers only ever grow): chain 0 carries
 // {n^, (sqrt n)^} -> {vH, D_a n | grad n (3), lap} -> flux (1 | 3) -> divergence (1); chain 1 the Wang-Teter powers (1-2) and / or
 // the six WGC99 spectra
-int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
+size_t dist_buffer_bytes(ofdft_ctx* c, int chain) {
     const unsigned m = c->mask;
     const bool g = m & kGgaAny, h = m & OFDFT_HARTREE, vw = m & OFDFT_VW;
     const int ng = g ? (c->gga_split ? 1 : 3) : 0;
@@ -126,7 +127,10 @@ int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
                ((m & OFDFT_WGC99_NL) ? 6 : 0);
     }
     if (narr < 1) narr = 1;
-    const size_t bytes = sizeof(cplx) * (size_t)c->g.total * narr;
+    return sizeof(cplx) * (size_t)c->g.total * narr;
+}
+int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
+    const size_t bytes = dist_buffer_bytes(c, chain);
     if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
     // (the ipc transport alternates between two receive buffers per chain: peers deliver stage k + 1 while stage k is still read)
     const char* rn[2][2] = {{"x:recv0", "x:recv0b"}, {"x:recv1", "x:recv1b"}};
@@ -762,7 +766,7 @@ void ofdft_destroy(ofdft_ctx* c) {
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->ws)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.p && !kv.second.borrowed) (void)hipFree(kv.second.p);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_reduced) (void)hipFree(c->d_reduced);
     if (c->d_scal) (void)hipFree(c->d_scal);

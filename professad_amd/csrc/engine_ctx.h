@@ -30,6 +30,7 @@ using namespace ofdft;
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool borrowed = false;      // a window of a larger allocation (the ipc arena): never freed on its own
 };
 
 struct ofdft_ctx {
@@ -207,6 +208,7 @@ int get_twiddle(ofdft_ctx* c, int n, cplx** out);
 int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out);
 int real_ws(ofdft_ctx* c, const char* name, real** out);
 int spec_ws(ofdft_ctx* c, const char* name, cplx** out);
+size_t dist_buffer_bytes(ofdft_ctx* c, int chain);
 int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv);
 int dist_exchange(ofdft_ctx* c, cplx* send, cplx* recv, hipStream_t st);
 int global_sums(ofdft_ctx* c, double* v, int n);

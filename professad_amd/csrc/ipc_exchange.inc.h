@@ -17,10 +17,14 @@
 
 struct ofdft_ipc_state {
     int P = 0, me = 0;
-    // exported / attached objects: 0..3 = receive buffers (chain 0 a / b, chain 1 a / b), 4 = mailbox
-    void* peer[5][16] = {};            // peer[w][p]: rank p's object w in THIS process' address space (p == me: the local pointer)
-    bool opened[5][16] = {};
-    size_t bytes[5] = {};              // size the exported buffers had (re-export when a set_terms grows them)
+    // ONE allocation per rank (the arena) holds everything peers write into -- the four receive buffers (chain 0 a / b,
+    // chain 1 a / b: objects 0..3) and the mailbox (object 4) -- so a rank opens exactly one hipIpc handle per peer
+    // (handles of several small allocations of one process may name the same underlying block, which cannot be opened twice)
+    void* arena = nullptr;
+    size_t arena_bytes = 0, off[5] = {}, bytes[5] = {};
+    void* peer_base[16] = {};          // rank p's arena in THIS process' address space (an opened handle)
+    hipIpcMemHandle_t peer_handle[16] = {};
+    void* peer[5][16] = {};            // peer[w][p]: rank p's object w (p == me: the local pointer)
     // mailbox layout (this rank's copy): flags [3 kinds][16 ranks] u32 | sums [2 kinds][16 ranks][16] f64
     unsigned* flags = nullptr;
     double* sums = nullptr;
@@ -40,10 +44,16 @@ constexpr size_t kIpcMailboxBytes = kIpcFlagWords * sizeof(unsigned) + 64 + kIpc
 void ipc_release(ofdft_ctx* c) {
     ofdft_ipc_state* s = c->ipc;
     if (!s) return;
-    for (int w = 0; w < 5; ++w)
-        for (int p = 0; p < 16; ++p)
-            if (s->opened[w][p] && s->peer[w][p]) (void)hipIpcCloseMemHandle(s->peer[w][p]);
-    if (s->flags) (void)hipFree(s->flags);
+    for (int p = 0; p < 16; ++p)
+        if (s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
+    for (const char* nm : {"x:recv0", "x:recv0b", "x:recv1", "x:recv1b"}) {        // the windows into the arena die with it
+        auto it = c->ws.find(nm);
+        if (it != c->ws.end() && it->second.borrowed) {
+            c->ws_bytes -= it->second.bytes;
+            c->ws.erase(it);
+        }
+    }
+    if (s->arena) (void)hipFree(s->arena);
     if (s->d_stamp) (void)hipFree(s->d_stamp);
     if (s->d_err) (void)hipFree(s->d_err);
     if (s->h_err) (void)hipHostFree(s->h_err);
@@ -103,11 +113,6 @@ int ipc_state(ofdft_ctx* c, ofdft_ipc_state** out) {
         s->P = c->nranks;
         s->me = c->rank;
         c->ipc = s;
-        void* mb = nullptr;
-        HIP_TRY(c, hipMalloc(&mb, kIpcMailboxBytes));
-        HIP_TRY(c, hipMemset(mb, 0, kIpcMailboxBytes));
-        s->flags = (unsigned*)mb;
-        s->sums = (double*)((char*)mb + kIpcFlagWords * sizeof(unsigned) + 64);
         HIP_TRY(c, hipMalloc((void**)&s->d_stamp, 64));
         HIP_TRY(c, hipMalloc((void**)&s->d_err, sizeof(int)));
         HIP_TRY(c, hipMemset(s->d_err, 0, sizeof(int)));
@@ -115,32 +120,66 @@ int ipc_state(ofdft_ctx* c, ofdft_ipc_state** out) {
         HIP_TRY(c, hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        s->peer[4][s->me] = mb;
     }
     *out = c->ipc;
     return 0;
 }
 
-// the local object `what` (allocating the exchange buffers at the size the active terms need)
-int ipc_local(ofdft_ctx* c, int what, void** ptr, size_t* bytes) {
+constexpr const char* kIpcRecvNames[4] = {"x:recv0", "x:recv0b", "x:recv1", "x:recv1b"};
+
+// true when the exported arena still serves the active terms (the four receive workspaces are its windows, big enough)
+bool ipc_arena_current(ofdft_ctx* c) {
+    ofdft_ipc_state* s = c->ipc;
+    if (!s || !s->arena) return false;
+    for (int w = 0; w < 4; ++w) {
+        auto it = c->ws.find(kIpcRecvNames[w]);
+        if (it == c->ws.end() || !it->second.borrowed || it->second.p != (char*)s->arena + s->off[w]) return false;
+        if (dist_buffer_bytes(c, w / 2) > s->bytes[w]) return false;
+    }
+    return true;
+}
+
+// (re)build the arena for the active terms and point the four receive-buffer workspaces into it
+int ipc_arena(ofdft_ctx* c) {
     ofdft_ipc_state* s;
     if (int rc = ipc_state(c, &s)) return rc;
-    if (what == 4) {
-        *ptr = s->peer[4][s->me];
-        *bytes = kIpcMailboxBytes;
-        return 0;
+    if (ipc_arena_current(c)) return 0;
+    // drop the old windows / arena (every peer has to attach again: ofdft_dist_closure checks that it did)
+    for (int w = 0; w < 4; ++w) {
+        auto it = c->ws.find(kIpcRecvNames[w]);
+        if (it != c->ws.end()) {
+            if (it->second.p && !it->second.borrowed) HIP_TRY(c, hipFree(it->second.p));
+            c->ws_bytes -= it->second.bytes;
+            c->ws.erase(it);
+        }
     }
-    const int chain = what / 2, par = what % 2;
-    const int keep = c->recv_parity[chain];
-    cplx *send, *recv;
-    c->recv_parity[chain] = par;
-    const int rc = dist_buffers(c, chain, &send, &recv);
-    c->recv_parity[chain] = keep;
-    if (rc) return rc;
-    *ptr = recv;
-    *bytes = c->ws[std::string(chain == 0 ? (par ? "x:recv0b" : "x:recv0") : (par ? "x:recv1b" : "x:recv1"))].bytes;
-    s->peer[what][s->me] = recv;
-    s->bytes[what] = *bytes;
+    if (s->arena) HIP_TRY(c, hipFree(s->arena));
+    s->arena = nullptr;
+    const size_t need[5] = {dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 1), dist_buffer_bytes(c, 1),
+                            kIpcMailboxBytes};
+    size_t tot = 0;
+    for (int w = 0; w < 5; ++w) {
+        s->off[w] = tot;
+        s->bytes[w] = need[w];
+        tot += (need[w] + 4095) & ~(size_t)4095;
+    }
+    HIP_TRY(c, hipMalloc(&s->arena, tot));
+    HIP_TRY(c, hipMemset((char*)s->arena + s->off[4], 0, kIpcMailboxBytes));
+    HIP_TRY(c, hipDeviceSynchronize());
+    s->arena_bytes = tot;
+    for (int w = 0; w < 4; ++w) {
+        DevBuf& b = c->ws[kIpcRecvNames[w]];
+        b.p = (char*)s->arena + s->off[w];
+        b.bytes = need[w];
+        b.borrowed = true;
+        c->ws_bytes += need[w];
+        s->peer[w][s->me] = b.p;
+    }
+    s->peer[4][s->me] = (char*)s->arena + s->off[4];
+    s->flags = (unsigned*)s->peer[4][s->me];
+    s->sums = (double*)((char*)s->peer[4][s->me] + kIpcFlagWords * sizeof(unsigned) + 64);
+    // (the epochs run on: a fresh mailbox holds zeros, which every later epoch exceeds)
+    c->version++;                                       // captured graphs hold workspace addresses
     return 0;
 }
 
@@ -184,39 +223,42 @@ int ipc_allreduce(ofdft_ctx* c, int kind, const double* src, int n, double* dst,
 }  // namespace
 extern "C" {
 
-// hipIpc handle (64 bytes) of this rank's object `what`: 0..3 = receive buffers (chain 0 a / b, chain 1 a / b), 4 = mailbox.
-// Call after ofdft_set_terms (the buffers are sized by the active terms); export again when ofdft_set_terms changes them.
-int ofdft_ipc_export(ofdft_ctx* c, int what, void* handle64) {
-    if (!c || !handle64 || what < 0 || what > 4) return OFDFT_EINVAL;
+// hipIpc handle (64 bytes) of this rank's arena and the byte offsets of its five objects in it (0..3: the receive buffers
+// chain 0 a / b, chain 1 a / b; 4: the mailbox).  Call after ofdft_set_terms (the buffers are sized by the active terms) and
+// again -- on EVERY rank, followed by a new round of ofdft_ipc_attach -- when ofdft_set_terms changes them.
+int ofdft_ipc_export(ofdft_ctx* c, void* handle64, unsigned long long* offsets5) {
+    if (!c || !handle64 || !offsets5) return OFDFT_EINVAL;
     if (c->nranks < 2 || c->nranks > 16) return fail(c, OFDFT_EINVAL, "the ipc transport serves 2..16 ranks");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     OFDFT_ON_DEVICE(c, c->device);
-    void* ptr;
-    size_t bytes;
-    if (int rc = ipc_local(c, what, &ptr, &bytes)) return rc;
+    if (int rc = ipc_arena(c)) return rc;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-    HIP_TRY(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, ptr));
+    HIP_TRY(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, c->ipc->arena));
+    for (int w = 0; w < 5; ++w) offsets5[w] = c->ipc->off[w];
     return OFDFT_OK;
 }
 
-// map rank `peer`'s object `what` from the handle that rank exported
-int ofdft_ipc_attach(ofdft_ctx* c, int peer, int what, const void* handle64) {
-    if (!c || !handle64 || what < 0 || what > 4 || peer < 0 || peer >= c->nranks) return OFDFT_EINVAL;
+// map rank `peer`'s arena from what that rank exported (a handle already open here is kept)
+int ofdft_ipc_attach(ofdft_ctx* c, int peer, const void* handle64, const unsigned long long* offsets5) {
+    if (!c || !handle64 || !offsets5 || peer < 0 || peer >= c->nranks) return OFDFT_EINVAL;
     OFDFT_ON_DEVICE(c, c->device);
     ofdft_ipc_state* s;
     if (int rc = ipc_state(c, &s)) return rc;
     if (peer == s->me) return OFDFT_OK;
-    if (s->opened[what][peer] && s->peer[what][peer]) {
-        (void)hipIpcCloseMemHandle(s->peer[what][peer]);
-        s->peer[what][peer] = nullptr;
-        s->opened[what][peer] = false;
-    }
     hipIpcMemHandle_t h;
     std::memcpy(&h, handle64, sizeof(h));
-    void* ptr = nullptr;
-    HIP_TRY(c, hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
-    s->peer[what][peer] = ptr;
-    s->opened[what][peer] = true;
+    if (!s->peer_base[peer] || std::memcmp(&h, &s->peer_handle[peer], sizeof(h)) != 0) {
+        for (int w = 0; w < 5; ++w) s->peer[w][peer] = nullptr;
+        if (s->peer_base[peer]) {
+            (void)hipIpcCloseMemHandle(s->peer_base[peer]);
+            s->peer_base[peer] = nullptr;
+        }
+        void* ptr = nullptr;
+        HIP_TRY(c, hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        s->peer_base[peer] = ptr;
+        s->peer_handle[peer] = h;
+    }
+    for (int w = 0; w < 5; ++w) s->peer[w][peer] = (char*)s->peer_base[peer] + offsets5[w];
     return OFDFT_OK;
 }
 
@@ -237,13 +279,9 @@ int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_loc
     ofdft_ipc_state* s = c->ipc;
     for (int w = 0; w < 5; ++w)
         for (int p = 0; p < s->P; ++p)
-            if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: object %d of rank %d is not attached", w, p);
-    for (int w = 0; w < 4; ++w) {       // a set_terms that grew the buffers after the export invalidates the peers' mappings
-        void* ptr;
-        size_t bytes;
-        if (int rc = ipc_local(c, w, &ptr, &bytes)) return rc;
-        if (bytes != s->bytes[w] || ptr != s->peer[w][s->me]) return fail(c, OFDFT_ESTATE, "ipc transport: exchange buffers changed since ofdft_ipc_export");
-    }
+            if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: object %d of rank %d is not attached (ofdft_ipc_export / ofdft_ipc_attach)", w, p);
+    if (!ipc_arena_current(c))          // a set_terms that needs bigger buffers than the exported arena invalidates the peers' mappings
+        return fail(c, OFDFT_ESTATE, "ipc transport: exchange buffers changed since ofdft_ipc_export (export and attach again on every rank)");
     const real* chi = (const real*)chi_local;
     // ---- sum chi^2 over all ranks -> closure scale on the device
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);

@@ -171,27 +171,43 @@ class HipStages(Engine):
         return self
 
     def attach_ipc(self, comm):
-        """Set up the library's own exchange (``ofdft_ipc_*``): export this rank's receive buffers and mailbox, pass the 64-byte
-        hipIpc handles around with ONE all-gather, map every peer's.  Afterwards `closure_ipc` runs an evaluation without
+        """Set up the library's own exchange (``ofdft_ipc_*``): export this rank's arena (receive buffers + mailbox, one
+        allocation), pass the 64-byte hipIpc handles and the object offsets around with ONE all-gather, map every peer's.  Afterwards `closure_ipc` runs an evaluation without
         any torch / RCCL call.  To be repeated after a `set_terms` that changes the exchange buffers."""
         if not comm.active:
             return False
-        mine = np.zeros((5, 64), dtype=np.uint8)
-        for w in range(5):
-            self._check(self.lib.ofdft_ipc_export(self._ctx, w, mine[w].ctypes.data_as(C.c_void_p)), 'ofdft_ipc_export')
-        t = torch.from_numpy(mine.reshape(-1).copy())
         dev = self.device if comm.backend == 'nccl' else 'cpu'
+
+        def agree(ok):          # every rank learns whether ALL ranks got through a step (no rank is left alone in a collective)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=comm.group)
+            return bool(int(t[0]))
+        mine = np.zeros(64 + 40, dtype=np.uint8)           # hipIpc handle of this rank's arena + the five objects' offsets in it
+        offs = (C.c_ulonglong * 5)()
+        err = None
+        try:
+            self._check(self.lib.ofdft_ipc_export(self._ctx, mine[:64].ctypes.data_as(C.c_void_p), offs), 'ofdft_ipc_export')
+            mine[64:] = np.frombuffer(bytes(offs), dtype=np.uint8)
+        except RuntimeError as e:
+            err = e
+        if not agree(err is None):
+            raise RuntimeError('ipc transport: exporting the exchange buffers failed on some rank (%r here)' % (err,))
+        t = torch.from_numpy(mine.copy())
         allh = [torch.empty_like(t, device=dev) for _ in range(comm.nranks)]
         dist.all_gather(allh, t.to(dev), group=comm.group)
-        for p, h in enumerate(allh):
-            if p == comm.rank:
-                continue
-            hh = np.ascontiguousarray(h.cpu().numpy().reshape(5, 64))
-            for w in range(5):
-                self._check(self.lib.ofdft_ipc_attach(self._ctx, p, w, hh[w].ctypes.data_as(C.c_void_p)), 'ofdft_ipc_attach')
+        try:
+            for p, h in enumerate(allh):
+                if p == comm.rank:
+                    continue
+                hh = np.ascontiguousarray(h.cpu().numpy())
+                po = (C.c_ulonglong * 5).from_buffer_copy(hh[64:].tobytes())
+                self._check(self.lib.ofdft_ipc_attach(self._ctx, p, hh[:64].ctypes.data_as(C.c_void_p), po), 'ofdft_ipc_attach')
+        except RuntimeError as e:
+            err = e
         if comm.backend == 'nccl':
             torch.cuda.synchronize(self.device)
-        dist.barrier(group=comm.group)                # nobody starts writing before everybody has mapped
+        if not agree(err is None):        # (also the barrier: nobody starts writing before everybody has mapped)
+            raise RuntimeError('ipc transport: mapping the peers\' buffers failed on some rank (%r here)' % (err,))
         self._ipc_terms = self._terms_key
         return True
 
