@@ -209,6 +209,40 @@ class Engine:
 _ENGINES = {}
 
 
+# extents whose line transforms run in registers / LDS, i.e. grids that take the fused pipelines (csrc/engine_ctx.h:
+# line_extent_ok / row_extent_ok); every other extent works too, through chirp-z line transforms and the unfused pipeline
+FUSED_EXTENTS_MIXED = (48, 96, 120, 144, 160, 192, 240, 250, 270, 288, 320, 384, 480)       # fp64 build only
+
+
+def fused_extents(axis=0, dtype=torch.double, nranks=1):
+    """sorted extents along `axis` (0, 1: lines; 2: the real-to-complex rows) served by the fused pipelines"""
+    lo, hi = (16, 2048) if axis == 2 else (8, 1024)
+    out = {1 << k for k in range(3, 12) if lo <= (1 << k) <= hi}
+    if dtype == torch.double and nranks == 1:        # slab-decomposed contexts: powers of two
+        out |= set(FUSED_EXTENTS_MIXED)
+    return sorted(out)
+
+
+def next_fast_extent(n, axis=0, dtype=torch.double, nranks=1):
+    """smallest fused-pipeline extent >= n along `axis` (ValueError beyond the largest one)"""
+    for e in fused_extents(axis, dtype, nranks):
+        if e >= n:
+            return e
+    raise ValueError('no fused-pipeline extent >= %d along axis %d' % (n, axis))
+
+
+def ecut2shape_fast(energy_cutoff, box_vecs, dtype=torch.double, nranks=1):
+    """Grid shape for an energy cutoff (eV) and lattice vectors (Angstrom): the reference's rule (system.py:74-89,
+    1 + 2 ceil(k_cut / |b_i|) points per axis -- always odd) rounded UP per axis to the next extent the fused pipelines
+    serve, so the cutoff is never lowered.  Returns (shape, reference_shape)."""
+    import numpy as np
+    A_per_b, eV_per_Ha = 5.29177210903e-11 * 1e10, 4.3597447222071e-18 / 1.602176634e-19       # CODATA 2018, as system.py:27-31
+    bvs = np.asarray(box_vecs, dtype=float) / A_per_b
+    kcut = np.sqrt(2.0 * float(energy_cutoff) / eV_per_Ha)
+    ref = tuple(int(1 + 2 * np.ceil(kcut / (2 * np.pi / np.sqrt((bvs[i] ** 2).sum())))) for i in range(3))
+    return tuple(next_fast_extent(r, i, dtype, nranks) for i, r in enumerate(ref)), ref
+
+
 def engine_for(shape, device, dtype=torch.double):
     """One cached Engine per (shape, device, dtype)."""
     dev = torch.device(device)

@@ -94,3 +94,23 @@ def test_recpot_reader(tmp_path):
     k2, v2, z2 = read_recpot(str(p))
     assert z2 == z and np.allclose(k2, ks, rtol=1e-12)
     assert np.allclose(v2[1:], v[1:] + 4 * np.pi * z / ks[1:] ** 2, rtol=1e-10) and abs(v2[0] - v[0]) < 1e-8 * abs(v[0])
+
+
+def test_fast_extent_helper_rounds_the_reference_rule_up():
+    """ecut2shape_fast: the reference's odd extents (system.py:74-89) rounded up per axis to fused-pipeline extents"""
+    import torch
+    import numpy as np
+    from professad_amd.engine import ecut2shape_fast, fused_extents, next_fast_extent
+    assert next_fast_extent(241) == 250 and next_fast_extent(255) == 256 and next_fast_extent(33) == 48
+    assert next_fast_extent(241, dtype=torch.float32) == 256 and next_fast_extent(241, nranks=8) == 256
+    assert next_fast_extent(9, axis=2) == 16 and next_fast_extent(1025, axis=2) == 2048
+    with pytest.raises(ValueError):
+        next_fast_extent(1025, axis=0)
+    assert fused_extents(0)[:4] == [8, 16, 32, 48]
+    box = np.diag([4.05, 4.05, 8.1])
+    shape, ref = ecut2shape_fast(2000.0, box)
+    kcut = np.sqrt(2 * 2000.0 / 27.211386245988)
+    want = tuple(int(1 + 2 * np.ceil(kcut / (2 * np.pi / (L / 0.529177210903)))) for L in (4.05, 4.05, 8.1))
+    assert ref == want and all(r % 2 == 1 for r in ref)
+    assert all(s_ >= r for s_, r in zip(shape, ref)) and shape[2] % 2 == 0
+    assert all(s_ in fused_extents(i) for i, s_ in enumerate(shape))
