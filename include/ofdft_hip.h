@@ -102,6 +102,7 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_Q_LAUNCH_COUNT     4  /* kernel launches of the last energy call                 */
 #define OFDFT_Q_YPASS_COUNT      5  /* whole-spectrum y line passes of the last energy call    */
 #define OFDFT_Q_GRAPH_REPLAYS     6  /* ofdft_energy_grad_chi calls served by a hipGraph replay so far */
+#define OFDFT_Q_RESIDENT_EVALS    7  /* ofdft_energy_grad_chi calls served by the persistent small-grid kernel so far */
 
 int  ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id);
 void ofdft_destroy(ofdft_ctx* ctx);
@@ -267,6 +268,11 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_MIXED_RADIX 9   /* 1 (default): extents with factors 3 and 5 that have a line-transform plan (48, 96, 120, 144, 160, 192, 240, 250, 270,
                                      288, 320, 384, 480) run the register / LDS transforms and the fused pipelines like the powers of two;
                                      0: they take the chirp-z transforms + the unfused pipeline like any other extent (validation, A/B) */
+#define OFDFT_OPT_RESIDENT 10     /* ofdft_energy_grad_chi on cubic 16^3 / 32^3 / 64^3 grids with local, Hartree, von Weizsaecker and Wang-Teter terms
+                                     runs as ONE persistent kernel (four phases, three grid barriers; csrc/resident.hip) instead of the staged
+                                     pipeline.  2 (default): the call is not bracketed by the HIP event pair that times it (OFDFT_Q_KERNEL_MS reads
+                                     0 for it) and the host watches a pinned word the last workgroup writes instead of waiting for the stream --
+                                     together ~8 microseconds of a ~45-microsecond call; 1: events + stream wait as everywhere else; 0: off */
 #define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
                                      registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
                                      group-parallel kernel that trades spectra through LDS */

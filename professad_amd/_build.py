@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'libofdft_hip.so')            # fp64 (the reference's precision)
 LIB_F32 = os.path.join(LIBDIR, 'libofdft_hip_f32.so')    # same sources with -DOFDFT_REAL_F32 (BASELINE config 5)
-SOURCES = ['engine.hip', 'lines.hip', 'xpass_a.hip', 'xpass_b.hip', 'zfused.hip']     # separately compiled (engine_ctx.h)
+SOURCES = ['engine.hip', 'lines.hip', 'xpass_a.hip', 'xpass_b.hip', 'zfused.hip', 'resident.hip']     # separately compiled (engine_ctx.h)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'ofdft_hip.h')]
 
 

@@ -24,10 +24,11 @@ TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x
               'pbe_x', 'pbe_c', 'gga_k', 'vwgtf']
 NTERMS = 14
 NPARAMS = 13
-Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPASS_COUNT, Q_GRAPH_REPLAYS = 0, 1, 2, 3, 4, 5, 6
+Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPASS_COUNT, Q_GRAPH_REPLAYS, Q_RESIDENT_EVALS = 0, 1, 2, 3, 4, 5, 6, 7
 OPT_GRAPH = 7
 OPT_XWAVE = 8
 OPT_MIXED_RADIX = 9
+OPT_RESIDENT = 10
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',

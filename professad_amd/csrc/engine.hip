@@ -1,6 +1,8 @@
 // C-ABI implementation of the OFDFT energy/gradient engine (include/ofdft_hip.h).  gfx950 only.
 // Core translation unit: context, workspaces, pipelines, entry points (engine_ctx.h lists the other sources).
 #include "engine_ctx.h"
+#include <atomic>
+#include <chrono>
 #ifndef OFDFT_REAL_F32
 #include "ion_kernels.h"
 #include "stress_kernels.h"
@@ -767,6 +769,8 @@ void ofdft_destroy(ofdft_ctx* c) {
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     for (auto& kv : c->ws)
         if (kv.second.p && !kv.second.borrowed) (void)hipFree(kv.second.p);
+    if (c->res_sync) (void)hipFree(c->res_sync);
+    if (c->res_done) (void)hipHostFree(c->res_done);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_reduced) (void)hipFree(c->d_reduced);
     if (c->d_scal) (void)hipFree(c->d_scal);
@@ -950,7 +954,8 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     hipStream_t st = (hipStream_t)stream;
     if (!c) return OFDFT_EINVAL;
     OFDFT_ON_DEVICE(c, c->device);
-    if (int rc = begin_call(c, st)) return rc;
+    const bool timed = !(c->resident == 2 && resident_serves(c) && !c->profiling);
+    if (int rc = begin_call(c, st, timed)) return rc;
     if (!chi || !E_terms) return fail(c, OFDFT_EINVAL, "null argument");
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
@@ -963,7 +968,44 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
         // (the final sums), nothing in between: the sequence is graph-capturable (closure_graph).
         double sums[kNSums];
         bool done = false;
-        if (int rc = closure_graph(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, sums, &done)) return rc;
+        if (resident_serves(c)) {
+            // grids that fit on chip: the whole evaluation is one persistent kernel (resident.hip)
+            if (int rc = resident_closure(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st)) return rc;
+            // (the kernel wrote the sums into the pinned host mirror itself)
+            bool arrived = false;
+            if (!timed) {
+                // untimed form: the host watches the word the workgroups count themselves out on (each behind a system-scope
+                // release of everything it wrote) instead of waiting for the stream -- the runtime's wake-up costs more than
+                // the last phase of the kernel; anything unexpected falls back to the stream wait, which reports errors
+                HIP_TRY(c, hipGetLastError());
+                volatile unsigned* w = c->res_done;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spins = 0; !arrived; ++spins) {
+                    arrived = (int)(*w - c->res_done_target) >= 0;
+                    if (!arrived && (spins & 1023u) == 1023u &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            if (arrived) {
+                c->last_ms = 0.f;
+                c->ms_pending = false;
+            } else {
+                if (int rc = end_call(c, st, timed)) return rc;
+            }
+            if (c->h_partial[13] != 0.0) {
+                (void)hipMemset(c->res_sync, 0, 64);
+                c->res_epoch = 0;
+                c->res_done_target = 0;
+                if (c->res_done) *c->res_done = 0;
+                return fail(c, OFDFT_EHIP, "resident kernel: a grid barrier ran into its time limit (workgroups not co-resident?)");
+            }
+            for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+            c->resident_evals++;
+            done = true;
+        }
+        if (!done)
+            if (int rc = closure_graph(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, sums, &done)) return rc;
         if (!done) {
             if (int rc = closure_enqueue(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st)) return rc;
             if (int rc = end_call(c, st)) return rc;
@@ -1260,6 +1302,10 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
         case OFDFT_OPT_XWAVE:
             c->use_xwave = (int)value;
             return OFDFT_OK;
+        case OFDFT_OPT_RESIDENT:
+            if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_RESIDENT takes 0, 1 or 2");
+            c->resident = (int)value;
+            return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);
 }
@@ -1303,6 +1349,10 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_LAUNCH_COUNT: *out = c->launch_count; return OFDFT_OK;
         case OFDFT_Q_YPASS_COUNT: *out = c->ypass_count; return OFDFT_OK;
         case OFDFT_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; return OFDFT_OK;
+        case OFDFT_Q_RESIDENT_EVALS: *out = (double)c->resident_evals; return OFDFT_OK;
+        case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27:      // phase clock of the last persistent-kernel evaluation (microseconds)
+            *out = c->h_partial[what] * 0.01;
+            return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown query %d", what);
 }

@@ -99,6 +99,14 @@ struct ofdft_ctx {
     std::vector<GraphEntry> graphs;
     unsigned long long version = 1;          // bumped by set_cell / set_terms / set_option
     bool use_graph = true;
+    // persistent small-grid kernel (resident.hip): 1 = serve eligible closure evaluations with it, 2 = the same without the
+    // event pair that times a call (OFDFT_Q_KERNEL_MS reads 0), 0 = off
+    int resident = 2;
+    unsigned* res_sync = nullptr;            // grid-barrier counter
+    unsigned res_epoch = 0;                  // its value after the launches so far
+    long long resident_evals = 0;
+    unsigned* res_done = nullptr;            // pinned host word the kernel's workgroups count themselves out on
+    unsigned res_done_target = 0;
     long long graph_replays = 0;
     hipStream_t cap_stream = nullptr;        // capture happens here: the caller's stream may be the (uncapturable) null stream
     // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
@@ -237,6 +245,8 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
 // x planes [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
 int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0, int nchunks = 1,
                       real* dzn = nullptr);
+bool resident_serves(const ofdft_ctx* c);
+int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st);
 int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1);
 int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, real* dfdn, double inv_n, int* blocks_out,
                 hipStream_t st, int chunk = 0, int nchunks = 1);

@@ -614,19 +614,22 @@ ZRun& zrun(ofdft_ctx* c) {
     return c->zr->r;
 }
 
-int begin_call(ofdft_ctx* c, hipStream_t st) {
+// timed = false: no event pair around the call (OFDFT_Q_KERNEL_MS then reads 0): two stream markers are a visible share of
+// a 30-microsecond evaluation
+int begin_call(ofdft_ctx* c, hipStream_t st, bool timed = true) {
     if (!c) return OFDFT_EINVAL;      // (the ABI function that called this holds the DeviceScope)
     if (!c->cell_set) return fail(c, OFDFT_ESTATE, "ofdft_set_cell has not been called");
     c->fft_count = 0;
     c->launch_count = 0;
     c->ypass_count = 0.0;
-    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev0, st));
     return 0;
 }
-int end_call(ofdft_ctx* c, hipStream_t st) {
-    HIP_TRY(c, hipEventRecord(c->ev1, st));
+int end_call(ofdft_ctx* c, hipStream_t st, bool timed = true) {
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev1, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    if (timed) HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    else c->last_ms = 0.f;
     c->ms_pending = false;
     HIP_TRY(c, hipGetLastError());
     if (c->profiling) prof_collect(c);

@@ -1,0 +1,532 @@
+// One persistent kernel for grids that fit on chip (cubic 16^3 / 32^3 / 64^3): the whole closure evaluation
+//   chi -> n = c chi^2 -> (E terms, mu, dE/dchi)
+// of the local + Hartree + von Weizsaecker + Wang-Teter term sets in ONE launch.  gfx950 only.
+//
+// On these grids the staged pipeline is latency: ~12 dependent launches of a few microseconds of work each (the graph
+// replay removes the host from between them, not the launch gaps).  Here N workgroups stay resident and walk the
+// evaluation in four phases separated by three grid barriers (agent-scope release / acquire on one counter):
+//   A  workgroup = x plane:  f(chi) rows -> z-forward (registers) -> plane in LDS -> y-forward -> T[a][ky][x][kz]
+//      (f = chi^2, |chi|, chi^(2 beta), chi^(2 alpha): the closure scale c = N_e / (sum chi^2 dV) is not known yet, and
+//       does not have to be -- the transforms are linear, c^p is applied in phase C)            + partial sum chi^2
+//   B  workgroup = ky slab:  x-forward -> multiply by 4 pi / k^2 | -k^2 | Lindhard kernel -> x-inverse, in place
+//   C  workgroup = x plane:  y-inverse (LDS) -> z-inverse (registers) -> potential + energy integrands (combine_point,
+//      the very function of the staged pipeline) -> v(r), partial sums
+//   D  workgroup = x plane:  mu from the ordered sum of the partials, chi.grad = 2 c dV chi (v - mu)
+// Every array is read and written in contiguous rows of kz (272 / 528 bytes); the spectra (<= 2.2 MB each) never
+// leave the L2 / Infinity Cache.  The barrier spins are bounded (~2 s) and report through the sums.
+// Reference path: system.py:830-838 (closure), functionals.py:46,72,223,245,646-651 (terms).
+#include "engine_ctx.h"
+
+namespace ofdft {
+
+constexpr int kResSlots = 16;        // doubles per workgroup in the partials: [0..9] combine sums, [10] sum chi^2
+
+struct ResArgs {
+    const real* chi;
+    const real* vext;
+    real* v;
+    real* grad;
+    cplx* T;                 // four spectra [a][ky][x][kz]; a: 0 chi^2 (Hartree), 1 |chi| (vW), 2 chi^(2 beta), 3 chi^(2 alpha)
+    real* R;                 // their convolutions back in real space [a][x][y][z] (unscaled)
+    acc_t* part;             // [N][kResSlots]
+    acc_t* reduced;          // the context's pinned host mirror of the sums, written by the kernel: [0..12] sums, [13] barrier time-out flag
+    unsigned* sync;          // [0] barrier counter
+    unsigned epoch0;         // counter value before this launch
+    unsigned* done;          // pinned host word: the last workgroup to finish stores done_target there (the host may spin on it
+                             // instead of waiting for the stream: a few microseconds less per evaluation)
+    unsigned done_target;    // value of the device-side count-out word sync[1] once every workgroup of this launch has left
+    int act[4];              // which of the four spectra the term set needs
+    int kinds[4], narr;      // the active ones, compacted (phase B walks this list)
+    KGeom kg;
+    CombineArgs ca;
+    acc_t nel, vol_over_npts, dV;
+    real inv_n, lind_p0, lind_p1;
+};
+
+// -DOFDFT_RES_CLOCK=1: workgroup 0 writes a phase clock into the host mirror (ofdft_query 16..27, tools/resident_probe.py);
+// off by default -- the stores cross the bus and every barrier waits for them
+#ifndef OFDFT_RES_CLOCK
+#define OFDFT_RES_CLOCK 0
+#endif
+#ifndef OFDFT_RES_THREADS
+#define OFDFT_RES_THREADS 512
+#endif
+constexpr int kResThreads = OFDFT_RES_THREADS;
+
+template <int N> struct ResCfg {
+    static constexpr int T = kResThreads, WAVES = T / 64;
+    static constexpr int M = N / 2, NZH = M + 1, PS = NZH;       // odd row stride of the LDS planes (complex elements)
+    static constexpr int AG = N >= 64 ? 2 : 4;                   // spectra whose planes sit in LDS together (a group)
+    // z rows: M/4 lanes per row (ZPlan<M, 4>); x / y lines: N/8 lanes per line (ZPlan<N, 8>); the lanes of a row / line
+    // sit in one wavefront, so the transforms synchronise at wave level only
+    static constexpr int EZ = 4, PZ = M / EZ, RPWV = 64 / PZ;
+    static constexpr int EL = 8, PL = N / EL, LPWV = 64 / PL;
+    static constexpr int up(int n, int m) { return (n + m - 1) / m * m; }
+    static constexpr int lo(int a, int b) { return a < b ? a : b; }
+    static constexpr int ROWS = lo(T / PZ, up(AG * N, RPWV));    // row slots of a pass (whole waves)
+    static constexpr int LINES = lo(T / PL, up(4 * NZH, LPWV));  // line slots of a pass
+    static constexpr int RB_Z = ROWS * LineBuf<M>::STRIDE, RB_L = LINES * LineBuf<N>::STRIDE;
+    static constexpr int RB = RB_Z > RB_L ? RB_Z : RB_L;         // reals of the row / line exchange buffers
+    static constexpr size_t LDS_FFT = sizeof(real) * RB + sizeof(cplx) * (M + N) + sizeof(cplx) * AG * N * PS;
+    static constexpr size_t LDS_RED = sizeof(double) * kCombineScalars * (T + T / 32);        // the ordered sums of phase C reuse the space
+    static constexpr size_t LDS = LDS_FFT > LDS_RED ? LDS_FFT : LDS_RED;
+};
+
+// all workgroups of the evaluation have arrived `phase` times since epoch0.  One thread per workgroup talks to the other
+// XCDs: its agent-scope release (after the workgroup's stores have reached the L2: workgroup-scope release + barrier)
+// writes the L2's dirty lines back once, its acquire invalidates what the CU / the L2 hold from other XCDs once.
+__device__ __forceinline__ void res_barrier(unsigned* ctr, unsigned target, int* timed_out) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
+                *timed_out = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// sum over the workgroups, in workgroup order, of slots `slot` .. `slot + cnt - 1` of the partials -> tot[0..cnt-1] (LDS).
+// The N * cnt loads (remote L2s / memory: a microsecond each) are issued by as many threads at once; the ordered sums then
+// read LDS.
+template <int N>
+__device__ __forceinline__ void res_totals(const acc_t* part, int slot, int cnt, acc_t* tot, acc_t* stage) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * cnt; i += kResThreads) {
+        const int s = i / N, g = i - s * N;
+        stage[i] = __builtin_nontemporal_load(part + g * kResSlots + slot + s);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+        acc_t t = 0.0;
+        for (int g = 0; g < N; ++g) t += stage[threadIdx.x * N + g];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// line transforms of the planes held in LDS: lines (array slot s < ns, kz) along y, in place (inverse) or out to T (forward)
+template <int N, bool INV>
+__device__ __forceinline__ void res_ylines(cplx* plane, int ns, real* rowbuf, const cplx* twN, cplx* Tout, const int* kind_of,
+                                           int x) {
+    using C = ResCfg<N>;
+    constexpr int NZH = C::NZH, PS = C::PS, EL = C::EL, PL = C::PL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ll = lane % C::LPWV, lj = lane / C::LPWV;
+    const int nlines = ns * NZH;
+    for (int L0 = 0; L0 < nlines; L0 += C::LINES) {
+        const int slot = wave * C::LPWV + ll;
+        if (wave * C::LPWV >= C::LINES || L0 + wave * C::LPWV >= nlines) continue;      // wave-uniform: no line for this wave
+        const int L = L0 + slot;
+        const bool valid = L < nlines;
+        const int s = valid ? L / NZH : 0, kz = valid ? L - s * NZH : 0;
+        real* mine = rowbuf + slot * LineBuf<N>::STRIDE;
+        cplx* pl = plane + s * (N * PS);
+        cplx u[EL];
+#pragma unroll
+        for (int q = 0; q < EL; ++q) u[q] = valid ? pl[(lj + PL * q) * PS + kz] : mkc(0.0, 0.0);
+        wave_line_fft<N, EL, INV>(u, lj, mine, twN);
+        exchange_sync<true>();
+        if (valid) {
+            if constexpr (INV) {
+#pragma unroll
+                for (int q = 0; q < EL; ++q) pl[(lj + PL * q) * PS + kz] = u[q];
+            } else {
+                cplx* o = Tout + ((long long)kind_of[s] * N * N + x) * NZH + kz;
+#pragma unroll
+                for (int q = 0; q < EL; ++q) o[(long long)(lj + PL * q) * N * NZH] = u[q];
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArgs A, const cplx* __restrict__ twM_g,
+                                                                           const cplx* __restrict__ twN_g) {
+    using C = ResCfg<N>;
+    constexpr int T = C::T, M = C::M, NZH = C::NZH, PS = C::PS, EZ = C::EZ, PZ = C::PZ, EL = C::EL, PL = C::PL, AG = C::AG;
+    const int bid = (int)blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    __shared__ acc_t red[C::WAVES][kCombineScalars];
+    __shared__ acc_t tot[kCombineScalars + 2];
+    __shared__ acc_t stage[kCombineScalars * 64];
+    real* rowbuf = lds;
+    cplx* twM = reinterpret_cast<cplx*>(lds + C::RB);
+    cplx* twN = twM + M;                                  // W_N^k, k < N: the r2c post-processing reads k < M, the x / y lines all of it
+    cplx* plane = twN + N;                                // AG planes [y][kz]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int zj = lane % PZ, zrw = lane / PZ;
+    const int zslot = wave * C::RPWV + zrw;
+    real* zmine = rowbuf + (zslot < C::ROWS ? zslot : 0) * LineBuf<M>::STRIDE;
+    const int ll = lane % C::LPWV, lj = lane / C::LPWV;
+    int timed_out = 0;
+    // phase clock of workgroup 0 (100 MHz ticks since kernel entry) -> reduced[16..22]
+    const unsigned long long clk0 = __builtin_amdgcn_s_memrealtime();
+    auto stamp = [&](int i) {
+#if OFDFT_RES_CLOCK
+        if (bid == 0 && tid == 0) A.reduced[16 + i] = (acc_t)(__builtin_amdgcn_s_memrealtime() - clk0);
+#endif
+    };
+    (void)clk0;
+    for (int i = tid; i < M; i += T) twM[i] = twM_g[i];
+    for (int i = tid; i < N; i += T) twN[i] = twN_g[i];
+    const real be = A.ca.wt_beta, al = A.ca.wt_alpha;
+    const int x = bid;                                    // phases A, C, D: this workgroup's x plane
+    const cplx* chi_pl = reinterpret_cast<const cplx*>(A.chi + (long long)x * N * N);
+
+    // ------------------------------------------------------------------ phase A
+    {
+        acc_t s2 = 0.0;
+        for (int i = tid; i < N * M; i += T) {
+            const cplx c = chi_pl[i];
+            s2 += (acc_t)c.x * c.x + (acc_t)c.y * c.y;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+        if (lane == 0) red[wave][0] = s2;
+        __syncthreads();                                  // (also publishes the twiddle tables)
+        if (tid == 0) {
+            acc_t t = 0.0;
+            for (int w = 0; w < C::WAVES; ++w) t += red[w][0];
+            A.part[bid * kResSlots + 10] = t;
+        }
+        for (int g0 = 0; g0 < A.narr; g0 += AG) {
+            const int ns = (A.narr - g0) < AG ? (A.narr - g0) : AG;
+            const int nrows = ns * N;
+            for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
+                if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
+                const int R = R0 + zslot;
+                const bool valid = R < nrows;
+                const int s = valid ? R / N : 0, y = valid ? R - s * N : 0;
+                const int kind = A.kinds[g0 + s];
+                const cplx* row = chi_pl + y * M;
+                cplx v[EZ];
+#pragma unroll
+                for (int q = 0; q < EZ; ++q) {
+                    const cplx c = valid ? row[zj + PZ * q] : mkc(0.0, 0.0);
+                    const real x2 = c.x * c.x, y2 = c.y * c.y;
+                    if (kind == 0) v[q] = mkc(x2, y2);
+                    else if (kind == 1) v[q] = mkc(fabs(c.x), fabs(c.y));
+                    else {
+                        const real e = kind == 2 ? be : al;
+                        v[q] = mkc(x2 > 0.0 ? fm::pow_pos(x2, e) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, e) : (real)0.0);
+                    }
+                }
+                real nyq;
+                const ZLane<M, EZ> z(zj, zrw, zmine, valid);
+                z_forward_regs<M, EZ>(v, z, twM, twN, nyq);
+                if (valid) {
+                    cplx* pr = plane + s * (N * PS) + y * PS;
+#pragma unroll
+                    for (int q = 0; q < EZ; ++q) pr[zj + PZ * q] = v[q];
+                    if (zj == 0) pr[M] = mkc(nyq, 0.0);
+                }
+            }
+            __syncthreads();
+            res_ylines<N, false>(plane, ns, rowbuf, twN, A.T, A.kinds + g0, x);
+            __syncthreads();
+        }
+    }
+    stamp(0);
+    res_barrier(A.sync, A.epoch0 + (unsigned)N, &timed_out);
+    stamp(1);
+
+    // ------------------------------------------------------------------ phase B: slab ky = bid, lines along x
+    {
+        const int ky = bid;
+        const int nlines = A.narr * NZH;
+        for (int L0 = 0; L0 < nlines; L0 += C::LINES) {
+            const int slot = wave * C::LPWV + ll;
+            if (wave * C::LPWV >= C::LINES || L0 + wave * C::LPWV >= nlines) continue;          // wave-uniform
+            const int L = L0 + slot;
+            const bool valid = L < nlines;
+            const int ai = valid ? L / NZH : 0, kz = valid ? L - ai * NZH : 0;
+            const int kind = A.kinds[ai];
+            real* mine = rowbuf + slot * LineBuf<N>::STRIDE;
+            cplx* base = A.T + ((long long)kind * N + ky) * N * NZH + kz;
+            cplx u[EL];
+#pragma unroll
+            for (int q = 0; q < EL; ++q) u[q] = valid ? base[(lj + PL * q) * NZH] : mkc(0.0, 0.0);
+            wave_line_fft<N, EL, false>(u, lj, mine, twN);
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EL; ++q) {
+                real kx_, ky_, kz_, k2;
+                kvec_xyz(A.kg, lj + PL * q, ky, kz, kx_, ky_, kz_, k2);
+                real cf;
+                if (kind == 0) cf = (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;                       // functionals.py:72
+                else if (kind == 1) cf = -k2;                                                  // functionals.py:245
+                else cf = A.lind_p0 * (real)lindhard_shape((k2 != 0.0) ? sqrt(k2) * A.lind_p1 : 0.0);     // functionals.py:646-651
+                u[q] = mkc(cf * u[q].x, cf * u[q].y);
+            }
+            wave_line_fft<N, EL, true>(u, lj, mine, twN);
+            exchange_sync<true>();
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < EL; ++q) base[(lj + PL * q) * NZH] = u[q];
+            }
+        }
+    }
+    stamp(2);
+    res_barrier(A.sync, A.epoch0 + 2u * (unsigned)N, &timed_out);
+    stamp(3);
+
+    // ------------------------------------------------------------------ phase C
+    // the loads that cross XCDs -- this plane of the first group's spectra and the partial sums of chi^2 -- go out together
+    constexpr int NLD = (AG * N * NZH + T - 1) / T;
+    acc_t cscale = 0.0;
+    if (A.narr == 0) {                                    // purely local term set: nothing to transform back
+        res_totals<N>(A.part, 10, 1, tot + kCombineScalars, stage);
+        cscale = A.nel / (tot[kCombineScalars] * A.vol_over_npts);
+    }
+    {
+        // real-space results of the four convolutions for this plane: R[kind][x][y][z] (unscaled), written and read back by
+        // this workgroup only
+        for (int g0 = 0; g0 < A.narr; g0 += AG) {
+            const int ns = (A.narr - g0) < AG ? (A.narr - g0) : AG;
+            cplx ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + k * T;
+                if (i < ns * N * NZH) {
+                    const int s = i / (N * NZH), r = i - s * (N * NZH);
+                    const int ky = r / NZH, kz = r - ky * NZH;
+                    ld[k] = A.T[(((long long)A.kinds[g0 + s] * N + ky) * N + x) * NZH + kz];
+                }
+            }
+            if (g0 == 0 && tid < N) stage[tid] = __builtin_nontemporal_load(A.part + tid * kResSlots + 10);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int i = tid + k * T;
+                if (i < ns * N * NZH) {
+                    const int s = i / (N * NZH), r = i - s * (N * NZH);
+                    const int ky = r / NZH, kz = r - ky * NZH;
+                    plane[s * (N * PS) + ky * PS + kz] = ld[k];
+                }
+            }
+            __syncthreads();
+            stamp(8);
+            if (g0 == 0) {
+                acc_t t = 0.0;
+                for (int g = 0; g < N; ++g) t += stage[g];             // same order in every thread and workgroup
+                cscale = A.nel / (t * A.vol_over_npts);                // system.py:833-834
+            }
+            res_ylines<N, true>(plane, ns, rowbuf, twN, nullptr, nullptr, x);
+            __syncthreads();
+            stamp(9);
+            const int nrows = ns * N;
+            for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
+                if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
+                const int R = R0 + zslot;
+                const bool valid = R < nrows;
+                const int s = valid ? R / N : 0, y = valid ? R - s * N : 0;
+                const cplx* pr = plane + s * (N * PS) + y * PS;
+                cplx v[EZ];
+#pragma unroll
+                for (int q = 0; q < EZ; ++q) v[q] = valid ? pr[zj + PZ * q] : mkc(0.0, 0.0);
+                const real nyq = (valid && zj == 0) ? pr[M].x : (real)0.0;
+                const ZLane<M, EZ> z(zj, zrw, zmine, valid);
+                z_inverse_regs<M, EZ>(v, z, twM, twN, nyq);
+                if (valid) {
+                    cplx* o = reinterpret_cast<cplx*>(A.R) + (((long long)A.kinds[g0 + s] * N + x) * N + y) * M;
+#pragma unroll
+                    for (int q = 0; q < EZ; ++q) o[zj + PZ * q] = v[q];
+                }
+            }
+            __syncthreads();
+        }
+        stamp(10);
+        // potential and energy integrands: the staged pipeline's combine_point on n = c chi^2 and the four convolutions
+        const real cs = (real)cscale;
+        const real f0 = A.inv_n * cs, f1 = A.inv_n * sqrt(cs);
+        const real f2 = A.act[2] ? A.inv_n * (real)::pow((double)cs, (double)be) : (real)0.0;
+        const real f3 = A.act[3] ? A.inv_n * (real)::pow((double)cs, (double)al) : (real)0.0;
+        acc_t acc[kCombineScalars];
+#pragma unroll
+        for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
+        const long long po = (long long)x * N * M;
+        const cplx* ep = reinterpret_cast<const cplx*>(A.vext ? A.vext : A.chi) + po;
+        const cplx* rp = reinterpret_cast<const cplx*>(A.R) + po;
+        cplx* vp = reinterpret_cast<cplx*>(A.v) + po;
+        constexpr long long AS = (long long)N * N * M;            // pairs per array
+        for (int i = tid; i < N * M; i += T) {
+            const cplx c = chi_pl[i], ve = ep[i];
+            const cplx r0 = A.act[0] ? rp[i] : mkc(0.0, 0.0), r1 = A.act[1] ? rp[AS + i] : mkc(0.0, 0.0);
+            const cplx r2 = A.act[2] ? rp[2 * AS + i] : mkc(0.0, 0.0), r3 = A.act[3] ? rp[3 * AS + i] : mkc(0.0, 0.0);
+            real vv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const real ch = h ? c.y : c.x;
+                CombinePoint p{};
+                p.n = cs * ch * ch;
+                p.vext = h ? ve.y : ve.x;
+                p.vh = f0 * (h ? r0.y : r0.x);
+                p.lap = f1 * (h ? r1.y : r1.x);
+                p.cb = f2 * (h ? r2.y : r2.x);
+                p.cva = f3 * (h ? r3.y : r3.x);
+                vv[h] = combine_point(A.ca, p, kCtf, acc);
+            }
+            vp[i] = mkc(vv[0], vv[1]);
+        }
+        stamp(11);
+        // ten sums over the workgroup's threads, through LDS in a fixed order (sixty dependent 64-bit wave shuffles took
+        // longer than the physics): [s][thread] -> 16 chunks per sum -> the sum
+        {
+            constexpr int SP = T + T / 32, CH = T / 16;
+            acc_t* st2 = reinterpret_cast<acc_t*>(lds);          // (the row buffers and planes are dead by now)
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < kCombineScalars; ++s) st2[s * SP + tid + tid / 32] = acc[s];
+            __syncthreads();
+            if (tid < 16 * kCombineScalars) {
+                const int s = tid / 16, ch = tid - s * 16;
+                acc_t t = 0.0;
+                for (int i = 0; i < CH; ++i) {
+                    const int k = ch * CH + i;
+                    t += st2[s * SP + k + k / 32];
+                }
+                stage[tid] = t;
+            }
+            __syncthreads();
+            if (tid < kCombineScalars) {
+                acc_t t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += stage[tid * 16 + i];
+                A.part[bid * kResSlots + tid] = t;
+            }
+        }
+    }
+    stamp(4);
+    res_barrier(A.sync, A.epoch0 + 3u * (unsigned)N, &timed_out);
+    stamp(5);
+
+    // ------------------------------------------------------------------ phase D: mu and chi.grad
+    res_totals<N>(A.part, 0, kCombineScalars, tot, stage);
+    if (bid == 0) {          // (a workgroup that never arrives stalls every barrier, this one's included: one flag suffices)
+        if (tid < kCombineScalars) A.reduced[tid] = tot[tid];
+        else if (tid < 13) A.reduced[tid] = 0.0;                                // no gradient-dependent terms here
+        if (tid == 0) A.reduced[13] = timed_out ? 1.0 : 0.0;
+    }
+    if (A.grad) {
+        const real mu = (real)((tot[8] * A.dV) / A.nel);                                        // system.py:851
+        const real c2dV = (real)(cscale * (2.0 * A.dV));                                        // system.py:836-837,853
+        const long long po = (long long)x * N * M;
+        const cplx* vp = reinterpret_cast<const cplx*>(A.v) + po;
+        cplx* gp = reinterpret_cast<cplx*>(A.grad) + po;
+        for (int i = tid; i < N * M; i += T) {       // the thread that wrote v[i] reads it
+            const cplx c = chi_pl[i], w = vp[i];
+            gp[i] = mkc(c2dV * c.x * (w.x - mu), c2dV * c.y * (w.y - mu));
+        }
+    }
+    stamp(6);
+    __syncthreads();
+    if (tid == 0) {
+        // count out on the device; the last workgroup tells the host (one write over the bus, not N atomics)
+        const unsigned old = __hip_atomic_fetch_add(A.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == A.done_target) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope
+            __hip_atomic_store(A.done, A.done_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+}  // namespace ofdft
+
+namespace eng {
+
+// term sets the resident kernel serves: everything local, Hartree, von Weizsaecker, Wang-Teter
+bool resident_serves(const ofdft_ctx* c) {
+    if (!c->resident || c->nranks != 1 || !c->fast) return false;
+    if (!(c->n0 == c->n1 && c->n1 == c->n2 && (c->n0 == 16 || c->n0 == 32 || c->n0 == 64))) return false;
+    if (c->mask & (kGgaAny | OFDFT_WGC99_NL)) return false;
+    if (wts_active(c)) return false;
+    return c->mask != 0;
+}
+
+template <int N>
+static int launch_res(ofdft_ctx* c, const ResArgs& a, hipStream_t st) {
+    cplx *twM, *twN;
+    if (int rc = get_twiddle(c, N / 2, &twM)) return rc;
+    if (int rc = get_twiddle(c, N, &twN)) return rc;
+    OFDFT_LAUNCH(c, st, "resident", (resident_closure_kernel<N>), dim3(N), dim3(kResThreads), ResCfg<N>::LDS, a, (const cplx*)twM,
+                 (const cplx*)twN);
+    return 0;
+}
+
+int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st) {
+    const int N = c->n0;
+    const unsigned mask = c->mask;
+    if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    ResArgs a{};
+    a.chi = chi;
+    a.vext = vext;
+    a.v = v;
+    a.grad = grad;
+    void* p;
+    if (int rc = get_ws(c, "res:T", sizeof(cplx) * 4 * (size_t)N * N * (N / 2 + 1), &p)) return rc;
+    a.T = (cplx*)p;
+    if (int rc = get_ws(c, "res:R", sizeof(real) * 4 * (size_t)N * N * N, &p)) return rc;
+    a.R = (real*)p;
+    if (int rc = get_ws(c, "res:part", sizeof(double) * 64 * kResSlots, &p)) return rc;
+    a.part = (acc_t*)p;
+    if (!c->res_sync) {
+        HIP_TRY(c, hipMalloc((void**)&c->res_sync, 64));
+        HIP_TRY(c, hipMemset(c->res_sync, 0, 64));
+        HIP_TRY(c, hipHostMalloc((void**)&c->res_done, 64));
+        *c->res_done = 0;
+        c->res_done_target = 0;
+        c->res_epoch = 0;
+    }
+    a.done = c->res_done;
+    a.reduced = c->h_partial;          // pinned, device-visible: no copy command behind the kernel
+    a.sync = c->res_sync;
+    a.epoch0 = c->res_epoch;
+    c->res_epoch += 3u * (unsigned)N;
+    c->res_done_target += (unsigned)N;
+    a.done_target = c->res_done_target;
+    const bool wt = mask & OFDFT_WT_NL;
+    const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
+    a.act[0] = (mask & OFDFT_HARTREE) ? 1 : 0;
+    a.act[1] = (mask & OFDFT_VW) ? 1 : 0;
+    a.act[2] = wt ? 1 : 0;
+    a.act[3] = (wt && al != be) ? 1 : 0;
+    for (int k = 0; k < 4; ++k)
+        if (a.act[k]) a.kinds[a.narr++] = k;
+    a.kg = c->kg;
+    CombineArgs& ca = a.ca;
+    ca.mask = mask;
+    ca.npts = c->npts;
+    ca.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
+    ca.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(nel) : 0.0;           // functionals.py:268-270
+    ca.conv_a = nullptr;
+    if (wt) {
+        const double nbar = nel / c->vol;                                                      // functionals.py:646-647
+        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+        a.lind_p0 = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - kFiveThirds));
+        a.lind_p1 = 1.0 / (2.0 * kf);
+        ca.wt_alpha = al;
+        ca.wt_beta = be;
+        ca.wt_nbar_pa = std::pow(nbar, al);
+        ca.wt_is_56 = (al == kFiveSixths && be == kFiveSixths) ? 1 : 0;
+        if (al != be) ca.conv_a = chi;      // any non-null pointer: combine_point only asks whether the second convolution exists
+    }
+    a.nel = nel;
+    a.vol_over_npts = c->vol / (double)c->npts;
+    a.dV = c->dV;
+    a.inv_n = 1.0 / (double)c->npts;
+    c->fft_count += 2 * a.narr;
+    switch (N) {
+        case 16: return launch_res<16>(c, a, st);
+        case 32: return launch_res<32>(c, a, st);
+        case 64: return launch_res<64>(c, a, st);
+    }
+    return fail(c, OFDFT_EINVAL, "resident kernel: unsupported grid");
+}
+
+}  // namespace eng

@@ -69,6 +69,8 @@ template <int M, int E> struct ZLane {
         valid = row < g.nrows;
         mine = lds + (wave * W::RPWV + rw) * W::RS;
     }
+    // a row group placed by the caller (the resident small-grid kernel): only j, rw, valid and mine are meaningful
+    __device__ __forceinline__ ZLane(int j_, int rw_, real* mine_, bool valid_) : j(j_), rw(rw_), row_u(0), row(rw_), valid(valid_), mine(mine_) {}
 };
 
 // The row transforms read ~9 twiddle factors per row and array; as global loads each of them was a dependent L2 round

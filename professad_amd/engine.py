@@ -47,6 +47,10 @@ class Engine:
         self._box_key = None
         self._terms_key = None
         self.npts = int(np.prod(self.shape))
+        self._dev_index = idx
+        self._dev_exact = torch.device('cuda', idx)
+        # (a private torch entry point, ~1.5 microseconds cheaper per call than torch.cuda.current_stream(); optional)
+        self._raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
     def close(self):
         if getattr(self, '_ctx', None) is not None and self._ctx.value:
@@ -69,6 +73,8 @@ class Engine:
             return None
         if not isinstance(t, torch.Tensor):
             raise TypeError('%s must be a torch.Tensor' % name)
+        if t.device == self._dev_exact and t.dtype == self.dtype and t.shape == self.shape and not t.requires_grad and t.is_contiguous():
+            return t                                      # the hot path's case: nothing to convert
         if t.device != self.device and not (t.device.type == 'cuda' and self.device.type == 'cuda'
                                             and (t.device.index or 0) == (self.device.index or 0)):
             raise ValueError('%s is on %s, engine is on %s' % (name, t.device, self.device))
@@ -77,9 +83,13 @@ class Engine:
                             'torch.float32 only)' % (name, self.dtype))
         if tuple(t.shape) != self.shape:
             raise ValueError('%s has shape %s, engine grid is %s' % (name, tuple(t.shape), self.shape))
-        return t.detach().contiguous()
+        if t.requires_grad or not t.is_contiguous():
+            t = t.detach().contiguous()
+        return t
 
     def _stream(self):
+        if self._raw_stream is not None:
+            return C.c_void_p(self._raw_stream(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- configuration
@@ -131,7 +141,7 @@ class Engine:
         mu = C.c_double(0.0)
         self._check(self.lib.ofdft_energy_grad_chi(self._ctx, _ptr(chi), _ptr(vext), float(n_elec), E, C.byref(mu),
                                                    _ptr(out), self._stream()), 'ofdft_energy_grad_chi')
-        return {nm: E[i] for i, nm in enumerate(N.TERM_ORDER)}, mu.value, out
+        return dict(zip(N.TERM_ORDER, E[:])), mu.value, out
 
     # -- validation entry points
     def rfftn(self, x):

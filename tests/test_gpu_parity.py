@@ -786,8 +786,9 @@ def test_graph_replay_is_bitwise_the_kernel_by_kernel_path(shape, cfg):
     nel = 7.0
     names = F.NativeTerms(_CFG_TERMS[cfg]).names
     # (graph-eligible grids keep the WGC99 part inside the combine kernel: same setting for the comparison engine)
-    plain = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_GRAPH, 0).set_option(4, 0)
-    eng = Engine(shape, DEV).set_cell(box).set_terms(names)
+    # (the persistent small-grid kernel would serve 32^3 cfg1 instead: off, this test is about the replay)
+    plain = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_GRAPH, 0).set_option(4, 0).set_option(N.OPT_RESIDENT, 0)
+    eng = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_RESIDENT, 0)
     for rep in range(5):
         if rep == 3:
             chi.mul_(1.0 + 0.05 * torch.as_tensor(rng.random(shape), device=DEV))      # new data behind the same pointer
@@ -804,6 +805,69 @@ def test_graph_replay_is_bitwise_the_kernel_by_kernel_path(shape, cfg):
     Eb, mub, gb = eng.set_terms(other).energy_grad_chi(chi, nel, None)
     assert Ea == Eb and mua == mub and torch.equal(ga, gb)
     plain.close()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------- persistent small-grid kernel
+_RES_TERMS = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
+              'local': ['tf', 'lda_x', 'pw_c'], 'vw_only': ['vw']}
+
+
+@pytest.mark.parametrize('n', [16, 32, 64])
+@pytest.mark.parametrize('cfg', ['cfg1', 'cfg2', 'local', 'vw_only', 'wt_ab', 'gtf'])
+def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
+    """cubic 16^3 / 32^3 / 64^3, term sets without gradient-dependent or WGC99 parts: the closure evaluation as ONE persistent
+    kernel (csrc/resident.hip) against the staged pipeline (itself pinned to the oracle and the reference's goldens),
+    energies / mu / chi.grad to 1e-12; repeated calls (the barrier counter runs on), new data, the untimed form"""
+    from professad_amd import _native as N
+    shape = (n, n, n)
+    rng = np.random.default_rng(5)
+    box = dev(synth.triclinic_cell(n / 4.0))
+    den = synth.smooth_density(shape, seed=3, amp=0.5) * (1 + 0.1 * rng.random(shape))
+    vext = dev(synth.random_potential(shape, seed=4))
+    chi = dev(np.sqrt(den) * np.where(rng.random(shape) < 0.3, -1.0, 1.0))        # chi may change sign: n = c chi^2
+    nel = 9.0
+    params = None
+    if cfg == 'wt_ab':
+        names, params = ['ion_electron', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c'], {'wt_alpha': 0.7, 'wt_beta': 0.9}
+    elif cfg == 'gtf':
+        names, params = ['ion_electron', 'hartree', 'vwgtf', 'lda_x', 'pw_c'], {'vwgtf_kind': 2}
+    else:
+        names = F.NativeTerms(_RES_TERMS[cfg]).names if cfg in ('cfg1', 'cfg2') else _RES_TERMS[cfg]
+    staged = Engine(shape, DEV).set_cell(box).set_terms(names, params).set_option(N.OPT_RESIDENT, 0)
+    res = Engine(shape, DEV).set_cell(box).set_terms(names, params).set_option(N.OPT_RESIDENT, 1)       # timed form first
+    ve = vext if 'ion_electron' in names else None
+    for rep in range(4):
+        if rep == 2:
+            chi = chi * (1.0 + 0.05 * torch.as_tensor(rng.random(shape), device=DEV))
+        if rep == 3:
+            res.set_option(N.OPT_RESIDENT, 2)
+        Ea, mua, ga = staged.energy_grad_chi(chi, nel, ve)
+        Eb, mub, gb = res.energy_grad_chi(chi, nel, ve)
+        for k in Ea:
+            assert abs(Ea[k] - Eb[k]) <= 1e-12 * max(abs(Ea[k]), 1e-2), (rep, k, Ea[k], Eb[k])
+        assert abs(mua - mub) <= 1e-12 * max(1.0, abs(mua))
+        assert float((ga - gb).abs().max()) <= 1e-12 * float(ga.abs().max()), rep
+    assert res.query(N.Q_RESIDENT_EVALS) == 4 and staged.query(N.Q_RESIDENT_EVALS) == 0
+    Ec, muc, _ = res.energy_grad_chi(chi, nel, ve, want_grad=False)                  # energy only
+    assert Ec == Eb and muc == mub
+    staged.close()
+    res.close()
+
+
+def test_resident_kernel_leaves_other_grids_and_terms_to_the_staged_pipeline():
+    from professad_amd import _native as N
+    chi = dev(np.sqrt(synth.smooth_density((32, 32, 32), seed=3)))
+    eng = Engine((32, 32, 32), DEV).set_cell(dev(synth.cubic_cell(32))).set_terms(F.NativeTerms(['hartree', 'wgc99', 'pbe']).names)
+    eng.energy_grad_chi(chi, 5.0, None)
+    assert eng.query(N.Q_RESIDENT_EVALS) == 0
+    eng.set_terms(['hartree', 'tf']).energy_grad_chi(chi, 5.0, None)
+    assert eng.query(N.Q_RESIDENT_EVALS) == 1
+    eng.close()
+    chi = dev(np.sqrt(synth.smooth_density((16, 32, 32), seed=3)))
+    eng = Engine((16, 32, 32), DEV).set_cell(dev(synth.cubic_cell(32))).set_terms(['hartree', 'tf'])
+    eng.energy_grad_chi(chi, 5.0, None)
+    assert eng.query(N.Q_RESIDENT_EVALS) == 0
     eng.close()
 
 

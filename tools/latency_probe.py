@@ -1,4 +1,5 @@
-"""Milliseconds per closure evaluation on small grids, kernel-by-kernel launches against the hipGraph replay.
+"""Milliseconds per closure evaluation on small grids: kernel-by-kernel launches, the hipGraph replay, the persistent kernel
+(host wall time per call, and the HIP-event time of the last call's device work).
 usage: python tools/latency_probe.py [N ...]"""
 import json
 import os
@@ -30,8 +31,11 @@ def main():
             vext = torch.as_tensor(synth.random_potential(shape, seed=4), dtype=dt, device=dev)
             row = {'grid': n, 'dtype': str(dt).replace('torch.', '')}
             for cfg, terms in CFG.items():
-                for graph in (0, 1):
-                    eng = Engine(shape, dev, dtype=dt).set_cell(box).set_terms(NativeTerms(terms).names).set_option(N.OPT_GRAPH, graph)
+                for mode in ('launches', 'graph', 'resident', 'resident_untimed'):
+                    graph = 0 if mode == 'launches' else 1
+                    res = {'resident': 1, 'resident_untimed': 2}.get(mode, 0)
+                    eng = (Engine(shape, dev, dtype=dt).set_cell(box).set_terms(NativeTerms(terms).names).set_option(N.OPT_GRAPH, graph)
+                           .set_option(N.OPT_RESIDENT, res))
                     for _ in range(6):
                         eng.energy_grad_chi(chi, 12.0, vext)
                     torch.cuda.synchronize()
@@ -40,8 +44,11 @@ def main():
                     for _ in range(reps):
                         eng.energy_grad_chi(chi, 12.0, vext)
                     torch.cuda.synchronize()
-                    row['%s_%s_ms' % (cfg, 'graph' if graph else 'launches')] = round((time.perf_counter() - t0) / reps * 1e3, 4)
-                    row['%s_replays' % cfg] = int(eng.query(N.Q_GRAPH_REPLAYS))
+                    if res and not eng.query(N.Q_RESIDENT_EVALS):
+                        eng.close()
+                        continue                                  # term set / grid the persistent kernel does not serve
+                    row['%s_%s_ms' % (cfg, mode)] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+                    row['%s_%s_kernel_ms' % (cfg, mode)] = round(eng.query(N.Q_KERNEL_MS), 4)
                     eng.close()
             print(json.dumps(row), flush=True)
 
