@@ -256,8 +256,7 @@ def main():
                 c_vext = torch.as_tensor(np.ascontiguousarray(vext_full[xs]), dtype=tdtype, device=device)
                 for _ in range(2):
                     Ep, _, _ = cand.energy_grad_chi(c_chi, n_elec, c_vext)
-                torch.cuda.synchronize(device)
-                dist.barrier()
+                torch.cuda.synchronize(device)          # (no barrier here: a rank that raised above must not leave the others in one)
                 t0 = time.perf_counter()
                 for _ in range(3):
                     Ep, _, _ = cand.energy_grad_chi(c_chi, n_elec, c_vext)

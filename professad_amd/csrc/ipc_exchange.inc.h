@@ -163,7 +163,13 @@ int ipc_arena(ofdft_ctx* c) {
         s->bytes[w] = need[w];
         tot += (need[w] + 4095) & ~(size_t)4095;
     }
-    HIP_TRY(c, hipMalloc(&s->arena, tot));
+    // fine-grained device memory: what a peer GPU stores here (spectra, epoch stamps) is coherent with this GPU's reads -- lines
+    // of a coarse-grained allocation may linger in the local L2 across evaluations, which remote stores do not invalidate
+    if (hipExtMallocWithFlags(&s->arena, tot, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        s->arena = nullptr;
+        HIP_TRY(c, hipMalloc(&s->arena, tot));
+    }
     HIP_TRY(c, hipMemset((char*)s->arena + s->off[4], 0, kIpcMailboxBytes));
     HIP_TRY(c, hipDeviceSynchronize());
     s->arena_bytes = tot;
