@@ -54,7 +54,10 @@ def class_alg_bytes(cfg, n, word, n_ypass):
     t = {'sum': R,                       # chi
          'chi_grad': 3 * R,              # chi, v -> grad
          'cpass_y': n_ypass * 2 * Cc, 'cpass_x': 2 * Cc, 'zfwd': R + Cc, 'zinv': R + Cc,
-         'xfused_lap': 2 * Cc}
+         'xfused_lap': 2 * Cc,
+         # persistent small-grid kernel (cfg2 term set on a cubic 16^3 / 32^3 / 64^3 grid): chi three times over (phase A per
+         # spectrum), three spectra written + read + rewritten + read, three real results written + read, v_ext, v twice, grad
+         'resident': (3 + 6 + 1 + 2 + 1) * R + 4 * 3 * Cc}
     if cfg == 'cfg3':
         t.update({'zf_density': 2 * R + 2 * Cc,         # chi -> n^, (sqrt n)^, D_c n
                   'yderiv': 2 * 2 * Cc,                 # D_b n (out of place) and D_b G_b (in place)
@@ -331,7 +334,8 @@ def main():
     n_fft = int(eng.query(0))
     n_launch = int(eng.query(4))
     n_ypass = float(eng.query(5))          # whole-spectrum y line passes actually executed
-    dev_ms = raw.query(3)                  # begin .. end of the last evaluation on this rank's stream (HIP events)
+    dev_ms = raw.query(3) or None          # begin .. end of the last evaluation on this rank's stream (HIP events); the
+                                           # persistent small-grid kernel's calls are not bracketed by events (reads 0)
 
     # ---- per-kernel HIP-event profile (separate pass, not inside the timed region; events are recorded on the streams the
     # kernels are launched on).  Durations are measured with the chains serialised on ONE stream: with the side streams
