@@ -162,18 +162,18 @@ __device__ __forceinline__ void repattern_out_to_in(cplx (&v)[PL::E], int j, rea
         exchange_sync<WAVE>();
 #pragma unroll
         for (int q = 0; q < E; ++q)
-            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpad(j + PL::cout(q))] = v[q].x;
+            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpos<PL>(j + PL::cout(q))] = v[q].x;
         exchange_sync<WAVE>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) re[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? line[lpad(j + PL::cin(q))] : (real)0.0;
-        exchange_sync<WAVE>();
-#pragma unroll
-        for (int q = 0; q < E; ++q)
-            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpad(j + PL::cout(q))] = v[q].y;
+        for (int q = 0; q < E; ++q) re[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? line[lpos<PL>(j + PL::cin(q))] : (real)0.0;
         exchange_sync<WAVE>();
 #pragma unroll
         for (int q = 0; q < E; ++q)
-            v[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? mkc(re[q], line[lpad(j + PL::cin(q))]) : mkc(0.0, 0.0);
+            if (PL::slot_out(q) && PL::lane_out(j, q)) line[lpos<PL>(j + PL::cout(q))] = v[q].y;
+        exchange_sync<WAVE>();
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            v[q] = (PL::slot_in(q) && PL::lane_in(j, q)) ? mkc(re[q], line[lpos<PL>(j + PL::cin(q))]) : mkc(0.0, 0.0);
         exchange_sync<WAVE>();
     }
 }

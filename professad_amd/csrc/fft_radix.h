@@ -377,6 +377,26 @@ template <int LEN> struct LineBuf {
     // doubles per line buffer; +2 staggers consecutive lines over the banks
     static constexpr int STRIDE = LEN + (LEN >> 4) + 2;
 };
+// Layout of a line buffer per PLAN.  The padded layout keeps the strided exchange writes of every radix on distinct bank
+// pairs, but a unit-stride read by the 32 lanes of one ds_read_b64 group crosses a pad and wraps onto its own first
+// bank pair: 2 LDS cycles instead of 1 (SQ_LDS_BANK_CONFLICT 40-49 % of the LDS cycles of the wave-local z kernels,
+// whose rows are read by 32 lanes).  The radix-4 plans of those kernels (ZPlan<LEN, 4>) therefore swizzle inside each
+// 16-element block instead: position i ^ 5 b with b = bits 4-5 of i -- aligned unit-stride runs of 32 stay a permutation
+// of the 32 bank pairs, and the stride-4 / stride-16 writes of radix-4 stages land on distinct pairs too (b reaches bits
+// 0-1 and 2-3).  Radix-8 / -16 stages need the padded form (their 16 write lanes differ in more than two block bits).
+#ifndef OFDFT_LDS_SWIZZLE_Z
+#define OFDFT_LDS_SWIZZLE_Z 1
+#endif
+template <class PL> struct LdsLayout { static constexpr bool SWIZZLE = false; };
+template <class PL> __device__ __forceinline__ int lpos(int i) {
+    if constexpr (LdsLayout<PL>::SWIZZLE) return i ^ (5 * ((i >> 4) & 3));
+    else return lpad(i);
+}
+template <class PL> constexpr int line_stride() {
+    // swizzled: whole 16-element blocks, then 16 more so that two 16-lane rows of one read group sit on opposite halves of
+    // the bank row
+    return LdsLayout<PL>::SWIZZLE ? ((PL::LEN + 15) / 16) * 16 + 16 : LineBuf<PL::LEN>::STRIDE;
+}
 
 // workgroup-wide or wave-local synchronisation of the LDS exchange.  WAVE = true is legal when all P
 // threads of a line are lanes of ONE wavefront: a wave's LDS instructions execute in program order, so a
@@ -444,7 +464,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
             for (int b = 0; b < NB; ++b)
                 if (FULL || j + b * P < NBF) {
 #pragma unroll
-                    for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].x;
+                    for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS)] = v[b + u * NB].x;
                 }
             exchange_sync<WAVE>();
             real re[E];
@@ -452,21 +472,21 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
             for (int b = 0; b < NB2; ++b)
                 if (FULL2 || j + b * P < NBF2) {
 #pragma unroll
-                    for (int t = 0; t < R2; ++t) re[b + t * NB2] = line[lpad(j + b * P + t * NBF2)];
+                    for (int t = 0; t < R2; ++t) re[b + t * NB2] = line[lpos<PL>(j + b * P + t * NBF2)];
                 }
             exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 if (FULL || j + b * P < NBF) {
 #pragma unroll
-                    for (int u = 0; u < R; ++u) line[lpad(base[b] + u * NS)] = v[b + u * NB].y;
+                    for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS)] = v[b + u * NB].y;
                 }
             exchange_sync<WAVE>();
 #pragma unroll
             for (int b = 0; b < NB2; ++b)
                 if (FULL2 || j + b * P < NBF2) {
 #pragma unroll
-                    for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpad(j + b * P + t * NBF2)]);
+                    for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpos<PL>(j + b * P + t * NBF2)]);
                 }
             StageP<PL, S + 1, NS * R, INV, WAVE>::run(v, j, line, tw);
         }
@@ -485,6 +505,7 @@ __device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, real* l
 // threads are lanes of one wave, so the exchanges need no barrier (extra stages only cost LDS traffic), and
 // the small register footprint leaves room for fused pointwise math.
 template <int LEN_, int E_> struct ZPlan;
+template <int LEN_> struct LdsLayout<ZPlan<LEN_, 4>> { static constexpr bool SWIZZLE = OFDFT_LDS_SWIZZLE_Z != 0; };
 #define OFDFT_ZPLAN(LEN_, E_, NST_, R0_, R1_, R2_, R3_)                                              \
     template <> struct ZPlan<LEN_, E_> : PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_> {     \
         static_assert(PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::E == E_ && PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::EXACT, "plan"); \

@@ -65,7 +65,8 @@ template <int N> struct ResCfg {
     static constexpr int lo(int a, int b) { return a < b ? a : b; }
     static constexpr int ROWS = lo(T / PZ, up(AG * N, RPWV));    // row slots of a pass (whole waves)
     static constexpr int LINES = lo(T / PL, up(4 * NZH, LPWV));  // line slots of a pass
-    static constexpr int RB_Z = ROWS * LineBuf<M>::STRIDE, RB_L = LINES * LineBuf<N>::STRIDE;
+    static constexpr int RSZ = line_stride<ZPlan<M, EZ>>();     // reals per z-row buffer (layout of that plan)
+    static constexpr int RB_Z = ROWS * RSZ, RB_L = LINES * LineBuf<N>::STRIDE;
     static constexpr int RB = RB_Z > RB_L ? RB_Z : RB_L;         // reals of the row / line exchange buffers
     static constexpr size_t LDS_FFT = sizeof(real) * RB + sizeof(cplx) * (M + N) + sizeof(cplx) * AG * N * PS;
     static constexpr size_t LDS_RED = sizeof(double) * kCombineScalars * (T + T / 32);        // the ordered sums of phase C reuse the space
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int zj = lane % PZ, zrw = lane / PZ;
     const int zslot = wave * C::RPWV + zrw;
-    real* zmine = rowbuf + (zslot < C::ROWS ? zslot : 0) * LineBuf<M>::STRIDE;
+    real* zmine = rowbuf + (zslot < C::ROWS ? zslot : 0) * C::RSZ;
     const int ll = lane % C::LPWV, lj = lane / C::LPWV;
     int timed_out = 0;
     // phase clock of workgroup 0 (100 MHz ticks since kernel entry) -> reduced[16..22]

@@ -36,7 +36,7 @@ template <int M, int E_> struct ZW {
     static constexpr int RPWV = 64 / P;             // rows per wave
     static constexpr int TPB = 256;
     static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
-    static constexpr int RS = LineBuf<M>::STRIDE;   // LDS doubles per row
+    static constexpr int RS = line_stride<PL>();    // LDS doubles per row
     static constexpr int ROWS = RPB * RS;           // reals of the row buffers; the staged twiddle tables follow them
 #if OFDFT_Z_LDS_TWIDDLES
     static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * 2 * M;
@@ -180,20 +180,20 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     exchange_sync<true>();
     if constexpr (PL::EXACT) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].x;
+        for (int q = 0; q < E; ++q) z.mine[lpos<PL>(z.j + P * q)] = v[q].x;
         exchange_sync<true>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpad((M - (z.j + P * q)) & (M - 1))];
+        for (int q = 0; q < E; ++q) cr_m[q] = z.mine[lpos<PL>((M - (z.j + P * q)) & (M - 1))];
         c0r = z.mine[0];
         exchange_sync<true>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) z.mine[lpad(z.j + P * q)] = v[q].y;
+        for (int q = 0; q < E; ++q) z.mine[lpos<PL>(z.j + P * q)] = v[q].y;
         exchange_sync<true>();
         const unsigned voff = z_spec_voff<M, E>(z, g);
         static_for<E>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             const int k = z.j + P * q;
-            const real ci_m = z.mine[lpad((M - k) & (M - 1))];
+            const real ci_m = z.mine[lpos<PL>((M - k) & (M - 1))];
             const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
             const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
             const cplx X = cadd(ev, cmul(twN[k], od));
@@ -202,21 +202,21 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     } else {          // rows with factors 3 / 5: slot q holds coefficient k = j + cout(q); general addressing
 #pragma unroll
         for (int q = 0; q < E; ++q)
-            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].x;
+            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpos<PL>(z.j + PL::cout(q))] = v[q].x;
         exchange_sync<true>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
+        for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpos<PL>(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
         c0r = z.mine[0];
         exchange_sync<true>();
 #pragma unroll
         for (int q = 0; q < E; ++q)
-            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].y;
+            if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpos<PL>(z.j + PL::cout(q))] = v[q].y;
         exchange_sync<true>();
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;
             const int k = z.j + PL::cout(q);
-            const real ci_m = z.mine[lpad(z_mirror<M>(k))];
+            const real ci_m = z.mine[lpos<PL>(z_mirror<M>(k))];
             const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
             const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
             const cplx X = cadd(ev, cmul(twN[k], od));
@@ -264,21 +264,21 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q)
-        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].x;
+        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpos<PL>(z.j + PL::cout(q))] = v[q].x;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
+    for (int q = 0; q < E; ++q) cr_m[q] = (PL::slot_out(q) && PL::lane_out(z.j, q)) ? z.mine[lpos<PL>(z_mirror<M>(z.j + PL::cout(q)))] : (real)0.0;
     c0r = z.mine[0];
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q)
-        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpad(z.j + PL::cout(q))] = v[q].y;
+        if (PL::slot_out(q) && PL::lane_out(z.j, q)) z.mine[lpos<PL>(z.j + PL::cout(q))] = v[q].y;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;
         const int k = z.j + PL::cout(q);
-        const real ci_m = z.mine[lpad(z_mirror<M>(k))];
+        const real ci_m = z.mine[lpos<PL>(z_mirror<M>(k))];
         const cplx ev = mkc(0.5 * (v[q].x + cr_m[q]), 0.5 * (v[q].y - ci_m));
         const cplx od = mkc(0.5 * (v[q].y + ci_m), -0.5 * (v[q].x - cr_m[q]));
         v[q] = cadd(ev, cmul(twN[k], od));
@@ -298,20 +298,20 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q)
-        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpad(z.j + PL::cin(q))] = v[q].x;
+        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpos<PL>(z.j + PL::cin(q))] = v[q].x;
     exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) xr_m[q] = (PL::slot_in(q) && PL::lane_in(z.j, q)) ? z.mine[lpad(z_mirror<M>(z.j + PL::cin(q)))] : (real)0.0;
+    for (int q = 0; q < E; ++q) xr_m[q] = (PL::slot_in(q) && PL::lane_in(z.j, q)) ? z.mine[lpos<PL>(z_mirror<M>(z.j + PL::cin(q)))] : (real)0.0;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q)
-        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpad(z.j + PL::cin(q))] = v[q].y;
+        if (PL::slot_in(q) && PL::lane_in(z.j, q)) z.mine[lpos<PL>(z.j + PL::cin(q))] = v[q].y;
     exchange_sync<true>();
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         if (!(PL::slot_in(q) && PL::lane_in(z.j, q))) continue;
         const int k = z.j + PL::cin(q);
-        const real xi_m = z.mine[lpad(z_mirror<M>(k))];
+        const real xi_m = z.mine[lpos<PL>(z_mirror<M>(k))];
         const cplx x = v[q];
         if (k == 0) {
             v[q] = mkc(x.x + nyq, x.x - nyq);
