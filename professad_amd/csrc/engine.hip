@@ -713,9 +713,9 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     c->gx.n1 = n1g / nranks;        // same nrows / totals as g
     // register / LDS line transforms (and with them the fused pipelines) for powers of two and the listed 2^a 3^b 5^c extents
     c->fast = line_extent_ok(n0g) && line_extent_ok(n1g) && row_extent_ok(n2) && is_pow2(nranks);
-    if (nranks > 1 && !(c->fast && all_pow2(c) && n2 / 2 <= 512 && c->gx.n1 >= 1)) {
+    if (nranks > 1 && !(c->fast && n2 / 2 <= 512 && c->gx.n1 >= 1)) {
         delete c;
-        return fail(nullptr, OFDFT_EINVAL, "the slab-decomposed path needs power-of-two extents (n2 <= 1024)");
+        return fail(nullptr, OFDFT_EINVAL, "the slab-decomposed path needs extents with a line-transform plan (powers of two; fp64: also the listed 2^a 3^b 5^c extents), n2 <= 1024");
     }
     c->xg.nxl = n0; c->xg.nyl = c->gx.n1; c->xg.nb = g.nzm / 8; c->xg.nrem = g.nzc - g.nzm;
     c->xg.log_nyl = 0;
@@ -1296,6 +1296,8 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             c->xchunk_mask = (int)value & 31;
             return OFDFT_OK;
         case OFDFT_OPT_MIXED_RADIX:
+            if (c->nranks > 1 && value == 0.0 && !all_pow2(c))
+                return fail(c, OFDFT_EINVAL, "a slab-decomposed context on extents with factors 3 / 5 has no other path than the mixed-radix plans");
             c->fast = line_extent_ok(c->n0g) && line_extent_ok(c->n1g) && row_extent_ok(c->n2) && is_pow2(c->nranks) &&
                       (value != 0.0 || all_pow2(c));
             return OFDFT_OK;

@@ -260,48 +260,49 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
     const long long b0 = uniform64(line_base(m, L0));
     cplx* ub = data + b0;
     const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
-    const long long qstep = uniform64((long long)P * m.se);
-    // buffer side: line part (per lane) and element part (y = j + P*q -> peer, yl)
+    // buffer side: line part (per lane) and element part (y = element index -> peer, yl)
+    using PL = Plan<LEN>;
     long long lb;
     int es;
     if (!in_rem) {               // L = (b*nxl + xl)*8 + kin
         const long long r = L >> 3;
         const int kin = (int)(L & 7), xl = (int)(r % xg.nxl);
         const long long b = r / xg.nxl;
-        lb = xl * xg.rec + a * xg.arr_sz + ((b << xg.log_nyl) << 3) + kin;
+        lb = xl * xg.rec + a * xg.arr_sz + b * xg.nyl * 8 + kin;
         es = 8;
     } else {                     // L = plane*nxl + xl
         const int xl = (int)(L % xg.nxl);
         const long long plane = L / xg.nxl;
-        lb = xl * xg.rec + a * xg.arr_sz + (((long long)xg.nb << xg.log_nyl) << 3) + (plane << xg.log_nyl);
+        lb = xl * xg.rec + a * xg.arr_sz + (long long)xg.nb * xg.nyl * 8 + plane * xg.nyl;
         es = 1;
     }
-    const int ymask = xg.nyl - 1;
-    cplx v[E];
-    if (valid) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            if (INV) {
-                const int e = j + P * q;
-                v[q] = nt_load_c(buf + lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es);
-            } else {
-                v[q] = buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + q * qstep, voff);
-            }
+    // position of line element e in the exchange buffer (power-of-two plans: nyl is a power of two as well)
+    auto bpos = [&](int e) -> long long {
+        int peer, yl;
+        if constexpr (PL::EXACT) {
+            peer = e >> xg.log_nyl;
+            yl = e & (xg.nyl - 1);
+        } else {
+            peer = e / xg.nyl;
+            yl = e - peer * xg.nyl;
         }
-    } else {
+        return lb + (long long)peer * xg.chunk + (long long)yl * es;
+    };
+    const long long se_u = uniform64(m.se);
+    cplx v[E];
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[q] = mkc(0.0, 0.0);
+    for (int q = 0; q < E; ++q) {
+        const bool on = valid && PL::slot_in(q) && PL::lane_in(j, q);
+        if (INV) v[q] = on ? nt_load_c(buf + bpos(j + PL::cin(q))) : mkc(0.0, 0.0);
+        else v[q] = on ? buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
     }
     line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
     if (valid) {
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-            if (INV) {
-                buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + q * qstep, voff, v[q]);
-            } else {
-                const int e = j + P * q;
-                nt_store_c(buf + lb + (long long)(e >> xg.log_nyl) * xg.chunk + (long long)(e & ymask) * es, v[q]);
-            }
+            if (!(PL::slot_out(q) && PL::lane_out(j, q))) continue;
+            if (INV) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + PL::cout(q) * se_u, voff, v[q]);
+            else nt_store_c(buf + bpos(j + PL::cout(q)), v[q]);
         }
     }
 }

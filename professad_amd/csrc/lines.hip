@@ -109,6 +109,7 @@ int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStrea
     switch (c->n1) {
         OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
         OFDFT_CASE(1024)
+        OFDFT_MIXED_LINES(OFDFT_CASE)
     }
 #undef OFDFT_CASE
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n1);

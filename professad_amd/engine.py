@@ -228,8 +228,10 @@ def fused_extents(axis=0, dtype=torch.double, nranks=1):
     """sorted extents along `axis` (0, 1: lines; 2: the real-to-complex rows) served by the fused pipelines"""
     lo, hi = (16, 2048) if axis == 2 else (8, 1024)
     out = {1 << k for k in range(3, 12) if lo <= (1 << k) <= hi}
-    if dtype == torch.double and nranks == 1:        # slab-decomposed contexts: powers of two
+    if dtype == torch.double:
         out |= set(FUSED_EXTENTS_MIXED)
+    if nranks > 1 and axis < 2:                       # slabs: axes 0 and 1 are cut into nranks pieces
+        out = {e for e in out if e % nranks == 0}
     return sorted(out)
 
 

@@ -78,7 +78,8 @@ def test_slab_decomposed_over_rccl_matches_single_gpu(shape, dtype, tmp_path):
         _check_worker_results(res, dtype)
 
 
-@pytest.mark.parametrize('world,shape,dtype', [(2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'), (2, '64x32x128', 'f64'), (4, '32x32x32', 'f32')])
+@pytest.mark.parametrize('world,shape,dtype', [(2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'), (2, '64x32x128', 'f64'), (4, '32x32x32', 'f32'),
+                                               (2, '48x96x120', 'f64')])
 def test_slab_decomposed_with_the_library_own_exchange(world, shape, dtype, tmp_path):
     """transport='ipc': the ranks map each other's receive buffers and mailboxes through hipIpc and the library moves the
     spectra itself (peer copies + epoch stamps + bounded waits), one C call per evaluation and no collective in it -- here with
@@ -88,7 +89,8 @@ def test_slab_decomposed_with_the_library_own_exchange(world, shape, dtype, tmp_
 
 
 @pytest.mark.parametrize('world,shape,dtype', [(1, '16x16x32', 'f64'), (2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'),
-                                               (2, '64x32x128', 'f64'), (2, '32x32x32', 'f32'), (4, '16x64x32', 'f32')])
+                                               (2, '64x32x128', 'f64'), (2, '32x32x32', 'f32'), (4, '16x64x32', 'f32'),
+                                               (2, '48x48x96', 'f64')])
 def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
     res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'))
     _check_worker_results(res, dtype)
@@ -126,7 +128,8 @@ def test_eight_rank_geometry_with_the_laplacian_dependent_pauli_gaussian():
         assert float((g - gr).abs().max()) <= 1e-12 * float(gr.abs().max())
 
 
-@pytest.mark.parametrize('nranks,shape', [(8, (32, 64, 16)), (8, (64, 64, 64)), (8, (256, 256, 256))])
+@pytest.mark.parametrize('nranks,shape', [(8, (32, 64, 16)), (8, (64, 64, 64)), (8, (256, 256, 256)),
+                                          (2, (48, 96, 120)), (4, (120, 144, 250)), (8, (240, 240, 240))])       # extents with factors 3 / 5
 def test_eight_rank_geometry_in_one_process(nranks, shape):
     """the slab geometry of an 8-GPU job (kernels, pack / un-pack, stage order), emulated with 8 contexts on one GPU"""
     import numpy as np
