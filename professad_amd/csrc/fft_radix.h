@@ -533,17 +533,17 @@ template <int M, int WANT> struct ZPick { static constexpr int E = (M / WANT <= 
     template <> struct ZPlan<M_, PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E> : PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_> {}; \
     template <> struct ZPick<M_, 4> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };   \
     template <> struct ZPick<M_, 8> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };
-OFDFT_ZGPLAN(24, 8, 2, 6, 4, 1, 1)        // E = 6
+OFDFT_ZGPLAN(24, 8, 3, 4, 3, 2, 1)        // E = 4
 OFDFT_ZGPLAN(48, 16, 3, 4, 4, 3, 1)       // E = 4
 OFDFT_ZGPLAN(60, 16, 3, 4, 5, 3, 1)       // E = 6
-OFDFT_ZGPLAN(72, 32, 3, 4, 6, 3, 1)       // E = 6
+OFDFT_ZGPLAN(72, 32, 3, 4, 6, 3, 1)       // E = 6 (4 x 3 x 3 x 2 with E = 4 measured 4 % slower at 144^3)
 OFDFT_ZGPLAN(80, 32, 3, 4, 4, 5, 1)       // E = 5
-OFDFT_ZGPLAN(96, 32, 3, 4, 4, 6, 1)       // E = 6
+OFDFT_ZGPLAN(96, 32, 4, 4, 4, 3, 2)       // E = 4 (was 4 x 4 x 6, E = 6: 192^3 1.81 -> 1.51 ms)
 OFDFT_ZGPLAN(120, 32, 3, 4, 5, 6, 1)      // E = 6
 OFDFT_ZGPLAN(125, 32, 3, 5, 5, 5, 1)      // E = 5
-OFDFT_ZGPLAN(135, 32, 3, 3, 9, 5, 1)      // E = 9
-OFDFT_ZGPLAN(144, 64, 3, 4, 6, 6, 1)      // E = 6
-OFDFT_ZGPLAN(160, 32, 3, 4, 8, 5, 1)      // E = 8
+OFDFT_ZGPLAN(135, 32, 3, 3, 9, 5, 1)      // E = 9 (3 x 3 x 3 x 5 over 64 lanes, E = 5: 270^3 11 % slower)
+OFDFT_ZGPLAN(144, 64, 4, 4, 4, 3, 3)      // E = 4 (was 4 x 6 x 6, E = 6: 288^3 8.34 -> 6.14 ms)
+OFDFT_ZGPLAN(160, 32, 3, 4, 8, 5, 1)      // E = 8 (4 x 4 x 2 x 5 over 64 lanes, E = 5: 320^3 12 % slower)
 OFDFT_ZGPLAN(192, 64, 4, 4, 4, 4, 3)      // E = 4
 OFDFT_ZGPLAN(240, 64, 4, 4, 4, 3, 5)      // E = 6
 #undef OFDFT_ZGPLAN
