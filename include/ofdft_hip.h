@@ -135,7 +135,7 @@ int  ofdft_query(ofdft_ctx* ctx, int what, double* out);
  * ofdft_dist_closure runs the whole closure evaluation of a slab-decomposed context in ONE call, the library moving the
  * spectra itself: every rank maps every peer's receive buffers and mailbox through hipIpc, copies a stage's spectra device
  * to device into chunk [rank] of each peer's buffer on the chain's stream (one direct xGMI link per peer pair), stamps an
- * epoch behind them and waits (bounded, ~4 s) for the peers' stamps in a one-wave kernel; the two small reductions use
+ * epoch behind them and waits (bounded, ~2 s) for the peers' stamps in a one-wave kernel; the two small reductions use
  * the same mailboxes and add the ranks' numbers in rank order.  Set-up, once per (context, term set): every rank exports
  * the handle of its arena -- ONE allocation that holds the two receive buffers of each chain and the mailbox -- with the
  * five objects' byte offsets, the host passes them around (64 + 40 bytes, any transport) and every rank attaches every peer's.  No torch / RCCL call per evaluation; results are
@@ -257,7 +257,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
  * that it overlaps the Hartree/vW/PBE chain (they only meet in the combine kernel); 0 = everything on the caller's stream. */
 #define OFDFT_OPT_XCHUNKS     2   /* z kernels + the y passes next to them walk the grid in x chunks: 0 = automatic (default, ~100 MB of spectra per chunk), 1 = off, 2..64 = count for six spectra */
 #define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default: measured -4 %), 4 PBE loop, 8 combine loop, 16 WGC99 x pass + y-inverse by kz blocks (all three measured neutral or slower at 256^3) */
-#define OFDFT_OPT_SPLIT_COMBINE 4 /* 1 (default): with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream */
+#define OFDFT_OPT_SPLIT_COMBINE 4 /* with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream; 2 (default): and in
+                                     closure evaluations (ofdft_energy_grad_chi) the combine kernel does not wait for it -- the potential stays in two
+                                     arrays that the chi.grad kernel adds, the part's share of sum(v n) joins the combine's; 1: the combine adds it; 0: off */
 #define OFDFT_OPT_BLUESTEIN 5     /* 1 (default): extents that are not powers of two (<= 512) use chirp-z line transforms; 0: plain DFT kernels */
 #define OFDFT_OPT_GGA_SPLIT 6     /* 1 (default): split-derivative GGA chain -- only the index derivative along x visits the x pass (and the exchange); 0: three Cartesian components */
 #define OFDFT_OPT_GRAPH 7         /* 1 (default): ofdft_energy_grad_chi replays a hipGraph captured on the second call with the same

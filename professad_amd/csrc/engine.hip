@@ -878,8 +878,10 @@ int closure_enqueue(ofdft_ctx* c, const real* chi, const real* vext, double nel,
     const DenSrc ds{chi, 0.0, 1, c->d_scal};
     if (int rc = zfused_enqueue(c, ds, nel, vext, v, c->h_partial /* any non-null: host copy wanted */, st, true)) return rc;
     if (grad) {
+        const ZRun& zr = zrun(c);
         OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v, grad,
-                     c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV, nel);
+                     c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV, nel,
+                     zr.vpart_deferred ? zr.za.v_part : (const real*)nullptr);
     }
     return 0;
 }
@@ -1151,6 +1153,9 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.stage[0] = r.stage[1] = 0;
     r.deferred.clear();
     r.forked = false;
+    r.closure = false;
+    r.vpart_deferred = false;
+    r.za.v_part_deferred = 0;
     r.xlist[0].clear();
     r.xlist[1].clear();
     return OFDFT_OK;
@@ -1291,6 +1296,7 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             return OFDFT_OK;
         case OFDFT_OPT_SPLIT_COMBINE:
             c->split_combine = value != 0.0;
+            c->defer_vpart = value != 1.0;
             return OFDFT_OK;
         case OFDFT_OPT_XCHUNK_MASK:
             c->xchunk_mask = (int)value & 31;

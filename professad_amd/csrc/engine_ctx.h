@@ -73,6 +73,7 @@ struct ofdft_ctx {
     bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
     bool gga_split = true;       // GGA chain in split-derivative form: only the x index-derivative visits the x pass
     bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
+    bool defer_vpart = true;     // ... and, in closure evaluations, merged into the potential by chi_grad (the combine kernel does not wait for it)
     int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
     int use_xwave = 1;   // fused x pass: 1 = wave-local kernel (xwave.h) where it measured faster (passes over >= 3 spectra, x extents <= 512), 2 = wherever it exists, 0 = group-parallel kernel only
     int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)

@@ -55,6 +55,8 @@ struct ZRun {
     real* dzn = nullptr;
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
+    bool closure = false;          // single-GPU closure evaluation: only chi.grad leaves the call, so v may stay in two parts
+    bool vpart_deferred = false;   // ... and does: zi_combine does not wait for zi_wgc, chi_grad adds v_part (zstage5)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
     int combine_blocks = 0, pbe_blocks = 0;
@@ -378,17 +380,20 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
             acc_t* part2;
             int blocks = 0;
             if ((rc = real_ws(c, "vpart", &vp))) return rc;
-            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * (size_t)c->partial_rows, (void**)&part2))) return rc;
+            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * 2 * (size_t)c->partial_rows, (void**)&part2))) return rc;
             if (r.forked) {
                 // (its own event: one event recorded on two different streams inside a stream capture crashes the runtime)
                 HIP_TRY(c, hipEventRecord(c->ev_c, sc));
                 HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_c, 0));
             }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
-            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 1,
-                         c->d_scal + 2);
+            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 2,
+                         c->d_scal + 2);                       // [2] energy sum, [3] this part's sum(v n)
             r.za.v_part = vp;
             r.wgc_split = true;
+            // closure evaluations leave v in two parts: the combine kernel then has nothing to wait for on this stream
+            r.vpart_deferred = r.closure && r.forked && c->defer_vpart;
+            r.za.v_part_deferred = r.vpart_deferred ? 1 : 0;
         }
         r.stage[1] = 3;
         return 0;
@@ -517,9 +522,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
     }
     r.xlist[0].clear();
     r.xlist[1].clear();
-    if (r.forked) {       // the combine needs both chains
-        HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    const bool late_join = r.forked && r.vpart_deferred && r.wgc_split;
+    if (r.forked) {       // the combine needs both chains -- unless the nonlocal chain's only product is the deferred v_part
+        if (!late_join) {
+            HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        }
         HIP_TRY(c, hipEventRecord(c->ev_join2, r.sc));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join2, 0));
     }
@@ -549,6 +557,12 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
                  r.combine_blocks, kCombineScalars, c->d_reduced);
     if (wts) OFDFT_LAUNCH(c, st, "reduce", wts_finalize_kernel, dim3(1), dim3(64), 0, c->d_reduced, (const acc_t*)(c->d_scal + 4));
+    if (late_join) {      // now the nonlocal chain: its share of sum(v n) joins the combine's (mu is formed from the total)
+        HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        OFDFT_LAUNCH(c, st, "reduce", (axpy_kernel<acc_t>), dim3(1), dim3(64), 0, (const acc_t*)(c->d_scal + 3), c->d_reduced + 8,
+                     (long long)1, 1);
+    }
     if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
     r.stage[0] = r.stage[1] = 5;
     if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
@@ -578,6 +592,9 @@ int zfused_enqueue(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext,
     r.vext = vext;
     r.v_out = v_out;
     r.deferred.clear();
+    r.closure = defer;            // (only the closure enqueues in deferred form; its consumer is chi_grad)
+    r.vpart_deferred = false;
+    r.za.v_part_deferred = 0;
     int rc;
     // Forking the nonlocal-KEDF chain (and the vW / second WGC99 half) onto their own streams lets their
     // latency-bound fused kernels overlap the other chain's bandwidth-bound passes.

@@ -65,14 +65,16 @@ void ipc_release(ofdft_ctx* c) {
 }
 
 // one wave: lane p waits until rank p's word has reached `epoch` (relaxed system-scope loads: the words are written by
-// other ranks' copy engines / kernels); every lane leaves after ~4 s at the latest and reports through err
+// other ranks' copy engines / kernels); every lane leaves after ~2 s at the latest and reports through err
 __global__ void ipc_wait_kernel(const unsigned* flags, int P, int me, unsigned epoch, int* err) {
     const int p = threadIdx.x;
     if (p >= P || p == me) return;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // an earlier wait of this evaluation
+                                                                                              // already gave up: do not stack time limits
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
     while ((int)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ULL) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
             *err = 1 + p;
             return;
         }
@@ -304,6 +306,9 @@ int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_loc
     r.stage[0] = r.stage[1] = 0;
     r.deferred.clear();
     r.forked = false;
+    r.closure = false;
+    r.vpart_deferred = false;
+    r.za.v_part_deferred = 0;
     r.xlist[0].clear();
     r.xlist[1].clear();
     // ---- the two chains on their own streams; a stage's exchange is enqueued right behind its kernels

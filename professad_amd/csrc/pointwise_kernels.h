@@ -871,17 +871,25 @@ static __global__ void wts_finalize_kernel(acc_t* __restrict__ sums, const acc_t
 
 static __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
                                 long long npts, real c2dV_host, const acc_t* __restrict__ cscale_dev, real two_dV,
-                                real mu_host, const acc_t* __restrict__ vn_dev = nullptr, acc_t dV = 0.0, acc_t n_elec = 1.0) {
+                                real mu_host, const acc_t* __restrict__ vn_dev = nullptr, acc_t dV = 0.0, acc_t n_elec = 1.0,
+                                const real* __restrict__ v2 = nullptr) {
     const real c2dV = cscale_dev ? (real)(cscale_dev[0] * two_dV) : c2dV_host;
     // mu = (sum(v n) dV) / N_e: from the host, or formed here from the device-resident sum (no host round trip: the
     // graph-captured evaluation); same operations in the same order as the host form
     const real mu = vn_dev ? (real)((vn_dev[0] * dV) / n_elec) : mu_host;
     const long long n2 = npts >> 1;
+    // v2: a part of the potential kept in its own array (the WGC99 part formed beside the combine kernel)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const cplx x = reinterpret_cast<const cplx*>(chi)[i], w = reinterpret_cast<const cplx*>(v)[i];
+        const cplx x = reinterpret_cast<const cplx*>(chi)[i];
+        cplx w = reinterpret_cast<const cplx*>(v)[i];
+        if (v2) {
+            const cplx w2 = reinterpret_cast<const cplx*>(v2)[i];
+            w = mkc(w.x + w2.x, w.y + w2.y);
+        }
         reinterpret_cast<cplx*>(g)[i] = mkc(c2dV * x.x * (w.x - mu), c2dV * x.y * (w.y - mu));
     }
-    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0) g[npts - 1] = c2dV * chi[npts - 1] * (v[npts - 1] - mu);
+    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        g[npts - 1] = c2dV * chi[npts - 1] * (v[npts - 1] + (v2 ? v2[npts - 1] : (real)0.0) - mu);
 }
 
 }  // namespace ofdft

@@ -687,6 +687,8 @@ struct ZCombineArgs {
     const cplx* div2;         // split-derivative form: the D_b part of the divergence (added to div)
     real* v_out;
     const real* v_part;     // split form: the WGC99 potential computed by zi_wgc_kernel (then u / gw are not read here)
+    int v_part_deferred;    // closure form: v_part is NOT added here (zi_wgc_kernel runs beside this kernel; chi_grad adds it, and
+                            // its share of sum(v n) arrives through zi_wgc's second sum)
     unsigned mask;
     real inv_n;
     real wt_alpha, wt_beta, wt_nbar_pa;
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     if (a.mask & 32u) {                                  // WGC99
         if (WGC_INLINE) {
             park[5 * 256] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, sc, ctf);
-        } else {                                         // computed by zi_wgc_kernel on the nonlocal chain's stream
+        } else if (!a.v_part_deferred) {                 // computed by zi_wgc_kernel on the nonlocal chain's stream
             z_load_real<M, E, true>(w, z, a.v_part);
 #pragma unroll
             for (int q = 0; q < E; ++q) {
@@ -990,11 +992,15 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(OFDFT_ZIWGC_WAVES))) void zi_wg
         n[q] = (z.valid && PL::slot_out(q) && PL::lane_out(z.j, q)) ? mkc(a.ds(n[q].x), a.ds(n[q].y)) : mkc(1.0, 1.0);
         vacc[q] = mkc(0.0, 0.0);
     }
-    acc_t acc[1];
+    acc_t acc[2];         // the WGC99 energy integrand, and this part's share of sum(v n) (for mu when the parts are merged later)
     acc[0] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, a.inv_n, ctf);
-    if (!z.valid) acc[0] = 0.0;
+    acc[1] = 0.0;
+#pragma unroll
+    for (int q = 0; q < E; ++q)
+        if (PL::slot_out(q) && PL::lane_out(z.j, q)) acc[1] += vacc[q].x * n[q].x + vacc[q].y * n[q].y;
+    if (!z.valid) acc[0] = acc[1] = 0.0;
     z_store_real<M, E>(vacc, z, v_part);
-    block_reduce_store<1>(acc, partial + (long long)g.blk0);
+    block_reduce_store<2>(acc, partial + (long long)g.blk0 * 2);
 }
 
 }  // namespace ofdft
