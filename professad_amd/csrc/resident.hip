@@ -413,6 +413,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
         if (tid < kCombineScalars) A.reduced[tid] = tot[tid];
         else if (tid < 13) A.reduced[tid] = 0.0;                                // no gradient-dependent terms here
         if (tid == 0) A.reduced[13] = timed_out ? 1.0 : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // system scope: the sums are in host memory before this workgroup counts out
     }
     if (A.grad) {
         const real mu = (real)((tot[8] * A.dV) / A.nel);                                        // system.py:851
