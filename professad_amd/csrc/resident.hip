@@ -1,42 +1,60 @@
 // One persistent kernel for grids that fit on chip (cubic 16^3 / 32^3 / 64^3): the whole closure evaluation
 //   chi -> n = c chi^2 -> (E terms, mu, dE/dchi)
-// of the local + Hartree + von Weizsaecker + Wang-Teter term sets in ONE launch.  gfx950 only.
+// of the local + Hartree + von Weizsaecker + Wang-Teter + GGA (PBE x / c, LKT, mu-only Pauli-Gaussian) term sets in ONE
+// launch.  gfx950 only.
 //
-// On these grids the staged pipeline is latency: ~12 dependent launches of a few microseconds of work each (the graph
+// On these grids the staged pipeline is latency: 12-25 dependent launches of a few microseconds of work each (the graph
 // replay removes the host from between them, not the launch gaps).  Here N workgroups stay resident and walk the
-// evaluation in four phases separated by three grid barriers (agent-scope release / acquire on one counter):
-//   A  workgroup = x plane:  f(chi) rows -> z-forward (registers) -> plane in LDS -> y-forward -> T[a][ky][x][kz]
-//      (f = chi^2, |chi|, chi^(2 beta), chi^(2 alpha): the closure scale c = N_e / (sum chi^2 dV) is not known yet, and
-//       does not have to be -- the transforms are linear, c^p is applied in phase C)            + partial sum chi^2
-//   B  workgroup = ky slab:  x-forward -> multiply by 4 pi / k^2 | -k^2 | Lindhard kernel -> x-inverse, in place
-//   C  workgroup = x plane:  y-inverse (LDS) -> z-inverse (registers) -> potential + energy integrands (combine_point,
-//      the very function of the staged pipeline) -> v(r), partial sums
-//   D  workgroup = x plane:  mu from the ordered sum of the partials, chi.grad = 2 c dV chi (v - mu)
-// Every array is read and written in contiguous rows of kz (272 / 528 bytes); the spectra (<= 2.2 MB each) never
-// leave the L2 / Infinity Cache.  The barrier spins are bounded (~2 s) and report through the sums.
-// Reference path: system.py:830-838 (closure), functionals.py:46,72,223,245,646-651 (terms).
+// evaluation in phases separated by grid barriers (agent-scope release / acquire on one counter):
+//   A   workgroup = x plane:  f(chi) rows -> z-forward (registers) -> planes in LDS -> y-forward -> T[slot][ky][x][kz]
+//       (f = chi^2, |chi|, chi^(2 beta), chi^(2 alpha): the closure scale c = N_e / (sum chi^2 dV) is not known yet, and
+//        does not have to be -- the transforms are linear, c^p is applied in phase C)            + partial sum chi^2
+//   B   workgroup = ky slab:  per (input, output) pair: x-forward -> multiply by 4 pi / k^2 | -k^2 | Lindhard kernel | i k_j
+//       -> x-inverse -> T[output slot]
+//   C   workgroup = x plane:  y-inverse (LDS) -> z-inverse (registers) -> R[slot][x][y][z]
+//       GGA only:  grad n -> pbe_point -> df/dn, flux_j (R) -> their z- / y-forward -> T        (barrier)
+//       B2  ky slab: x-forward of the three flux spectra, sum_j i k_j F_j, x-inverse            (barrier)
+//       C2  x plane: y- / z-inverse of the divergence -> R
+//       potential + energy integrands (combine_point, the very function of the staged pipeline) -> v(r), partial sums
+//   D   workgroup = x plane:  mu from the ordered sum of the partials, chi.grad = 2 c dV chi (v - mu)
+// Three barriers (five with a GGA term).  Every array is read and written in contiguous rows of kz (272 / 528 bytes); the
+// spectra (<= 2.2 MB each) never leave the L2 / Infinity Cache.  The barrier spins are bounded (~2 s) and report through
+// the sums.  Reference path: system.py:830-838 (closure), functionals.py:46,72,223,245,646-651,1597-1635 (terms).
 #include "engine_ctx.h"
 
 namespace ofdft {
 
-constexpr int kResSlots = 16;        // doubles per workgroup in the partials: [0..9] combine sums, [10] sum chi^2
+constexpr int kResSlots = 16;        // doubles per workgroup in the partials: [0..9] combine sums, [10] sum chi^2, [11..13] GGA sums
+
+constexpr int kResT = 8;             // spectrum slots: 0 chi^2 (Hartree in / out), 1 |chi| (vW), 2 chi^(2 beta), 3 chi^(2 alpha),
+                                     // 4-6 grad n -> flux -> (4) divergence, 7 v_H when the chi^2 spectrum also feeds the gradient
+constexpr int kResR = 9;             // real-space slots: the same, and 8 = df/dn of the GGA terms
+
+struct ResOp { int in, out, ck; };   // phase B: T[out] = F_x^-1[coef_ck(k) F_x[T[in]]]; ck: 0 4 pi / k^2, 1 -k^2, 2 Lindhard, 3-5 i k_x / i k_y / i k_z
 
 struct ResArgs {
     const real* chi;
     const real* vext;
     real* v;
     real* grad;
-    cplx* T;                 // four spectra [a][ky][x][kz]; a: 0 chi^2 (Hartree), 1 |chi| (vW), 2 chi^(2 beta), 3 chi^(2 alpha)
-    real* R;                 // their convolutions back in real space [a][x][y][z] (unscaled)
-    acc_t* part;             // [N][kResSlots]
+    cplx* T;                 // kResT spectra [slot][ky][x][kz]
+    real* R;                 // kResR real-space arrays [slot][x][y][z] (unscaled transforms; flux and df/dn as computed)
+    acc_t* part;             // [N][kResSlots]: [0..9] combine sums, [10] sum chi^2, [11..13] GGA energy sums
     acc_t* reduced;          // the context's pinned host mirror of the sums, written by the kernel: [0..12] sums, [13] barrier time-out flag
-    unsigned* sync;          // [0] barrier counter
+    unsigned* sync;          // [0] barrier counter, [1] count-out word
     unsigned epoch0;         // counter value before this launch
     unsigned* done;          // pinned host word: the last workgroup to finish stores done_target there (the host may spin on it
                              // instead of waiting for the stream: a few microseconds less per evaluation)
     unsigned done_target;    // value of the device-side count-out word sync[1] once every workgroup of this launch has left
-    int act[4];              // which of the four spectra the term set needs
-    int kinds[4], narr;      // the active ones, compacted (phase B walks this list)
+    int act[4];              // which of the four inputs f(chi) the term set needs (their forward spectra land in slots 0..3)
+    int kinds[4], narr;      // the active ones, compacted (phase A walks this list)
+    ResOp bop[8];            // phase B work list
+    int nb;
+    int outs[8], nout;       // slots transformed back to real space in phase C
+    int vh_slot;             // where v_H comes back (0, or 7 with a GGA term)
+    int gga;                 // gradient-dependent terms present (two more phases)
+    int flux_slots[3];       // {4, 5, 6}: the flux components (the divergence comes back in the first of them)
+    GgaSel sel;
     KGeom kg;
     CombineArgs ca;
     acc_t nel, vol_over_npts, dV;
@@ -147,6 +165,36 @@ __device__ __forceinline__ void res_ylines(cplx* plane, int ns, real* rowbuf, co
     }
 }
 
+// NS sums over the workgroup's threads, through LDS in a fixed order (dependent 64-bit wave shuffles took longer than the
+// physics): [s][thread] -> 16 chunks per sum -> out[0..NS-1].  `scratch` = the dynamic LDS (dead buffers), `stage` >= 16 NS.
+template <int NS>
+__device__ __forceinline__ void res_block_sums(const acc_t (&acc)[NS], real* scratch, acc_t* stage, acc_t* out) {
+    constexpr int T = kResThreads, SP = T + T / 32, CH = T / 16;
+    const int tid = threadIdx.x;
+    acc_t* st2 = reinterpret_cast<acc_t*>(scratch);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) st2[s * SP + tid + tid / 32] = acc[s];
+    __syncthreads();
+    if (tid < 16 * NS) {
+        const int s = tid / 16, ch = tid - s * 16;
+        acc_t t = 0.0;
+        for (int i = 0; i < CH; ++i) {
+            const int k = ch * CH + i;
+            t += st2[s * SP + k + k / 32];
+        }
+        stage[tid] = t;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        acc_t t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += stage[tid * 16 + i];
+        out[tid] = t;
+    }
+    __syncthreads();
+}
+
 template <int N>
 __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArgs A, const cplx* __restrict__ twM_g,
                                                                            const cplx* __restrict__ twN_g) {
@@ -155,8 +203,8 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
     const int bid = (int)blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     __shared__ acc_t red[C::WAVES][kCombineScalars];
-    __shared__ acc_t tot[kCombineScalars + 2];
-    __shared__ acc_t stage[kCombineScalars * 64];
+    __shared__ acc_t tot[16];
+    __shared__ acc_t stage[16 * 64];
     real* rowbuf = lds;
     cplx* twM = reinterpret_cast<cplx*>(lds + C::RB);
     cplx* twN = twM + M;                                  // W_N^k, k < N: the r2c post-processing reads k < M, the x / y lines all of it
@@ -181,6 +229,82 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
     const int x = bid;                                    // phases A, C, D: this workgroup's x plane
     const cplx* chi_pl = reinterpret_cast<const cplx*>(A.chi + (long long)x * N * N);
 
+    // ---- shared pieces ---------------------------------------------------------------------------------------------
+    // rows of this plane: real pairs from `load(s, y, e)` (s = position in the slot list) -> z-forward -> planes in LDS
+    auto rows_forward = [&](int ns, auto load) {
+        const int nrows = ns * N;
+        for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
+            if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
+            const int R = R0 + zslot;
+            const bool valid = R < nrows;
+            const int sI = valid ? R / N : 0, y = valid ? R - sI * N : 0;
+            cplx v[EZ];
+#pragma unroll
+            for (int q = 0; q < EZ; ++q) v[q] = valid ? load(sI, y, zj + PZ * q) : mkc(0.0, 0.0);
+            real nyq;
+            const ZLane<M, EZ> z(zj, zrw, zmine, valid);
+            z_forward_regs<M, EZ>(v, z, twM, twN, nyq);
+            if (valid) {
+                cplx* pr = plane + sI * (N * PS) + y * PS;
+#pragma unroll
+                for (int q = 0; q < EZ; ++q) pr[zj + PZ * q] = v[q];
+                if (zj == 0) pr[M] = mkc(nyq, 0.0);
+            }
+        }
+    };
+    // planes of `ns` spectra (T slots slots[0..ns-1]) of this x plane -> y-inverse -> z-inverse -> R[slot]
+    auto planes_inverse = [&](const int* slots, int ns, bool first_group) {
+        constexpr int NLD = (AG * N * NZH + T - 1) / T;
+        cplx ld[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * T;
+            if (i < ns * N * NZH) {
+                const int sI = i / (N * NZH), r = i - sI * (N * NZH);
+                const int ky = r / NZH, kz = r - ky * NZH;
+                ld[k] = A.T[(((long long)slots[sI] * N + ky) * N + x) * NZH + kz];
+            }
+        }
+        if (first_group && tid < N) stage[tid] = __builtin_nontemporal_load(A.part + tid * kResSlots + 10);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * T;
+            if (i < ns * N * NZH) {
+                const int sI = i / (N * NZH), r = i - sI * (N * NZH);
+                const int ky = r / NZH, kz = r - ky * NZH;
+                plane[sI * (N * PS) + ky * PS + kz] = ld[k];
+            }
+        }
+        __syncthreads();
+        res_ylines<N, true>(plane, ns, rowbuf, twN, nullptr, nullptr, x);
+        __syncthreads();
+        const int nrows = ns * N;
+        for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
+            if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
+            const int R = R0 + zslot;
+            const bool valid = R < nrows;
+            const int sI = valid ? R / N : 0, y = valid ? R - sI * N : 0;
+            const cplx* pr = plane + sI * (N * PS) + y * PS;
+            cplx v[EZ];
+#pragma unroll
+            for (int q = 0; q < EZ; ++q) v[q] = valid ? pr[zj + PZ * q] : mkc(0.0, 0.0);
+            const real nyq = (valid && zj == 0) ? pr[M].x : (real)0.0;
+            const ZLane<M, EZ> z(zj, zrw, zmine, valid);
+            z_inverse_regs<M, EZ>(v, z, twM, twN, nyq);
+            if (valid) {
+                cplx* o = reinterpret_cast<cplx*>(A.R) + (((long long)slots[sI] * N + x) * N + y) * M;
+#pragma unroll
+                for (int q = 0; q < EZ; ++q) o[zj + PZ * q] = v[q];
+            }
+        }
+        __syncthreads();
+    };
+    unsigned nbar = 0;                                    // barriers passed so far
+    auto barrier = [&]() {
+        ++nbar;
+        res_barrier(A.sync, A.epoch0 + nbar * (unsigned)N, &timed_out);
+    };
+
     // ------------------------------------------------------------------ phase A
     {
         acc_t s2 = 0.0;
@@ -199,167 +323,180 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
         }
         for (int g0 = 0; g0 < A.narr; g0 += AG) {
             const int ns = (A.narr - g0) < AG ? (A.narr - g0) : AG;
-            const int nrows = ns * N;
-            for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
-                if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
-                const int R = R0 + zslot;
-                const bool valid = R < nrows;
-                const int s = valid ? R / N : 0, y = valid ? R - s * N : 0;
-                const int kind = A.kinds[g0 + s];
-                const cplx* row = chi_pl + y * M;
-                cplx v[EZ];
-#pragma unroll
-                for (int q = 0; q < EZ; ++q) {
-                    const cplx c = valid ? row[zj + PZ * q] : mkc(0.0, 0.0);
-                    const real x2 = c.x * c.x, y2 = c.y * c.y;
-                    if (kind == 0) v[q] = mkc(x2, y2);
-                    else if (kind == 1) v[q] = mkc(fabs(c.x), fabs(c.y));
-                    else {
-                        const real e = kind == 2 ? be : al;
-                        v[q] = mkc(x2 > 0.0 ? fm::pow_pos(x2, e) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, e) : (real)0.0);
-                    }
-                }
-                real nyq;
-                const ZLane<M, EZ> z(zj, zrw, zmine, valid);
-                z_forward_regs<M, EZ>(v, z, twM, twN, nyq);
-                if (valid) {
-                    cplx* pr = plane + s * (N * PS) + y * PS;
-#pragma unroll
-                    for (int q = 0; q < EZ; ++q) pr[zj + PZ * q] = v[q];
-                    if (zj == 0) pr[M] = mkc(nyq, 0.0);
-                }
-            }
+            rows_forward(ns, [&](int sI, int y, int e) {
+                const int kind = A.kinds[g0 + sI];
+                const cplx c = chi_pl[y * M + e];
+                const real x2 = c.x * c.x, y2 = c.y * c.y;
+                if (kind == 0) return mkc(x2, y2);
+                if (kind == 1) return mkc(fabs(c.x), fabs(c.y));
+                const real ex = kind == 2 ? be : al;
+                return mkc(x2 > 0.0 ? fm::pow_pos(x2, ex) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, ex) : (real)0.0);
+            });
             __syncthreads();
             res_ylines<N, false>(plane, ns, rowbuf, twN, A.T, A.kinds + g0, x);
             __syncthreads();
         }
     }
     stamp(0);
-    res_barrier(A.sync, A.epoch0 + (unsigned)N, &timed_out);
+    barrier();
     stamp(1);
 
     // ------------------------------------------------------------------ phase B: slab ky = bid, lines along x
     {
         const int ky = bid;
-        const int nlines = A.narr * NZH;
+        const int nlines = A.nb * NZH;
         for (int L0 = 0; L0 < nlines; L0 += C::LINES) {
             const int slot = wave * C::LPWV + ll;
             if (wave * C::LPWV >= C::LINES || L0 + wave * C::LPWV >= nlines) continue;          // wave-uniform
             const int L = L0 + slot;
             const bool valid = L < nlines;
-            const int ai = valid ? L / NZH : 0, kz = valid ? L - ai * NZH : 0;
-            const int kind = A.kinds[ai];
+            const int oi = valid ? L / NZH : 0, kz = valid ? L - oi * NZH : 0;
+            const ResOp op = A.bop[oi];
             real* mine = rowbuf + slot * LineBuf<N>::STRIDE;
-            cplx* base = A.T + ((long long)kind * N + ky) * N * NZH + kz;
+            const cplx* src = A.T + ((long long)op.in * N + ky) * N * NZH + kz;
+            cplx* dst = A.T + ((long long)op.out * N + ky) * N * NZH + kz;
             cplx u[EL];
 #pragma unroll
-            for (int q = 0; q < EL; ++q) u[q] = valid ? base[(lj + PL * q) * NZH] : mkc(0.0, 0.0);
+            for (int q = 0; q < EL; ++q) u[q] = valid ? src[(lj + PL * q) * NZH] : mkc(0.0, 0.0);
             wave_line_fft<N, EL, false>(u, lj, mine, twN);
             exchange_sync<true>();
 #pragma unroll
             for (int q = 0; q < EL; ++q) {
                 real kx_, ky_, kz_, k2;
                 kvec_xyz(A.kg, lj + PL * q, ky, kz, kx_, ky_, kz_, k2);
-                real cf;
-                if (kind == 0) cf = (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;                       // functionals.py:72
-                else if (kind == 1) cf = -k2;                                                  // functionals.py:245
-                else cf = A.lind_p0 * (real)lindhard_shape((k2 != 0.0) ? sqrt(k2) * A.lind_p1 : 0.0);     // functionals.py:646-651
-                u[q] = mkc(cf * u[q].x, cf * u[q].y);
+                if (op.ck >= 3) {                                                              // i k_j: functional_tools.py:166-183
+                    const real kj = op.ck == 3 ? kx_ : (op.ck == 4 ? ky_ : kz_);
+                    u[q] = mkc(-kj * u[q].y, kj * u[q].x);
+                } else {
+                    real cf;
+                    if (op.ck == 0) cf = (k2 != 0.0) ? 4.0 * kPiR / k2 : 0.0;                  // functionals.py:72
+                    else if (op.ck == 1) cf = -k2;                                             // functionals.py:245
+                    else cf = A.lind_p0 * (real)lindhard_shape((k2 != 0.0) ? sqrt(k2) * A.lind_p1 : 0.0);     // functionals.py:646-651
+                    u[q] = mkc(cf * u[q].x, cf * u[q].y);
+                }
             }
             wave_line_fft<N, EL, true>(u, lj, mine, twN);
             exchange_sync<true>();
             if (valid) {
 #pragma unroll
-                for (int q = 0; q < EL; ++q) base[(lj + PL * q) * NZH] = u[q];
+                for (int q = 0; q < EL; ++q) dst[(lj + PL * q) * NZH] = u[q];
             }
         }
     }
     stamp(2);
-    res_barrier(A.sync, A.epoch0 + 2u * (unsigned)N, &timed_out);
+    barrier();
     stamp(3);
 
     // ------------------------------------------------------------------ phase C
     // the loads that cross XCDs -- this plane of the first group's spectra and the partial sums of chi^2 -- go out together
-    constexpr int NLD = (AG * N * NZH + T - 1) / T;
     acc_t cscale = 0.0;
-    if (A.narr == 0) {                                    // purely local term set: nothing to transform back
+    if (A.nout == 0) {                                    // purely local term set: nothing to transform back
         res_totals<N>(A.part, 10, 1, tot + kCombineScalars, stage);
         cscale = A.nel / (tot[kCombineScalars] * A.vol_over_npts);
     }
-    {
-        // real-space results of the four convolutions for this plane: R[kind][x][y][z] (unscaled), written and read back by
-        // this workgroup only
-        for (int g0 = 0; g0 < A.narr; g0 += AG) {
-            const int ns = (A.narr - g0) < AG ? (A.narr - g0) : AG;
-            cplx ld[NLD];
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = tid + k * T;
-                if (i < ns * N * NZH) {
-                    const int s = i / (N * NZH), r = i - s * (N * NZH);
-                    const int ky = r / NZH, kz = r - ky * NZH;
-                    ld[k] = A.T[(((long long)A.kinds[g0 + s] * N + ky) * N + x) * NZH + kz];
-                }
-            }
-            if (g0 == 0 && tid < N) stage[tid] = __builtin_nontemporal_load(A.part + tid * kResSlots + 10);
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = tid + k * T;
-                if (i < ns * N * NZH) {
-                    const int s = i / (N * NZH), r = i - s * (N * NZH);
-                    const int ky = r / NZH, kz = r - ky * NZH;
-                    plane[s * (N * PS) + ky * PS + kz] = ld[k];
-                }
-            }
+    for (int g0 = 0; g0 < A.nout; g0 += AG) {
+        const int ns = (A.nout - g0) < AG ? (A.nout - g0) : AG;
+        planes_inverse(A.outs + g0, ns, g0 == 0);
+        if (g0 == 0) {
+            acc_t t = 0.0;
+            for (int g = 0; g < N; ++g) t += stage[g];                 // same order in every thread and workgroup
+            cscale = A.nel / (t * A.vol_over_npts);                    // system.py:833-834
+            __syncthreads();                                           // (stage is reused below)
+        }
+    }
+    stamp(7);
+    const real cs = (real)cscale;
+    const long long po = (long long)x * N * M;
+    constexpr long long AS = (long long)N * N * M;            // pairs per real-space array
+    cplx* rp = reinterpret_cast<cplx*>(A.R) + po;
+    if (A.gga) {
+        // ---- GGA mid stage on this plane: grad n -> energy densities, df/dn, flux_j = df/d|grad n|^2 d_j n
+        //      (tools_for_tests.py:155-207; the staged pipeline's pbe_point)
+        const real fg = A.inv_n * cs;
+        acc_t pacc[kPbeScalars] = {0.0, 0.0, 0.0};
+        for (int i = tid; i < N * M; i += T) {
+            const cplx c = chi_pl[i];
+            const cplx gx = rp[4 * AS + i], gy = rp[5 * AS + i], gz = rp[6 * AS + i];
+            const real a0 = fg * gx.x, b0 = fg * gy.x, c0 = fg * gz.x, a1 = fg * gx.y, b1 = fg * gy.y, c1 = fg * gz.y;
+            const PbePoint p0 = pbe_point(cs * c.x * c.x, a0 * a0 + b0 * b0 + c0 * c0, A.sel);
+            const PbePoint p1 = pbe_point(cs * c.y * c.y, a1 * a1 + b1 * b1 + c1 * c1, A.sel);
+            pacc[0] += p0.fx + p1.fx;
+            pacc[1] += p0.fc + p1.fc;
+            pacc[2] += p0.fk + p1.fk;
+            rp[8 * AS + i] = mkc(p0.dfdn, p1.dfdn);
+            rp[4 * AS + i] = mkc(p0.dfdg * a0, p1.dfdg * a1);
+            rp[5 * AS + i] = mkc(p0.dfdg * b0, p1.dfdg * b1);
+            rp[6 * AS + i] = mkc(p0.dfdg * c0, p1.dfdg * c1);
+        }
+        res_block_sums<kPbeScalars>(pacc, lds, stage, A.part + bid * kResSlots + 11);
+        // flux components of this plane -> z- and y-forward -> T[4..6]
+        for (int g0 = 0; g0 < 3; g0 += AG) {
+            const int ns = (3 - g0) < AG ? (3 - g0) : AG;
+            rows_forward(ns, [&](int sI, int y, int e) { return rp[(4 + g0 + sI) * AS + y * M + e]; });
             __syncthreads();
-            stamp(8);
-            if (g0 == 0) {
-                acc_t t = 0.0;
-                for (int g = 0; g < N; ++g) t += stage[g];             // same order in every thread and workgroup
-                cscale = A.nel / (t * A.vol_over_npts);                // system.py:833-834
-            }
-            res_ylines<N, true>(plane, ns, rowbuf, twN, nullptr, nullptr, x);
-            __syncthreads();
-            stamp(9);
-            const int nrows = ns * N;
-            for (int R0 = 0; R0 < nrows; R0 += C::ROWS) {
-                if (wave * C::RPWV >= C::ROWS || R0 + wave * C::RPWV >= nrows) continue;       // wave-uniform
-                const int R = R0 + zslot;
-                const bool valid = R < nrows;
-                const int s = valid ? R / N : 0, y = valid ? R - s * N : 0;
-                const cplx* pr = plane + s * (N * PS) + y * PS;
-                cplx v[EZ];
-#pragma unroll
-                for (int q = 0; q < EZ; ++q) v[q] = valid ? pr[zj + PZ * q] : mkc(0.0, 0.0);
-                const real nyq = (valid && zj == 0) ? pr[M].x : (real)0.0;
-                const ZLane<M, EZ> z(zj, zrw, zmine, valid);
-                z_inverse_regs<M, EZ>(v, z, twM, twN, nyq);
-                if (valid) {
-                    cplx* o = reinterpret_cast<cplx*>(A.R) + (((long long)A.kinds[g0 + s] * N + x) * N + y) * M;
-#pragma unroll
-                    for (int q = 0; q < EZ; ++q) o[zj + PZ * q] = v[q];
-                }
-            }
+            res_ylines<N, false>(plane, ns, rowbuf, twN, A.T, A.flux_slots + g0, x);
             __syncthreads();
         }
-        stamp(10);
-        // potential and energy integrands: the staged pipeline's combine_point on n = c chi^2 and the four convolutions
-        const real cs = (real)cscale;
+        barrier();
+        // ---- phase B2: slab ky = bid: divergence spectrum sum_j i k_j F_j  ->  T[4]
+        {
+            const int ky = bid;
+            for (int L0 = 0; L0 < NZH; L0 += C::LINES) {
+                const int slot = wave * C::LPWV + ll;
+                if (wave * C::LPWV >= C::LINES || L0 + wave * C::LPWV >= NZH) continue;             // wave-uniform
+                const int kz = L0 + slot;
+                const bool valid = kz < NZH;
+                real* mine = rowbuf + slot * LineBuf<N>::STRIDE;
+                cplx acc[EL];
+#pragma unroll
+                for (int q = 0; q < EL; ++q) acc[q] = mkc(0.0, 0.0);
+#pragma unroll 1
+                for (int jc = 0; jc < 3; ++jc) {
+                    const cplx* src = A.T + ((long long)(4 + jc) * N + ky) * N * NZH + (valid ? kz : 0);
+                    cplx u[EL];
+#pragma unroll
+                    for (int q = 0; q < EL; ++q) u[q] = valid ? src[(lj + PL * q) * NZH] : mkc(0.0, 0.0);
+                    wave_line_fft<N, EL, false>(u, lj, mine, twN);
+                    exchange_sync<true>();
+#pragma unroll
+                    for (int q = 0; q < EL; ++q) {
+                        real kx_, ky_, kz_, k2;
+                        kvec_xyz(A.kg, lj + PL * q, ky, valid ? kz : 0, kx_, ky_, kz_, k2);
+                        const real kj = jc == 0 ? kx_ : (jc == 1 ? ky_ : kz_);
+                        acc[q] = mkc(acc[q].x - kj * u[q].y, acc[q].y + kj * u[q].x);
+                    }
+                }
+                wave_line_fft<N, EL, true>(acc, lj, mine, twN);
+                exchange_sync<true>();
+                if (valid) {
+                    cplx* dst = A.T + ((long long)4 * N + ky) * N * NZH + kz;
+#pragma unroll
+                    for (int q = 0; q < EL; ++q) dst[(lj + PL * q) * NZH] = acc[q];
+                }
+            }
+        }
+        barrier();
+        // ---- phase C2: the divergence back on this plane -> R[4]
+        planes_inverse(A.flux_slots, 1, false);
+    }
+    {
+        // potential and energy integrands: the staged pipeline's combine_point on n = c chi^2 and the convolutions
         const real f0 = A.inv_n * cs, f1 = A.inv_n * sqrt(cs);
         const real f2 = A.act[2] ? A.inv_n * (real)::pow((double)cs, (double)be) : (real)0.0;
         const real f3 = A.act[3] ? A.inv_n * (real)::pow((double)cs, (double)al) : (real)0.0;
+        const bool has_h = A.ca.mask & 2u;
         acc_t acc[kCombineScalars];
 #pragma unroll
         for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
-        const long long po = (long long)x * N * M;
         const cplx* ep = reinterpret_cast<const cplx*>(A.vext ? A.vext : A.chi) + po;
-        const cplx* rp = reinterpret_cast<const cplx*>(A.R) + po;
         cplx* vp = reinterpret_cast<cplx*>(A.v) + po;
-        constexpr long long AS = (long long)N * N * M;            // pairs per array
+        const long long hs = (long long)A.vh_slot * AS;
+        stamp(10);
         for (int i = tid; i < N * M; i += T) {
             const cplx c = chi_pl[i], ve = ep[i];
-            const cplx r0 = A.act[0] ? rp[i] : mkc(0.0, 0.0), r1 = A.act[1] ? rp[AS + i] : mkc(0.0, 0.0);
+            const cplx r0 = has_h ? rp[hs + i] : mkc(0.0, 0.0), r1 = A.act[1] ? rp[AS + i] : mkc(0.0, 0.0);
             const cplx r2 = A.act[2] ? rp[2 * AS + i] : mkc(0.0, 0.0), r3 = A.act[3] ? rp[3 * AS + i] : mkc(0.0, 0.0);
+            const cplx dn = A.gga ? rp[8 * AS + i] : mkc(0.0, 0.0), dv = A.gga ? rp[4 * AS + i] : mkc(0.0, 0.0);
             real vv[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -371,54 +508,30 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
                 p.lap = f1 * (h ? r1.y : r1.x);
                 p.cb = f2 * (h ? r2.y : r2.x);
                 p.cva = f3 * (h ? r3.y : r3.x);
+                p.dfdn = h ? dn.y : dn.x;
+                p.div = A.inv_n * (h ? dv.y : dv.x);
                 vv[h] = combine_point(A.ca, p, kCtf, acc);
             }
             vp[i] = mkc(vv[0], vv[1]);
         }
         stamp(11);
-        // ten sums over the workgroup's threads, through LDS in a fixed order (sixty dependent 64-bit wave shuffles took
-        // longer than the physics): [s][thread] -> 16 chunks per sum -> the sum
-        {
-            constexpr int SP = T + T / 32, CH = T / 16;
-            acc_t* st2 = reinterpret_cast<acc_t*>(lds);          // (the row buffers and planes are dead by now)
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < kCombineScalars; ++s) st2[s * SP + tid + tid / 32] = acc[s];
-            __syncthreads();
-            if (tid < 16 * kCombineScalars) {
-                const int s = tid / 16, ch = tid - s * 16;
-                acc_t t = 0.0;
-                for (int i = 0; i < CH; ++i) {
-                    const int k = ch * CH + i;
-                    t += st2[s * SP + k + k / 32];
-                }
-                stage[tid] = t;
-            }
-            __syncthreads();
-            if (tid < kCombineScalars) {
-                acc_t t = 0.0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t += stage[tid * 16 + i];
-                A.part[bid * kResSlots + tid] = t;
-            }
-        }
+        res_block_sums<kCombineScalars>(acc, lds, stage, A.part + bid * kResSlots);
     }
     stamp(4);
-    res_barrier(A.sync, A.epoch0 + 3u * (unsigned)N, &timed_out);
+    barrier();
     stamp(5);
 
     // ------------------------------------------------------------------ phase D: mu and chi.grad
-    res_totals<N>(A.part, 0, kCombineScalars, tot, stage);
+    res_totals<N>(A.part, 0, 14, tot, stage);
     if (bid == 0) {          // (a workgroup that never arrives stalls every barrier, this one's included: one flag suffices)
         if (tid < kCombineScalars) A.reduced[tid] = tot[tid];
-        else if (tid < 13) A.reduced[tid] = 0.0;                                // no gradient-dependent terms here
+        else if (tid < 13) A.reduced[tid] = A.gga ? tot[tid + 1] : 0.0;        // GGA energy sums (partials [11..13])
         if (tid == 0) A.reduced[13] = timed_out ? 1.0 : 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // system scope: the sums are in host memory before this workgroup counts out
     }
     if (A.grad) {
         const real mu = (real)((tot[8] * A.dV) / A.nel);                                        // system.py:851
         const real c2dV = (real)(cscale * (2.0 * A.dV));                                        // system.py:836-837,853
-        const long long po = (long long)x * N * M;
         const cplx* vp = reinterpret_cast<const cplx*>(A.v) + po;
         cplx* gp = reinterpret_cast<cplx*>(A.grad) + po;
         for (int i = tid; i < N * M; i += T) {       // the thread that wrote v[i] reads it
@@ -442,11 +555,14 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
 
 namespace eng {
 
-// term sets the resident kernel serves: everything local, Hartree, von Weizsaecker, Wang-Teter
+// term sets the resident kernel serves: everything local, Hartree, von Weizsaecker, Wang-Teter, the gradient-dependent
+// terms without a Laplacian
 bool resident_serves(const ofdft_ctx* c) {
     if (!c->resident || c->nranks != 1 || !c->fast) return false;
     if (!(c->n0 == c->n1 && c->n1 == c->n2 && (c->n0 == 16 || c->n0 == 32 || c->n0 == 64))) return false;
-    if (c->mask & (kGgaAny | OFDFT_WGC99_NL)) return false;
+    if (c->mask & OFDFT_WGC99_NL) return false;
+    if ((c->mask & kGgaAny) && (gga_needs_laplacian(c) || c->n0 > 32)) return false;      // (64^3 with a GGA term: five phases of 4096-point
+                                                                                          //  planes per workgroup measured slower than the graph replay)
     if (wts_active(c)) return false;
     return c->mask != 0;
 }
@@ -471,9 +587,9 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     a.v = v;
     a.grad = grad;
     void* p;
-    if (int rc = get_ws(c, "res:T", sizeof(cplx) * 4 * (size_t)N * N * (N / 2 + 1), &p)) return rc;
+    if (int rc = get_ws(c, "res:T", sizeof(cplx) * kResT * (size_t)N * N * (N / 2 + 1), &p)) return rc;
     a.T = (cplx*)p;
-    if (int rc = get_ws(c, "res:R", sizeof(real) * 4 * (size_t)N * N * N, &p)) return rc;
+    if (int rc = get_ws(c, "res:R", sizeof(real) * kResR * (size_t)N * N * N, &p)) return rc;
     a.R = (real*)p;
     if (int rc = get_ws(c, "res:part", sizeof(double) * 64 * kResSlots, &p)) return rc;
     a.part = (acc_t*)p;
@@ -485,21 +601,34 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
         c->res_done_target = 0;
         c->res_epoch = 0;
     }
+    const bool gga = mask & kGgaAny, har = mask & OFDFT_HARTREE, vw = mask & OFDFT_VW, wt = mask & OFDFT_WT_NL;
+    const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
     a.done = c->res_done;
     a.reduced = c->h_partial;          // pinned, device-visible: no copy command behind the kernel
     a.sync = c->res_sync;
     a.epoch0 = c->res_epoch;
-    c->res_epoch += 3u * (unsigned)N;
+    c->res_epoch += (gga ? 5u : 3u) * (unsigned)N;
     c->res_done_target += (unsigned)N;
     a.done_target = c->res_done_target;
-    const bool wt = mask & OFDFT_WT_NL;
-    const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-    a.act[0] = (mask & OFDFT_HARTREE) ? 1 : 0;
-    a.act[1] = (mask & OFDFT_VW) ? 1 : 0;
+    // inputs f(chi) -> forward spectra in slots 0..3
+    a.act[0] = (har || gga) ? 1 : 0;
+    a.act[1] = vw ? 1 : 0;
     a.act[2] = wt ? 1 : 0;
     a.act[3] = (wt && al != be) ? 1 : 0;
     for (int k = 0; k < 4; ++k)
         if (a.act[k]) a.kinds[a.narr++] = k;
+    // phase B work list and the slots that come back to real space
+    a.gga = gga ? 1 : 0;
+    a.vh_slot = gga ? 7 : 0;          // (with a gradient the chi^2 spectrum has several readers: v_H may not overwrite it)
+    a.flux_slots[0] = 4; a.flux_slots[1] = 5; a.flux_slots[2] = 6;
+    auto op = [&](int in, int out, int ck) { a.bop[a.nb++] = ResOp{in, out, ck}; a.outs[a.nout++] = out; };
+    if (har) op(0, a.vh_slot, 0);
+    if (vw) op(1, 1, 1);
+    if (wt) op(2, 2, 2);
+    if (a.act[3]) op(3, 3, 2);
+    if (gga)
+        for (int j = 0; j < 3; ++j) op(0, 4 + j, 3 + j);
+    a.sel = gga_sel(c);
     a.kg = c->kg;
     CombineArgs& ca = a.ca;
     ca.mask = mask;
@@ -522,7 +651,7 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     a.vol_over_npts = c->vol / (double)c->npts;
     a.dV = c->dV;
     a.inv_n = 1.0 / (double)c->npts;
-    c->fft_count += 2 * a.narr;
+    c->fft_count += a.narr + a.nout + (gga ? 4 : 0);
     switch (N) {
         case 16: return launch_res<16>(c, a, st);
         case 32: return launch_res<32>(c, a, st);

@@ -16,7 +16,8 @@ from professad_amd.engine import Engine  # noqa: E402
 from professad_amd.functionals import NativeTerms  # noqa: E402
 
 CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
-       'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe']}
+       'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe'],
+       'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe']}           # the reference's standard term set (tests/test_den_opt.py:59)
 
 
 def main():

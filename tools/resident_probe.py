@@ -14,7 +14,8 @@ from professad_amd import synth  # noqa: E402
 from professad_amd.engine import Engine  # noqa: E402
 from professad_amd.functionals import NativeTerms  # noqa: E402
 
-CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz']}
+CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
+       'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe']}
 
 n, cfg = int(sys.argv[1]), sys.argv[2]
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
