@@ -237,13 +237,22 @@ int  ofdft_ion_ion(ofdft_ctx* ctx, const double* frac_coords_host, const double*
  *   ofdft_lbfgs_commit  stores (push = 1) or discards the candidate pair (the caller applies the curvature test);
  *   ofdft_lbfgs_update  d = coef_g g + sum_j coef_s[j] S_j + coef_y[j] Y_j over the stored pairs (oldest first, the
  *                       just-committed pair last), x += t d in place, g_prev = g; returns the local sum |t d|_1.
- * The recursion itself runs on the coefficients (professad_amd/optimize.py), so the result is the same direction as
- * the reference's up to round-off. */
+ *   ofdft_lbfgs_direction  the host side between the two sweeps, natively: curvature test + commit, the Gram blocks of the stored
+ *                       pairs, the two-loop recursion on the COEFFICIENTS of d in {S_j, Y_j, g} (so the result is the reference's
+ *                       direction up to round-off) -> coef_s, coef_y, coef_g for ofdft_lbfgs_update, and g.d.  A host that wants
+ *                       its own recursion calls ofdft_lbfgs_commit itself instead (professad_amd/optimize.py keeps that form for
+ *                       backends without this entry).
+ * ofdft_lbfgs_update with abs_step_sum == NULL does not wait for the stream; ofdft_lbfgs_abs_step returns the sum after the
+ * stream's next synchronisation (the closure evaluation that follows an update does one). */
 typedef struct ofdft_lbfgs ofdft_lbfgs;
 int  ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history /* 1..8 */, int device_id);
 void ofdft_lbfgs_destroy(ofdft_lbfgs* h);
 const char* ofdft_lbfgs_last_error(const ofdft_lbfgs* h);
 int  ofdft_lbfgs_reset(ofdft_lbfgs* h);
+int  ofdft_lbfgs_direction(ofdft_lbfgs* h, const double* dots /* of ofdft_lbfgs_dots, summed over ranks */, int npairs, int first_iteration,
+                           double* coef_s /* [history] */, double* coef_y /* [history] */, double* coef_g, double* g_dot_d,
+                           int* npairs_out, int* pushed_out);
+int  ofdft_lbfgs_abs_step(ofdft_lbfgs* h, double* abs_step_sum);
 int  ofdft_lbfgs_dots(ofdft_lbfgs* h, const void* g_dev, double* dots_host /* [6*8+7] */, int* npairs, void* stream);
 int  ofdft_lbfgs_commit(ofdft_lbfgs* h, int push);
 int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef_y, double coef_g, double t, void* x_dev,

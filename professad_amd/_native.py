@@ -33,7 +33,7 @@ OPT_RESIDENT = 10
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',
            'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
-           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ipc_export', 'ofdft_ipc_attach', 'ofdft_dist_closure', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_dots',
+           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ipc_export', 'ofdft_ipc_attach', 'ofdft_dist_closure', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_direction', 'ofdft_lbfgs_abs_step', 'ofdft_lbfgs_dots',
            'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_collectives', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
@@ -138,6 +138,10 @@ def load(dtype=F64):
     lib.ofdft_lbfgs_commit.restype = ip
     lib.ofdft_lbfgs_update.argtypes = [vp, dp, dp, C.c_double, C.c_double, vp, vp, dp, vp]
     lib.ofdft_lbfgs_update.restype = ip
+    lib.ofdft_lbfgs_direction.argtypes = [vp, dp, ip, ip, dp, dp, dp, dp, C.POINTER(ip), C.POINTER(ip)]
+    lib.ofdft_lbfgs_direction.restype = ip
+    lib.ofdft_lbfgs_abs_step.argtypes = [vp, dp]
+    lib.ofdft_lbfgs_abs_step.restype = ip
     lib.ofdft_set_collectives.argtypes = [vp, A2A_FN, ALLREDUCE_FN, vp]
     lib.ofdft_set_collectives.restype = ip
     lib.ofdft_set_option.argtypes = [vp, ip, C.c_double]

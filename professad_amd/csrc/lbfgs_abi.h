@@ -17,10 +17,18 @@ struct ofdft_lbfgs {
     bool have_prev = false;        // a step (d, t) and the gradient before it exist
     bool pending = false;          // a candidate pair sits in the free slot
     double t_prev = 0.0;
+    // host side of the recursion (ofdft_lbfgs_direction): Gram blocks of the stored pairs, oldest first
+    int gk = 0;                    // pairs in the Gram blocks
+    double SS[kLbfgsMaxHist][kLbfgsMaxHist], SY[kLbfgsMaxHist][kLbfgsMaxHist], YY[kLbfgsMaxHist][kLbfgsMaxHist];
+    double gamma = 1.0;
+    bool abs_pending = false;      // an update's |step| sum is on its way to h_out[kAbsSlot]
     char err[256] = "";
 };
 
 namespace {
+
+static_assert(lbfgs_nscal(kLbfgsMaxHist) < 60, "scalar block");
+constexpr int kAbsSlot = 60;       // h_out slot of the last update's sum |t d| (behind the sums of a dots sweep)
 
 int lfail(ofdft_lbfgs* o, int code, const char* msg) {
     if (o) std::snprintf(o->err, sizeof(o->err), "%s", msg);
@@ -77,8 +85,8 @@ int ofdft_lbfgs_create(ofdft_lbfgs** out, long long n_local, int history, int de
     if (e == hipSuccess) e = hipMalloc((void**)&o->d, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&o->g_prev, vb);
     if (e == hipSuccess) e = hipMalloc((void**)&o->d_partial, sizeof(double) * kRedBlocks * lbfgs_nscal(kLbfgsMaxHist));
-    if (e == hipSuccess) e = hipMalloc((void**)&o->d_out, sizeof(double) * lbfgs_nscal(kLbfgsMaxHist));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&o->h_out, sizeof(double) * lbfgs_nscal(kLbfgsMaxHist));
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d_out, sizeof(double) * 64);           // the sums of a dots sweep (55) + the update's slot
+    if (e == hipSuccess) e = hipHostMalloc((void**)&o->h_out, sizeof(double) * 64);
     if (e != hipSuccess) {
         ofdft_lbfgs_destroy(o);
         return e == hipErrorOutOfMemory ? OFDFT_ENOMEM : OFDFT_EHIP;
@@ -156,7 +164,7 @@ int ofdft_lbfgs_commit(ofdft_lbfgs* o, int push) {
 int ofdft_lbfgs_update(ofdft_lbfgs* o, const double* coef_s, const double* coef_y, double coef_g, double t, void* x_dev,
                        const void* g_dev, double* abs_step_sum, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!o || !x_dev || !g_dev || !abs_step_sum || (o->count > 0 && (!coef_s || !coef_y))) return OFDFT_EINVAL;
+    if (!o || !x_dev || !g_dev || (o->count > 0 && (!coef_s || !coef_y))) return OFDFT_EINVAL;
     if (o->pending) return lfail(o, OFDFT_ESTATE, "ofdft_lbfgs_commit must follow ofdft_lbfgs_dots");
     DeviceScope device_scope_(o->device);
     L_TRY(o, device_scope_.err);
@@ -184,18 +192,125 @@ int ofdft_lbfgs_update(ofdft_lbfgs* o, const double* coef_s, const double* coef_
         default: launch_update<8>(o, v, c, g, t, x, blocks, st); break;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, st, (const double*)o->d_partial, blocks, 1,
-                       o->d_out);
-    L_TRY(o, hipMemcpyAsync(o->h_out, o->d_out, sizeof(double), hipMemcpyDeviceToHost, st));
-    L_TRY(o, hipStreamSynchronize(st));
-    L_TRY(o, hipGetLastError());
-    *abs_step_sum = o->h_out[0];
+                       o->d_out + kAbsSlot);
+    L_TRY(o, hipMemcpyAsync(o->h_out + kAbsSlot, o->d_out + kAbsSlot, sizeof(double), hipMemcpyDeviceToHost, st));
+    o->abs_pending = true;
+    if (abs_step_sum) {            // NULL: nobody waits here -- ofdft_lbfgs_abs_step reads the sum after the stream's next synchronisation
+        L_TRY(o, hipStreamSynchronize(st));
+        L_TRY(o, hipGetLastError());
+        *abs_step_sum = o->h_out[kAbsSlot];
+    }
     o->have_prev = true;
     o->t_prev = t;
     return OFDFT_OK;
 }
 
+// sum |t d| of the last ofdft_lbfgs_update that was called without an output pointer; valid once the stream of that call has
+// been synchronised (the closure evaluation and the dots sweep that follow an update both do)
+int ofdft_lbfgs_abs_step(ofdft_lbfgs* o, double* abs_step_sum) {
+    if (!o || !abs_step_sum) return OFDFT_EINVAL;
+    if (!o->abs_pending) return lfail(o, OFDFT_ESTATE, "no update has run");
+    *abs_step_sum = o->h_out[kAbsSlot];
+    return OFDFT_OK;
+}
+
+// Host side of one inner iteration (lbfgsnew.py:594-663 on coefficients): from the sums of the last ofdft_lbfgs_dots (all-reduced
+// by the caller on several ranks; layout [S|Y][j][s, y, g] then s.s, s.y, y.y, g.s, g.y, g.g, |g|_1) decide whether the candidate
+// pair enters the history (s.y > 1e-10 s.s, :622; `first` != 0: the very first iteration, history cleared), commit, keep the Gram
+// blocks S_i.S_j, S_i.Y_j, Y_i.Y_j of the stored pairs, and run the two-loop recursion on the coefficients of the direction
+// d = sum_j coef_s[j] S_j + coef_y[j] Y_j + coef_g g.  Outputs sized for `history` pairs; *npairs_out = pairs in use.
+int ofdft_lbfgs_direction(ofdft_lbfgs* o, const double* dots, int k, int first, double* coef_s, double* coef_y, double* coef_g,
+                          double* g_dot_d, int* npairs_out, int* pushed_out) {
+    if (!o || !dots || !coef_s || !coef_y || !coef_g || !g_dot_d || k < 0 || k > kLbfgsMaxHist) return OFDFT_EINVAL;
+    const double* tail = dots + 6 * k;
+    const double ss = tail[0], sy = tail[1], yy = tail[2], gs = tail[3], gy = tail[4], gg = tail[5];
+    double gS[kLbfgsMaxHist], gY[kLbfgsMaxHist];
+    int push = 0;
+    if (first) {
+        if (int rc = ofdft_lbfgs_commit(o, 0)) return rc;
+        o->gk = 0;
+        o->gamma = 1.0;
+    } else {
+        if (k != o->gk) return lfail(o, OFDFT_ESTATE, "ofdft_lbfgs_direction: the sums do not belong to the stored history");
+        push = sy > 1e-10 * ss;
+        if (int rc = ofdft_lbfgs_commit(o, push)) return rc;
+        const double *sS = dots, *sY = dots + 3 * k;        // [j][s, y, g]
+        int off = 0, kk = k;
+        if (push) {
+            if (k == o->hist) {                              // drop the oldest pair
+                for (int i = 1; i < k; ++i)
+                    for (int j = 1; j < k; ++j) {
+                        o->SS[i - 1][j - 1] = o->SS[i][j];
+                        o->SY[i - 1][j - 1] = o->SY[i][j];
+                        o->YY[i - 1][j - 1] = o->YY[i][j];
+                    }
+                off = 1;
+                kk = k - 1;
+            }
+            for (int j = 0; j < kk; ++j) {
+                const double* a = sS + 3 * (j + off);        // S_j . (s, y, g)
+                const double* b = sY + 3 * (j + off);        // Y_j . (s, y, g)
+                o->SS[kk][j] = o->SS[j][kk] = a[0];
+                o->YY[kk][j] = o->YY[j][kk] = b[1];
+                o->SY[kk][j] = b[0];                         // s_new . Y_j
+                o->SY[j][kk] = a[1];                         // S_j . y_new
+                gS[j] = a[2];
+                gY[j] = b[2];
+            }
+            o->SS[kk][kk] = ss;
+            o->YY[kk][kk] = yy;
+            o->SY[kk][kk] = sy;
+            gS[kk] = gs;
+            gY[kk] = gy;
+            o->gk = kk + 1;
+            o->gamma = sy / yy;
+        } else {
+            for (int j = 0; j < k; ++j) {
+                gS[j] = sS[3 * j + 2];
+                gY[j] = sY[3 * j + 2];
+            }
+        }
+    }
+    const int K = o->gk;
+    double dS[kLbfgsMaxHist], dY[kLbfgsMaxHist], al[kLbfgsMaxHist], rho[kLbfgsMaxHist], dg = -1.0;
+    for (int i = 0; i < K; ++i) {
+        dS[i] = dY[i] = 0.0;
+        rho[i] = 1.0 / o->SY[i][i];
+    }
+    for (int i = K - 1; i >= 0; --i) {
+        double a = dg * gS[i];
+        for (int j = 0; j < K; ++j) a += dS[j] * o->SS[j][i] + dY[j] * o->SY[i][j];
+        al[i] = a * rho[i];
+        dY[i] -= al[i];
+    }
+    for (int i = 0; i < K; ++i) {
+        dS[i] *= o->gamma;
+        dY[i] *= o->gamma;
+    }
+    dg *= o->gamma;
+    for (int i = 0; i < K; ++i) {
+        double b = dg * gY[i];
+        for (int j = 0; j < K; ++j) b += dS[j] * o->SY[j][i] + dY[j] * o->YY[j][i];
+        dS[i] += al[i] - b * rho[i];
+    }
+    double gtd = dg * gg;
+    for (int j = 0; j < K; ++j) gtd += dS[j] * gS[j] + dY[j] * gY[j];
+    for (int j = 0; j < K; ++j) {
+        coef_s[j] = dS[j];
+        coef_y[j] = dY[j];
+    }
+    *coef_g = dg;
+    *g_dot_d = gtd;
+    if (npairs_out) *npairs_out = K;
+    if (pushed_out) *pushed_out = push;
+    return OFDFT_OK;
+}
+
 int ofdft_lbfgs_reset(ofdft_lbfgs* o) {
     if (!o) return OFDFT_EINVAL;
+    o->gk = 0;
+    o->gamma = 1.0;
+    o->abs_pending = false;
     o->count = 0;
     o->have_prev = false;
     o->pending = false;

@@ -138,6 +138,7 @@ class HipLbfgsBackend:
         if rc != 0:
             raise RuntimeError('ofdft_lbfgs_create failed with code %d' % rc)
         self._buf = (C.c_double * (6 * 8 + 7))()
+        self._cs, self._cy, self._cg = (C.c_double * 8)(), (C.c_double * 8)(), 0.0
         self.n = int(n)
 
     def _check(self, rc, what):
@@ -156,6 +157,37 @@ class HipLbfgsBackend:
         k = C.c_int(0)
         self._check(self.lib.ofdft_lbfgs_dots(self._h, self._vec(g, 'g'), self._buf, C.byref(k), self._stream()), 'ofdft_lbfgs_dots')
         return np.array(self._buf[:6 * k.value + 7], dtype=np.float64), k.value
+
+    def dots_raw(self, g):
+        """the sums left in the backend's own buffer (for `direction`): -> (number of pairs, tail = s.s, s.y, y.y, g.s, g.y, g.g, |g|_1)"""
+        k = C.c_int(0)
+        self._check(self.lib.ofdft_lbfgs_dots(self._h, self._vec(g, 'g'), self._buf, C.byref(k), self._stream()), 'ofdft_lbfgs_dots')
+        kv = k.value
+        return kv, self._buf[6 * kv:6 * kv + 7]
+
+    def set_dots(self, vals):
+        """put all-reduced sums back into the buffer `direction` reads"""
+        for i, v in enumerate(vals):
+            self._buf[i] = v
+
+    def direction(self, k, first):
+        """curvature test + commit + Gram blocks + two-loop recursion, natively (ofdft_lbfgs_direction) -> g.d; the coefficients
+        stay in the backend for `update_direct`"""
+        cg, gtd = C.c_double(0.0), C.c_double(0.0)
+        self._check(self.lib.ofdft_lbfgs_direction(self._h, self._buf, int(k), 1 if first else 0, self._cs, self._cy, C.byref(cg),
+                                                   C.byref(gtd), None, None), 'ofdft_lbfgs_direction')
+        self._cg = cg.value
+        return gtd.value
+
+    def update_direct(self, t, x, g):
+        """x += t d with the coefficients of the last `direction`; nothing waits for the stream (`abs_step` reads the sum later)"""
+        self._check(self.lib.ofdft_lbfgs_update(self._h, self._cs, self._cy, self._cg, float(t), self._vec(x, 'x'), self._vec(g, 'g'),
+                                                None, self._stream()), 'ofdft_lbfgs_update')
+
+    def abs_step(self):
+        out = C.c_double(0.0)
+        self._check(self.lib.ofdft_lbfgs_abs_step(self._h, C.byref(out)), 'ofdft_lbfgs_abs_step')
+        return out.value
 
     def commit(self, push):
         self._check(self.lib.ofdft_lbfgs_commit(self._h, 1 if push else 0), 'ofdft_lbfgs_commit')
@@ -259,6 +291,8 @@ class VectorFreeLBFGS:
 
     def step(self, closure):
         """Same contract as FixedStepLBFGS.step."""
+        if hasattr(self.b, 'direction'):
+            return self._step_native(closure)
         loss0, g = closure()
         loss = loss0
         evals = 1
@@ -302,6 +336,54 @@ class VectorFreeLBFGS:
                 break
             if g1 <= self.tol_g or gtd > -self.tol_c:
                 break
+            if abs_step <= self.tol_c or abs(loss - prev_loss) < self.tol_c:
+                break
+        return loss0
+
+    # ---- the same iteration with the host side of the recursion inside the library (ofdft_lbfgs_direction): per inner
+    # iteration two ctypes calls and no numpy between the sweeps; the update does not wait for its stream (the closure
+    # evaluation that follows synchronises, the |step| sum is read after it)
+    def _dots_native(self, g):
+        k, tail = self.b.dots_raw(g.view(-1))
+        if self.all_reduce is not None:
+            vals = self.all_reduce(np.array(self.b._buf[:6 * k + 7], dtype=np.float64))
+            self.b.set_dots(vals)
+            tail = [float(v) for v in vals[6 * k:]]
+        return k, tail           # tail = s.s, s.y, y.y, g.s, g.y, g.g, |g|_1
+
+    def _step_native(self, closure):
+        loss0, g = closure()
+        loss = loss0
+        evals = 1
+        self.func_evals += 1
+        k, tail = self._dots_native(g)
+        g1 = tail[6]
+        if g1 <= self.tol_g:
+            return loss0
+        n_iter = 0
+        while n_iter < self.max_iter and not math.isnan(tail[5]):
+            n_iter += 1
+            self.total_iter += 1
+            gtd = self.b.direction(k, self.total_iter == 1)
+            prev_loss = loss
+            t = min(1.0, 1.0 / g1) * self.lr if self.total_iter == 1 else self.lr
+            self.b.update_direct(t, self.x.view(-1), g.view(-1))                       # x += t d, g_prev = g
+            last = n_iter == self.max_iter
+            if not last:
+                loss, g = closure()                                                   # (synchronises the stream)
+                k, tail = self._dots_native(g)
+                g1 = tail[6]
+                evals += 1
+                self.func_evals += 1
+                if math.isnan(g1):
+                    break
+            if last or evals >= self.max_eval:
+                break
+            if g1 <= self.tol_g or gtd > -self.tol_c:
+                break
+            abs_step = self.b.abs_step()
+            if self.all_reduce is not None:
+                abs_step = float(self.all_reduce(np.array([abs_step]))[0])
             if abs_step <= self.tol_c or abs(loss - prev_loss) < self.tol_c:
                 break
         return loss0

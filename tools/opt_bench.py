@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Density-optimisation loop timing on one GPU: outer steps of the fixed-step L-BFGS around the cfg3 closure at
-N^3, with the fused device-side optimiser and with the op-by-op torch form.  usage: opt_bench.py [N] [outer steps]"""
+N^3, with the fused device-side optimiser and with the op-by-op torch form.  usage: opt_bench.py [N] [outer steps] [cfg3|cfg1|wtpbe]"""
 import json
 import os
 import sys
@@ -20,14 +20,17 @@ from professad_amd.optimize import FixedStepLBFGS, HipLbfgsBackend, VectorFreeLB
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    cfg = sys.argv[3] if len(sys.argv) > 3 else 'cfg3'
+    terms = {'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe'], 'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'],
+             'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe']}[cfg]
     shape = (n, n, n)
     dev = torch.device('cuda:0')
     box = torch.as_tensor(synth.cubic_cell(n))
     vol = float(abs(np.linalg.det(box.numpy())))
     n_elec = 12.0 * (n // 32) ** 3
     vext = torch.as_tensor(synth.random_potential(shape, seed=42), device=dev)
-    eng = Engine(shape, dev).set_cell(box).set_terms(NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe']).names)
-    out = {'grid': n, 'outer_steps': steps}
+    eng = Engine(shape, dev).set_cell(box).set_terms(NativeTerms(terms).names)
+    out = {'grid': n, 'outer_steps': steps, 'cfg': cfg}
     for name in ('fused', 'torch'):
         chi = torch.full(shape, float(np.sqrt(n_elec / vol)), dtype=torch.double, device=dev)
         chi *= 1 + 0.05 * torch.as_tensor(synth.smooth_density(shape, seed=5, n0=1.0, amp=1.0), device=dev)
