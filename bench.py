@@ -436,6 +436,20 @@ def main():
     }
     if transport_probe:
         out['transport'] = {'used': transport, 'probe': transport_probe}
+    if world > 1:
+        # what crosses the fabric per evaluation and rank: every transposed spectrum leaves (world-1)/world
+        # of its slab; with the ipc transport the profiling pass also times the scatter kernels (all links driven at once) and
+        # the epoch waits (peer skew + delivery)
+        ntr = 19 if a.cfg == 'cfg3' else 6
+        sent = ntr * (Cc / world) * (world - 1) / world
+        ex = {'spectra_transposed_per_eval': ntr, 'sent_MB_per_rank_per_eval': round(sent / 1e6, 1),
+              'MB_per_link_per_eval': round(sent / (world - 1) / 1e6, 1)}
+        if 'ipc_scatter' in kernels:
+            ms = kernels['ipc_scatter']['ms_per_eval']
+            ex.update(scatter_ms_per_eval=ms, scatter_GBs_per_rank=round(sent / (ms * 1e-3) / 1e9, 1) if ms else None,
+                      scatter_GBs_per_link=round(sent / (world - 1) / (ms * 1e-3) / 1e9, 1) if ms else None,
+                      wait_ms_per_eval=kernels.get('ipc_sync', {}).get('ms_per_eval'))
+        out['exchange'] = ex
     chk = reference_check(n, a.cfg, a.dtype, E_tot, mu)
     out['reference_check'] = chk
     if world > 1 and rank == 0 and os.environ.get('OFDFT_BENCH_NO_PARITY') != '1':
