@@ -335,6 +335,11 @@ def test_density_optimisation_reaches_reference_ground_state(optimizer):
     assert relerr(res['den'].cpu().numpy(), den_ref) < 1e-4
     # first outer iteration (before the chaotic amplification sets in) matches the reference's log to all digits shown
     assert abs(res['history'][0][1] - 68.191536) < 1e-6 and abs(res['history'][0][3] - 0.593563) < 1e-6
+    # Later rows cannot be pinned the same way: two closures that agree to 1e-13 (the staged pipeline and the persistent kernel)
+    # give 65.989312 and 65.986863 eV in row 2 where the reference's log has 65.989145 (tools/opt_rows_probe.py) -- the fixed-
+    # step trajectory amplifies round-off by ~50x per inner iteration; both optimisers walk identical rows on the same closure.
+    # The optimiser's own semantics are pinned row by row on the CPU, with the oracle closure (tests/test_optimizer_cpu.py).
+    assert abs(res['history'][1][1] - 65.989145) < 5e-3
     eng.close()
 
 
