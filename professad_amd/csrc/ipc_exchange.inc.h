@@ -265,6 +265,13 @@ int ofdft_ipc_attach(ofdft_ctx* c, int peer, const void* handle64, const unsigne
         HIP_TRY(c, hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
         s->peer_base[peer] = ptr;
         s->peer_handle[peer] = h;
+        // prove the mapping with the runtime's own copies before any kernel stores through it (a copy that cannot reach the
+        // peer returns an error; a kernel would fault): read a mailbox word, write a spare one (the last word of the 64-byte gap
+        // between the flags and the sums)
+        char* mb = (char*)ptr + offsets5[4];
+        HIP_TRY(c, hipMemcpy(s->d_stamp, mb, sizeof(unsigned), hipMemcpyDeviceToDevice));
+        HIP_TRY(c, hipMemcpy(mb + kIpcFlagWords * sizeof(unsigned) + 60, s->d_stamp + 1, sizeof(unsigned), hipMemcpyDeviceToDevice));
+        HIP_TRY(c, hipDeviceSynchronize());
     }
     for (int w = 0; w < 5; ++w) s->peer[w][peer] = (char*)s->peer_base[peer] + offsets5[w];
     return OFDFT_OK;
