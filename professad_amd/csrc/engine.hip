@@ -856,6 +856,25 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
             if (int rc = device_sum(c, (const real*)den, false, &nsum, st)) return rc;
             nel = nsum / (double)c->npts * c->vol;
         }
+        if (resident_serves(c)) {
+            // grids that fit on chip: one persistent kernel (resident.hip), here on the density itself
+            if (int rc = resident_closure(c, (const real*)den, (const real*)vext, nel > 0.0 ? nel : 1.0, (real*)dEdn, nullptr, st, true))
+                return rc;
+            if (int rc = end_call(c, st)) return rc;
+            if (c->h_partial[13] != 0.0) {
+                (void)hipMemset(c->res_sync, 0, 64);
+                c->res_epoch = 0;
+                c->res_done_target = 0;
+                if (c->res_done) *c->res_done = 0;
+                return fail(c, OFDFT_EHIP, "resident kernel: a grid barrier ran into its time limit (workgroups not co-resident?)");
+            }
+            double sums[kNSums];
+            for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+            for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+            energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
+            c->resident_evals++;
+            return OFDFT_OK;
+        }
         const DenSrc ds{(const real*)den, 1.0, 0, nullptr};
         if (int rc = run_terms_zfused(c, ds, nel, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
         return end_call(c, st);

@@ -247,7 +247,8 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
 int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0, int nchunks = 1,
                       real* dzn = nullptr);
 bool resident_serves(const ofdft_ctx* c);
-int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st);
+// chi -> (sums, v, chi.grad) -- or, with from_den, density -> (sums, v) -- by the persistent small-grid kernel (resident.hip)
+int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, bool from_den = false);
 int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1);
 int launch_zpbe(ofdft_ctx* c, const DenSrc& ds, cplx* gx, cplx* gy, cplx* gz, real* dfdn, double inv_n, int* blocks_out,
                 hipStream_t st, int chunk = 0, int nchunks = 1);

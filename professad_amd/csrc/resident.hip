@@ -53,6 +53,7 @@ struct ResArgs {
     int outs[8], nout;       // slots transformed back to real space in phase C
     int vh_slot;             // where v_H comes back (0, or 7 with a GGA term)
     int gga;                 // gradient-dependent terms present (two more phases)
+    int from_den;            // the input array is the density itself (ofdft_energy_potential): no closure scale, no mu / chi.grad
     int flux_slots[3];       // {4, 5, 6}: the flux components (the divergence comes back in the first of them)
     GgaSel sel;
     KGeom kg;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
     // ------------------------------------------------------------------ phase A
     {
         acc_t s2 = 0.0;
-        for (int i = tid; i < N * M; i += T) {
+        for (int i = tid; i < N * M; i += T) {           // (density input: the sum is formed and ignored -- the scale is 1)
             const cplx c = chi_pl[i];
             s2 += (acc_t)c.x * c.x + (acc_t)c.y * c.y;
         }
@@ -326,9 +327,10 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             rows_forward(ns, [&](int sI, int y, int e) {
                 const int kind = A.kinds[g0 + sI];
                 const cplx c = chi_pl[y * M + e];
-                const real x2 = c.x * c.x, y2 = c.y * c.y;
+                const real x2 = A.from_den ? c.x : c.x * c.x, y2 = A.from_den ? c.y : c.y * c.y;       // n / c
                 if (kind == 0) return mkc(x2, y2);
-                if (kind == 1) return mkc(fabs(c.x), fabs(c.y));
+                if (kind == 1)                                                                          // sqrt(n / c)
+                    return A.from_den ? mkc(x2 > 0.0 ? sqrt(x2) : (real)0.0, y2 > 0.0 ? sqrt(y2) : (real)0.0) : mkc(fabs(c.x), fabs(c.y));
                 const real ex = kind == 2 ? be : al;
                 return mkc(x2 > 0.0 ? fm::pow_pos(x2, ex) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, ex) : (real)0.0);
             });
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
         }
     }
     stamp(7);
+    if (A.from_den) cscale = 1.0;
     const real cs = (real)cscale;
     const long long po = (long long)x * N * M;
     constexpr long long AS = (long long)N * N * M;            // pairs per real-space array
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             const cplx c = chi_pl[i];
             const cplx gx = rp[4 * AS + i], gy = rp[5 * AS + i], gz = rp[6 * AS + i];
             const real a0 = fg * gx.x, b0 = fg * gy.x, c0 = fg * gz.x, a1 = fg * gx.y, b1 = fg * gy.y, c1 = fg * gz.y;
-            const PbePoint p0 = pbe_point(cs * c.x * c.x, a0 * a0 + b0 * b0 + c0 * c0, A.sel);
-            const PbePoint p1 = pbe_point(cs * c.y * c.y, a1 * a1 + b1 * b1 + c1 * c1, A.sel);
+            const PbePoint p0 = pbe_point(A.from_den ? c.x : cs * c.x * c.x, a0 * a0 + b0 * b0 + c0 * c0, A.sel);
+            const PbePoint p1 = pbe_point(A.from_den ? c.y : cs * c.y * c.y, a1 * a1 + b1 * b1 + c1 * c1, A.sel);
             pacc[0] += p0.fx + p1.fx;
             pacc[1] += p0.fc + p1.fc;
             pacc[2] += p0.fk + p1.fk;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             for (int h = 0; h < 2; ++h) {
                 const real ch = h ? c.y : c.x;
                 CombinePoint p{};
-                p.n = cs * ch * ch;
+                p.n = A.from_den ? ch : cs * ch * ch;
                 p.vext = h ? ve.y : ve.x;
                 p.vh = f0 * (h ? r0.y : r0.x);
                 p.lap = f1 * (h ? r1.y : r1.x);
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
                 p.div = A.inv_n * (h ? dv.y : dv.x);
                 vv[h] = combine_point(A.ca, p, kCtf, acc);
             }
-            vp[i] = mkc(vv[0], vv[1]);
+            if (A.v) vp[i] = mkc(vv[0], vv[1]);
         }
         stamp(11);
         res_block_sums<kCombineScalars>(acc, lds, stage, A.part + bid * kResSlots);
@@ -577,7 +580,7 @@ static int launch_res(ofdft_ctx* c, const ResArgs& a, hipStream_t st) {
     return 0;
 }
 
-int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st) {
+int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, bool from_den) {
     const int N = c->n0;
     const unsigned mask = c->mask;
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
@@ -619,6 +622,7 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
         if (a.act[k]) a.kinds[a.narr++] = k;
     // phase B work list and the slots that come back to real space
     a.gga = gga ? 1 : 0;
+    a.from_den = from_den ? 1 : 0;
     a.vh_slot = gga ? 7 : 0;          // (with a gradient the chi^2 spectrum has several readers: v_H may not overwrite it)
     a.flux_slots[0] = 4; a.flux_slots[1] = 5; a.flux_slots[2] = 6;
     auto op = [&](int in, int out, int ck) { a.bop[a.nb++] = ResOp{in, out, ck}; a.outs[a.nout++] = out; };

@@ -865,6 +865,17 @@ def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
     assert res.query(N.Q_RESIDENT_EVALS) == (4 if served else 0) and staged.query(N.Q_RESIDENT_EVALS) == 0
     Ec, muc, _ = res.energy_grad_chi(chi, nel, ve, want_grad=False)                  # energy only
     assert Ec == Eb and muc == mub
+    # the density-input entry (ofdft_energy_potential: what the drop-in terms of professad_amd.functionals call)
+    den_t = chi * chi * (nel / float((chi * chi).sum() * abs(np.linalg.det(box.cpu().numpy())) / n ** 3))
+    before = res.query(N.Q_RESIDENT_EVALS)
+    Ea, va = staged.energy_potential(den_t, ve)
+    Eb, vb = res.energy_potential(den_t, ve)
+    assert res.query(N.Q_RESIDENT_EVALS) == before + (1 if served else 0)
+    for k in Ea:
+        assert abs(Ea[k] - Eb[k]) <= 1e-12 * max(abs(Ea[k]), 1e-2), (k, Ea[k], Eb[k])
+    assert float((va - vb).abs().max()) <= 1e-12 * float(va.abs().max())
+    Ec, vc = res.energy_potential(den_t, ve, want_potential=False)
+    assert vc is None and Ec == Eb
     staged.close()
     res.close()
 
