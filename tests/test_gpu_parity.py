@@ -898,6 +898,59 @@ def test_resident_kernel_leaves_other_grids_and_terms_to_the_staged_pipeline():
     eng.close()
 
 
+@pytest.mark.parametrize('shape,cfg', [((32, 32, 32), 'cfg1'), ((32, 32, 32), 'cfg3'), ((48, 32, 64), 'cfg2')])
+def test_calls_are_enqueued_on_the_callers_stream(shape, cfg):
+    """the engine works on torch's CURRENT stream (SURVEY 8b threading rule): inputs produced on a side stream just before the call,
+    outputs consumed on it right after -- persistent kernel, graph replay and the staged pipeline alike"""
+    box = dev(synth.cubic_cell(shape[0]))
+    names = F.NativeTerms(_CFG_TERMS[cfg]).names
+    base = dev(np.sqrt(synth.smooth_density(shape, seed=3)))
+    vext = dev(synth.random_potential(shape, seed=4))
+    eng = Engine(shape, DEV).set_cell(box).set_terms(names)
+    want = []
+    for k in range(3):                                  # default stream
+        E, mu, g = eng.energy_grad_chi(base * (1.0 + 0.01 * k), 6.0, vext)
+        want.append((E, mu, g.clone()))
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        for k in range(3):
+            chi = base * (1.0 + 0.01 * k)               # produced on the side stream, no synchronisation before the call
+            E, mu, g = eng.energy_grad_chi(chi, 6.0, vext)
+            gsum = (g - want[k][2]).abs().max()         # consumed on the side stream
+            assert E == want[k][0] and mu == want[k][1] and float(gsum) == 0.0, k
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    eng.close()
+
+
+def test_contexts_give_their_memory_back():
+    """create / evaluate / destroy in a loop (persistent kernel, graph replay, staged, L-BFGS handle): device memory returns"""
+    from professad_amd.optimize import HipLbfgsBackend
+    shape = (32, 32, 32)
+    chi = dev(np.sqrt(synth.smooth_density(shape, seed=3)))
+    vext = dev(synth.random_potential(shape, seed=4))
+    box = dev(synth.cubic_cell(32))
+
+    def cycle():
+        for cfg in ('cfg1', 'cfg3'):
+            eng = Engine(shape, DEV).set_cell(box).set_terms(F.NativeTerms(_CFG_TERMS[cfg]).names)
+            for _ in range(3):
+                eng.energy_grad_chi(chi, 6.0, vext)
+            eng.energy_potential(chi * chi, vext)
+            eng.close()
+        b = HipLbfgsBackend(chi.numel(), 8, DEV)
+        b.dots(chi.view(-1))
+        b.close()
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(DEV)[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(DEV)[0]
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
+
+
 def test_missing_vext_is_an_error_not_a_fault():
     """IonElectron without v_ext: every pipeline refuses the call (a null row pointer in a kernel would be a GPU fault)"""
     shape = (16, 16, 16)
