@@ -158,3 +158,13 @@ def test_eight_rank_geometry_in_one_process(nranks, shape):
         assert abs(E[k] - Er[k]) <= 1e-12 * max(1.0, abs(Er[k])), (k, E[k], Er[k])
     assert abs(mu - mur) <= 1e-12 * max(1.0, abs(mur))
     assert float((g - gr).abs().max()) <= 1e-12 * float(gr.abs().max())
+
+
+def test_rccl_calls_on_engine_owned_memory_with_one_rank():
+    """the torch.distributed (nccl = RCCL) calls of the collective transport on the tensors it passes them -- zero-copy views of
+    engine-owned device memory, async all-to-all on a side stream, in-place all-reduce of the device scalars -- in a one-rank group
+    (tests/nccl_one_rank_worker.py): what can be exercised of the RCCL branch on a one-GPU box"""
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29500 + os.getpid() % 400))
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'nccl_one_rank_worker.py')], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
