@@ -60,7 +60,11 @@ class Comm:
     """The two collectives the path needs, over a torch.distributed group (or trivially for one rank)."""
 
     def __init__(self, group=None):
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (OFDFT_COMM_ONE_RANK=1: also route a ONE-rank group's exchanges through the backend -- on a one-GPU box that is the
+        # only way to drive the whole staged evaluation through RCCL: tests/test_dist_gpu.py)
+        import os
+        self.active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get('OFDFT_COMM_ONE_RANK') == '1')
         self.group = group
         self.nranks = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0

@@ -168,3 +168,13 @@ def test_rccl_calls_on_engine_owned_memory_with_one_rank():
     env = dict(os.environ, MASTER_PORT=str(29500 + os.getpid() % 400))
     r = subprocess.run([sys.executable, os.path.join(HERE, 'nccl_one_rank_worker.py')], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize('shape,dtype', [('32x32x32', 'f64'), ('64x64x64', 'f32')])
+def test_whole_staged_evaluation_through_rccl_with_one_rank(shape, dtype, tmp_path):
+    """the complete slab-decomposed worker (closure + potential for three term sets, stress, ionic potential, forces) with backend
+    nccl and ONE rank whose exchanges are forced through the backend (OFDFT_COMM_ONE_RANK=1): every all-to-all is an RCCL call on
+    the engine's own buffers from the chain's stream, every small reduction an RCCL all-reduce -- against the single-GPU engine"""
+    res = _run_workers(1, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_COMM_ONE_RANK': '1'},
+                       timeout=400)
+    _check_worker_results(res, dtype)
