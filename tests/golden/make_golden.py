@@ -235,10 +235,11 @@ if __name__ == '__main__':
     ap.add_argument('--stress', action='store_true')
     ap.add_argument('--recpots', action='store_true')
     ap.add_argument('--bench', action='store_true')
+    ap.add_argument('--exact', action='store_true')
     ap.add_argument('--bench-grid', type=int, default=256)
     a = ap.parse_args()
     torch.set_num_threads(8)
-    if a.small or not (a.big or a.cfg1 or a.huge or a.ions or a.stress or a.recpots or a.bench):
+    if a.small or not (a.big or a.cfg1 or a.huge or a.ions or a.stress or a.recpots or a.bench or a.exact):
         gen_wavevecs()
         for c in cases.PER_TERM_CASES:
             gen_terms(c)
@@ -384,6 +385,54 @@ def gen_recpots():
 
 if __name__ == '__main__' and '--recpots' in sys.argv:
     gen_recpots()
+
+
+def gen_exact():
+    """The reference's exact single-orbital cases (tests/test_den_opt.py:13-40) run through its own System: hydrogen atom (Coulomb
+    recpot, E -> -0.5 Ha) and the quantum harmonic oscillator (E = 3/2 sqrt(k)), IonElectron + Weizsaecker, one electron, 20-bohr box,
+    grid of ecut2shape(250 eV).  Stored: the shape, both converged energies and iteration counts, the H recpot table (data file of
+    the reference's tests) and the ionic potential the reference built from it."""
+    import io
+    import contextlib
+    import professad.ion_utils as IU
+    os.chdir('/root/reference/tests')
+    from professad.system import System
+    L = 20.0
+    box_vecs = L * torch.eye(3, dtype=torch.double)
+    shape = System.ecut2shape(250, box_vecs)
+    ions = [['H', 'potentials/H.coulomb-kcut-15.recpot', torch.tensor([[0.5, 0.5, 0.5]]).double()]]
+    system = System(box_vecs, shape, ions, [F.IonElectron, F.Weizsaecker], units='b', coord_type='fractional')
+    system.set_electron_number(1)
+    out = {'shape': np.array(shape), 'box': box_vecs.numpy()}
+
+    def run(tag):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            system.optimize_density(ntol=1e-4, n_verbose=True)
+        rows = [ln.split() for ln in buf.getvalue().splitlines() if ln.strip() and ln.split()[0].isdigit()]
+        out[tag + '_E_Ha'] = np.float64(system.energy('Ha'))
+        out[tag + '_iterations'] = np.int64(len(rows) - 1 if rows else -1)
+        out[tag + '_log'] = np.array(buf.getvalue())
+        print(tag, system.energy('Ha'), len(rows))
+    out['h_vext'] = system.ionic_potential().detach().numpy()
+    run('h')
+    k = 10.0
+    f = [np.arange(n) / n for n in shape]
+    x, y, z = np.meshgrid(L * f[0], L * f[1], L * f[2], indexing='ij')
+    pot = 0.5 * k * ((x - L / 2) ** 2 + (y - L / 2) ** 2 + (z - L / 2) ** 2)
+    system.set_potential(torch.as_tensor(pot).double())
+    system.initialize_density()
+    run('qho')
+    out['qho_k'] = np.float64(k)
+    pot_t, k_max = _recpot_table('/root/reference/tests/potentials/H.coulomb-kcut-15.recpot', IU)
+    out['h_raw'] = pot_t
+    out['h_kmax'] = np.float64(k_max)
+    np.savez_compressed(os.path.join(HERE, 'exact_cases.npz'), **out)
+    print('exact_cases.npz', shape)
+
+
+if __name__ == '__main__' and '--exact' in sys.argv:
+    gen_exact()
 
 
 def gen_bench(n=256):

@@ -343,6 +343,39 @@ def test_density_optimisation_reaches_reference_ground_state(optimizer):
     eng.close()
 
 
+@pytest.mark.parametrize('n', [53, 64])
+def test_exact_single_orbital_cases(n):
+    """The reference's exact cases (tests/test_den_opt.py:13-40): one electron with IonElectron + Weizsaecker is the single-orbital
+    Schroedinger problem -- the hydrogen atom (Coulomb recpot; E -> -0.5 Ha, the reference asserts 2 places) and the harmonic
+    oscillator v = k r^2 / 2 (E = 3/2 sqrt(k), 5 places).  53^3 is the grid the reference's System.ecut2shape gives its 20-bohr box
+    (prime: chirp-z transforms, unfused pipeline; fixture = the reference's own run, tests/golden/exact_cases.npz), 64^3 the next
+    fused extent (persistent small-grid kernel)."""
+    from professad_amd.ions import ionic_potential, recpot_table
+    from professad_amd.optimize import optimize_density
+    g = load('exact_cases.npz')
+    L, k = 20.0, float(g['qho_k'])
+    box = L * np.eye(3)
+    eng = Engine((n, n, n), DEV).set_cell(dev(box)).set_terms(['ion_electron', 'vw'])
+    # harmonic oscillator
+    f = np.arange(n) / n
+    x, y, z = np.meshgrid(L * f, L * f, L * f, indexing='ij')
+    pot = 0.5 * k * ((x - L / 2) ** 2 + (y - L / 2) ** 2 + (z - L / 2) ** 2)
+    res = optimize_density(eng, 1.0, dev(pot), volume=L ** 3, ntol=1e-4)
+    assert res['converged'] and abs(res['E_Ha'] - 1.5 * np.sqrt(k)) < 5e-6
+    if n == 53:
+        assert abs(res['E_Ha'] - float(g['qho_E_Ha'])) < 2e-6 and abs(res['iterations'] - int(g['qho_iterations'])) <= 6
+    # hydrogen atom: the ionic potential from the recpot table (equal to the reference's on its grid), then the ground state
+    tab = recpot_table(g['h_raw'], float(g['h_kmax']))
+    vext = ionic_potential(eng, box, [(np.array([[0.5, 0.5, 0.5]]), tab)])
+    if n == 53:
+        assert relerr(vext.cpu().numpy(), g['h_vext']) < 1e-10
+    res = optimize_density(eng, 1.0, vext, volume=L ** 3, ntol=1e-4)
+    assert res['converged'] and abs(res['E_Ha'] + 0.5) < 5e-3
+    if n == 53:
+        assert abs(res['E_Ha'] - float(g['h_E_Ha'])) < 1e-5
+    eng.close()
+
+
 def test_ionic_potential_matches_reference_golden():
     """v_ext from ion positions (exact and PME structure factors) against the reference's lattice_sum outputs."""
     from professad_amd.ions import ionic_potential, recpot_table
