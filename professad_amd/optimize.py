@@ -389,8 +389,39 @@ class VectorFreeLBFGS:
         return loss0
 
 
+class TwoPointGradientDescent:
+    """Barzilai-Borwein two-point gradient descent on one flat variable -- the reference's alternative density optimiser
+    (`n_method='TPGD'`, system.py:823-824; _optimizers/tpgd/two_point_gradient_descent.py:25-65): one closure call per step,
+    step length (dx . dx) / (dx . dg) from the previous point, the fixed `lr` on the first step or when the quotient is not
+    positive.  `all_reduce(vec) -> vec` sums the two local dot products over ranks (None on one GPU)."""
+
+    def __init__(self, x, lr=0.1, all_reduce=None):
+        if lr <= 0.0:
+            raise ValueError('lr must be positive')
+        self.x, self.lr, self.all_reduce = x, float(lr), all_reduce
+        self.x_prev = self.g_prev = None
+        self.func_evals = 0
+        self.total_iter = 0
+
+    def step(self, closure):
+        loss, g = closure()
+        self.func_evals += 1
+        alpha = self.lr
+        if self.x_prev is not None:
+            dx, dg = self.x - self.x_prev, g - self.g_prev
+            dots = torch.stack(((dx * dx).sum(dtype=torch.double), (dx * dg).sum(dtype=torch.double))).cpu().numpy()
+            if self.all_reduce is not None:
+                dots = self.all_reduce(dots)
+            if dots[1] != 0.0 and dots[0] / dots[1] > 0.0:
+                alpha = float(dots[0] / dots[1])
+        self.x_prev, self.g_prev = self.x.clone(), g.clone()
+        self.x.add_(g, alpha=-alpha)
+        self.total_iter += 1
+        return loss
+
+
 def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_cond_count=3, n_step_size=0.1,
-                     n_maxiter=1000, conv_target='dE', verbose=False, volume=None, optimizer='fused'):
+                     n_maxiter=1000, conv_target='dE', verbose=False, volume=None, optimizer='fused', n_method='LBFGS'):
     """Minimise E[n = N_e chi^2 / int chi^2] with the engine's terms.  Returns a dict with the converged density,
     chi, energy [Ha], iteration count and the convergence history.
 
@@ -403,6 +434,8 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     suits fp64) or the loop runs to `n_maxiter`."""
     if conv_target not in ('dE', 'dEdchi', 'euler'):
         raise ValueError("Only 'dE', 'dEdchi' or 'euler' recognized as 'conv_target' argument")       # system.py:889-890
+    if n_method not in ('LBFGS', 'TPGD'):
+        raise ValueError("Only 'LBFGS' or 'TPGD' recognized for 'n_method' argument")                 # system.py:826
     if conv_target != 'dE' and volume is None:
         raise ValueError("conv_target=%r needs `volume` (the cell volume fixes dV)" % conv_target)
     comm = getattr(engine, 'comm', None)                    # DistEngine
@@ -437,7 +470,10 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         state.update(E=sum(E_terms.values()), mu=mu, g=g, E_terms=E_terms)
         return state['E'], g
 
-    if optimizer == 'fused':        # device-resident history, two sweeps per inner iteration
+    if n_method == 'TPGD':          # system.py:823-824
+        hook = (lambda v: comm.all_reduce_sum(np.ascontiguousarray(v, dtype=np.float64), dev)) if multi else None
+        opt = TwoPointGradientDescent(chi, lr=n_step_size, all_reduce=hook)
+    elif optimizer == 'fused':      # device-resident history, two sweeps per inner iteration
         hook = (lambda v: comm.all_reduce_sum(np.ascontiguousarray(v, dtype=np.float64), dev)) if multi else None
         opt = VectorFreeLBFGS(chi, HipLbfgsBackend(chi.numel(), 8, dev, dtype), lr=n_step_size, history_size=8, max_iter=6,
                               all_reduce=hook)

@@ -683,6 +683,40 @@ def test_fcc_aluminium_end_to_end_against_profess4_value():
     eng.close()
 
 
+def test_optimisers_agree_and_convergence_measures_are_consistent():
+    """The reference's tests/test_den_opt.py:43-75 on the native path: fcc-Al primitive cell with Hartree + LKT + PBE -- the
+    fixed-step L-BFGS and the two-point gradient descent (n_method='TPGD') reach the same energy (3 decimal places in eV); and
+    at the converged state max |dE/dchi| from the closure equals the formula from dE/dn (rtol 1e-10)."""
+    from professad_amd.ions import ionic_potential, recpot_table
+    from professad_amd.optimize import EV_PER_HA, optimize_density
+    g = load('ions.npz')
+    tab = recpot_table(g['recpot_raw'], float(g['recpot_kmax']))
+    box = 4.050 / 0.529177210903 * np.array([[0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]])
+    vol = abs(np.linalg.det(box))
+    shape = (20, 20, 20)
+    eng = Engine(shape, DEV).set_cell(dev(box))
+    vext = ionic_potential(eng, box, [(np.zeros((1, 3)), tab)])
+    eng.set_terms(F.NativeTerms(['ion_electron', 'hartree', 'tf', 'lkt', 'pbe']).names, {'ggak_kind': 0})
+    n_el = float(tab[2])
+    r1 = optimize_density(eng, n_el, vext, volume=vol, ntol=1e-4)
+    r2 = optimize_density(eng, n_el, vext, volume=vol, ntol=1e-4, n_conv_cond_count=5, n_method='TPGD')
+    assert r1['converged'] and r2['converged']
+    assert abs(r1['E_Ha'] - r2['E_Ha']) * EV_PER_HA < 5e-4
+    with pytest.raises(ValueError):
+        optimize_density(eng, n_el, vext, volume=vol, n_method='SD')
+    # convergence measure: chi.grad / dV of the closure against 2 c chi (dE/dn - mu) from the potential entry (system.py:377-447)
+    chi, den = r1['chi'], r1['den']
+    _, mu, grad = eng.energy_grad_chi(chi, n_el, vext)
+    _, dEdn = eng.energy_potential(den, vext)
+    dV = vol / np.prod(shape)
+    c = n_el / (float((chi * chi).sum()) * dV)
+    mu2 = float((dEdn * den).sum()) * dV / n_el
+    want = c * 2.0 * chi * (dEdn - mu2)
+    assert abs(mu - mu2) < 1e-10 * abs(mu)
+    assert abs(float(grad.abs().max()) / dV - float(want.abs().max())) <= 1e-10 * float(want.abs().max())
+    eng.close()
+
+
 def test_bcc_lithium_end_to_end_against_profess4_value():
     """second anchor of tests/test_match_profess4.py:26-37: bcc-Li, 18^3, IonIon + IonElectron + Hartree + SmargiassiMadden
     + PBE -> -14.741886997024537 eV (PROFESS 4.0, atol 1e-4)"""

@@ -108,3 +108,22 @@ def test_vector_free_lbfgs_sharded_sums():
         la, lb = a.step(ca), b.step(cb)
         assert abs(la - lb) <= 1e-10 * max(1.0, abs(la))
     assert float((xa - xb).abs().max()) <= 1e-9 * float(xa.abs().max())
+
+
+def test_two_point_gradient_descent_minimises_the_test_function():
+    """the reference's alternative optimiser (Barzilai-Borwein steps, one closure call per step): first step = lr * gradient,
+    later steps (dx.dx)/(dx.dg); reaches the minimum the L-BFGS reaches"""
+    from professad_amd.optimize import FixedStepLBFGS, TwoPointGradientDescent
+    make = _test_problem()
+    x = torch.zeros(400, dtype=torch.double)
+    opt = TwoPointGradientDescent(x, lr=0.1)
+    f0, g0 = make(x)()
+    opt.step(make(x))
+    assert torch.allclose(x, -0.1 * g0)                      # first step: fixed length
+    for _ in range(400):
+        opt.step(make(x))
+    y = torch.zeros(400, dtype=torch.double)
+    ref = FixedStepLBFGS(y, lr=0.1, history_size=8, max_iter=6)
+    for _ in range(80):
+        ref.step(make(y))
+    assert abs(make(x)()[0] - make(y)()[0]) < 1e-9 and opt.func_evals == 401
