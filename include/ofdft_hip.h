@@ -280,7 +280,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      288, 320, 384, 480) run the register / LDS transforms and the fused pipelines like the powers of two;
                                      0: they take the chirp-z transforms + the unfused pipeline like any other extent (validation, A/B) */
 #define OFDFT_OPT_RESIDENT 10     /* ofdft_energy_grad_chi on cubic 16^3 / 32^3 / 64^3 grids with local, Hartree, von Weizsaecker and Wang-Teter terms (up to
-                                     32^3 also PBE / LKT / mu-only Pauli-Gaussian)
+                                     32^3 also PBE / LKT / mu-only Pauli-Gaussian and WGC99)
                                      runs as ONE persistent kernel (four phases, three grid barriers; csrc/resident.hip) instead of the staged
                                      pipeline.  2 (default): the call is not bracketed by the HIP event pair that times it (OFDFT_Q_KERNEL_MS reads
                                      0 for it) and the host watches a pinned word the last workgroup writes instead of waiting for the stream --

@@ -268,6 +268,9 @@ int wgc_series_setup(ofdft_ctx* c, long long nel_rounded, hipStream_t st, WgcSer
     return 0;
 }
 
+}  // namespace
+namespace eng {
+// (also called by the persistent small-grid kernel's launcher, resident.hip)
 int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out) {
     const double nref = c->params[OFDFT_P_WGC_KAPPA] * ((double)nel_rounded / c->vol);
     *nref_out = nref;
@@ -286,6 +289,8 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     c->wgc_valid = true;
     return 0;
 }
+}  // namespace eng
+namespace {
 
 // ---------------------------------------------------------------------------------- combine / energies
 // launch the combine kernel and turn its partial sums into per-term energies

@@ -246,6 +246,8 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
 // x planes [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.
 int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, hipStream_t st, int chunk = 0, int nchunks = 1,
                       real* dzn = nullptr);
+// WGC99 kernel tables (w0, K1, K2, K3 interleaved per k-point, spectrum order) for round(N_e) = nel_rounded; *nref_out = kappa n0
+int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out);
 bool resident_serves(const ofdft_ctx* c);
 // chi -> (sums, v, chi.grad) -- or, with from_den, density -> (sums, v) -- by the persistent small-grid kernel (resident.hip)
 int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, bool from_den = false);

@@ -26,9 +26,10 @@ namespace ofdft {
 
 constexpr int kResSlots = 16;        // doubles per workgroup in the partials: [0..9] combine sums, [10] sum chi^2, [11..13] GGA sums
 
-constexpr int kResT = 8;             // spectrum slots: 0 chi^2 (Hartree in / out), 1 |chi| (vW), 2 chi^(2 beta), 3 chi^(2 alpha),
-                                     // 4-6 grad n -> flux -> (4) divergence, 7 v_H when the chi^2 spectrum also feeds the gradient
-constexpr int kResR = 9;             // real-space slots: the same, and 8 = df/dn of the GGA terms
+constexpr int kResT = 15;            // spectrum slots: 0 chi^2 (Hartree in / out), 1 |chi| (vW), 2 chi^(2 beta), 3 chi^(2 alpha),
+                                     // 4-6 grad n -> flux -> (4) divergence, 7 v_H when the chi^2 spectrum also feeds the gradient,
+                                     // 9-11 WGC99 A, B, C -> u0, u1, u2, 12-14 P, Q, S -> gA, gB, gC (functionals.py:974-981)
+constexpr int kResR = 15;            // real-space slots: the same, and 8 = df/dn of the GGA terms
 
 struct ResOp { int in, out, ck; };   // phase B: T[out] = F_x^-1[coef_ck(k) F_x[T[in]]]; ck: 0 4 pi / k^2, 1 -k^2, 2 Lindhard, 3-5 i k_x / i k_y / i k_z
 
@@ -46,11 +47,16 @@ struct ResArgs {
     unsigned* done;          // pinned host word: the last workgroup to finish stores done_target there (the host may spin on it
                              // instead of waiting for the stream: a few microseconds less per evaluation)
     unsigned done_target;    // value of the device-side count-out word sync[1] once every workgroup of this launch has left
-    int act[4];              // which of the four inputs f(chi) the term set needs (their forward spectra land in slots 0..3)
-    int kinds[4], narr;      // the active ones, compacted (phase A walks this list)
+    int act[4];              // which of the four scale-free inputs f(chi) the term set needs (their forward spectra land in slots 0..3)
+    int kinds[10], in_slots[10], narr;      // phase A work list: input kind (0..3 as above; 4..9 the six WGC99 inputs, which need the
+                             // closure scale: n^e theta^m / m!, e = beta | alpha, theta = n - n_ref) and the slot of its spectrum
+    int need_c;              // WGC99 present: sum chi^2 is reduced before phase A (one more barrier)
+    int nw;                  // WGC99 triples mixed in phase B (0 or 2: slots 9-11 and 12-14, in place)
+    const real* wtab;        // its kernel tables (w0, K1, K2, K3 per k-point, the staged pipeline's spectrum order)
+    SpecGeom wg;             // ... and that order
     ResOp bop[8];            // phase B work list
     int nb;
-    int outs[8], nout;       // slots transformed back to real space in phase C
+    int outs[14], nout;      // slots transformed back to real space in phase C
     int vh_slot;             // where v_H comes back (0, or 7 with a GGA term)
     int gga;                 // gradient-dependent terms present (two more phases)
     int from_den;            // the input array is the density itself (ofdft_energy_potential): no closure scale, no mu / chi.grad
@@ -224,8 +230,11 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
 #endif
     };
     (void)clk0;
-    for (int i = tid; i < M; i += T) twM[i] = twM_g[i];
-    for (int i = tid; i < N; i += T) twN[i] = twN_g[i];
+    auto stage_tables = [&]() {                           // (published by the next __syncthreads)
+        for (int i = tid; i < M; i += T) twM[i] = twM_g[i];
+        for (int i = tid; i < N; i += T) twN[i] = twN_g[i];
+    };
+    stage_tables();
     const real be = A.ca.wt_beta, al = A.ca.wt_alpha;
     const int x = bid;                                    // phases A, C, D: this workgroup's x plane
     const cplx* chi_pl = reinterpret_cast<const cplx*>(A.chi + (long long)x * N * N);
@@ -306,6 +315,8 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
         res_barrier(A.sync, A.epoch0 + nbar * (unsigned)N, &timed_out);
     };
 
+    acc_t cscale = 0.0;
+    bool have_c = false;
     // ------------------------------------------------------------------ phase A
     {
         acc_t s2 = 0.0;
@@ -322,6 +333,13 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             for (int w = 0; w < C::WAVES; ++w) t += red[w][0];
             A.part[bid * kResSlots + 10] = t;
         }
+        if (A.need_c) {       // the WGC99 inputs are not homogeneous in the closure scale (theta = n - n_ref): reduce sum chi^2 first
+            barrier();
+            res_totals<N>(A.part, 10, 1, tot + kCombineScalars, stage);
+            cscale = A.from_den ? (acc_t)1.0 : A.nel / (tot[kCombineScalars] * A.vol_over_npts);       // system.py:833-834
+            have_c = true;
+        }
+        const real cs0 = (real)cscale, wal = A.ca.wgc_alpha, wbe = A.ca.wgc_beta, nref = A.ca.nref;
         for (int g0 = 0; g0 < A.narr; g0 += AG) {
             const int ns = (A.narr - g0) < AG ? (A.narr - g0) : AG;
             rows_forward(ns, [&](int sI, int y, int e) {
@@ -331,11 +349,20 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
                 if (kind == 0) return mkc(x2, y2);
                 if (kind == 1)                                                                          // sqrt(n / c)
                     return A.from_den ? mkc(x2 > 0.0 ? sqrt(x2) : (real)0.0, y2 > 0.0 ? sqrt(y2) : (real)0.0) : mkc(fabs(c.x), fabs(c.y));
-                const real ex = kind == 2 ? be : al;
-                return mkc(x2 > 0.0 ? fm::pow_pos(x2, ex) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, ex) : (real)0.0);
+                if (kind < 4) {
+                    const real ex = kind == 2 ? be : al;
+                    return mkc(x2 > 0.0 ? fm::pow_pos(x2, ex) : (real)0.0, y2 > 0.0 ? fm::pow_pos(y2, ex) : (real)0.0);
+                }
+                // WGC99: n^e theta^m / m!  (functionals.py:974-981), on the scaled density
+                const real n0 = cs0 * x2, n1 = cs0 * y2, ex = kind < 7 ? wbe : wal;
+                const int m = (kind - 4) % 3;
+                real a0 = n0 > 0.0 ? fm::pow_pos(n0, ex) : (real)0.0, a1 = n1 > 0.0 ? fm::pow_pos(n1, ex) : (real)0.0;
+                if (m >= 1) { a0 *= n0 - nref; a1 *= n1 - nref; }
+                if (m == 2) { a0 *= 0.5 * (n0 - nref); a1 *= 0.5 * (n1 - nref); }
+                return mkc(a0, a1);
             });
             __syncthreads();
-            res_ylines<N, false>(plane, ns, rowbuf, twN, A.T, A.kinds + g0, x);
+            res_ylines<N, false>(plane, ns, rowbuf, twN, A.T, A.in_slots + g0, x);
             __syncthreads();
         }
     }
@@ -385,14 +412,62 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             }
         }
     }
+    // WGC99: (A, B, C) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) and the same for (P, Q, S), in place (the tables
+    // carry every prefactor, as in the staged pipeline's MixWgc)
+    if (A.nw) {
+        const int ky = bid;
+        const int nlines = A.nw * NZH;
+        for (int L0 = 0; L0 < nlines; L0 += C::LINES) {
+            const int slot = wave * C::LPWV + ll;
+            if (wave * C::LPWV >= C::LINES || L0 + wave * C::LPWV >= nlines) continue;          // wave-uniform
+            const int L = L0 + slot;
+            const bool valid = L < nlines;
+            const int tr = valid ? L / NZH : 0, kz = valid ? L - tr * NZH : 0;
+            real* mine = rowbuf + slot * LineBuf<N>::STRIDE;
+            cplx* base = A.T + ((long long)(9 + 3 * tr) * N + ky) * N * NZH + kz;
+            constexpr long long SS = (long long)N * N * NZH;          // one slot
+            cplx u[3][EL];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int q = 0; q < EL; ++q) u[a][q] = valid ? base[a * SS + (lj + PL * q) * NZH] : mkc(0.0, 0.0);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                wave_line_fft<N, EL, false>(u[a], lj, mine, twN);
+                exchange_sync<true>();
+            }
+#pragma unroll
+            for (int q = 0; q < EL; ++q) {
+                const long long ti = spec_index(A.wg, lj + PL * q, ky, kz);
+                const cplx t01 = reinterpret_cast<const cplx*>(A.wtab)[2 * ti], t23 = reinterpret_cast<const cplx*>(A.wtab)[2 * ti + 1];
+                const real w0 = t01.x, K1 = t01.y, K2 = t23.x, K3 = t23.y;
+                const cplx a0 = u[0][q], a1 = u[1][q], a2 = u[2][q];
+                u[0][q] = mkc(w0 * a0.x + K1 * a1.x + K2 * a2.x, w0 * a0.y + K1 * a1.y + K2 * a2.y);
+                u[1][q] = mkc(K1 * a0.x + K3 * a1.x, K1 * a0.y + K3 * a1.y);
+                u[2][q] = mkc(K2 * a0.x, K2 * a0.y);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                wave_line_fft<N, EL, true>(u[a], lj, mine, twN);
+                exchange_sync<true>();
+            }
+            if (valid) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                    for (int q = 0; q < EL; ++q) base[a * SS + (lj + PL * q) * NZH] = u[a][q];
+                }
+            }
+        }
+    }
     stamp(2);
     barrier();
     stamp(3);
 
     // ------------------------------------------------------------------ phase C
     // the loads that cross XCDs -- this plane of the first group's spectra and the partial sums of chi^2 -- go out together
-    acc_t cscale = 0.0;
-    if (A.nout == 0) {                                    // purely local term set: nothing to transform back
+    if (A.nout == 0 && !have_c) {                         // purely local term set: nothing to transform back
         res_totals<N>(A.part, 10, 1, tot + kCombineScalars, stage);
         cscale = A.nel / (tot[kCombineScalars] * A.vol_over_npts);
     }
@@ -400,9 +475,11 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
         const int ns = (A.nout - g0) < AG ? (A.nout - g0) : AG;
         planes_inverse(A.outs + g0, ns, g0 == 0);
         if (g0 == 0) {
-            acc_t t = 0.0;
-            for (int g = 0; g < N; ++g) t += stage[g];                 // same order in every thread and workgroup
-            cscale = A.nel / (t * A.vol_over_npts);                    // system.py:833-834
+            if (!have_c) {
+                acc_t t = 0.0;
+                for (int g = 0; g < N; ++g) t += stage[g];             // same order in every thread and workgroup
+                cscale = A.nel / (t * A.vol_over_npts);                // system.py:833-834
+            }
             __syncthreads();                                           // (stage is reused below)
         }
     }
@@ -432,6 +509,8 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             rp[6 * AS + i] = mkc(p0.dfdg * c0, p1.dfdg * c1);
         }
         res_block_sums<kPbeScalars>(pacc, lds, stage, A.part + bid * kResSlots + 11);
+        stage_tables();                                   // the ordered sums borrowed the dynamic LDS, twiddle tables included
+        __syncthreads();
         // flux components of this plane -> z- and y-forward -> T[4..6]
         for (int g0 = 0; g0 < 3; g0 += AG) {
             const int ns = (3 - g0) < AG ? (3 - g0) : AG;
@@ -500,6 +579,9 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
             const cplx r0 = has_h ? rp[hs + i] : mkc(0.0, 0.0), r1 = A.act[1] ? rp[AS + i] : mkc(0.0, 0.0);
             const cplx r2 = A.act[2] ? rp[2 * AS + i] : mkc(0.0, 0.0), r3 = A.act[3] ? rp[3 * AS + i] : mkc(0.0, 0.0);
             const cplx dn = A.gga ? rp[8 * AS + i] : mkc(0.0, 0.0), dv = A.gga ? rp[4 * AS + i] : mkc(0.0, 0.0);
+            cplx wv[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) wv[a] = A.nw ? rp[(9 + a) * AS + i] : mkc(0.0, 0.0);
             real vv[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -513,6 +595,12 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
                 p.cva = f3 * (h ? r3.y : r3.x);
                 p.dfdn = h ? dn.y : dn.x;
                 p.div = A.inv_n * (h ? dv.y : dv.x);
+                p.u0 = A.inv_n * (h ? wv[0].y : wv[0].x);
+                p.u1 = A.inv_n * (h ? wv[1].y : wv[1].x);
+                p.u2 = A.inv_n * (h ? wv[2].y : wv[2].x);
+                p.gA = A.inv_n * (h ? wv[3].y : wv[3].x);
+                p.gB = A.inv_n * (h ? wv[4].y : wv[4].x);
+                p.gC = A.inv_n * (h ? wv[5].y : wv[5].x);
                 vv[h] = combine_point(A.ca, p, kCtf, acc);
             }
             if (A.v) vp[i] = mkc(vv[0], vv[1]);
@@ -563,7 +651,7 @@ namespace eng {
 bool resident_serves(const ofdft_ctx* c) {
     if (!c->resident || c->nranks != 1 || !c->fast) return false;
     if (!(c->n0 == c->n1 && c->n1 == c->n2 && (c->n0 == 16 || c->n0 == 32 || c->n0 == 64))) return false;
-    if (c->mask & OFDFT_WGC99_NL) return false;
+    if ((c->mask & OFDFT_WGC99_NL) && c->n0 > 32) return false;      // (six more spectra: beyond 32^3 the graph replay is faster)
     if ((c->mask & kGgaAny) && (gga_needs_laplacian(c) || c->n0 > 32)) return false;      // (64^3 with a GGA term: five phases of 4096-point
                                                                                           //  planes per workgroup measured slower than the graph replay)
     if (wts_active(c)) return false;
@@ -610,7 +698,7 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     a.reduced = c->h_partial;          // pinned, device-visible: no copy command behind the kernel
     a.sync = c->res_sync;
     a.epoch0 = c->res_epoch;
-    c->res_epoch += (gga ? 5u : 3u) * (unsigned)N;
+    c->res_epoch += ((gga ? 5u : 3u) + ((mask & OFDFT_WGC99_NL) ? 1u : 0u)) * (unsigned)N;
     c->res_done_target += (unsigned)N;
     a.done_target = c->res_done_target;
     // inputs f(chi) -> forward spectra in slots 0..3
@@ -618,8 +706,20 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     a.act[1] = vw ? 1 : 0;
     a.act[2] = wt ? 1 : 0;
     a.act[3] = (wt && al != be) ? 1 : 0;
+    const bool wgc = mask & OFDFT_WGC99_NL;
     for (int k = 0; k < 4; ++k)
-        if (a.act[k]) a.kinds[a.narr++] = k;
+        if (a.act[k]) {
+            a.in_slots[a.narr] = k;
+            a.kinds[a.narr++] = k;
+        }
+    if (wgc) {
+        for (int k = 4; k < 10; ++k) {
+            a.in_slots[a.narr] = 9 + (k - 4);
+            a.kinds[a.narr++] = k;
+        }
+        a.need_c = 1;
+        a.nw = 2;
+    }
     // phase B work list and the slots that come back to real space
     a.gga = gga ? 1 : 0;
     a.from_den = from_den ? 1 : 0;
@@ -632,6 +732,18 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     if (a.act[3]) op(3, 3, 2);
     if (gga)
         for (int j = 0; j < 3; ++j) op(0, 4 + j, 3 + j);
+    if (wgc) {
+        for (int k = 0; k < 6; ++k) a.outs[a.nout++] = 9 + k;
+        const double wal = c->params[OFDFT_P_WGC_ALPHA], wbe = c->params[OFDFT_P_WGC_BETA];
+        double nref;
+        if (int rc = ensure_wgc_tables(c, std::llround(nel), st, &nref)) return rc;     // functionals.py:952 (rounded N_e)
+        a.wtab = (const real*)c->ws["t:wgc"].p;
+        a.wg = c->g;
+        a.ca.wgc_alpha = wal;
+        a.ca.wgc_beta = wbe;
+        a.ca.nref = nref;
+        a.ca.wgc_sum_53 = (std::fabs(wal + wbe - kFiveThirds) < 4e-16) ? 1 : 0;
+    }
     a.sel = gga_sel(c);
     a.kg = c->kg;
     CombineArgs& ca = a.ca;

@@ -268,3 +268,41 @@ def test_f32_engine_hands_ion_routines_to_the_fp64_sibling():
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     e32.close()
     e64.close()
+
+
+@pytest.mark.parametrize('n', [16, 32, 64])
+@pytest.mark.parametrize('terms', [['ion_electron', 'hartree', 'wt', 'pbe'], ['ion_electron', 'hartree', 'wgc99', 'pbe'],
+                                   ['ion_electron', 'hartree', 'tf', 'lkt', 'pz'], ['ion_electron', 'hartree', 'wt', 'pz']],
+                         ids=['wt_pbe', 'wgc_pbe', 'lkt', 'wt_lda'])
+def test_f32_persistent_kernel_matches_the_f32_staged_pipeline(n, terms):
+    """the persistent small-grid kernel in the fp32 build, every phase of it (gradient / flux / divergence, WGC99 triples): closure
+    and density-input entry against the staged fp32 pipeline (fp32 round-off) and the fp64 engine (the fp32 tolerances)"""
+    from professad_amd import _native as N
+    shape = (n, n, n)
+    rng = np.random.default_rng(7)
+    box = torch.as_tensor(synth.triclinic_cell(n / 4.0))
+    den = synth.smooth_density(shape, seed=3, amp=0.5) * (1 + 0.1 * rng.random(shape))
+    vext = synth.random_potential(shape, seed=4)
+    chi = np.sqrt(den)
+    names = F.NativeTerms(terms).names
+    nel = 9.0
+    e64 = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_RESIDENT, 0)
+    st = Engine(shape, DEV, dtype=F32).set_cell(box).set_terms(names).set_option(N.OPT_RESIDENT, 0)
+    rs = Engine(shape, DEV, dtype=F32).set_cell(box).set_terms(names)
+    Er, mur, gr = e64.energy_grad_chi(torch.as_tensor(chi, device=DEV), nel, torch.as_tensor(vext, device=DEV))
+    Ea, mua, ga = st.energy_grad_chi(dev32(chi), nel, dev32(vext))
+    Eb, mub, gb = rs.energy_grad_chi(dev32(chi), nel, dev32(vext))
+    served = int(rs.query(N.Q_RESIDENT_EVALS))
+    assert served == (0 if (n == 64 and ('pbe' in terms or 'lkt' in terms or 'wgc99' in terms)) else 1)
+    for k in Er:
+        assert abs(Eb[k] - Er[k]) <= E_RTOL * max(abs(Er[k]), 1e-3), (k, Eb[k], Er[k])
+    assert relerr(gb.cpu().numpy(), gr.cpu().numpy()) < V_RTOL
+    assert relerr(gb.cpu().numpy(), ga.cpu().numpy()) < 1e-4
+    dn = dev32(den * (nel / (den.mean() * abs(np.linalg.det(box.numpy())))))
+    Ea, va = st.energy_potential(dn, dev32(vext))
+    Eb, vb = rs.energy_potential(dn, dev32(vext))
+    assert relerr(vb.cpu().numpy(), va.cpu().numpy()) < 1e-4
+    for k in Ea:
+        assert abs(Ea[k] - Eb[k]) <= E_RTOL * max(abs(Ea[k]), 1e-3)
+    for e in (e64, st, rs):
+        e.close()

@@ -886,7 +886,7 @@ _RES_TERMS = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['i
 
 
 @pytest.mark.parametrize('n', [16, 32, 64])
-@pytest.mark.parametrize('cfg', ['cfg1', 'cfg2', 'local', 'vw_only', 'wt_ab', 'gtf', 'wt_pbe', 'lkt_pbe', 'pbe_only', 'pg1'])
+@pytest.mark.parametrize('cfg', ['cfg1', 'cfg2', 'local', 'vw_only', 'wt_ab', 'gtf', 'wt_pbe', 'lkt_pbe', 'pbe_only', 'pg1', 'cfg3', 'wgc_lda'])
 def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
     """cubic 16^3 / 32^3 / 64^3, term sets without gradient-dependent or WGC99 parts: the closure evaluation as ONE persistent
     kernel (csrc/resident.hip) against the staged pipeline (itself pinned to the oracle and the reference's goldens),
@@ -912,6 +912,10 @@ def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
         names = ['tf', 'pbe_x', 'pbe_c']
     elif cfg == 'pg1':                                      # Pauli-Gaussian, mu-only member
         names, params = ['ion_electron', 'hartree', 'vw', 'gga_k', 'lda_x', 'pz_c'], {'ggak_kind': 1, 'ggak_mu': 1.0}
+    elif cfg == 'cfg3':                                     # the bench's term set: WGC99 + PBE
+        names = F.NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe']).names
+    elif cfg == 'wgc_lda':                                  # WGC99 with other exponents, no gradient term
+        names, params = F.NativeTerms(['ion_electron', 'wgc99', 'pz']).names, {'wgc_alpha': 1.1, 'wgc_beta': 0.7, 'wgc_gamma': 3.2}
     elif cfg in _RES_TERMS:
         names = F.NativeTerms(_RES_TERMS[cfg]).names if cfg in ('cfg1', 'cfg2') else _RES_TERMS[cfg]
     staged = Engine(shape, DEV).set_cell(box).set_terms(names, params).set_option(N.OPT_RESIDENT, 0)
@@ -928,7 +932,7 @@ def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
             assert abs(Ea[k] - Eb[k]) <= 1e-12 * max(abs(Ea[k]), 1e-2), (rep, k, Ea[k], Eb[k])
         assert abs(mua - mub) <= 1e-12 * max(1.0, abs(mua))
         assert float((ga - gb).abs().max()) <= 1e-12 * float(ga.abs().max()), rep
-    served = not (n == 64 and cfg in ('wt_pbe', 'lkt_pbe', 'pbe_only', 'pg1'))        # 64^3 with a gradient term stays on the staged pipeline
+    served = not (n == 64 and cfg in ('wt_pbe', 'lkt_pbe', 'pbe_only', 'pg1', 'cfg3', 'wgc_lda'))     # 64^3 with a gradient or WGC99 term: staged pipeline
     assert res.query(N.Q_RESIDENT_EVALS) == (4 if served else 0) and staged.query(N.Q_RESIDENT_EVALS) == 0
     Ec, muc, _ = res.energy_grad_chi(chi, nel, ve, want_grad=False)                  # energy only
     assert Ec == Eb and muc == mub
@@ -950,9 +954,7 @@ def test_resident_kernel_matches_the_staged_pipeline(n, cfg):
 def test_resident_kernel_leaves_other_grids_and_terms_to_the_staged_pipeline():
     from professad_amd import _native as N
     chi = dev(np.sqrt(synth.smooth_density((32, 32, 32), seed=3)))
-    eng = Engine((32, 32, 32), DEV).set_cell(dev(synth.cubic_cell(32))).set_terms(F.NativeTerms(['hartree', 'wgc99', 'pbe']).names)
-    eng.energy_grad_chi(chi, 5.0, None)
-    assert eng.query(N.Q_RESIDENT_EVALS) == 0                      # WGC99: staged pipeline
+    eng = Engine((32, 32, 32), DEV).set_cell(dev(synth.cubic_cell(32)))
     eng.set_terms(['hartree', 'vw', 'gga_k', 'tf'], {'ggak_kind': 1, 'ggak_mu': 40 / 27, 'ggak_beta': 0.25}).energy_grad_chi(chi, 5.0, None)
     assert eng.query(N.Q_RESIDENT_EVALS) == 0                      # Laplacian-dependent Pauli-Gaussian member: staged pipeline
     eng.set_terms(['hartree', 'tf']).energy_grad_chi(chi, 5.0, None)
