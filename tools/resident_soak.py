@@ -18,7 +18,7 @@ from professad_amd.functionals import NativeTerms  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 dev = 'cuda:0'
 CASES = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
-         'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe']}
+         'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe'], 'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe']}
 out = []
 for n in (16, 32, 64):
     shape = (n, n, n)
