@@ -264,7 +264,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_PIPELINE 0
 /* OFDFT_OPT_SIDE_STREAM: 1 (default) = run the nonlocal-KEDF chain of the z-fused pipeline on a second HIP stream so
  * that it overlaps the Hartree/vW/PBE chain (they only meet in the combine kernel); 0 = everything on the caller's stream. */
-#define OFDFT_OPT_XCHUNKS     2   /* z kernels + the y passes next to them walk the grid in x chunks: 0 = automatic (default, ~100 MB of spectra per chunk), 1 = off, 2..64 = count for six spectra */
+#define OFDFT_OPT_XCHUNKS     2   /* z kernels + the y passes next to them walk the grid in x chunks: 1 = off (default), 0 = automatic (~100 MB of spectra per chunk: the round-1 default, -4 % then, +0.7 % with the round-2 kernels), 2..64 = count for six spectra */
 #define OFDFT_OPT_XCHUNK_MASK 3   /* which stage pairs are chunked (bits): 1 density forward, 2 nonlocal-KEDF forward (default: measured -4 %), 4 PBE loop, 8 combine loop, 16 WGC99 x pass + y-inverse by kz blocks (all three measured neutral or slower at 256^3) */
 #define OFDFT_OPT_SPLIT_COMBINE 4 /* with side streams, the WGC99 part of the combine runs as its own kernel on the nonlocal chain's stream; 2 (default): and in
                                      closure evaluations (ofdft_energy_grad_chi) the combine kernel does not wait for it -- the potential stays in two

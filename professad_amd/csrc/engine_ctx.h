@@ -76,7 +76,8 @@ struct ofdft_ctx {
     bool defer_vpart = true;     // ... and, in closure evaluations, merged into the potential by chi_grad (the combine kernel does not wait for it)
     int xchunk_mask = 2;    // which stage pairs are chunked: 1 density forward, 2 nonlocal forward, 4 PBE loop, 8 combine loop
     int use_xwave = 1;   // fused x pass: 1 = wave-local kernel (xwave.h) where it measured faster (passes over >= 3 spectra, x extents <= 512), 2 = wherever it exists, 0 = group-parallel kernel only
-    int xchunks = 0;    // 0: automatic (about 100 MB of spectra per chunk); 1: off; > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
+    int xchunks = 1;    // 1 (default since the round-2 kernels: -0.7 % at 256^3, neutral at 128^3 / 512^3): off; 0: automatic (about 100 MB of
+                        // spectra per chunk); > 1: z kernels and the y passes next to them walk the grid in x chunks (Infinity-Cache reuse)
     // optional per-kernel-class profiling (HIP events around every launch)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
