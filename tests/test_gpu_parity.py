@@ -717,6 +717,42 @@ def test_optimisers_agree_and_convergence_measures_are_consistent():
     eng.close()
 
 
+def test_native_lbfgs_recursion_walks_the_numpy_recursions_path():
+    """ofdft_lbfgs_direction (curvature test, commit, Gram blocks, two-loop recursion on coefficients inside the library) against the
+    numpy statement of the same host logic on the same device sweeps: a non-quadratic test function, history wrap-around, rejected
+    pairs, 60 outer steps -- identical losses and iterates to round-off"""
+    from professad_amd.optimize import HipLbfgsBackend, VectorFreeLBFGS
+
+    class NumpyRecursion(HipLbfgsBackend):          # the same sweeps, but VectorFreeLBFGS finds no `direction` and keeps its numpy path
+        def __getattribute__(self, name):
+            if name == 'direction':
+                raise AttributeError(name)
+            return super().__getattribute__(name)
+    n = 4096
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((64, n)) / 8.0
+    At, b = dev(A), dev(rng.standard_normal(n))
+    diag = dev(np.linspace(0.05, 3.0, n))
+
+    def make(x):
+        def closure():
+            xx = x.detach().clone().requires_grad_(True)
+            f = 0.5 * ((At @ xx) ** 2).sum() + 0.5 * (diag * xx * xx).sum() - b @ xx + 0.05 * (xx ** 4).sum()
+            f.backward()
+            return float(f.detach()), xx.grad.detach()
+        return closure
+    xa = torch.zeros(n, dtype=torch.double, device=DEV)
+    xb = torch.zeros(n, dtype=torch.double, device=DEV)
+    oa = VectorFreeLBFGS(xa, HipLbfgsBackend(n, 8, DEV))
+    ob = VectorFreeLBFGS(xb, NumpyRecursion(n, 8, DEV))
+    assert hasattr(oa.b, 'direction') and not hasattr(ob.b, 'direction')
+    for step in range(60):
+        la, lb = oa.step(make(xa)), ob.step(make(xb))
+        assert abs(la - lb) <= 1e-10 * max(1.0, abs(lb)), step
+    assert oa.total_iter == ob.total_iter and oa.func_evals == ob.func_evals
+    assert float((xa - xb).abs().max()) <= 1e-8 * float(xb.abs().max())
+
+
 def test_bcc_lithium_end_to_end_against_profess4_value():
     """second anchor of tests/test_match_profess4.py:26-37: bcc-Li, 18^3, IonIon + IonElectron + Hartree + SmargiassiMadden
     + PBE -> -14.741886997024537 eV (PROFESS 4.0, atol 1e-4)"""
