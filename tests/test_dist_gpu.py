@@ -173,8 +173,10 @@ def test_rccl_calls_on_engine_owned_memory_with_one_rank():
 @pytest.mark.parametrize('shape,dtype', [('32x32x32', 'f64'), ('64x64x64', 'f32')])
 def test_whole_staged_evaluation_through_rccl_with_one_rank(shape, dtype, tmp_path):
     """the complete slab-decomposed worker (closure + potential for three term sets, stress, ionic potential, forces) with backend
-    nccl and ONE rank whose exchanges are forced through the backend (OFDFT_COMM_ONE_RANK=1): every all-to-all is an RCCL call on
-    the engine's own buffers from the chain's stream, every small reduction an RCCL all-reduce -- against the single-GPU engine"""
+    nccl and ONE rank whose collectives are forced through the backend (OFDFT_COMM_ONE_RANK=1): the staged ABI, the side-stream
+    sequencing and every small reduction (RCCL all-reduces in place on the context's device scalars, host vectors of the per-step
+    routines) -- against the single-GPU engine.  (A one-rank context has nothing to transpose, so the all-to-all itself is
+    covered by tests/nccl_one_rank_worker.py and, with real peers, by the >= 2-GPU test above.)"""
     res = _run_workers(1, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_COMM_ONE_RANK': '1'},
                        timeout=400)
     _check_worker_results(res, dtype)
