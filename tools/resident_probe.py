@@ -1,5 +1,5 @@
 """Closure evaluations on one small grid through the persistent kernel (for rocprofv3 --kernel-trace --stats).
-usage: python tools/resident_probe.py N cfg1|cfg2 [mode 1|3] [reps]"""
+usage: python tools/resident_probe.py N cfg1|cfg2|wtpbe|cfg3 [mode 1|2] [reps]"""
 import json
 import os
 import sys
@@ -15,7 +15,7 @@ from professad_amd.engine import Engine  # noqa: E402
 from professad_amd.functionals import NativeTerms  # noqa: E402
 
 CFG = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
-       'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe']}
+       'wtpbe': ['ion_electron', 'hartree', 'wt', 'pbe'], 'cfg3': ['ion_electron', 'hartree', 'wgc99', 'pbe']}
 
 n, cfg = int(sys.argv[1]), sys.argv[2]
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
