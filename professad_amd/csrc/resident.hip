@@ -652,8 +652,8 @@ bool resident_serves(const ofdft_ctx* c) {
     if (!c->resident || c->nranks != 1 || !c->fast) return false;
     if (!(c->n0 == c->n1 && c->n1 == c->n2 && (c->n0 == 16 || c->n0 == 32 || c->n0 == 64))) return false;
     if ((c->mask & OFDFT_WGC99_NL) && c->n0 > 32) return false;      // (six more spectra: beyond 32^3 the graph replay is faster)
-    if ((c->mask & kGgaAny) && (gga_needs_laplacian(c) || c->n0 > 32)) return false;      // (64^3 with a GGA term: five phases of 4096-point
-                                                                                          //  planes per workgroup measured slower than the graph replay)
+    if ((c->mask & kGgaAny) && (gga_needs_laplacian(c) || (c->n0 > 32 && sizeof(real) == 8))) return false;      // (64^3 fp64 with a GGA term: five phases of
+                                                                                          //  4096-point planes per workgroup measured slower than the graph replay, 0.160 vs 0.153 ms; fp32: 0.118 vs 0.150)
     if (wts_active(c)) return false;
     return c->mask != 0;
 }
