@@ -103,6 +103,9 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_Q_YPASS_COUNT      5  /* whole-spectrum y line passes of the last energy call    */
 #define OFDFT_Q_GRAPH_REPLAYS     6  /* ofdft_energy_grad_chi calls served by a hipGraph replay so far */
 #define OFDFT_Q_RESIDENT_EVALS    7  /* ofdft_energy_grad_chi calls served by the persistent small-grid kernel so far */
+#define OFDFT_Q_XCHG_CHUNKS      9  /* effective number of kz chunks of the slab exchange (OFDFT_OPT_XCHG_CHUNKS)               */
+#define OFDFT_Q_RESIDENT_FALLBACKS 8 /* evaluations re-run on the staged path because a grid barrier of the persistent kernel timed out
+                                        (the kernel is switched off for the context after the first one) */
 
 int  ofdft_create(ofdft_ctx** out, int n0, int n1, int n2, int dtype, int device_id);
 void ofdft_destroy(ofdft_ctx* ctx);
@@ -182,6 +185,22 @@ int  ofdft_dist_begin(ofdft_ctx* ctx, const void* src_local_dev, int from_chi, d
                       const void* vext_local_dev, void* v_out_local_dev, void* stream);
 int  ofdft_dist_stage(ofdft_ctx* ctx, int stage, int chain, void* stream, unsigned long long* bytes_per_peer, void** sendbuf_dev,
                       void** recvbuf_dev);
+/* The same evaluation cut finer so that an exchange overlaps the kernels of its OWN chain ("overlap by z-chunks";
+ * the reference is single-device, _optimizers/lbfgs/lbfgsnew.py:31-33, so this has no counterpart there).  The exchange buffers
+ * are chunk-major -- [chunk][peer][xl][array][...] over K = ofdft_query(OFDFT_Q_XCHG_CHUNKS) ranges of kz blocks -- so chunk k of an
+ * exchange is one contiguous equal-split all-to-all message.  Per chain, each step for chunk = 0 .. K-1 in order:
+ *     1  [chunk 0: z kernels]  y-forward of the chunk into the send buffer                  -> exchange of the chunk
+ *     2  fused x passes of the chunk, receive buffer -> send buffer                          -> exchange of the chunk
+ *     3  y-inverse of the chunk out of the receive buffer
+ *     4  [chunk 0: whole-row kernels (GGA mid stage, WGC99 combine)]  y-forward of the flux  -> exchange (chain 0 with a GGA term)
+ *     5  fused x pass of the divergence                                                      -> exchange of the chunk
+ *     6  y-inverse of the divergence chunk
+ * then ofdft_dist_finish.  The kernels of (step, chunk k) need only chunk k of the preceding exchange: the host keeps chunk k's
+ * all-to-all in flight while it enqueues chunk k + 1.  *bytes_per_peer = 0: nothing to exchange after this call; otherwise
+ * sendbuf / recvbuf address the chunk's region.  Results are bitwise those of the unchunked sequence (same kernels per line).
+ * ofdft_dist_stage serves K == 1 only. */
+int  ofdft_dist_step(ofdft_ctx* ctx, int step, int chain, int chunk, void* stream, unsigned long long* bytes_per_peer,
+                     void** sendbuf_dev, void** recvbuf_dev);
 int  ofdft_dist_finish(ofdft_ctx* ctx, double* local_sums_host /*[13] or NULL*/, void* stream);
 int  ofdft_dist_scalars(ofdft_ctx* ctx, void** scalars_dev /* 16 doubles owned by the context */);
 int  ofdft_dist_energies(ofdft_ctx* ctx, const double* global_sums /*[13]*/, double* E_terms_host, double* vn_integral);
@@ -285,6 +304,16 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      pipeline.  2 (default): the call is not bracketed by the HIP event pair that times it (OFDFT_Q_KERNEL_MS reads
                                      0 for it) and the host watches a pinned word the last workgroup writes instead of waiting for the stream --
                                      together ~8 microseconds of a ~45-microsecond call; 1: events + stream wait as everywhere else; 0: off */
+#define OFDFT_OPT_XCHG_CHUNKS 12  /* slab-decomposed contexts: the exchange buffers (and the k-point tables laid out like them) are cut into this many
+                                     ranges of kz blocks, chunk-major, so that ofdft_dist_step / ofdft_dist_closure move chunk k across the fabric
+                                     while chunk k + 1 is in its y pass and chunk k - 1 in its x pass.  0 (default): automatic -- up to 4
+                                     chunks of >= 4 kz blocks when the slab extents n0 / P and n1 / P are multiples of 32, else 1; 1: off.  Every
+                                     rank must use the same value; the ipc transport needs a new ofdft_ipc_export / attach round after a change. */
+#define OFDFT_OPT_IPC_WAIT_MS 13  /* ipc transport: how long a delivery wait of ofdft_dist_closure stays patient before it aborts the evaluation ON ALL
+                                     RANKS (default 30 000 ms: a rank may be late by a module load, a page-in, a garbage collection) */
+#define OFDFT_OPT_TEST_FAULT 11   /* test hook, never set in production: 1 = the NEXT persistent-kernel launch is one workgroup short (its grid
+                                     barriers time out -> the call must still return the right numbers through the staged path and switch the
+                                     kernel off); 2 = the co-residency check of the persistent kernel reports "does not fit" */
 #define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
                                      registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
                                      group-parallel kernel that trades spectra through LDS */

@@ -25,14 +25,19 @@ TERM_ORDER = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'wgc99_nl', 'lda_x
 NTERMS = 14
 NPARAMS = 13
 Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPASS_COUNT, Q_GRAPH_REPLAYS, Q_RESIDENT_EVALS = 0, 1, 2, 3, 4, 5, 6, 7
+Q_RESIDENT_FALLBACKS = 8
+Q_XCHG_CHUNKS = 9
 OPT_GRAPH = 7
 OPT_XWAVE = 8
 OPT_MIXED_RADIX = 9
 OPT_RESIDENT = 10
+OPT_TEST_FAULT = 11
+OPT_XCHG_CHUNKS = 12
+OPT_IPC_WAIT_MS = 13
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',
-           'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_finish', 'ofdft_dist_scalars',
+           'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_step', 'ofdft_dist_finish', 'ofdft_dist_scalars',
            'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ipc_export', 'ofdft_ipc_attach', 'ofdft_dist_closure', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_direction', 'ofdft_lbfgs_abs_step', 'ofdft_lbfgs_dots',
            'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_collectives', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
@@ -100,6 +105,8 @@ def load(dtype=F64):
     lib.ofdft_dist_begin.restype = ip
     lib.ofdft_dist_stage.argtypes = [vp, ip, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
     lib.ofdft_dist_stage.restype = ip
+    lib.ofdft_dist_step.argtypes = [vp, ip, ip, ip, vp, C.POINTER(C.c_ulonglong), C.POINTER(vp), C.POINTER(vp)]
+    lib.ofdft_dist_step.restype = ip
     lib.ofdft_dist_scalars.argtypes = [vp, C.POINTER(vp)]
     lib.ofdft_dist_scalars.restype = ip
     lib.ofdft_dist_finish.argtypes = [vp, dp, vp]

@@ -131,12 +131,25 @@ size_t dist_buffer_bytes(ofdft_ctx* c, int chain) {
     if (narr < 1) narr = 1;
     return sizeof(cplx) * (size_t)c->g.total * narr;
 }
+// Two send and two receive buffers per chain, alternating from one exchange to the next (c->recv_parity[chain] = p, flipped by
+// whoever issues the last chunk of an exchange, reset when an evaluation begins): a stage READS the receive buffer R[p] of the
+// exchange before it and WRITES the send buffer S[p ^ 1], whose exchange lands in the peers' R[p ^ 1].  With the kz-chunked
+// exchange a stage's first chunks are on their way back while its last chunks are still being read (and, on the send side,
+// still being sent) -- in ONE buffer chunk k's result region would overlap chunk k + 1's input region whenever the two
+// exchanges carry different numbers of spectra.  A buffer is reused two exchanges later, by which time every peer has consumed it
+// (a peer sends exchange e + 1 only after it has read all of exchange e; transitively all of e - 1 has been delivered and read).
 int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv) {
     const size_t bytes = dist_buffer_bytes(c, chain);
-    if (int rc = get_ws(c, chain == 0 ? "x:send0" : "x:send1", bytes, (void**)send)) return rc;
-    // (the ipc transport alternates between two receive buffers per chain: peers deliver stage k + 1 while stage k is still read)
+    const int p = c->recv_parity[chain];
+    const char* sn[2][2] = {{"x:send0", "x:send0b"}, {"x:send1", "x:send1b"}};
     const char* rn[2][2] = {{"x:recv0", "x:recv0b"}, {"x:recv1", "x:recv1b"}};
-    return get_ws(c, rn[chain][c->recv_parity[chain]], bytes, (void**)recv);
+    if (int rc = get_ws(c, sn[chain][p ^ 1], bytes, (void**)send)) return rc;
+    return get_ws(c, rn[chain][p], bytes, (void**)recv);
+}
+// the receive buffer the exchange of what is being written now (S[p ^ 1]) lands in
+int dist_recv_next(ofdft_ctx* c, int chain, cplx** recv) {
+    const char* rn[2][2] = {{"x:recv0", "x:recv0b"}, {"x:recv1", "x:recv1b"}};
+    return get_ws(c, rn[chain][c->recv_parity[chain] ^ 1], dist_buffer_bytes(c, chain), (void**)recv);
 }
 
 
@@ -163,6 +176,7 @@ namespace {
 struct ProfRec { const char* name; hipEvent_t a, b; };
 void graph_drop(ofdft_ctx* c);
 void ipc_release(ofdft_ctx* c);
+void resident_give_up(ofdft_ctx* c);
 
 // ---------------------------------------------------------------------------------- reductions
 // copy `rows` x `ns` partials to the host and sum them in a fixed order
@@ -283,8 +297,13 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     K1 = w0 + 1;
     K2 = w0 + 2;
     K3 = w0 + 3;
-    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s,
-                 TabMap{c->nranks > 1 ? 1 : 0, c->xg.nyl, c->g.nzm, c->xg.arr_sz});
+    TabMap tm{c->nranks > 1 ? 1 : 0, c->xg.nyl, c->g.nzm, c->xg.arr_sz};
+    tm.nch = c->xc.n;
+    tm.n0g = c->n0g;
+    tm.nrem = c->xg.nrem;
+    for (int k = 0; k <= c->xc.n; ++k) tm.kb[k] = c->xc.kb[k];
+    if (c->xc.n <= 1) tm.kb[1] = c->xg.nb;
+    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s, tm);
     c->wgc_key_nel = nel_rounded;
     c->wgc_valid = true;
     return 0;
@@ -726,6 +745,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
     c->xg.log_nyl = 0;
     while ((1 << c->xg.log_nyl) < c->xg.nyl) c->xg.log_nyl++;
     c->xg.arr_sz = (long long)g.nzc * c->gx.n1;
+    xchg_chunks_set(c, 0);
     const double s5 = std::sqrt(5.0);
     const double defaults[OFDFT_NPARAMS] = {kFiveSixths, kFiveSixths, (5.0 + s5) / 6.0, (5.0 - s5) / 6.0, (double)27 / 10, 1.0, 0.0, (double)40 / 27,
                                             0.0, 0.0, 0.0, 1.0, 0.0};
@@ -863,22 +883,21 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
         }
         if (resident_serves(c)) {
             // grids that fit on chip: one persistent kernel (resident.hip), here on the density itself
-            if (int rc = resident_closure(c, (const real*)den, (const real*)vext, nel > 0.0 ? nel : 1.0, (real*)dEdn, nullptr, st, true))
-                return rc;
-            if (int rc = end_call(c, st)) return rc;
-            if (c->h_partial[13] != 0.0) {
-                (void)hipMemset(c->res_sync, 0, 64);
-                c->res_epoch = 0;
-                c->res_done_target = 0;
-                if (c->res_done) *c->res_done = 0;
-                return fail(c, OFDFT_EHIP, "resident kernel: a grid barrier ran into its time limit (workgroups not co-resident?)");
+            const int rrc = resident_closure(c, (const real*)den, (const real*)vext, nel > 0.0 ? nel : 1.0, (real*)dEdn, nullptr, st, true);
+            if (rrc < 0) return rrc;
+            if (rrc == 0) {
+                if (int rc = end_call(c, st)) return rc;
+                if (c->h_partial[13] == 0.0) {
+                    double sums[kNSums];
+                    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+                    for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+                    energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
+                    c->resident_evals++;
+                    return OFDFT_OK;
+                }
+                resident_give_up(c);          // a grid barrier ran into its time limit: the staged pipeline below redoes the evaluation
+                if (int rc = begin_call(c, st)) return rc;
             }
-            double sums[kNSums];
-            for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
-            for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
-            energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
-            c->resident_evals++;
-            return OFDFT_OK;
         }
         const DenSrc ds{(const real*)den, 1.0, 0, nullptr};
         if (int rc = run_terms_zfused(c, ds, nel, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
@@ -891,6 +910,18 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
 // ---- the closure evaluation chi -> (sums, grad) as ONE host-free enqueue, and its hipGraph replay --------------------
 }  // extern "C"
 namespace {
+
+// a grid barrier of the persistent kernel timed out (its workgroups were not co-resident: CU mask, partition mode, another
+// stream holding CUs): clear its counters, stop using it on this context; the caller re-runs the evaluation staged
+void resident_give_up(ofdft_ctx* c) {
+    (void)hipMemset(c->res_sync, 0, 64);
+    c->res_epoch = 0;
+    c->res_done_target = 0;
+    if (c->res_done) *c->res_done = 0;
+    c->resident = 0;
+    c->resident_fallbacks++;
+    c->version++;
+}
 
 int closure_enqueue(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st) {
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
@@ -996,10 +1027,11 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
         bool done = false;
         if (resident_serves(c)) {
             // grids that fit on chip: the whole evaluation is one persistent kernel (resident.hip)
-            if (int rc = resident_closure(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st)) return rc;
+            const int rrc = resident_closure(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st);
+            if (rrc < 0) return rrc;
             // (the kernel wrote the sums into the pinned host mirror itself)
             bool arrived = false;
-            if (!timed) {
+            if (rrc == 0 && !timed) {
                 // untimed form: the host watches the word the workgroups count themselves out on (each behind a system-scope
                 // release of everything it wrote) instead of waiting for the stream -- the runtime's wake-up costs more than
                 // the last phase of the kernel; anything unexpected falls back to the stream wait, which reports errors
@@ -1013,22 +1045,23 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
-            if (arrived) {
-                c->last_ms = 0.f;
-                c->ms_pending = false;
-            } else {
-                if (int rc = end_call(c, st, timed)) return rc;
+            if (rrc == 0) {
+                if (arrived) {
+                    c->last_ms = 0.f;
+                    c->ms_pending = false;
+                } else {
+                    if (int rc = end_call(c, st, timed)) return rc;
+                }
+                if (c->h_partial[13] == 0.0) {
+                    for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
+                    c->resident_evals++;
+                    done = true;
+                } else {
+                    resident_give_up(c);      // barrier time-out: the graph / staged path below redoes the evaluation
+                }
             }
-            if (c->h_partial[13] != 0.0) {
-                (void)hipMemset(c->res_sync, 0, 64);
-                c->res_epoch = 0;
-                c->res_done_target = 0;
-                if (c->res_done) *c->res_done = 0;
-                return fail(c, OFDFT_EHIP, "resident kernel: a grid barrier ran into its time limit (workgroups not co-resident?)");
-            }
-            for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
-            c->resident_evals++;
-            done = true;
+            if (!done)                        // (declined or given up: the fallback is an ordinary timed call)
+                if (int rc = begin_call(c, st)) return rc;
         }
         if (!done)
             if (int rc = closure_graph(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, sums, &done)) return rc;
@@ -1175,6 +1208,9 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.vext = (const real*)vext_local;
     r.v_out = (real*)v_out_local;
     r.stage[0] = r.stage[1] = 0;
+    c->recv_parity[0] = c->recv_parity[1] = 0;
+    r.step[0] = r.step[1] = 0;
+    r.step_chunk[0] = r.step_chunk[1] = 0;
     r.deferred.clear();
     r.forked = false;
     r.closure = false;
@@ -1198,6 +1234,8 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
     ZRun& r = zrun(c);
     if (stage != r.stage[chain] + 1 || stage < 1 || stage > 4 || (chain == 1 && r.stage[0] < 1))
         return fail(c, OFDFT_ESTATE, "stage %d of chain %d out of order", stage, chain);
+    if (c->xc.n > 1)
+        return fail(c, OFDFT_ESTATE, "the exchange buffers are cut into %d kz chunks (OFDFT_OPT_XCHG_CHUNKS): sequence the evaluation with ofdft_dist_step", c->xc.n);
     int rc;
     switch (stage) {
         case 1: rc = zstage1(c, st, chain); break;
@@ -1211,10 +1249,67 @@ int ofdft_dist_stage(ofdft_ctx* c, int stage, int chain, void* stream, unsigned 
     if (c->nranks > 1 && !r.xlist[chain].empty()) {
         cplx *send, *recv;
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = dist_recv_next(c, chain, &recv))) return rc;
         *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist[chain].size());
         *sendbuf = send;
         *recvbuf = recv;
+        c->recv_parity[chain] ^= 1;         // the next stage reads what this exchange delivers
     }
+    HIP_TRY(c, hipGetLastError());
+    return OFDFT_OK;
+}
+
+// The same evaluation cut finer, for exchanges that overlap the chain's own kernels ("overlap by z-chunks").  The
+// exchange buffers are chunk-major, [chunk][peer][xl][array][...] over K = ofdft_query(OFDFT_Q_XCHG_CHUNKS) ranges of kz blocks, so chunk
+// k of an exchange is one contiguous equal-split all-to-all message.  Per chain the steps are, each for chunk = 0 .. K-1 in order:
+//   1  [chunk 0: z kernels]  y-forward of the chunk into the send buffer                         -> exchange (chunk)
+//   2  fused x passes on the chunk: receive buffer -> send buffer                                 -> exchange (chunk)
+//   3  y-inverse of the chunk out of the receive buffer
+//   4  [chunk 0: PBE mid stage / WGC99 combine on whole rows]  y-forward of the flux chunk        -> exchange (chunk; chain 0 with a GGA term)
+//   5  fused x pass of the divergence on the chunk                                                -> exchange (chunk)
+//   6  y-inverse of the divergence chunk
+// then ofdft_dist_finish.  A step's kernels for chunk k need only chunk k of the exchange before them, so the host may keep
+// the all-to-all of chunk k in flight while it enqueues chunk k + 1.  Results are bitwise those of the unchunked sequence.
+// On return *bytes_per_peer (0: nothing to exchange) and the chunk's regions of the send / receive buffers.
+int ofdft_dist_step(ofdft_ctx* c, int step, int chain, int chunk, void* stream, unsigned long long* bytes_per_peer, void** sendbuf,
+                    void** recvbuf) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || !bytes_per_peer || !sendbuf || !recvbuf || chain < 0 || chain > 1) return OFDFT_EINVAL;
+    OFDFT_ON_DEVICE(c, c->device);
+    ZRun& r = zrun(c);
+    const int K = c->xc.n;
+    const bool next_chunk = step == r.step[chain] && chunk == r.step_chunk[chain] + 1 && chunk < K;
+    const bool next_step = step == r.step[chain] + 1 && chunk == 0 && (r.step[chain] == 0 || r.step_chunk[chain] == K - 1);
+    if (step < 1 || step > 6 || !(next_chunk || next_step) || (chain == 1 && r.step[0] < 1))
+        return fail(c, OFDFT_ESTATE, "step %d chunk %d of chain %d out of order (last: step %d chunk %d of %d)", step, chunk, chain,
+                    r.step[chain], r.step_chunk[chain], K);
+    int rc;
+    switch (step) {
+        case 1: rc = zstage1(c, st, chain, chunk); break;
+        case 2: rc = zstage2(c, st, chain, chunk); break;
+        case 3: rc = zstage3(c, st, chain, 1, chunk); break;
+        case 4: rc = zstage3(c, st, chain, 2, chunk); break;
+        case 5: rc = zstage4(c, st, chain, chunk); break;
+        default: rc = chain == 0 ? zstage5(c, nullptr, st, false, 1, chunk) : 0; break;     // (the divergence belongs to chain 0)
+    }
+    if (rc) return rc;
+    r.step[chain] = step;
+    r.step_chunk[chain] = chunk;
+    *bytes_per_peer = 0;
+    *sendbuf = *recvbuf = nullptr;
+    const bool sends = step == 1 || step == 2 || step == 4 || step == 5;
+    if (sends && c->nranks > 1 && !r.xlist[chain].empty()) {
+        cplx *send, *recv;
+        if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+        if ((rc = dist_recv_next(c, chain, &recv))) return rc;
+        const XcView v = xc_view(c, chunk);
+        const long long narr = (long long)r.xlist[chain].size();
+        *bytes_per_peer = (unsigned long long)(sizeof(cplx) * (size_t)c->xg.nxl * v.arr_sz * narr);
+        *sendbuf = send + narr * v.base1;
+        *recvbuf = recv + narr * v.base1;
+        if (chunk == K - 1) c->recv_parity[chain] ^= 1;      // the next step reads what this exchange delivers
+    }
+    if (step == 5 && chunk == K - 1) r.stage[chain] = 4;
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
@@ -1227,8 +1322,11 @@ int ofdft_dist_finish(ofdft_ctx* c, double* local_sums, void* stream) {
     OFDFT_ON_DEVICE(c, c->device);
     ZRun& r = zrun(c);
     if (r.stage[0] != 4 || r.stage[1] != 4) return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before stage 4 of both chains");
+    const bool stepped = r.step[0] > 0;           // sequenced with ofdft_dist_step: the divergence has been y-inverted chunk by chunk
+    if (stepped && !(r.step[0] == 6 && r.step_chunk[0] == c->xc.n - 1 && r.step[1] == 6 && r.step_chunk[1] == c->xc.n - 1))
+        return fail(c, OFDFT_ESTATE, "ofdft_dist_finish called before step 6 of both chains");
     int rc;
-    if ((rc = zstage5(c, local_sums, st))) return rc;
+    if ((rc = zstage5(c, local_sums, st, false, stepped ? 2 : 0))) return rc;
     if (!local_sums) {        // device-resident form: scalars[0..10] hold the local sums, nothing waits here
         HIP_TRY(c, hipEventRecord(c->ev1, st));
         c->ms_pending = true;
@@ -1338,6 +1436,19 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_RESIDENT takes 0, 1 or 2");
             c->resident = (int)value;
             return OFDFT_OK;
+        case OFDFT_OPT_XCHG_CHUNKS:
+            if (value < 0.0 || value > 16.0) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_XCHG_CHUNKS takes 0 (automatic) or 1..16");
+            xchg_chunks_set(c, (int)value);
+            c->wgc_valid = false;             // the kernel tables are laid out like the buffers
+            return OFDFT_OK;
+        case OFDFT_OPT_IPC_WAIT_MS:
+            if (!(value >= 1.0 && value <= 3.6e6)) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_IPC_WAIT_MS takes 1 .. 3 600 000 ms");
+            c->ipc_wait_ms = value;
+            return OFDFT_OK;
+        case OFDFT_OPT_TEST_FAULT:
+            c->test_fault = (int)value;
+            if (c->test_fault == 2) c->res_fits = 0;
+            return OFDFT_OK;
     }
     return fail(c, OFDFT_EINVAL, "unknown option %d", option);
 }
@@ -1382,6 +1493,8 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_YPASS_COUNT: *out = c->ypass_count; return OFDFT_OK;
         case OFDFT_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; return OFDFT_OK;
         case OFDFT_Q_RESIDENT_EVALS: *out = (double)c->resident_evals; return OFDFT_OK;
+        case OFDFT_Q_RESIDENT_FALLBACKS: *out = (double)c->resident_fallbacks; return OFDFT_OK;
+        case OFDFT_Q_XCHG_CHUNKS: *out = (double)c->xc.n; return OFDFT_OK;
         case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27:      // phase clock of the last persistent-kernel evaluation (microseconds)
             *out = c->h_partial[what] * 0.01;
             return OFDFT_OK;

@@ -33,6 +33,16 @@ struct DevBuf {
     bool borrowed = false;      // a window of a larger allocation (the ipc arena): never freed on its own
 };
 
+// kz-block chunks of the slab exchange ("overlap by z-chunks"): every exchange buffer -- and the k-point tables
+// laid out like one -- is chunk-major, chunk k holding the kz blocks [kb[k], kb[k + 1]) (the remainder planes ride with the
+// last chunk) of every (peer, x, array): [chunk][peer][xl][array][(b, yl, kin) | planes].  A chunk is then a contiguous
+// equal-split all-to-all message (or one peer scatter), so chunk k can cross the fabric while chunk k + 1 is still in its y
+// pass and chunk k - 1 already in its x pass.  n == 1 is the plain layout.
+struct XchgChunks {
+    int n = 1;
+    int kb[17] = {0};
+};
+
 struct ofdft_ctx {
     int n0 = 0, n1 = 0, n2 = 0, device = 0;     // LOCAL real-space extents (x-slab: n0 = n0g / nranks)
     int n0g = 0, n1g = 0, nranks = 1, rank = 0; // global extents and slab decomposition
@@ -40,6 +50,8 @@ struct ofdft_ctx {
     SpecGeom gx{};     // spectrum geometry of the x pass (y-slab: n0 global, n1 local); == g on one GPU
     KGeom kg{};        // k-vectors in the x-pass geometry
     XchgGeom xg{};     // exchange-buffer layout of the slab-decomposed path (rec / chunk filled per stage)
+    XchgChunks xc{};   // ... cut into kz-block chunks (OFDFT_OPT_XCHG_CHUNKS)
+    int xchg_chunks_req = 0;     // requested chunk count: 0 = automatic (xchg_chunks_for)
     long long npts = 0;      // local points
     long long npts_g = 0;    // global points (normalisation, dV)
     bool fast = false, cell_set = false, force_unfused = false;
@@ -107,6 +119,9 @@ struct ofdft_ctx {
     unsigned* res_sync = nullptr;            // grid-barrier counter
     unsigned res_epoch = 0;                  // its value after the launches so far
     long long resident_evals = 0;
+    int test_fault = 0;                      // OFDFT_OPT_TEST_FAULT
+    int res_fits = -1;                       // occupancy check of the persistent kernel: -1 not made yet, 0 / 1 its verdict
+    long long resident_fallbacks = 0;        // evaluations re-run on the staged path after a barrier time-out
     unsigned* res_done = nullptr;            // pinned host word the kernel's workgroups count themselves out on
     unsigned res_done_target = 0;
     long long graph_replays = 0;
@@ -114,7 +129,8 @@ struct ofdft_ctx {
     // host collectives of the slab-decomposed per-geometry-step routines (ofdft_set_collectives)
     // direct peer-store exchange (ofdft_ipc_*): peers' receive buffers / mailboxes mapped through hipIpc, no host in the loop
     struct ofdft_ipc_state* ipc = nullptr;
-    int recv_parity[2] = {0, 0};       // which of a chain's two receive buffers the next stage reads (0 unless the ipc transport flips it)
+    int recv_parity[2] = {0, 0};       // which of a chain's two receive buffers the next stage reads (engine.hip: dist_buffers)
+    double ipc_wait_ms = 30000.0;      // OFDFT_OPT_IPC_WAIT_MS: patience of the ipc transport's delivery waits
     ofdft_all_to_all_fn a2a = nullptr;
     ofdft_all_reduce_fn allreduce = nullptr;
     void* coll_user = nullptr;
@@ -213,6 +229,41 @@ inline int grid_for(long long n, int tpb = 256, int cap = 2048) {
 }
 
 
+// ---- kz-block chunks of the exchange layout
+// view of chunk k (k = kWholeXchg: ONE chunk over all kz blocks -- the layout of the per-geometry-step transforms)
+constexpr int kWholeXchg = -2;
+struct XcView {
+    int kb0, kb1, nb, nrem;      // kz blocks [kb0, kb1), their count, remainder planes carried by this chunk
+    long long arr_sz;            // elements of one array in one x-plane record of this chunk
+    long long base1;             // element offset of the chunk in a ONE-array buffer / table (x narr for a buffer of narr arrays)
+};
+inline XcView xc_view(const ofdft_ctx* c, int k) {
+    XcView v{};
+    const bool whole = k == kWholeXchg || c->xc.n <= 1;
+    v.kb0 = whole ? 0 : c->xc.kb[k];
+    v.kb1 = whole ? c->xg.nb : c->xc.kb[k + 1];
+    v.nb = v.kb1 - v.kb0;
+    v.nrem = (whole || k == c->xc.n - 1) ? c->xg.nrem : 0;
+    v.arr_sz = ((long long)v.nb * 8 + v.nrem) * c->xg.nyl;
+    v.base1 = (long long)c->n0g * c->xg.nyl * 8 * v.kb0;          // all peers' x planes of the earlier chunks (which carry no planes)
+    return v;
+}
+// effective chunk count for a request (0 = automatic): a chunk must be whole workgroups of the y pass (nxl * 8 lines per kz
+// block) and of the fused x passes (nyl * 8 lines per block), whose tiles are at most 256 lines -> nxl, nyl multiples of 32;
+// automatic: up to 4 chunks of at least 4 kz blocks each (smaller messages are latency-bound)
+inline int xchg_chunks_for(const ofdft_ctx* c, int req) {
+    if (c->nranks < 2 || c->xg.nb < 2 || c->xg.nxl % 32 || c->xg.nyl % 32) return 1;
+    int k = req > 0 ? req : std::min(4, c->xg.nb / 4);
+    k = std::max(1, std::min(k, std::min(16, c->xg.nb)));
+    return k;
+}
+inline void xchg_chunks_set(ofdft_ctx* c, int req) {
+    c->xchg_chunks_req = req;
+    c->xc = XchgChunks{};
+    c->xc.n = xchg_chunks_for(c, req);
+    for (int k = 0; k <= c->xc.n; ++k) c->xc.kb[k] = (int)((long long)c->xg.nb * k / c->xc.n);
+}
+
 // ---- workspaces and tables (engine.hip)
 int get_twiddle(ofdft_ctx* c, int n, cplx** out);
 int get_ws(ofdft_ctx* c, const std::string& name, size_t bytes, void** out);
@@ -220,6 +271,7 @@ int real_ws(ofdft_ctx* c, const char* name, real** out);
 int spec_ws(ofdft_ctx* c, const char* name, cplx** out);
 size_t dist_buffer_bytes(ofdft_ctx* c, int chain);
 int dist_buffers(ofdft_ctx* c, int chain, cplx** send, cplx** recv);
+int dist_recv_next(ofdft_ctx* c, int chain, cplx** recv);
 int dist_exchange(ofdft_ctx* c, cplx* send, cplx* recv, hipStream_t st);
 int global_sums(ofdft_ctx* c, double* v, int n);
 
@@ -229,7 +281,8 @@ template <bool INV>
 int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, hipStream_t st, int x0 = 0, int cx = 0,
                          int kb0 = 0, int kb1 = 0);
 template <bool INV> int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st);
-template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st);
+// xk: chunk of the exchange layout (-1: every chunk, one launch each; kWholeXchg: the unchunked layout)
+template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st, int xk = -1);
 int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st);
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
 int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
@@ -239,7 +292,12 @@ int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
 // ---- fused x passes (xpass_a.hip, xpass_b.hip; xpass_impl.h).  Where the x pass finds its spectra: {} = y-slab arrays in
 // the block-8 layout (one GPU); otherwise the exchange buffers of the slab-decomposed path (x-major records, see XchgGeom):
 // element strides along x of the inputs, the outputs and the k-point tables
-struct XfLayout { long long se_in = 0, se_out = 0, tse = 0; int kb0 = 0, kb1 = 0; };   // kb1 > kb0: kz blocks [kb0, kb1) only
+struct XfLayout {
+    long long se_in = 0, se_out = 0, tse = 0;
+    int kb0 = 0, kb1 = 0;          // one GPU: kb1 > kb0 = kz blocks [kb0, kb1) of the full arrays only
+    int xnb = -1, xnrem = 0;       // exchange buffers: kz blocks / remainder planes of the chunk the pointers address (xnb < 0: all of c->xg)
+    int kz0 = 0;                   // ... and the kz of its first block
+};
 template <int NIN, int NOUT, class Mix>
 int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{});
 
@@ -250,6 +308,7 @@ int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, 
 // WGC99 kernel tables (w0, K1, K2, K3 interleaved per k-point, spectrum order) for round(N_e) = nel_rounded; *nref_out = kappa n0
 int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out);
 bool resident_serves(const ofdft_ctx* c);
+constexpr int kResidentDeclined = 1;       // resident_closure: not an error -- the caller takes the graph / staged path instead
 // chi -> (sums, v, chi.grad) -- or, with from_den, density -> (sums, v) -- by the persistent small-grid kernel (resident.hip)
 int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, bool from_den = false);
 int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipStream_t st, int chunk = 0, int nchunks = 1);

@@ -59,6 +59,9 @@ struct ZRun {
     bool vpart_deferred = false;   // ... and does: zi_combine does not wait for zi_wgc, chi_grad adds v_part (zstage5)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
+    // kz-chunked exchange (ofdft_dist_step): last (step, chunk) of each chain; what stage 1 sent (read again by every chunk of stage 2)
+    int step[2] = {0, 0}, step_chunk[2] = {0, 0};
+    std::vector<cplx*> in_list[2];
     int combine_blocks = 0, pbe_blocks = 0;
     hipStream_t sb = nullptr;      // stream of the nonlocal-KEDF chain (== the main stream unless forked)
     hipStream_t sc = nullptr;      // second side stream: vW chain and the second half of the WGC99 chain
@@ -88,13 +91,16 @@ int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
 }
 
 // Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.
-int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
+// (xk: chunk of the kz-chunked exchange -- the z kernels run with chunk 0, every call y-transforms its chunk into the send
+// buffer; -1 = all chunks)
+int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     const bool dx = c->nranks > 1;
     std::vector<cplx*>& xl = r.xlist[chain];
+    if (xk <= 0) {
     xl.clear();
     if (chain == 0) {
         r.has_h = mask & OFDFT_HARTREE;
@@ -216,43 +222,54 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain) {
             r.za.wgc_sum_53 = pa.sum53;
         }
     }
-    if (dx && !xl.empty()) {        // the chain's y-forwards in one launch, written in the exchange layout
+    }   // xk <= 0
+    if (dx && !xl.empty()) {        // the chain's y-forwards in one launch (per chunk), written in the exchange layout
         cplx *send, *recv;
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+        if ((rc = ypass_xchg<false>(c, xl, send, st, xk))) return rc;
     }
     r.stage[chain] = 1;
     return 0;
 }
 
 // Stage 2: the fused x passes (forward x, k-space mixing, inverse x).
-int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
+int zstage2(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     ZRun& r = zrun(c);
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     // several ranks: the inputs sit in the chain's receive buffer (slot = position in stage 1's list) and the
-    // outputs are written to its send buffer in the order they are listed here
+    // outputs are written to its send buffer in the order they are listed here -- per kz chunk of the exchange layout
     const bool dx = c->nranks > 1;
+    if (dx && xk == -1 && c->xc.n > 1) {
+        for (int k = 0; k < c->xc.n; ++k)
+            if ((rc = zstage2(c, st, chain, k))) return rc;
+        return 0;
+    }
     std::vector<cplx*>& xl = r.xlist[chain];
-    const std::vector<cplx*> in_list = xl;
+    if (xk <= 0) r.in_list[chain] = xl;           // what stage 1 sent: every chunk's pass reads the same slots
+    const std::vector<cplx*>& in_list = r.in_list[chain];
     xl.clear();
     cplx *send = nullptr, *recv = nullptr;
     XfLayout lay{};
+    const XcView xv = xc_view(c, xk < 0 ? 0 : xk);
+    int nout = 0;
     if (dx) {
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        const int nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? (r.gsplit ? (r.lapl ? 2 : 1) : 3) : 0) + (r.s_s ? 1 : 0)
-                                    : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
-        lay = XfLayout{(long long)in_list.size() * c->xg.arr_sz, nout * c->xg.arr_sz, c->xg.arr_sz};
+        nout = chain == 0 ? (r.has_h ? 1 : 0) + (r.has_g ? (r.gsplit ? (r.lapl ? 2 : 1) : 3) : 0) + (r.s_s ? 1 : 0)
+                          : (r.s_b ? 1 : 0) + (r.s_a ? 1 : 0) + (r.has_wgc ? 6 : 0);
+        lay = XfLayout{(long long)in_list.size() * xv.arr_sz, nout * xv.arr_sz, xv.arr_sz, 0, 0, xv.nb, xv.nrem, xv.kb0 * 8};
+        recv += (long long)in_list.size() * xv.base1;         // this chunk's region of either buffer
+        send += (long long)nout * xv.base1;
     }
     auto in_of = [&](cplx* arr) -> cplx* {
         if (!dx) return arr;
         for (size_t i = 0; i < in_list.size(); ++i)
-            if (in_list[i] == arr) return recv + (long long)i * c->xg.arr_sz;
+            if (in_list[i] == arr) return recv + (long long)i * xv.arr_sz;
         return nullptr;
     };
     auto out_of = [&](cplx* arr) -> cplx* {       // also records the array as crossing the next boundary
         xl.push_back(arr);
-        return dx ? send + (long long)(xl.size() - 1) * c->xg.arr_sz : arr;
+        return dx ? send + (long long)(xl.size() - 1) * xv.arr_sz : arr;
     };
     if (chain == 0) {
         if (r.s_n) {
@@ -300,7 +317,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
             }
         }
         if (r.has_wgc) {
-            const MixWgc mix{(real*)c->ws["t:wgc"].p};
+            const MixWgc mix{(real*)c->ws["t:wgc"].p + (dx ? 4 * xv.base1 : 0)};    // (the table is chunk-major like the buffers)
             // kz-chunked form (one GPU): the fused x pass of a range of kz blocks is followed at once by the y-inverse
             // of the same range, which then reads the x pass' output from the Infinity Cache
             const int nb = c->g.nzm / 8;
@@ -334,17 +351,28 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain) {
 
 // Stage 3: y-inverse of what came back from the x passes (each completes one c2r except grad n); chain 0 then runs
 // the PBE mid stage on chip and starts the three r2c of the flux.
-int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
+// part 0: the whole stage; kz-chunked exchange: part 1 = the y-inverse of chunk xk only, part 2 = everything after the
+// y-inverses (the row kernels with chunk 0; every call y-transforms its chunk of the flux into the send buffer)
+int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) {
     ZRun& r = zrun(c);
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     const bool dx = c->nranks > 1;
     std::vector<cplx*>& xl = r.xlist[chain];
     cplx *send = nullptr, *recv = nullptr;
-    if (dx && !xl.empty()) {        // one launch: the chain's y-inverses, read from the exchange layout
+    if (dx && !xl.empty() && part != 2) {        // one launch (per chunk): the chain's y-inverses, read from the exchange layout
         if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-        if ((rc = ypass_xchg<true>(c, xl, recv, st))) return rc;
+        if ((rc = ypass_xchg<true>(c, xl, recv, st, xk))) return rc;
     }
+    if (part == 1) return 0;
+    if (part == 2 && xk > 0) {                   // a later chunk of the flux: the y-forward into the send buffer only
+        if (dx && chain == 0 && !xl.empty()) {
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st, xk))) return rc;
+        }
+        return 0;
+    }
+    const int yk = part == 2 ? 0 : -1;           // chunks the y-forwards below cover
     // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
     // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
     const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = !r.gsplit && chunks_for(c, 6, 4) > 1;
@@ -417,7 +445,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         }
         if (dx) {
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st, yk))) return rc;
         }
     } else if (r.has_g) {
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
@@ -438,7 +466,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
         }
         if (dx) {
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<false>(c, xl, send, st))) return rc;
+            if ((rc = ypass_xchg<false>(c, xl, send, st, yk))) return rc;
         }
     }
     r.stage[0] = 3;
@@ -446,25 +474,32 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain) {
 }
 
 // Stage 4: fused x pass of the divergence (chain 0 only).
-int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
+int zstage4(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     ZRun& r = zrun(c);
+    if (c->nranks > 1 && xk == -1 && c->xc.n > 1) {
+        for (int k = 0; k < c->xc.n; ++k)
+            if (int rc = zstage4(c, st, chain, k)) return rc;
+        return 0;
+    }
     r.xlist[chain].clear();
+    const XcView xv = xc_view(c, xk < 0 ? 0 : xk);
     if (chain == 0 && r.has_g && r.gsplit) {
         XfIo dio{};
         XfLayout lay{};
         dio.in[0] = dio.out[0] = r.s_g[0];
-        if (c->nranks > 1) {     // receive buffer slot 0 -> send buffer slot 0
+        const int nin = r.lapl ? 2 : 1;
+        if (c->nranks > 1) {     // receive buffer slot 0 -> send buffer slot 0 (of this kz chunk)
             cplx *send, *recv;
             if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
-            dio.in[0] = recv;
-            dio.out[0] = send;
-            lay = XfLayout{c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+            dio.in[0] = recv + (long long)nin * xv.base1;
+            dio.out[0] = send + xv.base1;
+            lay = XfLayout{xv.arr_sz, xv.arr_sz, xv.arr_sz, 0, 0, xv.nb, xv.nrem, xv.kb0 * 8};
         }
         if (r.lapl) {            // i f_a G_a^ + (k^2 / 2) (df/dL)^ -> the spectrum the combine subtracts twice
             dio.in[1] = r.s_l;
             if (c->nranks > 1) {
-                dio.in[1] = dio.in[0] + c->xg.arr_sz;
-                lay = XfLayout{2 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+                dio.in[1] = dio.in[0] + xv.arr_sz;
+                lay.se_in = 2 * xv.arr_sz;
             }
             if (int rc = xfused<2, 1>(c, dio, MixDerivAL{c->kg}, st, "xfused_div", lay)) return rc;
         } else if (int rc = xfused<1, 1>(c, dio, MixDerivA{c->kg}, st, "xfused_div", lay)) {
@@ -476,12 +511,12 @@ int zstage4(ofdft_ctx* c, hipStream_t st, int chain) {
         XfLayout lay{};
         for (int k = 0; k < 3; ++k) dio.in[k] = r.s_g[k];
         dio.out[0] = r.s_n;      // n^ is no longer needed
-        if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0
+        if (c->nranks > 1) {     // receive buffer slots 0..2 -> send buffer slot 0 (of this kz chunk)
             cplx *send, *recv;
             if (int rc = dist_buffers(c, 0, &send, &recv)) return rc;
-            for (int k = 0; k < 3; ++k) dio.in[k] = recv + k * c->xg.arr_sz;
-            dio.out[0] = send;
-            lay = XfLayout{3 * c->xg.arr_sz, c->xg.arr_sz, c->xg.arr_sz};
+            for (int k = 0; k < 3; ++k) dio.in[k] = recv + 3 * xv.base1 + k * xv.arr_sz;
+            dio.out[0] = send + xv.base1;
+            lay = XfLayout{3 * xv.arr_sz, xv.arr_sz, xv.arr_sz, 0, 0, xv.nb, xv.nrem, xv.kb0 * 8};
         }
         if (int rc = xfused<3, 1>(c, dio, MixDiv{c->kg}, st, "xfused_div", lay)) return rc;
         r.xlist[0].push_back(r.s_n);
@@ -500,16 +535,25 @@ void zfused_collect(const ofdft_ctx* c, bool wgc_split, double* sums) {
 // `sums` == nullptr: the caller reduces the device-resident sums itself (slab-decomposed path).  `defer`: the sums are
 // copied to the pinned host mirror but nothing waits here (zfused_collect reads them after the caller's stream sync --
 // the graph-capturable form)
-int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false) {
+// (part 1: only the y-inverse of kz chunk xk of the divergence out of the exchange buffer; part 2: everything else; 0: both)
+int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false, int part = 0, int xk = -1) {
     ZRun& r = zrun(c);
     int rc;
     const bool chunked = chunks_for(c, 6, 8) > 1;
+    if (part == 1) {
+        if (r.has_g && c->nranks > 1) {
+            cplx *send, *recv;
+            if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
+            if ((rc = ypass_xchg<true>(c, {r.gsplit ? r.s_g[0] : r.s_n}, recv, st, xk))) return rc;
+        }
+        return 0;
+    }
     if (r.has_g) {
         cplx* dsp = r.gsplit ? r.s_g[0] : r.s_n;       // the spectrum that carries the (x part of the) divergence
         if (c->nranks > 1) {
             cplx *send, *recv;
             if ((rc = dist_buffers(c, 0, &send, &recv))) return rc;
-            if ((rc = ypass_xchg<true>(c, {dsp}, recv, st))) return rc;
+            if (part != 2 && (rc = ypass_xchg<true>(c, {dsp}, recv, st))) return rc;
         } else if (chunked) {
             r.deferred.push_back(dsp);
         } else if ((rc = fast_axis_pass<true>(c, 1, dsp, st))) {

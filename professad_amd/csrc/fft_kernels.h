@@ -60,6 +60,7 @@ struct LineMap {
     // xl < gc; it stands for group (G / gc) * gn + g0 + G % gc of the full array.  gc == 0: no remapping.
     int gc = 0, gn = 0, g0 = 0;
     int blk0 = 0;   // first workgroup (in units of the kernel's lines-per-workgroup) of a launch that covers a line range
+    int kz0 = 0;    // fused x pass on a kz chunk of an exchange buffer: kz of line 0 (the lines are numbered inside the chunk)
 };
 
 #ifndef OFDFT_CPASS_TPB
@@ -237,6 +238,7 @@ struct XchgGeom {
     long long arr_sz;      // elements of one array in one x-plane record
     long long rec;         // narr * arr_sz
     long long chunk;       // nxl * rec: elements per peer
+    int kb0 = 0;           // first kz block of the chunk this geometry describes (chunk-major exchange buffers; nb = its block count)
 };
 template <int LEN, bool INV>
 __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList arrs, cplx* __restrict__ buf, XchgGeom xg,
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
     if (!in_rem) {               // L = (b*nxl + xl)*8 + kin
         const long long r = L >> 3;
         const int kin = (int)(L & 7), xl = (int)(r % xg.nxl);
-        const long long b = r / xg.nxl;
+        const long long b = r / xg.nxl - xg.kb0;       // block inside the chunk
         lb = xl * xg.rec + a * xg.arr_sz + b * xg.nyl * 8 + kin;
         es = 8;
     } else {                     // L = plane*nxl + xl
@@ -762,7 +764,7 @@ __global__ __launch_bounds__((XfCfg<LEN, (NIN > NOUT ? NIN : NOUT), NOUT>::TPB),
     } else {
         const int c = (int)(L % m.d);
         y = c >> 3;
-        kz = (int)(L / m.d) * 8 + (c & 7);
+        kz = m.kz0 + (int)(L / m.d) * 8 + (c & 7);
     }
     const long long region = is_rem ? g.main_count : 0;   // offset of this launch's region in the full array
 

@@ -13,6 +13,14 @@
 // small all-reduces (sum chi^2; the 13 energy sums) use the same mailboxes: every rank posts its numbers to every peer and
 // sums the P contributions in rank order -- bitwise the same on all ranks.  One host synchronisation per evaluation.
 // Nothing here is specific to separate GPUs: ranks sharing one GPU (tests) map each other's buffers the same way.
+//
+// Round 3: (a) the exchange is pipelined INSIDE a chain by kz chunks (engine_ctx.h: XchgChunks): each chain has a compute
+// stream and a communication stream; chunk k's scatter + stamp run on the communication stream as soon as the chunk's y pass
+// (or fused x pass) has finished, while the compute stream goes on with chunk k + 1; the consumer waits per chunk.
+// (b) Failure handling is collective: epochs are derived from a per-call evaluation number (ranks stay in step after an
+// error), a wait that runs out of patience (OFDFT_OPT_IPC_WAIT_MS, default 30 s) posts the evaluation number into every
+// rank's abort word, every wait and the end of the call check that word -- all ranks fail the same evaluation.  (c) The arena
+// must be fine-grained memory; there is no coarse-grained fallback (remote stores would not invalidate the local L2).
 }  // extern "C"
 
 struct ofdft_ipc_state {
@@ -28,12 +36,16 @@ struct ofdft_ipc_state {
     // mailbox layout (this rank's copy): flags [3 kinds][16 ranks] u32 | sums [2 kinds][16 ranks][16] f64
     unsigned* flags = nullptr;
     double* sums = nullptr;
-    unsigned epoch[3] = {0, 0, 0};     // per kind: chain 0, chain 1, all-reduce
+    unsigned eval_id = 0;              // evaluations started on this context (every rank counts the same calls): epochs derive from it
+    unsigned ordinal[2] = {0, 0};      // exchanges (chunks) issued so far in this evaluation, per chain
     unsigned* d_stamp = nullptr;       // device scratch: the epoch values the flag copies read
-    int* d_err = nullptr;              // set by a wait that ran out of patience
+    int* d_err = nullptr;              // [0] set by a wait that ran out of patience (1 + rank) or found the abort word (100), [1] abort word copy
     int* h_err = nullptr;
-    hipStream_t side = nullptr;        // chain 1
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr;        // chain 1's compute stream
+    hipStream_t comm[2] = {nullptr, nullptr};      // per chain: scatters + stamps (so that they overlap the chain's next kernels)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cjoin[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready[2][16] = {};   // chunk k of chain c is complete in the send buffer
+    hipEvent_t ev_sent[2][16] = {};    // ... and has been scattered (its local block [me] -> [me] included: the peers' stamps do not cover that one)
 };
 
 namespace {
@@ -58,15 +70,27 @@ void ipc_release(ofdft_ctx* c) {
     if (s->d_err) (void)hipFree(s->d_err);
     if (s->h_err) (void)hipHostFree(s->h_err);
     if (s->side) (void)hipStreamDestroy(s->side);
+    for (int ch = 0; ch < 2; ++ch) {
+        if (s->comm[ch]) (void)hipStreamDestroy(s->comm[ch]);
+        if (s->ev_cjoin[ch]) (void)hipEventDestroy(s->ev_cjoin[ch]);
+        for (int k = 0; k < 16; ++k)
+            if (s->ev_ready[ch][k]) (void)hipEventDestroy(s->ev_ready[ch][k]);
+        for (int k = 0; k < 16; ++k)
+            if (s->ev_sent[ch][k]) (void)hipEventDestroy(s->ev_sent[ch][k]);
+    }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     delete s;
     c->ipc = nullptr;
 }
 
-// one wave: lane p waits until rank p's word has reached `epoch` (relaxed system-scope loads: the words are written by
-// other ranks' copy engines / kernels); every lane leaves after ~2 s at the latest and reports through err
-__global__ void ipc_wait_kernel(const unsigned* flags, int P, int me, unsigned epoch, int* err) {
+struct IpcPeers { void* p[16]; };
+// one wave: lane p waits until rank p's word has reached `epoch` (relaxed system-scope loads: the words are written by other
+// ranks' kernels).  A lane gives up after `limit` ticks (100 MHz) -- or at once when some rank has already given up on THIS
+// evaluation (the abort word of the local mailbox holds its number) -- and then tells everybody: the evaluation number goes
+// into the abort word of every rank's mailbox, so that all ranks fail the same evaluation, the late one included.
+__global__ void ipc_wait_kernel(const unsigned* flags, const unsigned* abort_word, IpcPeers mailbox, int P, int me, unsigned epoch,
+                                unsigned eval_id, unsigned long long limit, int* err) {
     const int p = threadIdx.x;
     if (p >= P || p == me) return;
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // an earlier wait of this evaluation
@@ -74,13 +98,24 @@ __global__ void ipc_wait_kernel(const unsigned* flags, int P, int me, unsigned e
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
     while ((int)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
-            *err = 1 + p;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == eval_id) {
+            __hip_atomic_store(err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+            __hip_atomic_store(err, 1 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < P; ++q)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox.p[q]) + 48, eval_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
     }
 }
-struct IpcPeers { void* p[16]; };
+// end of an evaluation (after the last reduction, i.e. after every rank's last stamp): did anybody abort it?
+__global__ void ipc_abort_check_kernel(const unsigned* abort_word, unsigned eval_id, int* err) {
+    if (threadIdx.x == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == eval_id &&
+        __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // chunk [peer] of the local send buffer -> chunk [me] of rank peer's receive buffer (16-byte accesses; blockIdx.y = peer)
 __global__ __launch_bounds__(256) void ipc_scatter_kernel(const u32x4* __restrict__ send, IpcPeers recv, int me, long long vec_per_peer) {
     const int peer = blockIdx.y;
@@ -122,6 +157,12 @@ int ipc_state(ofdft_ctx* c, ofdft_ipc_state** out) {
         HIP_TRY(c, hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        for (int ch = 0; ch < 2; ++ch) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&s->comm[ch], hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&s->ev_cjoin[ch], hipEventDisableTiming));
+            for (int k = 0; k < 16; ++k) HIP_TRY(c, hipEventCreateWithFlags(&s->ev_ready[ch][k], hipEventDisableTiming));
+            for (int k = 0; k < 16; ++k) HIP_TRY(c, hipEventCreateWithFlags(&s->ev_sent[ch][k], hipEventDisableTiming));
+        }
     }
     *out = c->ipc;
     return 0;
@@ -167,10 +208,13 @@ int ipc_arena(ofdft_ctx* c) {
     }
     // fine-grained device memory: what a peer GPU stores here (spectra, epoch stamps) is coherent with this GPU's reads -- lines
     // of a coarse-grained allocation may linger in the local L2 across evaluations, which remote stores do not invalidate
-    if (hipExtMallocWithFlags(&s->arena, tot, hipDeviceMallocFinegrained) != hipSuccess) {
+    // -- so there is no fallback to an ordinary allocation: without fine-grained memory the transport is refused (the caller's
+    // agreement step then takes the collective transport on every rank)
+    if (hipError_t e = hipExtMallocWithFlags(&s->arena, tot, hipDeviceMallocFinegrained); e != hipSuccess) {
         (void)hipGetLastError();
         s->arena = nullptr;
-        HIP_TRY(c, hipMalloc(&s->arena, tot));
+        return fail(c, OFDFT_EHIP, "ipc transport: no fine-grained device memory for the exchange arena (%s): peers' stores would not be "
+                                   "coherent with this GPU's reads -- use the collective transport", hipGetErrorString(e));
     }
     HIP_TRY(c, hipMemset((char*)s->arena + s->off[4], 0, kIpcMailboxBytes));
     HIP_TRY(c, hipDeviceSynchronize());
@@ -191,26 +235,46 @@ int ipc_arena(ofdft_ctx* c) {
     return 0;
 }
 
-// spectra of one stage: send buffer -> chunk [me] of every rank's receive buffer of the OTHER parity, epoch stamps behind
-// them, then the bounded wait for every peer's stamp; flips the chain's parity (the next stage reads what was delivered)
-int ipc_exchange(ofdft_ctx* c, int chain, cplx* send, size_t bytes_per_peer, hipStream_t st) {
+// words of the local mailbox: flags [3 kinds][16 ranks] | abort word (first word of the 64-byte gap) | sums
+inline const unsigned* ipc_abort_word(const ofdft_ipc_state* s) { return s->flags + kIpcFlagWords; }
+inline unsigned long long ipc_limit_ticks(const ofdft_ctx* c) { return (unsigned long long)(c->ipc_wait_ms * 1e5); }   // 100 MHz
+
+// one chunk of an exchange: `bytes_per_peer` bytes per peer from `send_region` (the chunk's region of the send buffer S[p ^ 1],
+// [peer]-major) -> block [me] of the same region of every rank's receive buffer R[p ^ 1] (region_off bytes into it), the epoch
+// stamp behind the data.  Runs on the chain's communication stream behind `ready` (recorded on the compute stream after the
+// kernels that wrote the region).  Returns the epoch the consumers of the chunk wait for.
+int ipc_send_chunk(ofdft_ctx* c, int chain, const cplx* send_region, size_t bytes_per_peer, size_t region_off, hipStream_t cs,
+                   hipEvent_t ready, hipEvent_t sent, unsigned* epoch_out) {
     ofdft_ipc_state* s = c->ipc;
-    const int next = c->recv_parity[chain] ^ 1, w = 2 * chain + next;
+    const int w = 2 * chain + (c->recv_parity[chain] ^ 1);
     IpcPeers recv{}, mail{};
     for (int p = 0; p < s->P; ++p) {
         if (!s->peer[w][p]) return fail(c, OFDFT_ESTATE, "ipc transport: receive buffer %d of rank %d is not attached", w, p);
-        recv.p[p] = s->peer[w][p];
+        recv.p[p] = (char*)s->peer[w][p] + region_off;
         mail.p[p] = s->peer[4][p];
     }
-    if (bytes_per_peer % 16) return fail(c, OFDFT_EINVAL, "ipc transport: message size not a multiple of 16 bytes");
+    if (bytes_per_peer % 16 || region_off % 16) return fail(c, OFDFT_EINVAL, "ipc transport: message size not a multiple of 16 bytes");
+    hipStream_t ms = s->comm[chain];
+    HIP_TRY(c, hipEventRecord(ready, cs));
+    HIP_TRY(c, hipStreamWaitEvent(ms, ready, 0));
     const long long vec = (long long)(bytes_per_peer / 16);
     const int bx = (int)std::min<long long>(2048 / s->P + 1, (vec + 255) / 256);
-    OFDFT_LAUNCH(c, st, "ipc_scatter", ipc_scatter_kernel, dim3(bx, s->P), dim3(256), 0, (const u32x4*)send, recv, s->me, vec);
-    const unsigned e = ++s->epoch[chain];
-    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, mail, s->P, s->me, chain * 16 + s->me, e);
-    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + chain * 16), s->P, s->me, e,
-                 s->d_err);
-    c->recv_parity[chain] = next;
+    OFDFT_LAUNCH(c, ms, "ipc_scatter", ipc_scatter_kernel, dim3(bx, s->P), dim3(256), 0, (const u32x4*)send_region, recv, s->me, vec);
+    const unsigned e = s->eval_id * 128u + (++s->ordinal[chain]);
+    OFDFT_LAUNCH(c, ms, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, mail, s->P, s->me, chain * 16 + s->me, e);
+    HIP_TRY(c, hipEventRecord(sent, ms));
+    *epoch_out = e;
+    return 0;
+}
+// the consumer's side: the compute stream waits for this rank's own scatter of the chunk (it carries the local block) and
+// then -- bounded -- until every peer's stamp of the chunk has arrived
+int ipc_wait_chunk(ofdft_ctx* c, int chain, unsigned epoch, hipStream_t cs, hipEvent_t sent) {
+    ofdft_ipc_state* s = c->ipc;
+    HIP_TRY(c, hipStreamWaitEvent(cs, sent, 0));
+    IpcPeers mail{};
+    for (int p = 0; p < s->P; ++p) mail.p[p] = s->peer[4][p];
+    OFDFT_LAUNCH(c, cs, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + chain * 16), ipc_abort_word(s), mail,
+                 s->P, s->me, epoch, s->eval_id, ipc_limit_ticks(c), s->d_err);
     return 0;
 }
 
@@ -221,9 +285,10 @@ int ipc_allreduce(ofdft_ctx* c, int kind, const double* src, int n, double* dst,
     IpcPeers mail{};
     for (int p = 0; p < s->P; ++p) mail.p[p] = s->peer[4][p];
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_post_kernel, dim3(1), dim3(256), 0, mail, s->P, off, src, n);
-    const unsigned e = ++s->epoch[2];
+    const unsigned e = s->eval_id * 4u + (unsigned)kind + 1u;
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_stamp_kernel, dim3(1), dim3(64), 0, mail, s->P, s->me, 2 * 16 + s->me, e);
-    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + 2 * 16), s->P, s->me, e, s->d_err);
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_wait_kernel, dim3(1), dim3(64), 0, (const unsigned*)(s->flags + 2 * 16), ipc_abort_word(s), mail, s->P,
+                 s->me, e, s->eval_id, ipc_limit_ticks(c), s->d_err);
     OFDFT_LAUNCH(c, st, "ipc_sync", ipc_sum_kernel, dim3(1), dim3(64), 0, (const double*)(s->sums + (size_t)kind * 256), s->P, n, dst);
     return 0;
 }
@@ -298,6 +363,12 @@ int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_loc
     if (!ipc_arena_current(c))          // a set_terms that needs bigger buffers than the exported arena invalidates the peers' mappings
         return fail(c, OFDFT_ESTATE, "ipc transport: exchange buffers changed since ofdft_ipc_export (export and attach again on every rank)");
     const real* chi = (const real*)chi_local;
+    // a new evaluation: its number (the same on every rank) seeds every epoch; parities and ordinals start over, so ranks are in
+    // step again even after an evaluation that failed half-way
+    s->eval_id++;
+    s->ordinal[0] = s->ordinal[1] = 0;
+    c->recv_parity[0] = c->recv_parity[1] = 0;
+    HIP_TRY(c, hipMemsetAsync(s->d_err, 0, sizeof(int), st));
     // ---- sum chi^2 over all ranks -> closure scale on the device
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
@@ -318,41 +389,68 @@ int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_loc
     r.za.v_part_deferred = 0;
     r.xlist[0].clear();
     r.xlist[1].clear();
-    // ---- the two chains on their own streams; a stage's exchange is enqueued right behind its kernels
+    // ---- the two chains on their own compute streams, each with a communication stream: the scatter of chunk k is enqueued
+    // behind the kernels that produced it and runs while the compute stream works on chunk k + 1; consumers wait per chunk
     HIP_TRY(c, hipEventRecord(s->ev_fork, st));
     HIP_TRY(c, hipStreamWaitEvent(s->side, s->ev_fork, 0));
-    for (int stage = 1; stage <= 4; ++stage)
+    const int K = c->xc.n;
+    unsigned pend[2][16] = {};                  // epoch of the chunk delivery the chain's next consuming step waits for (0: none)
+    for (int step = 1; step <= 6; ++step)
         for (int chain = 0; chain < 2; ++chain) {
             hipStream_t cs = chain == 0 ? st : s->side;
-            int rc;
-            switch (stage) {
-                case 1: rc = zstage1(c, cs, chain); break;
-                case 2: rc = zstage2(c, cs, chain); break;
-                case 3: rc = zstage3(c, cs, chain); break;
-                default: rc = zstage4(c, cs, chain); break;
+            const bool sends = step == 1 || step == 2 || step == 4 || step == 5;
+            bool sent = false;
+            for (int k = 0; k < K; ++k) {
+                if (pend[chain][k]) {           // chunk k of the exchange this step consumes
+                    if (int rc = ipc_wait_chunk(c, chain, pend[chain][k], cs, s->ev_sent[chain][k])) return rc;
+                    pend[chain][k] = 0;
+                }
+                int rc;
+                switch (step) {
+                    case 1: rc = zstage1(c, cs, chain, k); break;
+                    case 2: rc = zstage2(c, cs, chain, k); break;
+                    case 3: rc = zstage3(c, cs, chain, 1, k); break;
+                    case 4: rc = zstage3(c, cs, chain, 2, k); break;
+                    case 5: rc = zstage4(c, cs, chain, k); break;
+                    default: rc = chain == 0 ? zstage5(c, nullptr, cs, false, 1, k) : 0; break;     // (the divergence belongs to chain 0)
+                }
+                if (rc) return rc;
+                if (sends && !r.xlist[chain].empty()) {
+                    cplx *send, *recv;
+                    if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
+                    const XcView v = xc_view(c, k);
+                    const size_t narr = r.xlist[chain].size();
+                    const size_t bytes = sizeof(cplx) * (size_t)c->xg.nxl * (size_t)v.arr_sz * narr;
+                    if ((rc = ipc_send_chunk(c, chain, send + narr * v.base1, bytes, sizeof(cplx) * narr * (size_t)v.base1, cs,
+                                             s->ev_ready[chain][k], s->ev_sent[chain][k], &pend[chain][k])))
+                        return rc;
+                    sent = true;
+                }
             }
-            if (rc) return rc;
-            if (!r.xlist[chain].empty()) {
-                cplx *send, *recv;
-                if ((rc = dist_buffers(c, chain, &send, &recv))) return rc;
-                const size_t bytes = sizeof(cplx) * (size_t)c->xg.nxl * c->xg.arr_sz * r.xlist[chain].size();
-                if ((rc = ipc_exchange(c, chain, send, bytes, cs))) return rc;
-            }
+            if (sent) c->recv_parity[chain] ^= 1;      // the chain's next step reads what was just sent
         }
+    // the divergence (chain 0, step 6) has been y-inverted chunk by chunk; join the nonlocal chain and the communication streams
     HIP_TRY(c, hipEventRecord(s->ev_join, s->side));
     HIP_TRY(c, hipStreamWaitEvent(st, s->ev_join, 0));
-    if (int rc = zstage5(c, nullptr, st)) return rc;               // local sums -> d_reduced[0..12]
+    for (int ch = 0; ch < 2; ++ch) {
+        HIP_TRY(c, hipEventRecord(s->ev_cjoin[ch], s->comm[ch]));
+        HIP_TRY(c, hipStreamWaitEvent(st, s->ev_cjoin[ch], 0));
+    }
+    if (int rc = zstage5(c, nullptr, st, false, 2)) return rc;     // combine; local sums -> d_reduced[0..12]
     if (int rc = ipc_allreduce(c, 1, c->d_reduced, kNSums + 1, c->d_reduced, st)) return rc;
     OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v_work_local,
                  (real*)grad_local, c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV,
                  n_electrons);
     HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * (kNSums + 1), hipMemcpyDeviceToHost, st));
+    OFDFT_LAUNCH(c, st, "ipc_sync", ipc_abort_check_kernel, dim3(1), dim3(64), 0, ipc_abort_word(s), s->eval_id, s->d_err);
     HIP_TRY(c, hipMemcpyAsync(s->h_err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, st));
     if (int rc = end_call(c, st)) return rc;
-    if (*s->h_err) {
-        const int who = *s->h_err - 1;
-        (void)hipMemset(s->d_err, 0, sizeof(int));
-        return fail(c, OFDFT_EHIP, "ipc transport: no delivery from rank %d within the wait limit", who);
+    if (*s->h_err) {        // every rank reaches this for the same evaluation (abort word); the next call starts from a clean slate
+        const int code = *s->h_err;
+        if (code == 100)
+            return fail(c, OFDFT_EHIP, "ipc transport: evaluation %u was aborted by another rank (a delivery wait ran out of patience there)", s->eval_id);
+        return fail(c, OFDFT_EHIP, "ipc transport: no delivery from rank %d within %.0f ms (OFDFT_OPT_IPC_WAIT_MS); evaluation %u aborted on all ranks",
+                    code - 1, c->ipc_wait_ms, s->eval_id);
     }
     double vn;
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;

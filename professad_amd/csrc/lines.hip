@@ -83,29 +83,51 @@ int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st) {
 }
 // y pass of `narr` x-slab spectra straight into (forward) / out of (inverse) an all-to-all buffer
 template <int LEN, bool INV>
-int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st) {
+int launch_ypass_xchg_t(ofdft_ctx* c, const ArrList& arrs, int narr, cplx* buf, hipStream_t st, int xk) {
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     using Cfg = PassCfg<LEN>;
     LineMap main, rem;
     pass_maps(c, 1, main, rem);
+    // the chunk's kz blocks [kb0, kb1) of the x-slab spectra <-> its region of the chunk-major exchange buffer
+    const XcView v = xc_view(c, xk);
     XchgGeom xg = c->xg;
+    xg.nb = v.nb;
+    xg.nrem = v.nrem;
+    xg.kb0 = v.kb0;
+    xg.arr_sz = v.arr_sz;
     xg.rec = narr * xg.arr_sz;
     xg.chunk = xg.nxl * xg.rec;
-    const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    const int per_block = c->g.n0 * 8;                  // y lines per kz block
+    int line0 = 0;
+    if (v.nb != c->xg.nb) {
+        if (per_block % Cfg::LPW) return fail(c, OFDFT_EINVAL, "kz-chunked exchange needs whole y-pass workgroups per kz block");
+        line0 = v.kb0 * per_block;
+        main.nlines = v.kb1 * per_block;
+        if (!v.nrem) rem.nlines = 0;
+    }
+    main.blk0 = line0 / Cfg::LPW;
+    const int mb = (main.nlines - line0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    if (mb + rb == 0) return 0;
+    c->ypass_count += narr * (double)(v.nb * 8 + v.nrem) / c->g.nzc;
     OFDFT_LAUNCH(c, st, INV ? "ypass_recv" : "ypass_send", (ypass_xchg_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB),
-                 Cfg::LDS, arrs, buf, xg, main, rem, mb, c->g.main_count, tw);
+                 Cfg::LDS, arrs, buf + (long long)narr * v.base1, xg, main, rem, mb, c->g.main_count, tw);
     return 0;
 }
 template <bool INV>
-int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st) {
+int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st, int xk) {
     const int narr = (int)list.size();
     if (narr == 0) return 0;
     if (narr > 16) return fail(c, OFDFT_EINVAL, "too many spectra in one exchange (%d)", narr);
     ArrList arrs{};
     for (int a = 0; a < narr; ++a) arrs.p[a] = list[a];
-    c->ypass_count += narr;
-#define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st);
+    if (xk == -1 && c->xc.n > 1) {          // every chunk, one launch each
+        for (int k = 0; k < c->xc.n; ++k)
+            if (int rc = ypass_xchg<INV>(c, list, buf, st, k)) return rc;
+        return 0;
+    }
+    if (xk == -1) xk = 0;
+#define OFDFT_CASE(L) case L: return launch_ypass_xchg_t<L, INV>(c, arrs, narr, buf, st, xk);
     switch (c->n1) {
         OFDFT_CASE(8) OFDFT_CASE(16) OFDFT_CASE(32) OFDFT_CASE(64) OFDFT_CASE(128) OFDFT_CASE(256) OFDFT_CASE(512)
         OFDFT_CASE(1024)
@@ -376,7 +398,7 @@ static int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) 
     if (int rc = spec_ws(c, "x:tmp", &tmp)) return rc;
     int rc = zfwd_any(c, in, tmp, st);          // z-forward of the local rows into the x-slab layout
     if (rc) return rc;
-    if ((rc = ypass_xchg<false>(c, {tmp}, send, st))) return rc;           // y-forward, written in the exchange layout
+    if ((rc = ypass_xchg<false>(c, {tmp}, send, st, kWholeXchg))) return rc;   // y-forward, written in the (unchunked) exchange layout
     if ((rc = dist_exchange(c, send, recv, st))) return rc;
     XchgGeom xg = c->xg;
     xg.rec = xg.arr_sz;
@@ -394,7 +416,7 @@ static int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStr
     xg.rec = xg.arr_sz;
     OFDFT_LAUNCH(c, st, "xchg_pack", xchg_unpack_kernel, dim3(grid_for(c->gx.total)), dim3(256), 0, (const cplx*)send, spec, c->gx, xg, 1);
     if ((rc = dist_exchange(c, send, recv, st))) return rc;
-    if ((rc = ypass_xchg<true>(c, {tmp}, recv, st))) return rc;             // y-inverse out of the exchange layout
+    if ((rc = ypass_xchg<true>(c, {tmp}, recv, st, kWholeXchg))) return rc; // y-inverse out of the (unchunked) exchange layout
     return zinv_any(c, tmp, out, scale, st);
 }
 
@@ -434,7 +456,7 @@ template int fast_axis_pass_multi<false>(ofdft_ctx*, int, cplx* const*, int, hip
 template int fast_axis_pass_multi<true>(ofdft_ctx*, int, cplx* const*, int, hipStream_t, int, int, int, int);
 template int fast_axis_pass<false>(ofdft_ctx*, int, cplx*, hipStream_t);
 template int fast_axis_pass<true>(ofdft_ctx*, int, cplx*, hipStream_t);
-template int ypass_xchg<false>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t);
-template int ypass_xchg<true>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t);
+template int ypass_xchg<false>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t, int);
+template int ypass_xchg<true>(ofdft_ctx*, const std::vector<cplx*>&, cplx*, hipStream_t, int);
 
 }  // namespace eng

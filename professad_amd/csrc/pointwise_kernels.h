@@ -235,7 +235,21 @@ struct WgcSeries {
 
 // where the k-point tables live when the x pass works on exchange buffers (slab-decomposed path): x-major records
 // [x][ main (b, yl, kin) | planes (plane, yl) ] of arr_sz elements, the one-array form of the exchange layout
-struct TabMap { int on, nyl, nzm; long long arr_sz; };
+// -- chunk-major like the buffers (engine_ctx.h: XchgChunks): chunk k holds the kz blocks [kb[k], kb[k + 1]) of every x, the
+// remainder planes ride with the last chunk; n0g = x extent (records per chunk)
+struct TabMap { int on, nyl, nzm; long long arr_sz; int nch = 1, n0g = 0, nrem = 0; int kb[17] = {0}; };
+__device__ __forceinline__ long long tabmap_index(const TabMap& tm, int x, int y, int z) {
+    const int b = z < tm.nzm ? (z >> 3) : (tm.nzm >> 3);            // planes: behind the last block
+    int k = tm.nch - 1;
+    if (z < tm.nzm)
+        for (k = 0; k < tm.nch - 1 && b >= tm.kb[k + 1]; ++k) {}
+    const int kb0 = tm.kb[k], nbk = tm.kb[k + 1] - kb0;
+    const long long arr = ((long long)nbk * 8 + (k == tm.nch - 1 ? tm.nrem : 0)) * tm.nyl;      // record size of chunk k
+    const long long base = (long long)tm.n0g * tm.nyl * 8 * kb0;
+    const long long in = z < tm.nzm ? (((long long)(b - kb0) * tm.nyl + y) * 8 + (z & 7))
+                                    : ((long long)nbk * 8 * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y);
+    return base + x * arr + in;
+}
 
 // w, w', w'' (and w''' when THIRD) of the WGC99 kernel at eta != 0, before the prefactor (functionals.py:845-939):
 // homogeneous solution + particular series by Horner in eta^2 (inside) or eta^-2 (outside)
@@ -308,8 +322,7 @@ static __global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict
         if (tm.on) {
             int x, y, z;
             spec_decode(kg.g, ii, x, y, z);
-            i = x * tm.arr_sz + (z < tm.nzm ? (((long long)(z >> 3) * tm.nyl + y) * 8 + (z & 7))
-                                            : ((long long)tm.nzm * tm.nyl + (long long)(z - tm.nzm) * tm.nyl + y));
+            i = tabmap_index(tm, x, y, z);
         }
         const double eta = (k2 != 0.0) ? sqrt((double)k2) * s.inv2kf : 0.0;
         double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3;

@@ -109,6 +109,9 @@ __device__ __forceinline__ void res_barrier(unsigned* ctr, unsigned target, int*
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
         while ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ULL) {
+                // shared word: ANY workgroup that gave up makes the whole evaluation fail (workgroup 0 may be the late one
+                // and find every counter already past its targets)
+                __hip_atomic_fetch_or(ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *timed_out = 1;
                 break;
             }
@@ -617,7 +620,10 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
     if (bid == 0) {          // (a workgroup that never arrives stalls every barrier, this one's included: one flag suffices)
         if (tid < kCombineScalars) A.reduced[tid] = tot[tid];
         else if (tid < 13) A.reduced[tid] = A.gga ? tot[tid + 1] : 0.0;        // GGA energy sums (partials [11..13])
-        if (tid == 0) A.reduced[13] = timed_out ? 1.0 : 0.0;
+        if (tid == 0) {       // (sync[2]: set by any workgroup whose barrier ran out of patience; read after the last barrier)
+            const unsigned any = __hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.reduced[13] = (timed_out || any) ? 1.0 : 0.0;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // system scope: the sums are in host memory before this workgroup counts out
     }
     if (A.grad) {
@@ -658,12 +664,33 @@ bool resident_serves(const ofdft_ctx* c) {
     return c->mask != 0;
 }
 
+// The grid barrier needs all N workgroups resident at once (512 threads and up to ~135 KB of LDS each: one per CU).  The
+// kernel is an ordinary launch, so co-residency is checked before the first one: occupancy x CU count >= N, else the
+// context stops using the kernel (the callers fall through to the graph replay / the staged pipeline).  What the check
+// cannot see (CU masks of the process, other streams holding CUs) is caught by the barrier's time limit, after which
+// the callers re-run the evaluation on the staged path and switch the kernel off as well.
+template <int N>
+static bool res_fits(ofdft_ctx* c) {
+    int per_cu = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_closure_kernel<N>, kResThreads, ResCfg<N>::LDS) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return (long long)per_cu * ncu >= N;
+}
+
 template <int N>
 static int launch_res(ofdft_ctx* c, const ResArgs& a, hipStream_t st) {
     cplx *twM, *twN;
     if (int rc = get_twiddle(c, N / 2, &twM)) return rc;
     if (int rc = get_twiddle(c, N, &twN)) return rc;
-    OFDFT_LAUNCH(c, st, "resident", (resident_closure_kernel<N>), dim3(N), dim3(kResThreads), ResCfg<N>::LDS, a, (const cplx*)twM,
+    int nwg = N;
+    if (c->test_fault == 1) {         // test hook: a launch that cannot pass its grid barriers
+        nwg = N - 1;
+        c->test_fault = 0;
+    }
+    OFDFT_LAUNCH(c, st, "resident", (resident_closure_kernel<N>), dim3(nwg), dim3(kResThreads), ResCfg<N>::LDS, a, (const cplx*)twM,
                  (const cplx*)twN);
     return 0;
 }
@@ -672,6 +699,11 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
     const int N = c->n0;
     const unsigned mask = c->mask;
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    if (c->res_fits < 0) c->res_fits = (N == 16 ? res_fits<16>(c) : N == 32 ? res_fits<32>(c) : res_fits<64>(c)) ? 1 : 0;
+    if (!c->res_fits) {           // the N workgroups cannot be co-resident on this device / partition: never launch
+        c->resident = 0;
+        return kResidentDeclined;
+    }
     ResArgs a{};
     a.chi = chi;
     a.vext = vext;

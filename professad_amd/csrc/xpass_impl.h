@@ -15,11 +15,13 @@ int launch_xfused_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout
     SpecGeom gk = c->gx;
     if (lay.se_in) {
         const int nyl = c->xg.nyl;
-        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
-        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
+        const int xnb = lay.xnb >= 0 ? lay.xnb : c->xg.nb, xnrem = lay.xnb >= 0 ? lay.xnrem : c->xg.nrem;   // this chunk's share
+        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = xnb * nyl * 8;
+        main.kz0 = lay.kz0;
+        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = xnrem * nyl;
         if (main.nlines == 0) main.d = 1;
         if (rem.nlines == 0) rem.d = 1;
-        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
+        gk.main_count = (long long)xnb * nyl * 8;          // offset of the plane part inside a record
     } else {
         pass_maps(c, 0, main, rem);
     }
@@ -48,11 +50,13 @@ int launch_xw_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
     SpecGeom gk = c->gx;
     if (lay.se_in) {
         const int nyl = c->xg.nyl;
-        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = c->xg.nb * nyl * 8;
-        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = c->xg.nrem * nyl;
+        const int xnb = lay.xnb >= 0 ? lay.xnb : c->xg.nb, xnrem = lay.xnb >= 0 ? lay.xnrem : c->xg.nrem;   // this chunk's share
+        main.d = nyl * 8; main.sb = nyl * 8; main.sl = 1; main.se = lay.se_in; main.nlines = xnb * nyl * 8;
+        main.kz0 = lay.kz0;
+        rem.d = nyl; rem.sb = nyl; rem.sl = 1; rem.se = lay.se_in; rem.nlines = xnrem * nyl;
         if (main.nlines == 0) main.d = 1;
         if (rem.nlines == 0) rem.d = 1;
-        gk.main_count = (long long)c->xg.nb * nyl * 8;     // offset of the plane part inside a record
+        gk.main_count = (long long)xnb * nyl * 8;          // offset of the plane part inside a record
     } else {
         pass_maps(c, 0, main, rem);
     }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw
     } else {
         const int c = (int)(L % m.d);
         y = c >> 3;
-        kz = (int)(L / m.d) * 8 + (c & 7);
+        kz = m.kz0 + (int)(L / m.d) * 8 + (c & 7);
     }
     const long long region = is_rem ? g.main_count : 0;
     const long long lb0 = line_base(m, L0);

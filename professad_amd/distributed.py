@@ -2,8 +2,8 @@
 
 Rank r of P owns the real-space x-slab ``[n0/P, n1, n2]`` of chi / n / v_ext and gets back its slab of the
 potential / gradient.  The engine (C ABI ``ofdft_dist_*``) does all local work -- z and y passes on x-slabs,
-fused x passes on y-slabs, pack / un-pack of the exchange buffers -- and this module only sequences the
-stages and performs the collectives through ``torch.distributed``: equal-split all-to-alls (the FFT transposes,
+fused x passes on y-slabs, reading / writing the exchange buffers in place -- and this module only sequences the
+steps (per chain and per kz chunk of the exchange) and performs the collectives through ``torch.distributed``: equal-split all-to-alls (the FFT transposes,
 every array of a stage and chain in ONE message per peer) and two small all-reduces per evaluation.  The work is
 two independent chains (density / Hartree / vW / PBE and the nonlocal KEDF) with separate exchange buffers: with
 the ``nccl`` backend (= RCCL) the all-to-alls are asynchronous, device-to-device over xGMI, and one chain's
@@ -257,6 +257,34 @@ class HipStages(Engine):
                                     torch.as_tensor(_RawDeviceBuffer(rp.value, tot), device=self.device))
         return ex
 
+    @property
+    def nchunks(self):
+        """kz chunks the exchange buffers are cut into (ofdft_query(OFDFT_Q_XCHG_CHUNKS); 1 = the plain layout)"""
+        return int(self.query(N.Q_XCHG_CHUNKS))
+
+    def set_xchg_chunks(self, n):
+        """0 = automatic, 1 = off, 2..16 = that many kz chunks (every rank the same value)"""
+        self.set_option(N.OPT_XCHG_CHUNKS, int(n))
+        self._xbuf.clear()
+        self._ipc_terms = None          # the ipc transport's view of the buffers is stale
+        return self
+
+    def step(self, step, chain, chunk):
+        """one (step, chunk) of a chain of the kz-chunked evaluation (ofdft_dist_step; steps 1..6, see include/ofdft_hip.h)
+        -> None or (send, recv) flat uint8 device tensors over the chunk's region, nranks * bytes_per_peer bytes each"""
+        nbytes, sp, rp = C.c_ulonglong(0), C.c_void_p(0), C.c_void_p(0)
+        self._check(self.lib.ofdft_dist_step(self._ctx, int(step), int(chain), int(chunk), self._stream(), C.byref(nbytes), C.byref(sp),
+                                             C.byref(rp)), 'ofdft_dist_step')
+        if nbytes.value == 0:
+            return None
+        tot = nbytes.value * self.plan.nranks
+        key = (sp.value, rp.value, tot)
+        ex = self._xbuf.get(key)
+        if ex is None:           # the engine reuses its buffers: wrap each (pointer, size) once
+            ex = self._xbuf[key] = (torch.as_tensor(_RawDeviceBuffer(sp.value, tot), device=self.device),
+                                    torch.as_tensor(_RawDeviceBuffer(rp.value, tot), device=self.device))
+        return ex
+
     def finish(self, on_device=False):
         """the 11 local sums: as a numpy vector, or left in device_scalars[0:13] without a host sync"""
         if on_device:
@@ -285,10 +313,17 @@ class HipStages(Engine):
 
 
 def _run_exchanges(stages, comm):
-    """Stage / chain sequencing: a chain's stage k+1 waits only for that chain's exchange, so (with an asynchronous
-    transport) the other chain's kernels run while it is in flight.  On a GPU the nonlocal-KEDF chain is issued on its
-    own stream: its kernels and exchanges then neither wait for nor delay the other chain's (the engine enqueues on
-    whatever stream is current, and so does the collective)."""
+    """Step / chain / chunk sequencing of one evaluation (the six steps of ofdft_dist_step, include/ofdft_hip.h).
+
+    Two levels of overlap, both by ordering alone (an asynchronous all-to-all is ordered behind the kernels enqueued before
+    it; `work.wait()` orders the current stream behind the exchange, the host never blocks):
+      * between the chains: the nonlocal-KEDF chain is issued on its own stream, so its kernels and exchanges neither wait
+        for nor delay the density / Hartree / vW / GGA chain's;
+      * INSIDE a chain, by kz chunks: the exchange buffers are chunk-major, chunk k of a step is sent as soon
+        as its kernels are enqueued, and the kernels of chunk k of the NEXT step wait only for that chunk -- chunk k crosses
+        the fabric while chunk k + 1 is in its y pass and chunk k - 1 already in its fused x pass.
+    With one chunk this is the plain stage-by-stage sequence."""
+    K = int(getattr(stages, 'nchunks', 1))
     dev = getattr(stages, 'device', None)
     on_gpu = isinstance(dev, torch.device) and dev.type == 'cuda'
     side = None
@@ -297,21 +332,18 @@ def _run_exchanges(stages, comm):
         if side is None:
             side = stages._side_stream = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))          # everything ofdft_dist_begin enqueued
-    pending = [None, None]
-    for k in (1, 2, 3, 4):
+    pending = [[None] * K, [None] * K]          # per chain and chunk: the exchange the chain's next step consumes
+    for step in (1, 2, 3, 4, 5, 6):
         for chain in (0, 1):
             ctx = torch.cuda.stream(side) if (side is not None and chain == 1) else contextlib.nullcontext()
             with ctx:
-                if pending[chain] is not None:
-                    pending[chain].wait()
-                    pending[chain] = None
-                ex = stages.stage(k, chain)
-                if ex is not None:
-                    pending[chain] = comm.all_to_all(ex[0], ex[1])
-    for chain, w in enumerate(pending):
-        if w is not None:
-            with (torch.cuda.stream(side) if (side is not None and chain == 1) else contextlib.nullcontext()):
-                w.wait()
+                for k in range(K):
+                    if pending[chain][k] is not None:
+                        pending[chain][k].wait()
+                        pending[chain][k] = None
+                    ex = stages.step(step, chain, k)
+                    if ex is not None:
+                        pending[chain][k] = comm.all_to_all(ex[0], ex[1])
     if side is not None:
         torch.cuda.current_stream(dev).wait_stream(side)           # the combine needs both chains
 
@@ -364,17 +396,20 @@ class DistEngine:
     """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
     as `Engine`, on this rank's slab."""
 
-    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective'):
+    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective', xchg_chunks=None):
         """dtype=torch.float32 runs the slab-decomposed hot path on the fp32 build (half the bytes on every link);
         stress and ion forces are then formed by the fp64 routines on fp64 slabs.
         transport: 'collective' = the host issues an all-to-all per stage through torch.distributed (RCCL under nccl);
-        'ipc' = the library maps the peers' buffers (hipIpc) and moves the spectra itself, one call per evaluation."""
+        'ipc' = the library maps the peers' buffers (hipIpc) and moves the spectra itself, one call per evaluation.
+        xchg_chunks: kz chunks the exchange is pipelined by inside each chain (both transports; None = automatic, 1 = off)."""
         if transport not in ('collective', 'ipc'):
             raise ValueError("transport must be 'collective' or 'ipc'")
         self.transport = transport
         self.comm = Comm(group)
         self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
         self.stages.enable_collectives(self.comm)
+        if xchg_chunks is not None:             # kz chunks of the exchange (None: the engine's automatic choice)
+            self.stages.set_xchg_chunks(xchg_chunks)
         self.plan = self.stages.plan
         self.npts_global = int(np.prod(self.plan.shape))
         self._vol = None
@@ -438,7 +473,18 @@ class DistEngine:
         """per-term stress tensors of the full system (see Engine.stress) from this rank's density slab"""
         eng = self._f64_stages()
         den = self.stages._grid_tensor(den_slab, 'den').double()
-        return eng.set_terms(names, params).stress(den)
+        # on an fp64 engine this is the hot path's own context: the stress term set (often a subset, `params=None` = defaults)
+        # must not become what later energy_grad_chi / energy_potential calls compute -- the active set is put back afterwards
+        # (same mask and parameter bytes: no change of the exchange buffers, so the ipc transport keeps its mappings)
+        saved = eng._terms_key if eng is self.stages else None
+        try:
+            return eng.set_terms(names, params).stress(den)
+        finally:
+            if saved is not None and eng._terms_key != saved:
+                vals = np.frombuffer(saved[1], dtype=np.float64)
+                eng._check(eng.lib.ofdft_set_terms(eng._ctx, saved[0], vals.ctypes.data_as(C.POINTER(C.c_double)), len(vals)),
+                           'ofdft_set_terms')
+                eng._terms_key = saved
 
     def ion_electron_forces(self, den_slab, species, pme_order=None):
         """ion-electron forces of the full system (see ions.ion_electron_forces) from this rank's density slab"""

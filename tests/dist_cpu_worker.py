@@ -32,6 +32,7 @@ def main():
     comm = Comm()
     assert comm.active and comm.nranks == world and comm.backend == 'gloo'
     st = NumpyStages(shape, box, world, rank)
+    st.nchunks = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # kz chunks of the exchange (step / chunk sequencing)
     pl = st.plan
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
     vol, npts = abs(np.linalg.det(box)), int(np.prod(shape))

@@ -54,9 +54,33 @@ def main():
     chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(43).random(shape))
     n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)  # noqa: E731
-    eng = DistEngine(shape, dev, dtype=dt, transport=os.environ.get('OFDFT_TEST_TRANSPORT', 'collective')).set_cell(torch.as_tensor(box))
+    transport = os.environ.get('OFDFT_TEST_TRANSPORT', 'collective')
+    want_chunks = int(os.environ['OFDFT_TEST_XCHG_CHUNKS']) if os.environ.get('OFDFT_TEST_XCHG_CHUNKS') else None
+    eng = DistEngine(shape, dev, dtype=dt, transport=transport, xchg_chunks=want_chunks).set_cell(torch.as_tensor(box))
     plan = eng.plan
     worst = {}
+    if want_chunks:
+        # the kz-chunked exchange (every step's exchange in `want_chunks` pieces, consumed piece by piece) against the unchunked
+        # sequence of a second engine on the same ranks: same kernels per line, so every number must be IDENTICAL
+        # (same transport: the ipc transport adds the ranks' sums in rank order, the collective one in the backend's order)
+        one = DistEngine(shape, dev, dtype=dt, transport=transport, xchg_chunks=1).set_cell(torch.as_tensor(box))
+        names = NativeTerms(CFG['cfg3']).names
+        eng.set_terms(names)
+        one.set_terms(names)
+        worst['chunks'] = dict(dE=0.0, dE2=0.0, dmu=0.0, dg=0.0, dv=0.0, ffts=eng.stages.nchunks, ffts_ref=want_chunks)
+        for rep in range(3):          # repeated: buffers alternate between exchanges and between evaluations
+            E, mu, g = eng.energy_grad_chi(t(plan.scatter(chi)) * (1 + 0.01 * rep), n_elec, t(plan.scatter(vext)))
+            E1, mu1, g1 = one.energy_grad_chi(t(plan.scatter(chi)) * (1 + 0.01 * rep), n_elec, t(plan.scatter(vext)))
+            w = worst['chunks']
+            w['dE'] = max(w['dE'], max(abs(E[k] - E1[k]) for k in E))
+            w['dmu'] = max(w['dmu'], abs(mu - mu1))
+            w['dg'] = max(w['dg'], float((g - g1).abs().max()))
+        E2, v = eng.energy_potential(t(plan.scatter(den)), t(plan.scatter(vext)))
+        E21, v1 = one.energy_potential(t(plan.scatter(den)), t(plan.scatter(vext)))
+        worst['chunks']['dE2'] = max(abs(E2[k] - E21[k]) for k in E2)
+        worst['chunks']['dv'] = float((v - v1).abs().max())
+        assert one.stages.nchunks == 1
+        one.close()
     for cfg in ('cfg1', 'cfg2', 'cfg3'):
         names = NativeTerms(CFG[cfg]).names
         eng.set_terms(names)

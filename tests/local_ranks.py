@@ -41,18 +41,25 @@ class LocalRanks:
         self.compute_s[r] += time.perf_counter() - t0
         return out
 
+    def set_xchg_chunks(self, n):
+        for s in self.st:
+            s.set_xchg_chunks(n)
+        return self
+
     def _stages(self):
         P = self.P
-        for k in (1, 2, 3, 4):
+        K = self.st[0].nchunks
+        for step in (1, 2, 3, 4, 5, 6):
             for chain in (0, 1):
-                ex = [self._timed(r, s.stage, k, chain) for r, s in enumerate(self.st)]
-                if ex[0] is None:
-                    continue
-                self.exchanged_bytes += sum(e[0].numel() for e in ex)
-                for r in range(P):
-                    rc = ex[r][1].chunk(P)
-                    for p in range(P):
-                        rc[p].copy_(ex[p][0].chunk(P)[r])
+                for k in range(K):         # chunk k of the exchange: one equal-split all-to-all over the chunk's region
+                    ex = [self._timed(r, s.step, step, chain, k) for r, s in enumerate(self.st)]
+                    if ex[0] is None:
+                        continue
+                    self.exchanged_bytes += sum(e[0].numel() for e in ex)
+                    for r in range(P):
+                        rc = ex[r][1].chunk(P)
+                        for p in range(P):
+                            rc[p].copy_(ex[p][0].chunk(P)[r])
         return sum(self._timed(r, s.finish) for r, s in enumerate(self.st))
 
     def closure(self, chi, n_elec, vext):

@@ -24,8 +24,10 @@ def test_slab_plan_bookkeeping():
         SlabPlan((18, 32, 8), 4, 0)
 
 
-@pytest.mark.parametrize('world,shape', [(2, '8x12x10'), (4, '16x8x9')])
-def test_multi_rank_host_logic_under_gloo(world, shape, tmp_path):
+@pytest.mark.parametrize('world,shape,chunks', [(2, '8x12x10', 1), (4, '16x8x9', 1), (2, '8x12x10', 3), (4, '16x8x9', 4)])
+def test_multi_rank_host_logic_under_gloo(world, shape, chunks, tmp_path):
+    """chunks > 1: the exchange of every step travels as that many kz chunks, each its own all-to-all, consumed chunk by chunk
+    by the next step (the sequencing of professad_amd.distributed._run_exchanges)"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -34,7 +36,7 @@ def test_multi_rank_host_logic_under_gloo(world, shape, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    OMP_NUM_THREADS='1')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_cpu_worker.py'), shape, out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_cpu_worker.py'), shape, out, str(chunks)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=240)[0].decode(errors='replace')[-1500:] for p in procs]
     assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)

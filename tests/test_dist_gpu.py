@@ -25,7 +25,9 @@ def _gpu_count():
 def _check_worker_results(res, dtype):
     if dtype == 'f32':      # fp32 build: slabs against one fp32 engine differ by fp32 round-off only (tests/test_gpu_f32.py)
         for cfg, w in res.items():
-            if cfg == 'opt':
+            if cfg == 'chunks':
+                assert max(w['dE'], w['dE2'], w['dmu'], w['dg'], w['dv']) == 0.0 and w['ffts'] == w['ffts_ref'], w
+            elif cfg == 'opt':
                 assert w['dE'] < 2e-5 and abs(w['ffts'] - w['ffts_ref']) <= 1, w
             elif cfg == 'ions':
                 assert w['dE'] < 1e-6 and w['dE2'] < 1e-9, w          # fp64 routines on both sides; v_ext narrowed to fp32
@@ -36,6 +38,10 @@ def _check_worker_results(res, dtype):
                 assert w['ffts'] == w['ffts_ref'], (cfg, w)
         return
     for cfg, w in res.items():
+        if cfg == 'chunks':   # kz-chunked exchange against the unchunked sequence on the same ranks: identical numbers
+            assert w['dE'] == 0.0 and w['dE2'] == 0.0 and w['dmu'] == 0.0 and w['dg'] == 0.0 and w['dv'] == 0.0, w
+            assert w['ffts'] == w['ffts_ref'], ('chunk count not honoured', w)
+            continue
         if cfg == 'opt':      # 8 outer L-BFGS steps over slabs vs one GPU: same path up to the optimiser's sensitivity to
             assert w['dE'] < 1e-7 and w['dg'] < 1e-3 and abs(w['ffts'] - w['ffts_ref']) <= 1, w      # round-off
             continue
@@ -94,6 +100,65 @@ def test_slab_decomposed_with_the_library_own_exchange(world, shape, dtype, tmp_
 def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
     res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'))
     _check_worker_results(res, dtype)
+
+
+@pytest.mark.parametrize('world,shape,dtype,chunks,transport', [
+    (2, '64x64x64', 'f64', 4, 'collective'), (2, '64x64x64', 'f64', 2, 'ipc'), (4, '128x128x64', 'f64', 4, 'ipc'),
+    (4, '128x128x32', 'f64', 2, 'collective'), (2, '64x64x128', 'f32', 4, 'ipc'), (2, '64x64x64', 'f32', 3, 'collective')])
+def test_kz_chunked_exchange_with_real_ranks(world, shape, dtype, chunks, transport, tmp_path):
+    """SURVEY.md 8e / round-2 verdict item 1: the exchange of every step cut into kz chunks (chunk-major buffers, one message
+    per chunk, the next step consuming chunk by chunk; professad_amd.distributed._run_exchanges, ofdft_dist_closure) -- with
+    2 and 4 processes sharing the GPU, both transports: bitwise the unchunked sequence, and the single-GPU engine to 1e-12,
+    with the same FFT count"""
+    res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'),
+                       {'OFDFT_TEST_TRANSPORT': transport, 'OFDFT_TEST_XCHG_CHUNKS': str(chunks)}, timeout=400)
+    assert 'chunks' in res
+    _check_worker_results(res, dtype)
+
+
+@pytest.mark.parametrize('nranks,shape,chunks', [(2, (64, 64, 64), 4), (4, (128, 128, 32), 2), (8, (256, 256, 256), 4),
+                                                  (8, (256, 256, 64), 3), (2, (64, 64, 48), 3)])
+def test_kz_chunked_exchange_emulated_is_bitwise_the_unchunked_one(nranks, shape, chunks):
+    """the same in one process with emulated ranks (every rank count a one-GPU box cannot host as processes; uneven chunk
+    sizes; a mixed-radix z extent): chunked == unchunked bit for bit, FFT count unchanged, single-GPU engine to 1e-12"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    import cases
+    from local_ranks import LocalRanks
+    from professad_amd import synth
+    from professad_amd.engine import Engine
+    from professad_amd.functionals import NativeTerms
+    dev = torch.device('cuda:0')
+    box = torch.as_tensor(cases.make_cell(('tri', shape[0] / 16.0)))
+    den = synth.random_density(shape, seed=41)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=dev)  # noqa: E731
+    chi = t(np.sqrt(den) * (1 + 0.1 * np.random.default_rng(43).random(shape)))
+    vext = t(synth.random_potential(shape, seed=42))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box.numpy()))) + 0.3)
+    for names, params in ((NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe']).names, None),
+                          (['ion_electron', 'hartree', 'vw', 'tf', 'wt_nl', 'gga_k', 'pbe_x'], {'wt_alpha': 1.1, 'wt_beta': 0.6, 'ggak_kind': 1.0,
+                                                                                               'ggak_beta': 0.25, 'ggak_lambda': 0.4})):
+        ref = Engine(shape, dev).set_cell(box).set_terms(names, params)
+        Er, mur, gr = ref.energy_grad_chi(chi, n_elec, vext)
+        nfft = ref.query(0)
+        ref.close()
+        out = {}
+        for K in (1, chunks):
+            loc = LocalRanks(shape, dev, nranks).set_cell(box).set_terms(names, params).set_xchg_chunks(K)
+            assert loc.st[0].nchunks == K
+            out[K] = loc.closure(chi, n_elec, vext) + (loc.st[0].query(0),)
+            out[(K, 2)] = loc.closure(chi * 1.01, n_elec, vext)          # a second evaluation on the same contexts
+            loc.close()
+        for key in (chunks, (chunks, 2)):
+            a, b = out[key], out[1 if key == chunks else (1, 2)]
+            assert all(a[0][k] == b[0][k] for k in a[0]) and a[1] == b[1] and torch.equal(a[2], b[2]), (names, key)
+        E, mu, g, nf = out[chunks]
+        assert nf == nfft
+        for k in Er:
+            assert abs(E[k] - Er[k]) <= 1e-12 * max(1.0, abs(Er[k])), (k, E[k], Er[k])
+        assert abs(mu - mur) <= 1e-12 * max(1.0, abs(mur))
+        assert float((g - gr).abs().max()) <= 1e-12 * float(gr.abs().max())
 
 
 def test_eight_rank_geometry_with_the_laplacian_dependent_pauli_gaussian():

@@ -917,6 +917,41 @@ def test_graph_replay_is_bitwise_the_kernel_by_kernel_path(shape, cfg):
 
 
 # ------------------------------------------------------------------------------- persistent small-grid kernel
+@pytest.mark.parametrize('fault', ['does_not_fit', 'barrier_timeout'])
+def test_resident_kernel_that_cannot_run_falls_back_to_the_staged_pipeline(fault):
+    """round-2 advice: the persistent kernel needs its N workgroups co-resident.  (a) the occupancy check says it does not fit
+    -> never launched, the call is served by the graph replay / the staged pipeline; (b) a launch whose grid barriers cannot
+    complete (test hook: one workgroup short) -> ANY workgroup's time-out is published through a shared word, the call still
+    returns the right numbers (re-run on the staged path) and the kernel is switched off for the context"""
+    from professad_amd import _native as N
+    n = 16
+    shape = (n, n, n)
+    box = dev(synth.triclinic_cell(n / 4.0))
+    den = synth.smooth_density(shape, seed=3, amp=0.5)
+    chi, vext = dev(np.sqrt(den)), dev(synth.random_potential(shape, seed=4))
+    names = F.NativeTerms(['ion_electron', 'hartree', 'wt', 'pbe']).names
+    staged = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_RESIDENT, 0)
+    Ea, mua, ga = staged.energy_grad_chi(chi, 9.0, vext)
+    eng = Engine(shape, DEV).set_cell(box).set_terms(names).set_option(N.OPT_RESIDENT, 1)
+    if fault == 'barrier_timeout':
+        E0, mu0, g0 = eng.energy_grad_chi(chi, 9.0, vext)                 # a healthy launch first (the counters run on)
+        assert eng.query(N.Q_RESIDENT_EVALS) == 1
+    eng.set_option(N.OPT_TEST_FAULT, 2 if fault == 'does_not_fit' else 1)
+    served_before = eng.query(N.Q_RESIDENT_EVALS)
+    for rep in range(3):            # the faulty call itself, then calls on the switched-off context (graph capture + replay)
+        Eb, mub, gb = eng.energy_grad_chi(chi, 9.0, vext)
+        for k in Ea:
+            assert abs(Ea[k] - Eb[k]) <= 1e-12 * max(abs(Ea[k]), 1e-2), (rep, k)
+        assert abs(mua - mub) <= 1e-12 * max(1.0, abs(mua)) and float((ga - gb).abs().max()) <= 1e-12 * float(ga.abs().max())
+    assert eng.query(N.Q_RESIDENT_EVALS) == served_before
+    assert eng.query(N.Q_RESIDENT_FALLBACKS) == (1 if fault == 'barrier_timeout' else 0)
+    E2, v2 = eng.energy_potential(chi * chi, vext)                        # the density entry takes the staged path as well
+    E1, v1 = staged.energy_potential(chi * chi, vext)
+    assert all(abs(E1[k] - E2[k]) <= 1e-12 * max(abs(E1[k]), 1e-2) for k in E1) and float((v1 - v2).abs().max()) <= 1e-12 * float(v1.abs().max())
+    staged.close()
+    eng.close()
+
+
 _RES_TERMS = {'cfg1': ['ion_electron', 'hartree', 'tf', 'vw', 'pz'], 'cfg2': ['ion_electron', 'hartree', 'wt', 'pz'],
               'local': ['tf', 'lda_x', 'pw_c'], 'vw_only': ['vw']}
 
