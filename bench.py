@@ -404,7 +404,7 @@ def main():
     vext = torch.as_tensor(vext_h, dtype=tdtype, device=device)
     default_options = True
     for env, opt in (('OFDFT_SIDE_STREAM', 1), ('OFDFT_XCHUNKS', 2), ('OFDFT_XCHUNK_MASK', 3), ('OFDFT_SPLIT_COMBINE', 4),
-                     ('OFDFT_GGA_SPLIT', 6), ('OFDFT_XWAVE', 8), ('OFDFT_MIXED_RADIX', 9)):          # A/B switches (never set by the driver)
+                     ('OFDFT_GGA_SPLIT', 6), ('OFDFT_XWAVE', 8), ('OFDFT_MIXED_RADIX', 9), ('OFDFT_YBATCH', 14)):          # A/B switches (never set by the driver)
         if os.environ.get(env):
             raw.set_option(opt, int(os.environ[env]))
             default_options = False

@@ -309,6 +309,7 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      while chunk k + 1 is in its y pass and chunk k - 1 in its x pass.  0 (default): automatic -- up to 4
                                      chunks of >= 4 kz blocks when the slab extents n0 / P and n1 / P are multiples of 32, else 1; 1: off.  Every
                                      rank must use the same value; the ipc transport needs a new ofdft_ipc_export / attach round after a change. */
+#define OFDFT_OPT_YBATCH 14       /* 1 (default): the y passes of the three spectra of each WGC99 half run as one launch (grid.y = 3); 0: three launches */
 #define OFDFT_OPT_IPC_WAIT_MS 13  /* ipc transport: how long a delivery wait of ofdft_dist_closure stays patient before it aborts the evaluation ON ALL
                                      RANKS (default 30 000 ms: a rank may be late by a module load, a page-in, a garbage collection) */
 #define OFDFT_OPT_TEST_FAULT 11   /* test hook, never set in production: 1 = the NEXT persistent-kernel launch is one workgroup short (its grid

@@ -1441,6 +1441,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             xchg_chunks_set(c, (int)value);
             c->wgc_valid = false;             // the kernel tables are laid out like the buffers
             return OFDFT_OK;
+        case OFDFT_OPT_YBATCH:
+            c->ybatch = (int)value;
+            return OFDFT_OK;
         case OFDFT_OPT_IPC_WAIT_MS:
             if (!(value >= 1.0 && value <= 3.6e6)) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_IPC_WAIT_MS takes 1 .. 3 600 000 ms");
             c->ipc_wait_ms = value;

@@ -212,8 +212,13 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
                 HIP_TRY(c, hipEventRecord(c->ev_b, sb));
                 HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_b, 0));
             }
+            if (!dx && nch == 1 && c->ybatch) {       // a half's three y passes as ONE launch (grid.y = 3): more workgroups than the
+                                                      // chip holds at once, so loads, transforms and stores of different tiles overlap
+                if ((rc = fast_axis_pass_multi<false>(c, 1, r.sw, 3, sb))) return rc;
+                if ((rc = fast_axis_pass_multi<false>(c, 1, r.sw + 3, 3, sc))) return rc;
+            }
             for (int i = 0; i < 6; ++i) {
-                if (!dx && nch == 1 && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
+                if (!dx && nch == 1 && !c->ybatch && (rc = fast_axis_pass<false>(c, 1, r.sw[i], i < 3 ? sb : sc))) return rc;
                 xl.push_back(r.sw[i]);
             }
             r.za.wgc_alpha = al;
@@ -376,13 +381,18 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
     // x-chunked pipeline: the y-inverse of every spectrum the combine kernel consumes moves into the combine loop
     // (stage 5) and that of grad n into the PBE loop below, so the consumer reads the lines from the Infinity Cache
     const bool chunked = chunks_for(c, 6, 8) > 1, pbe_chunked = !r.gsplit && chunks_for(c, 6, 4) > 1;
+    const bool wbatch = !dx && c->ybatch && chain == 1 && r.has_wgc && !r.wgc_yinv_done && !chunked && xl.size() >= 6;
+    if (wbatch) {           // the six WGC99 results: one batched y-inverse per half (see stage 1)
+        if ((rc = fast_axis_pass_multi<true>(c, 1, r.sw, 3, sb))) return rc;
+        if ((rc = fast_axis_pass_multi<true>(c, 1, r.sw + 3, 3, sc))) return rc;
+    }
     for (cplx* sp : xl) {
         const bool on_b = sp == r.s_b || sp == r.s_a || sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2];
         const bool on_c = sp == r.s_s || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
         const bool is_g = sp == r.s_g[0] || sp == r.s_g[1] || sp == r.s_g[2] || (r.s_l && sp == r.s_l);
         const bool is_w = sp == r.sw[0] || sp == r.sw[1] || sp == r.sw[2] || sp == r.sw[3] || sp == r.sw[4] || sp == r.sw[5];
-        if (is_w && r.wgc_yinv_done) {
-            // already y-inverted next to the x pass
+        if (is_w && (r.wgc_yinv_done || wbatch)) {
+            // already y-inverted next to the x pass / by the batched launches above
         } else if (is_g ? pbe_chunked : chunked) {
             if (!is_g) r.deferred.push_back(sp);
         } else if (!dx && (rc = fast_axis_pass<true>(c, 1, sp, on_b ? sb : (on_c ? sc : st)))) {

@@ -7,7 +7,11 @@
 // tests and the 1e-8 Ha/atom bar of the north star) for POSITIVE, FINITE, NORMAL arguments -- which is what a density,
 // a Wigner-Seitz radius or a PBE enhancement argument is -- and cost 5 (1/x), ~32 (log), ~20 (exp), ~25 (n^(-1/6) with
 // every root of n the GGA formulas need derived from it by multiplications).
-// The fp32 build (real = float) keeps the ordinary library calls: its transcendentals are single instructions.
+// The fp32 build (real = float) uses the hardware's transcendental instructions directly (v_rcp_f32, v_log_f32, v_exp_f32:
+// 1 ulp, quarter rate) instead of the library's IEEE wrappers -- logf / expf / cbrtf / the division sequence cost 8-25
+// instructions each, which made the fp32 GGA mid stage as long an instruction stream as the fp64 one (3 677 vs 3 695 VALU
+// instructions per wave, profiles/r03_sq_counters_f32_before.md).  Arguments are positive normal numbers as above; relative
+// errors stay at a few fp32 ulp (the fp32 parity tolerances are 5e-6 / 5e-4, tests/test_gpu_f32.py).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,7 +26,7 @@ __device__ __forceinline__ double rcp(double x) {
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
-__device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ---- natural logarithm, x > 0 finite normal:  x = m 2^e, m in [sqrt(1/2), sqrt(2)),  log m = 2 atanh(s), s = (m-1)/(m+1)
 __device__ __forceinline__ double log(double x) {
@@ -52,7 +56,7 @@ __device__ __forceinline__ double log(double x) {
     const double ln2_hi = 0x1.62e42fefa38p-1, ln2_lo = 0x1.ef35793c7673p-45;
     return __builtin_fma(de, ln2_hi, __builtin_fma(de, ln2_lo, lm));
 }
-__device__ __forceinline__ float log(float x) { return ::logf(x); }
+__device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }     // v_log_f32 = log2
 
 // ---- exponential, |x| < ~700:  x = k ln 2 + r, |r| <= ln(2)/2, Taylor to r^13/13! (next term < 5e-18)
 __device__ __forceinline__ double exp(double x) {
@@ -75,11 +79,11 @@ __device__ __forceinline__ double exp(double x) {
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)k);
 }
-__device__ __forceinline__ float exp(float x) { return ::expf(x); }
+__device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // x^y for x > 0
 __device__ __forceinline__ double pow_pos(double x, double y) { return exp(y * log(x)); }
-__device__ __forceinline__ float pow_pos(float x, float y) { return ::expf(y * ::logf(x)); }
+__device__ __forceinline__ float pow_pos(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 
 // ---- n^(-1/6) for n > 0 finite normal, any magnitude: n = m 2^(6q + r) with m 2^r in [0.5, 32); fp32 seed
 // (v_log_f32 / v_exp_f32, ~2^-21) + two Newton steps on y^-6 = n (error -> 3.5 error^2 per step)
@@ -116,12 +120,20 @@ __device__ __forceinline__ Roots<double> roots(double n) {
     r.inv_n = y4 * r.inv13;
     return r;
 }
+// fp32: n^(-1/6) = 2^(-log2(n) / 6) from the hardware log2 / exp2 (error ~ |log2 n| / 6 ulp) + ONE Newton step on y^-6 = n
+__device__ __forceinline__ float rsixth(float n) {
+    float y = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(n) * (-1.0f / 6.0f));
+    const float y2 = y * y, y3 = y2 * y;
+    const float h = __builtin_fmaf(-n, y3 * y3, 1.0f);          // 1 - n y^6
+    return __builtin_fmaf(y * h, 1.0f / 6.0f, y);
+}
 __device__ __forceinline__ Roots<float> roots(float n) {
     Roots<float> r;
-    r.n13 = ::cbrtf(n);
-    r.inv13 = 1.0f / r.n13;
-    r.y = ::sqrtf(r.inv13);
-    r.inv_n = 1.0f / n;
+    r.y = rsixth(n);
+    r.inv13 = r.y * r.y;
+    const float y4 = r.inv13 * r.inv13;
+    r.n13 = n * y4;
+    r.inv_n = y4 * r.inv13;
     return r;
 }
 

@@ -80,7 +80,11 @@ int launch_xw_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
 template <int NIN, int NOUT, class Mix>
 int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay) {
     // measured at 256^3 (A/B on one box): 3 -> 3 (WGC99) 0.55 -> 0.53 ms, 1 -> 2 0.112 -> 0.097 ms, but 1 -> 1 0.062 -> 0.079 ms
-    if (c->use_xwave == 2 || (c->use_xwave == 1 && NIN + NOUT >= 3)) {
+    // (at 512 points per line the wave-local kernel -- one line per wave: 16 useful bytes per cache line and load -- costs 1.5 x its
+    // 256-point self per grid point, tools/shape_probe.py, and the group-parallel kernel is faster ALONE, 5.4 vs 6.3 ms for the WGC99
+    // pair at 512^3; with the two chains overlapped the evaluation is nevertheless 3-4 % faster with the wave-local one, 24.6-25.0 vs
+    // 25.8-25.9 ms in two alternations on one box: option value 4 selects the group-parallel kernel at 512 for A/B)
+    if (c->use_xwave == 2 || ((c->use_xwave == 1 || (c->use_xwave == 4 && c->n0g < 512)) && NIN + NOUT >= 3)) {
         switch (c->n0g) {
             case 8: return launch_xw_t<8, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
             case 16: return launch_xw_t<16, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);

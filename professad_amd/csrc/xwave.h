@@ -17,14 +17,58 @@
 
 namespace ofdft {
 
+// LDS layout of this kernel's line buffers.  Its lanes interleave the wave's 64 / P lines (lane = j * LPWV + l), so the 32
+// lanes of a read group span several line buffers; with the padded layout of the other kernels every exchange access then
+// costs 2 LDS cycles (SQ_LDS_BANK_CONFLICT 48.8 % of the LDS cycles, profiles/r02_final_sq_counters.md: the kernel is bound
+// by its LDS phases).  Per length and precision: XOR swizzle parameters (fft_radix.h: lpos) and the line-buffer stride that
+// make every read group and every write group of every stage hit distinct banks (enumerated against the bank rules of
+// MI355X_MICROARCH.md, tools/lds_conflicts.py).  OFDFT_XW_SWIZZLE=0 keeps the padded layout (A/B).
+#ifndef OFDFT_XW_SWIZZLE
+#define OFDFT_XW_SWIZZLE 1
+#endif
+template <int LEN> struct XwSwz { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = LineBuf<LEN>::STRIDE; };
+#if OFDFT_XW_SWIZZLE
+#ifdef OFDFT_REAL_F32
+// (b32 accesses: reads and writes in two 32-lane groups over 32 banks)
+template <> struct XwSwz<32> { static constexpr int XS = 3, XM = 1, XMUL = 1, LMUL = 0, RS = 34; };
+template <> struct XwSwz<64> { static constexpr int XS = 3, XM = 3, XMUL = 1, LMUL = 0, RS = 68; };
+template <> struct XwSwz<128> { static constexpr int XS = 3, XM = 7, XMUL = 1, LMUL = 0, RS = 136; };
+template <> struct XwSwz<256> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 272; };
+template <> struct XwSwz<512> { static constexpr int XS = 3, XM = 31, XMUL = 1, LMUL = 0, RS = 512; };
+#else
+// (b64 accesses: reads in two 32-lane groups over 64 banks, writes in four 16-lane groups over 32 banks -- the two rules ask
+// for different strides between the interleaved lines, which the line-dependent XOR (LMUL * line) & 31 reconciles)
+template <> struct XwSwz<32> { static constexpr int XS = 1, XM = 1, XMUL = 1, LMUL = 1, RS = 48; };
+template <> struct XwSwz<64> { static constexpr int XS = 1, XM = 1, XMUL = 1, LMUL = 1, RS = 72; };
+template <> struct XwSwz<128> { static constexpr int XS = 1, XM = 15, XMUL = 1, LMUL = 5, RS = 144; };
+template <> struct XwSwz<256> { static constexpr int XS = 3, XM = 7, XMUL = 1, LMUL = 8, RS = 272; };
+template <> struct XwSwz<512> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 512; };
+#endif
+#endif
+template <int LEN> struct XwPlan : ZPlan<LEN, 8> {};
+template <int LEN> struct LdsLayout<XwPlan<LEN>> : LdsLayoutDefault {
+    static constexpr int XS = XwSwz<LEN>::XS, XM = XwSwz<LEN>::XM, XMUL = XwSwz<LEN>::XMUL;
+};
+template <int LEN, bool INV>
+__device__ __forceinline__ void xw_line_fft(cplx (&v)[8], int j, real* line, const cplx* __restrict__ tw, int lx) {
+    StageP<XwPlan<LEN>, 0, 1, INV, true>::run(v, j, line, tw, lx);
+}
+
 template <int LEN> struct XwCfg {
     static constexpr int E = 8;
     using PL = ZPlan<LEN, E>;
     static constexpr int P = LEN / E;                 // lanes per line (1..64)
     static constexpr int LPWV = 64 / P;               // lines per wave
-    static constexpr int TPB = 256;
+    // (OFDFT_XW_TPB512=1: 8 waves per workgroup where a line takes a whole wave, LEN = 512, so that a workgroup covers whole
+    // 128-byte lines like the 256-point kernel does -- measured neutral at 512^3, 6.10 vs 6.20 ms for the WGC99 pair: the
+    // 512-point kernel's 1.5 x cost per point is the one-line-per-wave access shape itself, 16 useful bytes per cache line and
+    // load instruction; xpass_impl.h therefore hands 512-point lines to the group-parallel kernel)
+#ifndef OFDFT_XW_TPB512
+#define OFDFT_XW_TPB512 0
+#endif
+    static constexpr int TPB = (P == 64 && OFDFT_XW_TPB512) ? 512 : 256;
     static constexpr int LPB = LPWV * (TPB / 64);     // lines per workgroup
-    static constexpr int RS = LineBuf<LEN>::STRIDE;   // LDS reals per line buffer
+    static constexpr int RS = XwSwz<LEN>::RS;         // LDS reals per line buffer
     static constexpr int ROWS = LPB * RS;
     static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * LEN;     // line buffers + the staged twiddle table
 };
@@ -73,7 +117,7 @@ __device__ __forceinline__ void xw_outputs(cplx (&out)[NOUT], const cplx (&in)[N
 #endif
 
 template <int LEN, int NIN, int NOUT, class Mix>
-__global__ __launch_bounds__(256, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw_kernel(XfIo io, LineMap m_main, LineMap m_rem,
+__global__ __launch_bounds__(XwCfg<LEN>::TPB, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw_kernel(XfIo io, LineMap m_main, LineMap m_rem,
                                                                                      int main_blocks, SpecGeom g,
                                                                                      const cplx* __restrict__ tw_g, Mix mix,
                                                                                      XfStride xs) {
@@ -150,9 +194,10 @@ __global__ __launch_bounds__(256, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw
     }
     __syncthreads();
     real* mine = lds + (wave * LPWV + l) * Cfg::RS;
+    const int lx = (l * XwSwz<LEN>::LMUL) & 31;       // line-dependent part of the LDS swizzle
     static_for<NIN>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        wave_line_fft<LEN, E, false>(a[I], j, mine, tw);
+        xw_line_fft<LEN, false>(a[I], j, mine, tw, lx);
         exchange_sync<true>();
     });
     // ---- mix, in registers: the lane owns k-points x = j + P q of its line in every spectrum
@@ -168,7 +213,7 @@ __global__ __launch_bounds__(256, (NIN + NOUT > 3 ? OFDFT_XW_WAVES : 3)) void xw
     }
     static_for<NOUT>([&](auto oc) {
         constexpr int O = decltype(oc)::value;
-        wave_line_fft<LEN, E, true>(a[O], j, mine, tw);
+        xw_line_fft<LEN, true>(a[O], j, mine, tw, lx);
         exchange_sync<true>();
         if (valid) {
             cplx* ub = io.out[O] + b0;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-kernel-class time per grid point for non-cubic shapes (which axis makes a pass slow?): cfg3 closure, streams serialised.
+usage: python tools/shape_probe.py 256x256x256 512x256x256 ...   -> one JSON line per shape"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from professad_amd.engine import Engine  # noqa: E402
+
+CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c']
+for arg in sys.argv[1:]:
+    shape = tuple(int(x) for x in arg.split('x'))
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(1)
+    chi = (0.17 * (1.0 + 0.2 * torch.rand(shape, generator=g, dtype=torch.double))).sqrt().to(dev)
+    vext = (0.1 * torch.rand(shape, generator=g, dtype=torch.double)).to(dev)
+    box = np.diag([7.65 * s / 32.0 for s in shape])
+    nel = float(0.17 * 1.1 * np.prod(np.diag(box)))
+    eng = Engine(shape, dev).set_cell(torch.as_tensor(box)).set_terms(CFG3)
+    for _ in range(3):
+        eng.energy_grad_chi(chi, nel, vext)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.energy_grad_chi(chi, nel, vext)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    eng.set_option(1, 0)
+    eng.set_profiling(True)
+    for _ in range(3):
+        eng.energy_grad_chi(chi, nel, vext)
+    prof = eng.profile()
+    npts = float(np.prod(shape))
+    print(json.dumps({'shape': shape, 'ms': round(ms, 3), 'ns_per_point': round(ms * 1e6 / npts, 4),
+                      'ps_per_point': {k: round(v[0] / 3 * 1e9 / npts, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}), flush=True)
+    eng.close()
+    del chi, vext
