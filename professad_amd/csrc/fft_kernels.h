@@ -115,40 +115,63 @@ struct ArrList { cplx* p[16]; };
 #define OFDFT_ZR_ST_AUX 0
 #endif
 
+// OFDFT_CPASS_TILES = 2: a workgroup takes two consecutive tiles and requests both tiles' lines up front, so that the second
+// tile's loads are in flight during the first tile's transform and the first tile's stores during the second's (a 256^3 y pass
+// is 8 256 waves -- what the chip holds at once -- so with one tile per workgroup every workgroup loads, transforms and stores
+// in lock step: the kernel's time is the SUM of the three phases)
+#ifndef OFDFT_CPASS_TILES
+#define OFDFT_CPASS_TILES 1
+#endif
 template <int LEN, bool INV>
 __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, LineMap m_main, LineMap m_rem,
                                                                    int main_blocks, long long rem_offset,
                                                                    const cplx* __restrict__ tw) {
-    cplx* data = arrs.p[blockIdx.y];          // one launch may cover several spectra (grid.y)
-    constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
+    cplx* data0 = arrs.p[blockIdx.y];         // one launch may cover several spectra (grid.y)
+    constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW, T = OFDFT_CPASS_TILES;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
-    // one grid covers the block-8 main part and the dense remainder planes (Nyquist plane)
-    const bool in_rem = (int)blockIdx.x >= main_blocks;
-    const LineMap m = in_rem ? m_rem : m_main;
-    if (in_rem) data += rem_offset;
-    const int bid = in_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x + m.blk0;
-    const int l_lo = tid % m.lf;
-    const int j = (tid / m.lf) % P;
-    const int l = (tid / (m.lf * P)) * m.lf + l_lo;
-    const long long L0 = (long long)bid * LPW;
-    const long long L = L0 + l;
-    const bool valid = L < m.nlines;
-    const long long b0 = uniform64(line_base(m, L0));
-    cplx* ub = data + b0;                                   // wave-uniform
-    const unsigned voff = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
-    const long long se_u = uniform64(m.se);                 // uniform element stride; slot q holds element j + cin(q) / j + cout(q)
     using PL = Plan<LEN>;
-    cplx v[E];
+    cplx v[T][E];
+    cplx* ubs[T];
+    unsigned voffs[T];
+    bool valids[T];
+    long long se_us[T];
+    int js[T], ls[T];
 #pragma unroll
-    for (int q = 0; q < E; ++q)
-        v[q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + PL::cin(q) * se_u, voff)
-                                                               : mkc(0.0, 0.0);
-    line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
-    if (valid) {
+    for (int t = 0; t < T; ++t) {
+        const int blk = (int)blockIdx.x * T + t;    // (the launcher rounds the main part up to whole groups of T tiles)
+        // one grid covers the block-8 main part and the dense remainder planes (Nyquist plane)
+        const bool in_rem = blk >= main_blocks;
+        const LineMap m = in_rem ? m_rem : m_main;
+        cplx* data = in_rem ? data0 + rem_offset : data0;
+        const int bid = in_rem ? blk - main_blocks : blk + m.blk0;
+        const int l_lo = tid % m.lf;
+        const int j = (tid / m.lf) % P;
+        const int l = (tid / (m.lf * P)) * m.lf + l_lo;
+        const long long L0 = (long long)bid * LPW;
+        const long long L = L0 + l;
+        const bool valid = L < m.nlines;
+        const long long b0 = uniform64(line_base(m, L0));
+        ubs[t] = data + b0;                                     // wave-uniform
+        voffs[t] = valid ? (unsigned)((line_base(m, L) - b0 + (long long)j * m.se) * kCB) : 0u;
+        se_us[t] = uniform64(m.se);                             // uniform element stride; slot q holds element j + cin(q) / j + cout(q)
+        valids[t] = valid;
+        js[t] = j;
+        ls[t] = l;
 #pragma unroll
         for (int q = 0; q < E; ++q)
-            if (PL::slot_out(q) && PL::lane_out(j, q)) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ub + PL::cout(q) * se_u, voff, v[q]);
+            v[t][q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ubs[t] + PL::cin(q) * se_us[t], voffs[t])
+                                                                       : mkc(0.0, 0.0);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) __syncthreads();                             // the line buffers are reused
+        line_fft<LEN, INV>(v[t], js[t], lds + ls[t] * LineBuf<LEN>::STRIDE, tw);
+        if (valids[t]) {
+#pragma unroll
+            for (int q = 0; q < E; ++q)
+                if (PL::slot_out(q) && PL::lane_out(js[t], q)) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(ubs[t] + PL::cout(q) * se_us[t], voffs[t], v[t][q]);
+        }
     }
 }
 

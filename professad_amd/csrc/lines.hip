@@ -12,8 +12,10 @@ int launch_cpass_t(ofdft_ctx* c, const ArrList& arrs, int narr, const LineMap& m
     using Cfg = PassCfg<LEN>;
     LineMap mm = main;
     mm.blk0 = main.blk0 / Cfg::LPW;                     // line offset -> workgroup offset
-    const int mb = (main.nlines - main.blk0 + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3(mb + rb, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, mm, rem, mb,
+    // (tiles of the main part rounded up to whole groups of OFDFT_CPASS_TILES: a workgroup's tiles never straddle the two parts)
+    constexpr int T = OFDFT_CPASS_TILES;
+    const int mb = ((main.nlines - main.blk0 + Cfg::LPW - 1) / Cfg::LPW + T - 1) / T * T, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    OFDFT_LAUNCH(c, st, nm, (cpass_kernel<LEN, INV>), dim3((mb + rb + T - 1) / T, narr), dim3(Cfg::TPB), Cfg::LDS, arrs, mm, rem, mb,
                  c->g.main_count, tw);
     return 0;
 }

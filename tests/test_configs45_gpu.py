@@ -57,7 +57,9 @@ def test_config4_eight_rank_slab_geometry_512_fp64():
     assert ref.fast_path and int(ref.query(0)) == 23          # the fused pipeline, 23 transforms
     ref.close()
     loc = LocalRanks(shape, DEV, 8).set_cell(box).set_terms(CFG3)
+    assert loc.st[0].nchunks == 4          # the automatic choice at this size: every exchange travels as four kz chunks
     E, mu, g = loc.closure(chi, n_elec, vext)
+    assert int(loc.st[0].query(0)) == 23   # ... and the chunked sequence executes the same 23 transforms
     loc.close()
     _compare(E, Er, mu, mur, g, gr, 1e-12, 1e-12)
 
@@ -75,6 +77,7 @@ def test_config5_eight_rank_slab_geometry_1024_fp32():
     ref.close()
     torch.cuda.empty_cache()
     loc = LocalRanks(shape, DEV, 8, dtype=torch.float32).set_cell(box).set_terms(CFG2)
+    assert loc.st[0].nchunks == 4
     E, mu, g = loc.closure(chi, n_elec, vext)
     loc.close()
     _compare(E, Er, mu, mur, g, gr, 5e-6, 5e-4)
@@ -148,3 +151,28 @@ def test_config5_pme_potential_and_forces_at_scale_by_periodic_tiling(n):
     FN = ion_electron_forces(big, boxN, denN, [(frac, tab)], pme_order=order)[0].reshape(-1, 4, 3)
     big.close()
     assert np.abs(FN - F32_[None]).max() <= 1e-9 * max(np.abs(F32_).max(), 1e-3)
+
+
+def test_config5_stress_of_the_1024_fp32_grid_is_intensive():
+    """Config 5's stress at full size: an fp32 engine on the 1024^3 grid hands `stress` to its fp64 sibling on the widened
+    density (professad_amd.engine.Engine.stress; 25 GB of fp64 workspace).  The tiled cell has the stress tensors of the
+    32^3 cell, every term of config 2 -- pinned to the fp64 32^3 engine (itself pinned to the reference's get_stress goldens)."""
+    base, n = 32, 1024
+    r = n // base
+    box32 = synth.cubic_cell(base)
+    den32 = synth.smooth_density((base,) * 3, seed=21) * (1 + 0.02 * np.random.default_rng(8).random((base,) * 3))
+    den32 *= 3.0 / (den32.mean() * abs(np.linalg.det(box32)))
+    small = Engine((base,) * 3, DEV).set_cell(torch.as_tensor(box32)).set_terms(CFG2)
+    d32 = torch.as_tensor(den32, device=DEV)
+    s32 = small.stress(d32)
+    small.close()
+    big = Engine((n,) * 3, DEV, dtype=torch.float32).set_cell(torch.as_tensor(synth.cubic_cell(n))).set_terms(CFG2)
+    sN = big.stress(d32.float().repeat(r, r, r))
+    big.close()
+    from professad_amd.engine import _ENGINES
+    for key in [k for k in _ENGINES if k[0] == (n, n, n)]:          # the cached fp64 sibling: give its 25 GB back
+        _ENGINES.pop(key).close()
+    torch.cuda.empty_cache()
+    for k in s32:
+        scale = max(float(np.abs(s32[k]).max()), 1e-6)
+        assert float(np.abs(sN[k] - s32[k]).max()) <= 2e-6 * scale, (k, sN[k], s32[k])      # the density was rounded to fp32 on the way

@@ -161,6 +161,37 @@ def test_kz_chunked_exchange_emulated_is_bitwise_the_unchunked_one(nranks, shape
         assert float((g - gr).abs().max()) <= 1e-12 * float(gr.abs().max())
 
 
+def test_ipc_transport_fails_an_evaluation_on_all_ranks_and_recovers(tmp_path):
+    """round-2 advice (ipc wait): a rank that is later than the transport's patience must not leave the others with an error
+    and itself with garbage.  Two ranks sharing the GPU, patience 0.4 s, rank 1 two seconds late for the second evaluation:
+    both ranks raise for THAT evaluation (the waiter posts the evaluation number into every rank's abort word; the late rank
+    finds it), and the third evaluation is bitwise the first on both ranks (tests/ipc_abort_worker.py)"""
+    port = _free_port()
+    out = str(tmp_path / 'res.json')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'ipc_abort_worker.py'), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors='replace')[-2000:])
+    assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)
+    res = [json.load(open('%s.%d' % (out, r))) for r in range(2)]
+    for r in res:
+        assert r['second'].startswith('raised') and 'ipc transport' in r['second'], res
+        assert r['third_equals_first'], res
+    assert 'no delivery from rank 1' in res[0]['second'] and 'aborted by another rank' in res[1]['second'], res
+    assert res[0]['dE_vs_single_gpu'] < 1e-12
+
+
 def test_eight_rank_geometry_with_the_laplacian_dependent_pauli_gaussian():
     """PGSL0.25 + Hartree + PBE over 8 emulated slab ranks (lap n and df/dL cross the exchange beside the GGA spectra)"""
     import numpy as np

@@ -340,6 +340,14 @@ def test_density_optimisation_reaches_reference_ground_state(optimizer):
     # step trajectory amplifies round-off by ~50x per inner iteration; both optimisers walk identical rows on the same closure.
     # The optimiser's own semantics are pinned row by row on the CPU, with the oracle closure (tests/test_optimizer_cpu.py).
     assert abs(res['history'][1][1] - 65.989145) < 5e-3
+    # ... with the STAGED closure (the bench's pipeline; persistent kernel off) row 2 lands within 1.7e-4 eV of the reference's
+    # log: pinned at 5e-4 (round-2 verdict, item 9)
+    from professad_amd import _native as N
+    eng.set_option(N.OPT_RESIDENT, 0)
+    res2 = optimize_density(eng, n_elec, dev(vext), volume=abs(np.linalg.det(box)), optimizer=optimizer)
+    assert res2['converged'] and abs(res2['iterations'] - 17) <= 3 and abs(res2['E_Ha'] - float(d['E_Ha'])) < 2e-8
+    assert abs(res2['history'][0][1] - 68.191536) < 1e-6
+    assert abs(res2['history'][1][1] - 65.989145) < 5e-4, res2['history'][1]
     eng.close()
 
 
