@@ -306,8 +306,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
                                      together ~8 microseconds of a ~45-microsecond call; 1: events + stream wait as everywhere else; 0: off */
 #define OFDFT_OPT_XCHG_CHUNKS 12  /* slab-decomposed contexts: the exchange buffers (and the k-point tables laid out like them) are cut into this many
                                      ranges of kz blocks, chunk-major, so that ofdft_dist_step / ofdft_dist_closure move chunk k across the fabric
-                                     while chunk k + 1 is in its y pass and chunk k - 1 in its x pass.  0 (default): automatic -- up to 4
-                                     chunks of >= 4 kz blocks when the slab extents n0 / P and n1 / P are multiples of 32, else 1; 1: off.  Every
+                                     while chunk k + 1 is in its y pass and chunk k - 1 in its x pass.  0 (default): automatic -- 4 chunks
+                                     from 8 M points per rank, 2 from 1 M, else 1 (and only when the slab extents n0 / P and n1 / P are multiples
+                                     of 32, with >= 4 kz blocks per chunk); 1: off.  Every
                                      rank must use the same value; the ipc transport needs a new ofdft_ipc_export / attach round after a change. */
 #define OFDFT_OPT_YBATCH 14       /* 1 (default): the y passes of the three spectra of each WGC99 half run as one launch (grid.y = 3); 0: three launches */
 #define OFDFT_OPT_IPC_WAIT_MS 13  /* ipc transport: how long a delivery wait of ofdft_dist_closure stays patient before it aborts the evaluation ON ALL

@@ -253,11 +253,18 @@ inline XcView xc_view(const ofdft_ctx* c, int k) {
     return v;
 }
 // effective chunk count for a request (0 = automatic): a chunk must be whole workgroups of the y pass (nxl * 8 lines per kz
-// block) and of the fused x passes (nyl * 8 lines per block), whose tiles are at most 256 lines -> nxl, nyl multiples of 32;
-// automatic: up to 4 chunks of at least 4 kz blocks each (smaller messages are latency-bound)
+// block) and of the fused x passes (nyl * 8 lines per block), whose tiles are at most 256 lines -> nxl, nyl multiples of 32.
+// Automatic: by the size of the rank's slab -- every chunk costs its share of host work (a step call, two events, a scatter
+// or a collective, a wait: ~30 us through the library's own transport, more through Python + RCCL), which has to stay small
+// beside the chunk's kernels: 4 chunks from 8 M points per rank (512^3 on 8 ranks: 202-MB messages of the nonlocal chain),
+// 2 from 1 M (256^3 on 8), else 1; never fewer than 4 kz blocks per chunk.
 inline int xchg_chunks_for(const ofdft_ctx* c, int req) {
     if (c->nranks < 2 || c->xg.nb < 2 || c->xg.nxl % 32 || c->xg.nyl % 32) return 1;
-    int k = req > 0 ? req : std::min(4, c->xg.nb / 4);
+    int k = req;
+    if (k <= 0) {
+        k = c->npts >= (8LL << 20) ? 4 : (c->npts >= (1LL << 20) ? 2 : 1);
+        k = std::min(k, c->xg.nb / 4);
+    }
     k = std::max(1, std::min(k, std::min(16, c->xg.nb)));
     return k;
 }

@@ -66,7 +66,11 @@ template <int LEN> struct XwCfg {
 #ifndef OFDFT_XW_TPB512
 #define OFDFT_XW_TPB512 0
 #endif
+#ifdef OFDFT_XW_TPB
+    static constexpr int TPB = OFDFT_XW_TPB;          // (A/B: threads per workgroup for every length)
+#else
     static constexpr int TPB = (P == 64 && OFDFT_XW_TPB512) ? 512 : 256;
+#endif
     static constexpr int LPB = LPWV * (TPB / 64);     // lines per workgroup
     static constexpr int RS = XwSwz<LEN>::RS;         // LDS reals per line buffer
     static constexpr int ROWS = LPB * RS;

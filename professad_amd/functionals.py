@@ -57,7 +57,7 @@ class _NativeEnergy(torch.autograd.Function):
         eng = engine_for(den.shape, den.device)
         box_np, vol = _host_box(box_vecs)
         eng.set_cell(box_np)
-        eng.set_terms(term_names, dict(params))
+        eng.set_terms(term_names, params)          # (hashable tuples: memoised in the engine)
         need_box = box_vecs.requires_grad
         need_v = den.requires_grad or need_box
         E_terms, v = eng.energy_potential(den, v_ext, want_potential=need_v)
@@ -125,7 +125,7 @@ class NativeTerms:
         """dE/dn grid -- the reference's ``potentials=`` hook signature f(box_vecs, den) (system.py:849)."""
         eng = engine_for(den.shape, den.device)
         eng.set_cell(_host_box(box_vecs)[0])
-        eng.set_terms(self.names, dict(self.params))
+        eng.set_terms(self.names, self.params)
         self.last_energies, v = eng.energy_potential(den, v_ext if self.needs_vext else None)
         return v
 

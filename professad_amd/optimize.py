@@ -468,6 +468,10 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
     def closure():
         E_terms, mu, g = engine.energy_grad_chi(chi, n_elec, vext)
         state.update(E=sum(E_terms.values()), mu=mu, g=g, E_terms=E_terms)
+        if conv_target == 'euler':          # the Euler residual belongs to the density of THIS call (see below): keep its chi
+            if 'chi_c' not in state:
+                state['chi_c'] = torch.empty_like(chi)
+            state['chi_c'].copy_(chi)
         return state['E'], g
 
     if n_method == 'TPGD':          # system.py:823-824
@@ -496,12 +500,15 @@ def optimize_density(engine, n_elec, vext=None, chi0=None, ntol=1e-7, n_conv_con
         history.append((it, E, dE, dEdchi))
         if verbose:
             print('%5d %16.8f %12.4e %12.4e' % history[-1])
-        if conv_target == 'euler':            # max |mu - dE/dn| at the current density (system.py:377-412)
-            c2 = n_elec / (gsum(float((chi.double() * chi.double()).sum())) / npts_global * volume)
-            den_now = (c2 * chi * chi).to(dtype)
-            _, v_now = engine.energy_potential(den_now, vext)
-            mu_now = gsum(float((v_now.double() * den_now.double()).sum())) * dV / n_elec
-            stop = gmax(float((mu_now - v_now.double()).abs().max()))
+        if conv_target == 'euler':
+            # max |mu - dE/dn| (system.py:377-412) at the density of the step's LAST closure call -- the reference's System keeps
+            # that density (system.py:833-834) and check_density_convergence differentiates at it, not at the chi the optimiser
+            # moved to afterwards.  No extra evaluation: the closure's gradient is chi.grad = 2 c chi (dE/dn - mu) dV
+            # (system.py:850-853), so mu - dE/dn = -chi.grad / (2 c chi dV) wherever chi != 0.
+            chi_c = state['chi_c'].double()
+            c2 = n_elec / (gsum(float((chi_c * chi_c).sum())) / npts_global * volume)
+            res = torch.where(chi_c != 0, state['g'].double() / (2.0 * c2 * dV * chi_c), torch.zeros_like(chi_c))
+            stop = gmax(float(res.abs().max()))
         else:
             stop = abs(dE) if conv_target == 'dE' else dEdchi
         if it > 5:

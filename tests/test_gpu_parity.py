@@ -722,6 +722,12 @@ def test_optimisers_agree_and_convergence_measures_are_consistent():
     want = c * 2.0 * chi * (dEdn - mu2)
     assert abs(mu - mu2) < 1e-10 * abs(mu)
     assert abs(float(grad.abs().max()) / dV - float(want.abs().max())) <= 1e-10 * float(want.abs().max())
+    # conv_target='euler' (system.py:377-412,873-874): max |mu - dE/dn| at the density of the step's last closure call, formed
+    # from that call's gradient without another evaluation -- equals the direct evaluation at the same chi
+    resid = torch.where(chi != 0, grad / (2.0 * c * dV * chi), torch.zeros_like(chi))
+    assert abs(float(resid.abs().max()) - float((mu2 - dEdn).abs().max())) <= 1e-9 * float((mu2 - dEdn).abs().max())
+    r3 = optimize_density(eng, n_el, vext, volume=vol, ntol=2e-5, conv_target='euler')
+    assert r3['converged'] and abs(r3['E_Ha'] - r1['E_Ha']) * EV_PER_HA < 5e-4
     eng.close()
 
 
