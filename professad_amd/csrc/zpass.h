@@ -48,7 +48,17 @@ template <int M, int E_> struct ZW {
 
 // waves per SIMD the fused z kernels are compiled for: the power-of-two rows up to 512 keep 4 points per lane (two or three
 // waves); rows of 1024 (8 points) and rows with factors 3 / 5 (5..9 points per lane) need a whole SIMD's registers
-template <int M, int E> constexpr int z_waves(int want) { return (M >= 512 || E > 4) ? (want > 2 ? 2 : 1) : want; }
+// Round 3 (tools/shape_probe.py, A/B on one box): plans with 5 and 6 points per lane keep two waves without spilling -- the GGA
+// mid stage at 240^3 59 -> 39 ps per point, evaluation 3.23 -> 3.11 ms, 120^3 0.553 -> 0.526 ms; the GGA mid stage alone also
+// with 8 / 9 points (270^3: 53 -> 34 ps per point, evaluation 5.28 -> 5.12 ms), where the power and combine kernels spill
+// (zf_powers at 320^3 13.7 -> 27.5 ps per point) and keep one wave.
+#ifndef OFDFT_Z_EMAX
+#define OFDFT_Z_EMAX 6          // most points per lane that still get the kernel's wanted waves per SIMD
+#endif
+#ifndef OFDFT_Z_EMAX_PBE
+#define OFDFT_Z_EMAX_PBE 9      // ... for the GGA mid stage (zpbe2)
+#endif
+template <int M, int E, int EMAX = OFDFT_Z_EMAX> constexpr int z_waves(int want) { return (M >= 512 || E > EMAX) ? (want > 2 ? 2 : 1) : want; }
 
 // lane geometry of the z kernels
 template <int M, int E> struct ZLane {
@@ -574,7 +584,7 @@ struct Bmat { real b[9]; };
 // (lap n)^ = -k^2 n^ (x and y already back in real space); on exit the rows of the spectrum of df/d(lap n), whose
 // Laplacian joins the divergence in the next x pass (MixDerivAL).
 template <int M, int E, bool LAPL>
-__global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
+__global__ __launch_bounds__(256, (z_waves<M, E, OFDFT_Z_EMAX_PBE>(2))) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
                                                                       const real* __restrict__ dzn,
                                                                       real* __restrict__ dfdn, real inv_n, real inv_nz,
                                                                       GgaSel sel, Bmat bm, SpecGeom g,

@@ -57,7 +57,7 @@ CLASSES = [('cpass_kernel', 'cpass_y'), ('yderiv_kernel', 'yderiv'), ('ypass_xch
            ('sum_kernel', 'sum'), ('wgc_table_kernel', 'wgc_table'), ('reduce_partials_kernel', 'reduce'),
            ('closure_scale_kernel', 'reduce'), ('axpy_kernel', 'reduce'), ('resident_closure_kernel', 'resident'),
            ('ipc_scatter_kernel', 'ipc_scatter'), ('ipc_wait_kernel', 'ipc_sync'), ('ipc_stamp_kernel', 'ipc_sync'),
-           ('ipc_post_kernel', 'ipc_sync'), ('ipc_sum_kernel', 'ipc_sync'), ('xchg_unpack_kernel', 'xchg_unpack')]
+           ('ipc_post_kernel', 'ipc_sync'), ('ipc_sum_kernel', 'ipc_sync'), ('ipc_abort_check_kernel', 'ipc_sync'), ('xchg_unpack_kernel', 'xchg_unpack')]
 # not engine kernels: runtime copies, torch's own kernels in bench.py's copy-bandwidth probe
 FOREIGN = ('__amd_rocclr', 'at::native', 'elementwise_kernel', 'vectorized_elementwise')
 
