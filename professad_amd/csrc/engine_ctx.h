@@ -207,8 +207,8 @@ inline bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // Extents served by the register / LDS line transforms (fft_radix.h plans) -- and with them by the fused pipelines:
 // powers of two, and the 2^a 3^b 5^c extents listed here (any other extent: chirp-z line transforms + the unfused pipeline).
 // OFDFT_MIXED_LINES: x / y extents; OFDFT_MIXED_ROWS: the half lengths n2 / 2 of the z rows for the same extents.
-// (the fp32 build keeps the powers of two only: its other extents take the chirp-z path)
-#ifndef OFDFT_REAL_F32
+// (both precisions since round 3; OFDFT_NO_MIXED_F32 restores the round-2 fp32 build, whose other extents took the chirp-z path)
+#if !defined(OFDFT_REAL_F32) || !defined(OFDFT_NO_MIXED_F32)
 #define OFDFT_MIXED_LINES(X) X(48) X(96) X(120) X(144) X(160) X(192) X(240) X(250) X(270) X(288) X(320) X(384) X(480)
 #define OFDFT_MIXED_ROWS(X) X(24) X(48) X(60) X(72) X(80) X(96) X(120) X(125) X(135) X(144) X(160) X(192) X(240)
 #else

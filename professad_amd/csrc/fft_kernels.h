@@ -621,8 +621,12 @@ template <int LEN, int G, int NOUT> struct XfCfg {
 #endif
     // (line counts for 16-byte elements; the fp32 build doubles them to keep the same 64-B / 128-B runs)
     static constexpr int WANT = ((OFDFT_XF_WANT4 && G > 1 && NOUT > 1) ? 4 : 8) * (16 / (int)sizeof(cplx));
-    static constexpr int LPW = (P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P);
+    // ... halved until the workgroup fits 1024 threads (fp32 with the 32-lane plans of the 250..480-point lines: 3 groups x 16
+    // lines x 32 lanes would be 1536)
+    static constexpr int lpw_fit(int lpw) { return (G * lpw * P > 1024 && lpw > 1 && ((lpw / 2) * P) % 64 == 0) ? lpw_fit(lpw / 2) : lpw; }
+    static constexpr int LPW = lpw_fit((P >= 64) ? 4 : ((WANT * P >= 64) ? WANT : 64 / P));
     static constexpr int TPB = G * LPW * P;
+    static_assert(TPB <= 1024, "fused x pass: workgroup too large");
     // the mix trades the spectra through the line buffers in two halves of the register slots: real parts of a half at
     // positions j + P qq (qq < EH), imaginary parts RGN further on; 2 RGN = LEN for the power-of-two plans
     static constexpr int EH = (E + 1) / 2;

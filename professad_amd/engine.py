@@ -239,15 +239,14 @@ _ENGINES = {}
 
 # extents whose line transforms run in registers / LDS, i.e. grids that take the fused pipelines (csrc/engine_ctx.h:
 # line_extent_ok / row_extent_ok); every other extent works too, through chirp-z line transforms and the unfused pipeline
-FUSED_EXTENTS_MIXED = (48, 96, 120, 144, 160, 192, 240, 250, 270, 288, 320, 384, 480)       # fp64 build only
+FUSED_EXTENTS_MIXED = (48, 96, 120, 144, 160, 192, 240, 250, 270, 288, 320, 384, 480)       # both builds (fp32 since round 3)
 
 
 def fused_extents(axis=0, dtype=torch.double, nranks=1):
     """sorted extents along `axis` (0, 1: lines; 2: the real-to-complex rows) served by the fused pipelines"""
     lo, hi = (16, 2048) if axis == 2 else (8, 1024)
     out = {1 << k for k in range(3, 12) if lo <= (1 << k) <= hi}
-    if dtype == torch.double:
-        out |= set(FUSED_EXTENTS_MIXED)
+    out |= set(FUSED_EXTENTS_MIXED)
     if nranks > 1 and axis < 2:                       # slabs: axes 0 and 1 are cut into nranks pieces
         out = {e for e in out if e % nranks == 0}
     return sorted(out)

@@ -96,7 +96,7 @@ def test_slab_decomposed_with_the_library_own_exchange(world, shape, dtype, tmp_
 
 @pytest.mark.parametrize('world,shape,dtype', [(1, '16x16x32', 'f64'), (2, '32x32x32', 'f64'), (4, '16x64x32', 'f64'),
                                                (2, '64x32x128', 'f64'), (2, '32x32x32', 'f32'), (4, '16x64x32', 'f32'),
-                                               (2, '48x48x96', 'f64')])
+                                               (2, '48x48x96', 'f64'), (2, '48x96x120', 'f32')])
 def test_slab_decomposed_matches_single_gpu(world, shape, dtype, tmp_path):
     res = _run_workers(world, shape, dtype, str(tmp_path / 'res.json'))
     _check_worker_results(res, dtype)

@@ -38,7 +38,8 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize('shape', [(8, 8, 16), (16, 32, 64), (64, 64, 64), (256, 8, 32), (8, 1024, 16), (8, 8, 2048),
-                                   (128, 128, 128), (18, 20, 16), (5, 6, 7), (17, 17, 17)])
+                                   (128, 128, 128), (18, 20, 16), (5, 6, 7), (17, 17, 17),
+                                   (48, 96, 120), (144, 160, 192), (240, 250, 270), (288, 48, 320), (384, 96, 480), (96, 480, 144)])
 def test_rfftn_irfftn_match_numpy_f32(shape):
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
@@ -50,7 +51,8 @@ def test_rfftn_irfftn_match_numpy_f32(shape):
     yk = (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape)).astype(np.complex64)
     got_r = eng.irfftn(torch.as_tensor(yk, device=DEV)).cpu().numpy()
     assert relerr(got_r, np.fft.irfftn(yk.astype(np.complex128), s=shape, axes=(0, 1, 2))) < 2e-6
-    assert eng.fast_path == all((s & (s - 1)) == 0 for s in shape)
+    mixed = (48, 96, 120, 144, 160, 192, 240, 250, 270, 288, 320, 384, 480)          # mixed-radix plans: in the fp32 build since round 3
+    assert eng.fast_path == all((s & (s - 1)) == 0 or s in mixed for s in shape)
     with pytest.raises(TypeError):
         eng.rfftn(torch.zeros(shape, dtype=torch.double, device=DEV))       # an fp32 engine takes fp32 tensors only
     eng.close()
@@ -181,6 +183,41 @@ def test_f32_slab_decomposed_stages_match_single_engine(ranks):
     assert err < V_RTOL, err
     one.close()
     loc.close()
+
+
+@pytest.mark.parametrize('shape', [(48, 96, 120), (144, 160, 192), (240, 250, 270), (320, 384, 96), (250, 270, 240)])
+def test_f32_mixed_radix_extents_run_the_fused_pipelines(shape):
+    """round-2 verdict, missing 4: extents with factors 3 and 5 in the fp32 build.  The mixed-radix plans (fft_radix.h) now
+    compile for fp32 too: such grids take the z-fused pipeline instead of chirp-z + unfused.  Against the fp32 chirp-z path
+    (option 9 off: independent transforms and pipeline), the x-fused-only and unfused pipelines, and the fp64 engine."""
+    box = torch.as_tensor(cases.make_cell(('tri', shape[0] / 24.0)))
+    den = synth.random_density(shape, seed=71)
+    vext = synth.random_potential(shape, seed=72)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(73).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box.numpy()))) + 0.3)
+    e32 = Engine(shape, DEV, dtype=F32).set_cell(box)
+    e64 = Engine(shape, DEV).set_cell(box)
+    assert e32.fast_path and e64.fast_path
+    sets = [(F.NativeTerms(names).names, None) for names in _CFG_TERMS.values()]
+    sets.append((('hartree', 'vw', 'gga_k', 'pbe_x', 'pbe_c'), {'ggak_kind': 1.0, 'ggak_beta': 0.25, 'ggak_lambda': 0.4, 'ggak_sigma': 0.2}))
+    for names, params in sets:
+        e64.set_terms(names, params)
+        E64, mu64, g64 = e64.energy_grad_chi(torch.as_tensor(chi, device=DEV), n_elec, torch.as_tensor(vext, device=DEV))
+        e32.set_terms(names, params)
+        launches = {}
+        for key, (mixed, mode) in {'chirp': (0, 0), 'zf': (1, 0), 'xf': (1, 2), 'un': (1, 1)}.items():
+            e32.set_option(9, mixed).set_option(0, mode)
+            assert e32.fast_path == bool(mixed)
+            E, mu, g = e32.energy_grad_chi(dev32(chi), n_elec, dev32(vext))
+            launches[key] = int(e32.query(4))
+            for k in E64:
+                assert abs(E[k] - E64[k]) <= E_RTOL * max(abs(E64[k]), 1e-3), (names, key, k, E[k], E64[k])
+            assert abs(mu - mu64) < 5e-6 * max(1.0, abs(mu64)), (names, key)
+            assert relerr(g.cpu().numpy(), g64.cpu().numpy()) < V_RTOL, (names, key)
+        assert launches['zf'] < launches['un']             # the fused pipeline really ran
+        e32.set_option(9, 1).set_option(0, 0)
+    e32.close()
+    e64.close()
 
 
 @pytest.mark.parametrize('shape', [(64, 32, 128), (32, 32, 1024), (8, 64, 32)])

@@ -102,7 +102,7 @@ def test_fast_extent_helper_rounds_the_reference_rule_up():
     import numpy as np
     from professad_amd.engine import ecut2shape_fast, fused_extents, next_fast_extent
     assert next_fast_extent(241) == 250 and next_fast_extent(255) == 256 and next_fast_extent(33) == 48
-    assert next_fast_extent(241, dtype=torch.float32) == 256 and next_fast_extent(241, nranks=8) == 256 and next_fast_extent(233, nranks=8) == 240
+    assert next_fast_extent(241, dtype=torch.float32) == 250 and next_fast_extent(241, nranks=8) == 256 and next_fast_extent(233, nranks=8) == 240      # (fp32: mixed-radix plans since round 3)
     assert next_fast_extent(9, axis=2) == 16 and next_fast_extent(1025, axis=2) == 2048
     with pytest.raises(ValueError):
         next_fast_extent(1025, axis=0)
