@@ -48,12 +48,26 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
         }
     }
     const bool conj_in = b.inv != 0;      // inverse transform = conjugated chirps and filter
-    cplx v[E];
+    // Round 3: the kernel sat 60 % of its wave cycles waiting (profiles/r03_sq_chirpz_255.md): of its 30 loads per wave only 8
+    // fetch data -- chirp (twice), filter and the stage twiddles were requested one by one where they were used, each a
+    // dependent L2 round trip between barrier-separated phases.  Now every table value a lane needs is requested up front
+    // with its data (the chirp once: it serves the pre- AND the post-multiplication; M >= 2 N - 1 means only the lower half
+    // of the register slots ever holds data) and the M twiddles are staged in LDS behind the line buffers.
+    constexpr int EH = (E + 1) / 2;           // slots that can hold an element e = j + P q < N <= (M + 1) / 2
+    cplx v[E], wch[EH], fl[E];
+    cplx* tw_l = reinterpret_cast<cplx*>(lds + LPW * LineBuf<M>::STRIDE);
+    constexpr int TWC = (M + PassCfg<M>::TPB - 1) / PassCfg<M>::TPB;
+    cplx twr[TWC];
+#pragma unroll
+    for (int t = 0; t < TWC; ++t) {
+        const int i = tid + t * PassCfg<M>::TPB;
+        twr[t] = twM[i < M ? i : 0];
+    }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = j + P * q;
         cplx a = mkc(0.0, 0.0);
-        if (valid && e < N) {
+        if (q < EH && valid && e < N) {
             if (b.mode == 0) {
                 a = spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)];
             } else if (b.mode == 1) {
@@ -64,29 +78,51 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __rest
                 if (e >= g.nzc) a.y = -a.y;
                 if (e == 0 || (2 * e == N)) a.y = 0.0;
             }
-            cplx w = chirp[e];
-            if (conj_in) w.y = -w.y;
-            a = cmul(a, w);
         }
         v[q] = a;
     }
-    real* mine = lds + l * LineBuf<M>::STRIDE;
-    line_fft<M, false>(v, j, mine, twM);
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-        cplx f = filt[j + P * q];
-        if (conj_in) f.y = -f.y;
-        v[q] = cmul(v[q], f);
+    for (int q = 0; q < EH; ++q) {
+        const int e = j + P * q;
+        wch[q] = chirp[e < N ? e : 0];
+        if (conj_in) wch[q].y = -wch[q].y;
     }
-    __syncthreads();
-    line_fft<M, true>(v, j, mine, twM);
+    // (the filter values: up front for the short transforms; for M >= 256 the 2 E more registers cost more occupancy than the
+    // one round trip they save -- 255^3 11.4 -> 13.2 ms with them prefetched -- so there they are requested after the first FFT)
+    constexpr bool PREF = M <= 128;
+    if constexpr (PREF) {
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
+        for (int q = 0; q < E; ++q) {
+            fl[q] = filt[j + P * q];
+            if (conj_in) fl[q].y = -fl[q].y;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TWC; ++t) {
+        const int i = tid + t * PassCfg<M>::TPB;
+        if (i < M) tw_l[i] = twr[t];
+    }
+#pragma unroll
+    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);       // (slots without an element hold zero)
+    real* mine = lds + l * LineBuf<M>::STRIDE;
+    __syncthreads();                                               // the staged twiddles
+    line_fft<M, false>(v, j, mine, tw_l);
+    if constexpr (!PREF) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            fl[q] = filt[j + P * q];
+            if (conj_in) fl[q].y = -fl[q].y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], fl[q]);
+    __syncthreads();
+    line_fft<M, true>(v, j, mine, tw_l);
+#pragma unroll
+    for (int q = 0; q < EH; ++q) {
         const int e = j + P * q;
         if (!valid || e >= N) continue;
-        cplx w = chirp[e];
-        if (conj_in) w.y = -w.y;
-        const cplx r = cmul(v[q], w);
+        const cplx r = cmul(v[q], wch[q]);
         if (b.mode == 0) {
             spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)] = r;
         } else if (b.mode == 1) {

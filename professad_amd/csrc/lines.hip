@@ -270,7 +270,9 @@ int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const real* rin, real* rout, co
     if (int rc = get_twiddle(c, M, &tw)) return rc;
     using Cfg = PassCfg<M>;
     const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
-    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, spec, rin, rout, c->g, b,
+    // line buffers + the staged twiddle table (M = 8 has a one-stage plan and no line buffers: Cfg::LDS is 0 there)
+    const size_t lds = sizeof(real) * Cfg::LPW * LineBuf<M>::STRIDE + sizeof(cplx) * M;
+    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), lds, spec, rin, rout, c->g, b,
                  (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
     return 0;
 }
