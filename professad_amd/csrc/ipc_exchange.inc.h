@@ -109,6 +109,8 @@ __global__ void ipc_wait_kernel(const unsigned* flags, const unsigned* abort_wor
             return;
         }
     }
+    // system-scope acquire: what the peers stored before their stamps is what the kernels behind this one read
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 // end of an evaluation (after the last reduction, i.e. after every rank's last stamp): did anybody abort it?
 __global__ void ipc_abort_check_kernel(const unsigned* abort_word, unsigned eval_id, int* err) {
@@ -123,6 +125,9 @@ __global__ __launch_bounds__(256) void ipc_scatter_kernel(const u32x4* __restric
     u32x4* dst = reinterpret_cast<u32x4*>(recv.p[peer]) + (long long)me * vec_per_peer;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_peer; i += (long long)gridDim.x * blockDim.x)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    // system-scope release of this thread's stores: the stamp kernel behind this one tells another GPU that the data is there, and a
+    // kernel boundary between two kernels of one queue need not be more than an agent-scope fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 }
 // lane p: epoch -> word `word` of rank p's mailbox (system scope: another agent polls it)
 __global__ void ipc_stamp_kernel(IpcPeers mailbox, int P, int me, int word, unsigned epoch) {
