@@ -125,9 +125,10 @@ __global__ __launch_bounds__(256) void ipc_scatter_kernel(const u32x4* __restric
     u32x4* dst = reinterpret_cast<u32x4*>(recv.p[peer]) + (long long)me * vec_per_peer;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_peer; i += (long long)gridDim.x * blockDim.x)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
-    // system-scope release of this thread's stores: the stamp kernel behind this one tells another GPU that the data is there, and a
-    // kernel boundary between two kernels of one queue need not be more than an agent-scope fence
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    // (No fence here.  A system-scope release per thread was tried as insurance for the first run on separate GPUs: it is an L2
+    // write-back per wave on this multi-XCD part -- the scatter kernels ran 10 x longer and dragged the kernels beside them along,
+    // 5.1 -> 22.5 ms per evaluation for two ranks at 256^3.  The stores target the peer's fine-grained arena, which the local L2
+    // does not hold dirty; the kernel's completion orders them before the stamp kernel's system-scope store.)
 }
 // lane p: epoch -> word `word` of rank p's mailbox (system scope: another agent polls it)
 __global__ void ipc_stamp_kernel(IpcPeers mailbox, int P, int me, int word, unsigned epoch) {
