@@ -513,7 +513,18 @@ __device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, real* l
 // threads are lanes of one wave, so the exchanges need no barrier (extra stages only cost LDS traffic), and
 // the small register footprint leaves room for fused pointwise math.
 template <int LEN_, int E_> struct ZPlan;
-template <int LEN_> struct LdsLayout<ZPlan<LEN_, 4>> : LdsLayoutDefault { static constexpr bool SWIZZLE = OFDFT_LDS_SWIZZLE_Z != 0; };
+// (fp32, rows of 128 and 256 points: the b32 bank rules -- two 32-lane groups over 32 banks for reads AND writes -- leave the
+// i ^ 5b swizzle with 2-way write conflicts; i ^ ((i >> 2) & 31) is conflict-free in the enumeration (tools/lds_conflicts.py).
+// Measured (fp32, 256^3, two alternations): zi_combine 0.154 -> 0.141 ms, zi_wgc 0.140 -> 0.135, zf_powers 0.108 -> 0.103,
+// evaluation 1.69 -> 1.65 ms.  OFDFT_Z4_XOR_F32=0: the fp64 swizzle in the fp32 build too)
+#ifndef OFDFT_Z4_XOR_F32
+#define OFDFT_Z4_XOR_F32 1
+#endif
+template <int LEN_> struct LdsLayout<ZPlan<LEN_, 4>> : LdsLayoutDefault {
+    static constexpr bool XORF = OFDFT_Z4_XOR_F32 && sizeof(real) == 4 && LEN_ >= 128;
+    static constexpr bool SWIZZLE = OFDFT_LDS_SWIZZLE_Z != 0;
+    static constexpr int XS = XORF ? 2 : 0, XM = XORF ? 31 : 0, XMUL = XORF ? 1 : 0;
+};
 #define OFDFT_ZPLAN(LEN_, E_, NST_, R0_, R1_, R2_, R3_)                                              \
     template <> struct ZPlan<LEN_, E_> : PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_> {     \
         static_assert(PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::E == E_ && PlanBase<LEN_, LEN_ / E_, NST_, R0_, R1_, R2_, R3_>::EXACT, "plan"); \
