@@ -573,7 +573,10 @@ def main():
         working = [tr for tr, v in (transport_probe or {}).items() if not v.get('failed') and not v.get('disagrees_with_collective')]
         eng.close()
         del g
-        sc = scale_512_block(dist, device, backend, rank, world, tdtype, names, box, chi_full, vext_full, n_elec, E_tot, working)
+        try:
+            sc = scale_512_block(dist, device, backend, rank, world, tdtype, names, box, chi_full, vext_full, n_elec, E_tot, working)
+        except Exception as e:  # noqa: BLE001  (a failure every rank shares, e.g. memory: the 256^3 line above must survive it)
+            sc = {'error': repr(e)[:300]}
         if rank == 0:
             out['scale_512'] = sc
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
