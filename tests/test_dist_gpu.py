@@ -79,8 +79,10 @@ def test_slab_decomposed_over_rccl_matches_single_gpu(shape, dtype, tmp_path):
     Runs wherever the box has >= 2 GPUs (a one-GPU box cannot host two RCCL ranks)."""
     world = 2 if _gpu_count() < 4 else 4
     for transport in ('collective', 'ipc'):          # RCCL all-to-alls issued by the host; peer copies issued by the library
-        res = _run_workers(world, shape, dtype, str(tmp_path / ('res_%s.json' % transport)),
-                           {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_TEST_TRANSPORT': transport}, timeout=600)
+        env = {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_TEST_TRANSPORT': transport}
+        if shape == '64x64x64' and world == 2:       # ... and the kz-chunked exchange against the unchunked one on the same GPUs
+            env['OFDFT_TEST_XCHG_CHUNKS'] = '2'      # (256^3 runs chunked by the automatic choice)
+        res = _run_workers(world, shape, dtype, str(tmp_path / ('res_%s.json' % transport)), env, timeout=600)
         _check_worker_results(res, dtype)
 
 
