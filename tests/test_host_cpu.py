@@ -114,3 +114,30 @@ def test_fast_extent_helper_rounds_the_reference_rule_up():
     assert ref == want and all(r % 2 == 1 for r in ref)
     assert all(s_ >= r for s_, r in zip(shape, ref)) and shape[2] % 2 == 0
     assert all(s_ in fused_extents(i) for i, s_ in enumerate(shape))
+
+
+def test_lds_layout_table_of_the_wave_local_x_pass_is_a_conflict_free_permutation():
+    """csrc/xwave.h: XwSwz (XOR layout of the line buffers, per length and precision) against the enumeration in
+    tools/lds_conflicts.py: the header and the tool carry the same table, every entry is a permutation that stays inside its line
+    buffer, and under the bank rules of MI355X_MICROARCH.md every read and write group of every exchange costs one LDS cycle
+    (the padded layout it replaces: two) -- the model the 48.8 % -> 1.9 % conflict rate of profiles/r03_sq_counters.md confirmed"""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import lds_conflicts as lc
+    src = open(os.path.join(ROOT, 'professad_amd', 'csrc', 'xwave.h')).read()
+    f32_part, f64_part = src.split('#ifdef OFDFT_REAL_F32', 1)[1].split('#else', 1)
+    f64_part = f64_part.split('#endif', 1)[0]
+    pat = re.compile(r'XwSwz<(\d+)> \{ static constexpr int XS = (\d+), XM = (\d+), XMUL = (\d+), LMUL = (\d+), RS = (\d+); \}')
+    for prec, part in (('f32', f32_part), ('f64', f64_part)):
+        found = {int(m[0]): tuple(int(x) for x in m[1:]) for m in pat.findall(part)}
+        assert found == lc.TABLE[prec], (prec, found)
+        for LEN, (xs, xm, mul, lmul, RS) in found.items():
+            f = lc.xor_layout(xs, xm, mul)
+            for line in range(max(1, 64 // (LEN // 8))):
+                img = [f(i) ^ ((line * lmul) & 31) for i in range(LEN)]
+                assert len(set(img)) == LEN and max(img) < RS, (prec, LEN, line)
+            rd, wr = lc.conflicts(LEN, lc.PLANS[LEN], f, RS, prec == 'f32', lmul)
+            assert rd == 1.0 and wr == 1.0, (prec, LEN, rd, wr)
+            old = lc.conflicts(LEN, lc.PLANS[LEN], lambda i: i + (i >> 4), LEN + (LEN >> 4) + 2, prec == 'f32')
+            assert old[0] >= 2.0, (prec, LEN, old)
