@@ -33,4 +33,19 @@ for label, terms in (('ion_electron', ['ion_electron']), ('hartree', ['hartree']
         torch.cuda.synchronize()
         row['%s_%s_ms' % (label, 'resident' if mode else 'staged')] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
         eng.close()
+# the drop-in terms themselves, called the way the reference's System calls them (system.py:771): f(box_vecs, den) with box_vecs a
+# DEVICE tensor that System keeps for the whole optimisation -- and, for comparison, with a fresh box tensor per call (round 2's cost:
+# a device -> host copy of the lattice vectors, i.e. a stream synchronisation, per term call)
+from professad_amd import functionals as F  # noqa: E402
+box_dev = torch.as_tensor(synth.cubic_cell(n), device=dev)
+for label, fn in (('Hartree', F.Hartree), ('WangTeter', F.WangTeter), ('PerdewBurkeErnzerhof', F.PerdewBurkeErnzerhof)):
+    for fresh in (False, True):
+        for _ in range(5):
+            fn(box_dev, den)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            float(fn(box_dev.clone() if fresh else box_dev, den))          # (float(): System reads the energy, system.py:871)
+        torch.cuda.synchronize()
+        row['dropin_%s_%s_ms' % (label, 'fresh_box' if fresh else 'same_box')] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
 print(json.dumps(row))
