@@ -46,7 +46,25 @@ class LocalRanks:
             s.set_xchg_chunks(n)
         return self
 
+    legacy_stage_api = False      # True: sequence with ofdft_dist_stage (whole stages; one chunk only) instead of ofdft_dist_step
+
+    def _stages_legacy(self):
+        P = self.P
+        for k in (1, 2, 3, 4):
+            for chain in (0, 1):
+                ex = [self._timed(r, s.stage, k, chain) for r, s in enumerate(self.st)]
+                if ex[0] is None:
+                    continue
+                self.exchanged_bytes += sum(e[0].numel() for e in ex)
+                for r in range(P):
+                    rc = ex[r][1].chunk(P)
+                    for p in range(P):
+                        rc[p].copy_(ex[p][0].chunk(P)[r])
+        return sum(self._timed(r, s.finish) for r, s in enumerate(self.st))
+
     def _stages(self):
+        if self.legacy_stage_api:
+            return self._stages_legacy()
         P = self.P
         K = self.st[0].nchunks
         for step in (1, 2, 3, 4, 5, 6):

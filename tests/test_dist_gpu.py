@@ -194,6 +194,41 @@ def test_ipc_transport_fails_an_evaluation_on_all_ranks_and_recovers(tmp_path):
     assert res[0]['dE_vs_single_gpu'] < 1e-12
 
 
+def test_whole_stage_entry_point_equals_the_step_sequence():
+    """ofdft_dist_stage (the one-chunk, whole-stage form of the ABI) against ofdft_dist_step on the same emulated ranks: identical
+    numbers; and it refuses a context whose exchange is cut into chunks"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    import cases
+    from local_ranks import LocalRanks
+    from professad_amd import synth
+    from professad_amd.functionals import NativeTerms
+    dev = torch.device('cuda:0')
+    shape = (64, 64, 32)
+    box = torch.as_tensor(cases.make_cell(('tri', 4.0)))
+    den = synth.random_density(shape, seed=41)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.double, device=dev)  # noqa: E731
+    chi, vext = t(np.sqrt(den)), t(synth.random_potential(shape, seed=42))
+    names = NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe']).names
+    out = {}
+    for legacy in (False, True):
+        loc = LocalRanks(shape, dev, 2).set_cell(box).set_terms(names).set_xchg_chunks(1)
+        loc.legacy_stage_api = legacy
+        out[legacy] = loc.closure(chi, 7.3, vext)
+        out[(legacy, 2)] = loc.closure(chi * 1.02, 7.3, vext)
+        loc.close()
+    for key in (False, (False, 2)):
+        a, b = out[key], out[True if key is False else (True, 2)]
+        assert all(a[0][k] == b[0][k] for k in a[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+    loc = LocalRanks(shape, dev, 2).set_cell(box).set_terms(names).set_xchg_chunks(2)
+    assert loc.st[0].nchunks == 2
+    loc.legacy_stage_api = True
+    with pytest.raises(RuntimeError, match='ofdft_dist_step'):
+        loc.closure(chi, 7.3, vext)
+    loc.close()
+
+
 def test_eight_rank_geometry_with_the_laplacian_dependent_pauli_gaussian():
     """PGSL0.25 + Hartree + PBE over 8 emulated slab ranks (lap n and df/dL cross the exchange beside the GGA spectra)"""
     import numpy as np
