@@ -18,15 +18,33 @@ struct BsArgs {
     real scale;
 };
 
+// one launch may cover several arrays (blockIdx.y): the unfused pipeline transforms its spectra in groups of three (gradient,
+// flux, the WGC99 triples) and small grids are bound by their launch count, not by bytes
+constexpr int kBsBatch = 4;
+struct BsIo {
+    cplx* spec[kBsBatch];
+    const real* rin[kBsBatch];
+    real* rout[kBsBatch];
+};
+
 template <int M>
-__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(cplx* __restrict__ spec, const real* __restrict__ rin,
-                                                                    real* __restrict__ rout, SpecGeom g, BsArgs b,
+__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
                                                                     const cplx* __restrict__ chirp,   // w_n, n < N
                                                                     const cplx* __restrict__ filt,    // FFT_M(b) / M
                                                                     const cplx* __restrict__ twM) {
     constexpr int P = PassCfg<M>::P, E = PassCfg<M>::E, LPW = PassCfg<M>::LPW;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
+    cplx* __restrict__ spec = io.spec[0];
+    const real* __restrict__ rin = io.rin[0];
+    real* __restrict__ rout = io.rout[0];
+#pragma unroll
+    for (int a = 1; a < kBsBatch; ++a)          // (select without dynamic indexing into the kernel arguments)
+        if ((int)blockIdx.y == a) {
+            spec = io.spec[a];
+            rin = io.rin[a];
+            rout = io.rout[a];
+        }
     // complex lines (mode 0): consecutive lanes take consecutive LINES, enumerated kz-fastest, so that a wave's accesses
     // for one element index fall on the 8 x 16-B runs of the block-8 layout; z rows (modes 1, 2): consecutive lanes take
     // consecutive elements of one contiguous row

@@ -418,9 +418,11 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             if (int rc = real_ws(c, "dfdn", &dfdn)) return rc;
             if (int rc = real_ws(c, "div", &dv)) return rc;
             OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
-            if (int rc = irfftn_internal(c, s1, gx, inv_n, st)) return rc;
-            if (int rc = irfftn_internal(c, s2, gy, inv_n, st)) return rc;
-            if (int rc = irfftn_internal(c, s3, gz, inv_n, st)) return rc;
+            {       // the three components in one batch (one launch per pass on the chirp-z path)
+                cplx* sg[3] = {s1, s2, s3};
+                real* rg[3] = {gx, gy, gz};
+                if (int rc = irfftn_internal_multi(c, sg, rg, 3, inv_n, st)) return rc;
+            }
             const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
             real* lapn = nullptr;
             cplx* s4 = nullptr;
@@ -433,9 +435,11 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
                                gga_sel(c), c->d_partial, lapn);
             if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
-            if (int rc = rfftn_internal(c, gx, s1, st)) return rc;
-            if (int rc = rfftn_internal(c, gy, s2, st)) return rc;
-            if (int rc = rfftn_internal(c, gz, s3, st)) return rc;
+            {
+                cplx* sg[3] = {s1, s2, s3};
+                const real* rg[3] = {gx, gy, gz};
+                if (int rc = rfftn_internal_multi(c, rg, sg, 3, st)) return rc;
+            }
             OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
             if (lapn) {      // v += lap(df/dL): the combine forms v += df/dn - 2 div, so div -= lap(df/dL) / 2, i.e. s0 += k^2 (df/dL)^ / 2
                 if (int rc = rfftn_internal(c, lapn, s4, st)) return rc;
@@ -504,13 +508,11 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         for (int pass = 0; pass < 2; ++pass) {
             OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
                                nref);
-            if (int rc = rfftn_internal(c, t0, s0, st)) return rc;
-            if (int rc = rfftn_internal(c, t1, s1, st)) return rc;
-            if (int rc = rfftn_internal(c, t2, s2, st)) return rc;
+            cplx* sw[3] = {s0, s1, s2};
+            const real* tw3[3] = {t0, t1, t2};
+            if (int rc = rfftn_internal_multi(c, tw3, sw, 3, st)) return rc;
             OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, w0, K1, K2, K3, c->g.total);
-            if (int rc = irfftn_internal(c, s0, o[3 * pass + 0], inv_n, st)) return rc;
-            if (int rc = irfftn_internal(c, s1, o[3 * pass + 1], inv_n, st)) return rc;
-            if (int rc = irfftn_internal(c, s2, o[3 * pass + 2], inv_n, st)) return rc;
+            if (int rc = irfftn_internal_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
         }
         ca.u0 = o[0]; ca.u1 = o[1]; ca.u2 = o[2];
         ca.gA = o[3]; ca.gB = o[4]; ca.gC = o[5];

@@ -296,6 +296,8 @@ template <bool INV> int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipSt
 template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st, int xk = -1);
 int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st);
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
+int rfftn_internal_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st);
+int irfftn_internal_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st);
 int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
 int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
 int inv_yz(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);

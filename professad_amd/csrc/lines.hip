@@ -264,22 +264,20 @@ int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
 }
 
 template <int M>
-int launch_bluestein_t(ofdft_ctx* c, cplx* spec, const real* rin, real* rout, const BsArgs& b, const BsTables& t,
-                       hipStream_t st) {
+int launch_bluestein_t(ofdft_ctx* c, const BsIo& io, int narr, const BsArgs& b, const BsTables& t, hipStream_t st) {
     cplx* tw;
     if (int rc = get_twiddle(c, M, &tw)) return rc;
     using Cfg = PassCfg<M>;
     const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
     // line buffers + the staged twiddle table (M = 8 has a one-stage plan and no line buffers: Cfg::LDS is 0 there)
     const size_t lds = sizeof(real) * Cfg::LPW * LineBuf<M>::STRIDE + sizeof(cplx) * M;
-    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks), dim3(Cfg::TPB), lds, spec, rin, rout, c->g, b,
+    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks, narr), dim3(Cfg::TPB), lds, io, c->g, b,
                  (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
     return 0;
 }
 
-// one generic-length pass: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
-int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const real* rin, real* rout, double scale,
-                   hipStream_t st) {
+// one generic-length pass over `narr` (<= kBsBatch) arrays: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)
+int bluestein_pass_multi(ofdft_ctx* c, int mode, int axis, int inv, const BsIo& io, int narr, double scale, hipStream_t st) {
     const int N = mode == 0 ? (axis == 0 ? c->n0 : c->n1) : c->n2;
     BsTables t;
     if (int rc = get_bluestein(c, N, &t)) return rc;
@@ -291,19 +289,29 @@ int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const 
     b.scale = scale;
     b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : c->g.nrows;
     switch (t.M) {
-        case 8: return launch_bluestein_t<8>(c, spec, rin, rout, b, t, st);
-        case 16: return launch_bluestein_t<16>(c, spec, rin, rout, b, t, st);
-        case 32: return launch_bluestein_t<32>(c, spec, rin, rout, b, t, st);
-        case 64: return launch_bluestein_t<64>(c, spec, rin, rout, b, t, st);
-        case 128: return launch_bluestein_t<128>(c, spec, rin, rout, b, t, st);
-        case 256: return launch_bluestein_t<256>(c, spec, rin, rout, b, t, st);
-        case 512: return launch_bluestein_t<512>(c, spec, rin, rout, b, t, st);
-        case 1024: return launch_bluestein_t<1024>(c, spec, rin, rout, b, t, st);
+        case 8: return launch_bluestein_t<8>(c, io, narr, b, t, st);
+        case 16: return launch_bluestein_t<16>(c, io, narr, b, t, st);
+        case 32: return launch_bluestein_t<32>(c, io, narr, b, t, st);
+        case 64: return launch_bluestein_t<64>(c, io, narr, b, t, st);
+        case 128: return launch_bluestein_t<128>(c, io, narr, b, t, st);
+        case 256: return launch_bluestein_t<256>(c, io, narr, b, t, st);
+        case 512: return launch_bluestein_t<512>(c, io, narr, b, t, st);
+        case 1024: return launch_bluestein_t<1024>(c, io, narr, b, t, st);
     }
     return fail(c, OFDFT_EINVAL, "no Bluestein plan for length %d", N);
 }
 
+int bluestein_pass(ofdft_ctx* c, int mode, int axis, int inv, cplx* spec, const real* rin, real* rout, double scale,
+                   hipStream_t st) {
+    BsIo io{};
+    io.spec[0] = spec;
+    io.rin[0] = rin;
+    io.rout[0] = rout;
+    return bluestein_pass_multi(c, mode, axis, inv, io, 1, scale, st);
+}
+
 bool bluestein_ok(const ofdft_ctx* c) { return c->use_bluestein && c->n0 <= 512 && c->n1 <= 512 && c->n2 <= 512; }
+static bool bluestein_ok_fwd(const ofdft_ctx* c) { return bluestein_ok(c); }
 
 // ---- slab-decomposed 3-D transforms for the per-geometry-step routines (stress, ionic potential, forces): a real x-slab
 // [n0/P][n1][n2] <-> the y-slab of the half spectrum in the block-8 layout of the x-pass geometry (c->gx: all of x, n1/P of
@@ -324,6 +332,43 @@ static __global__ void xchg_unpack_kernel(const cplx* __restrict__ buf, cplx* __
 }
 static int dist_rfftn(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
 static int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
+
+static bool bluestein_ok_fwd(const ofdft_ctx* c);
+// `n` (<= kBsBatch) transforms at once: on the chirp-z path every pass covers all of them in ONE launch (small odd grids -- the
+// reference's ecut2shape gives 30..100 points per axis -- are bound by their launch count: 69 chirp-z launches for the bench's
+// term set); every other path transforms them one by one
+int rfftn_internal_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st) {
+    if (n > 1 && n <= kBsBatch && c->nranks == 1 && !c->fast && bluestein_ok_fwd(c)) {
+        BsIo io{};
+        for (int a = 0; a < n; ++a) {
+            io.spec[a] = spec[a];
+            io.rin[a] = in[a];
+        }
+        c->fft_count += n;
+        if (int rc = bluestein_pass_multi(c, 1, 2, 0, io, n, 1.0, st)) return rc;
+        if (int rc = bluestein_pass_multi(c, 0, 1, 0, io, n, 1.0, st)) return rc;
+        return bluestein_pass_multi(c, 0, 0, 0, io, n, 1.0, st);
+    }
+    for (int a = 0; a < n; ++a)
+        if (int rc = rfftn_internal(c, in[a], spec[a], st)) return rc;
+    return 0;
+}
+int irfftn_internal_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st) {
+    if (n > 1 && n <= kBsBatch && c->nranks == 1 && !c->fast && bluestein_ok_fwd(c)) {
+        BsIo io{};
+        for (int a = 0; a < n; ++a) {
+            io.spec[a] = spec[a];
+            io.rout[a] = out[a];
+        }
+        c->fft_count += n;
+        if (int rc = bluestein_pass_multi(c, 0, 0, 1, io, n, 1.0, st)) return rc;
+        if (int rc = bluestein_pass_multi(c, 0, 1, 1, io, n, 1.0, st)) return rc;
+        return bluestein_pass_multi(c, 2, 2, 1, io, n, scale, st);
+    }
+    for (int a = 0; a < n; ++a)
+        if (int rc = irfftn_internal(c, spec[a], out[a], scale, st)) return rc;
+    return 0;
+}
 
 // real [n0][n1][n2] -> internal half spectrum (unnormalised, like torch.fft.rfftn)
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st) {
