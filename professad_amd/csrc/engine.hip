@@ -398,18 +398,60 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
     cplx *s0 = nullptr, *s1 = nullptr, *s2 = nullptr, *s3 = nullptr;
     if (int rc = spec_ws(c, "s0", &s0)) return rc;
 
-    if (mask & (OFDFT_HARTREE | kGgaAny)) {
-        if (int rc = rfftn_internal(c, den, s0, st)) return rc;             // n^ (shared)
-        if (int rc = spec_ws(c, "s1", &s1)) return rc;
-        if (mask & OFDFT_HARTREE) {
-            real* vh;
-            if (int rc = real_ws(c, "vh", &vh)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, s1, c->kg, 0.0, 0.0);
-            if (int rc = irfftn_internal(c, s1, vh, inv_n, st)) return rc;
-            ca.vh = vh;
+    // The transforms of the density-derived inputs are independent of one another, and so are the inverse transforms of the
+    // convolution results: they run as BATCHES (rfftn_internal_multi / irfftn_internal_multi: on the chirp-z path one launch per
+    // pass for up to kBsBatch arrays -- small odd grids are bound by their launch count).  Phase A: pointwise inputs + forward
+    // batch; B: spectral multiplies; C: inverse batches; D: the GGA mid stage and its flux / divergence transforms.
+    const bool has_n = mask & (OFDFT_HARTREE | kGgaAny), has_h = mask & OFDFT_HARTREE, has_g = mask & kGgaAny, has_vw = mask & OFDFT_VW,
+               has_wt = mask & OFDFT_WT_NL;
+    const double wal = c->params[OFDFT_P_WT_ALPHA], wbe = c->params[OFDFT_P_WT_BETA];
+    const bool wt2 = has_wt && wal != wbe;
+    real *t_sqrt = nullptr, *t_pb = nullptr, *t_pa = nullptr;
+    cplx *s_vw = nullptr, *s_wb = nullptr, *s_wa = nullptr, *s4 = nullptr;
+    real *vh = nullptr, *gx = nullptr, *gy = nullptr, *gz = nullptr, *dfdn = nullptr, *dv = nullptr, *lapn = nullptr, *lap = nullptr,
+         *cb = nullptr, *cva = nullptr;
+    const bool lapl = has_g && gga_needs_laplacian(c);
+    // ---- A: forward batch
+    {
+        const real* fin[4];
+        cplx* fout[4];
+        int nf = 0;
+        if (has_n) {
+            fin[nf] = den;
+            fout[nf++] = s0;
         }
-        if (mask & kGgaAny) {
-            real *gx, *gy, *gz, *dfdn, *dv;
+        if (has_vw) {
+            if (int rc = real_ws(c, "t0", &t_sqrt)) return rc;
+            if (int rc = spec_ws(c, "svw", &s_vw)) return rc;
+            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, t_sqrt, npts, 0.0);
+            fin[nf] = t_sqrt;
+            fout[nf++] = s_vw;
+        }
+        if (has_wt) {
+            if (int rc = real_ws(c, "t1", &t_pb)) return rc;
+            if (int rc = spec_ws(c, "swb", &s_wb)) return rc;
+            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pb, npts, wbe);
+            fin[nf] = t_pb;
+            fout[nf++] = s_wb;
+            if (wt2) {
+                if (int rc = real_ws(c, "t2", &t_pa)) return rc;
+                if (int rc = spec_ws(c, "swa", &s_wa)) return rc;
+                OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pa, npts, wal);
+                fin[nf] = t_pa;
+                fout[nf++] = s_wa;
+            }
+        }
+        if (nf)
+            if (int rc = rfftn_internal_multi(c, fin, fout, nf, st)) return rc;
+    }
+    // ---- B: spectral multiplies; C: inverse batches (at most kBsBatch arrays each)
+    {
+        cplx* iin[8];
+        real* iout[8];
+        int ni = 0;
+        if (has_n && (has_h || has_g))
+            if (int rc = spec_ws(c, "s1", &s1)) return rc;
+        if (has_g) {
             if (int rc = spec_ws(c, "s2", &s2)) return rc;
             if (int rc = spec_ws(c, "s3", &s3)) return rc;
             if (int rc = real_ws(c, "gx", &gx)) return rc;
@@ -417,78 +459,77 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             if (int rc = real_ws(c, "gz", &gz)) return rc;
             if (int rc = real_ws(c, "dfdn", &dfdn)) return rc;
             if (int rc = real_ws(c, "div", &dv)) return rc;
+        }
+        if (has_h) {
+            cplx* svh = s1;
+            if (has_g)
+                if (int rc = spec_ws(c, "svh", &svh)) return rc;       // (s1 carries a gradient component then)
+            if (int rc = real_ws(c, "vh", &vh)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, svh, c->kg, 0.0, 0.0);
+            iin[ni] = svh;
+            iout[ni++] = vh;
+            ca.vh = vh;
+        }
+        if (has_g) {
             OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
-            {       // the three components in one batch (one launch per pass on the chirp-z path)
-                cplx* sg[3] = {s1, s2, s3};
-                real* rg[3] = {gx, gy, gz};
-                if (int rc = irfftn_internal_multi(c, sg, rg, 3, inv_n, st)) return rc;
-            }
-            const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
-            real* lapn = nullptr;
-            cplx* s4 = nullptr;
-            if (gga_needs_laplacian(c)) {            // lap n = F^-1[-k^2 n^]  (reduced Laplacian q, functional_tools.py:271-287)
+            iin[ni] = s1; iout[ni++] = gx;
+            iin[ni] = s2; iout[ni++] = gy;
+            iin[ni] = s3; iout[ni++] = gz;
+            if (lapl) {              // lap n = F^-1[-k^2 n^]  (reduced Laplacian q, functional_tools.py:271-287)
                 if (int rc = real_ws(c, "lapn", &lapn)) return rc;
                 if (int rc = spec_ws(c, "s4", &s4)) return rc;
                 OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s0, s4, c->kg, 0.0, 0.0);
-                if (int rc = irfftn_internal(c, s4, lapn, inv_n, st)) return rc;
+                iin[ni] = s4; iout[ni++] = lapn;
             }
-            OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
-                               gga_sel(c), c->d_partial, lapn);
-            if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
-            {
-                cplx* sg[3] = {s1, s2, s3};
-                const real* rg[3] = {gx, gy, gz};
-                if (int rc = rfftn_internal_multi(c, rg, sg, 3, st)) return rc;
-            }
-            OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
-            if (lapn) {      // v += lap(df/dL): the combine forms v += df/dn - 2 div, so div -= lap(df/dL) / 2, i.e. s0 += k^2 (df/dL)^ / 2
-                if (int rc = rfftn_internal(c, lapn, s4, st)) return rc;
-                OFDFT_LAUNCH(c, st, "spec_scale", spec_add_lap_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)s4, s0, c->kg, 0.5);
-            }
-            if (int rc = irfftn_internal(c, s0, dv, inv_n, st)) return rc;
-            ca.dfdn = dfdn;
-            ca.div = dv;
         }
-    }
-    if (mask & OFDFT_VW) {
-        real *tmp, *lap;
-        if (int rc = real_ws(c, "t0", &tmp)) return rc;
-        if (int rc = real_ws(c, "lap", &lap)) return rc;
-        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, 0.0);
-        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
-        OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, 0.0, 0.0);
-        if (int rc = irfftn_internal(c, s0, lap, inv_n, st)) return rc;
-        ca.lap_s = lap;
-    }
-    if (mask & OFDFT_WT_NL) {
-        const double al = c->params[OFDFT_P_WT_ALPHA], be = c->params[OFDFT_P_WT_BETA];
-        const double nbar = nel / c->vol;                                    // functionals.py:646-647
-        const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
-        const double pref = 5.0 / (9.0 * al * be * std::pow(nbar, al + be - kFiveThirds));
-        real *tmp, *cb;
-        if (int rc = real_ws(c, "t0", &tmp)) return rc;
-        if (int rc = real_ws(c, "conv_b", &cb)) return rc;
-        OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, be);
-        if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
-        OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, pref,
-                           1.0 / (2.0 * kf));
-        if (int rc = irfftn_internal(c, s0, cb, inv_n, st)) return rc;
-        ca.conv_b = cb;
-        ca.conv_a = nullptr;
-        if (al != be) {
-            real* cva;
-            if (int rc = real_ws(c, "conv_a", &cva)) return rc;
-            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, tmp, npts, al);
-            if (int rc = rfftn_internal(c, tmp, s0, st)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s0, s0, c->kg, pref,
+        if (has_vw) {
+            if (int rc = real_ws(c, "lap", &lap)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s_vw, s_vw, c->kg, 0.0, 0.0);
+            iin[ni] = s_vw; iout[ni++] = lap;
+            ca.lap_s = lap;
+        }
+        if (has_wt) {
+            const double nbar = nel / c->vol;                                    // functionals.py:646-647
+            const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
+            const double pref = 5.0 / (9.0 * wal * wbe * std::pow(nbar, wal + wbe - kFiveThirds));
+            if (int rc = real_ws(c, "conv_b", &cb)) return rc;
+            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wb, s_wb, c->kg, pref,
                                1.0 / (2.0 * kf));
-            if (int rc = irfftn_internal(c, s0, cva, inv_n, st)) return rc;
-            ca.conv_a = cva;
+            iin[ni] = s_wb; iout[ni++] = cb;
+            ca.conv_b = cb;
+            ca.conv_a = nullptr;
+            if (wt2) {
+                if (int rc = real_ws(c, "conv_a", &cva)) return rc;
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wa, s_wa, c->kg, pref,
+                                   1.0 / (2.0 * kf));
+                iin[ni] = s_wa; iout[ni++] = cva;
+                ca.conv_a = cva;
+            }
+            ca.wt_alpha = wal;
+            ca.wt_beta = wbe;
+            ca.wt_nbar_pa = std::pow(nbar, wal);
+            ca.wt_is_56 = (wal == kFiveSixths && wbe == kFiveSixths) ? 1 : 0;
         }
-        ca.wt_alpha = al;
-        ca.wt_beta = be;
-        ca.wt_nbar_pa = std::pow(nbar, al);
-        ca.wt_is_56 = (al == kFiveSixths && be == kFiveSixths) ? 1 : 0;
+        for (int b0 = 0; b0 < ni; b0 += 4)
+            if (int rc = irfftn_internal_multi(c, iin + b0, iout + b0, std::min(4, ni - b0), inv_n, st)) return rc;
+    }
+    // ---- D: GGA mid stage (needs grad n [, lap n] in real space), flux forward batch, divergence inverse
+    if (has_g) {
+        const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
+        OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
+                           gga_sel(c), c->d_partial, lapn);
+        if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
+        {
+            cplx* sg[4] = {s1, s2, s3, s4};
+            const real* rg[4] = {gx, gy, gz, lapn};
+            if (int rc = rfftn_internal_multi(c, rg, sg, lapl ? 4 : 3, st)) return rc;
+        }
+        OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
+        if (lapl)        // v += lap(df/dL): the combine forms v += df/dn - 2 div, so div -= lap(df/dL) / 2, i.e. s0 += k^2 (df/dL)^ / 2
+            OFDFT_LAUNCH(c, st, "spec_scale", spec_add_lap_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)s4, s0, c->kg, 0.5);
+        if (int rc = irfftn_internal(c, s0, dv, inv_n, st)) return rc;
+        ca.dfdn = dfdn;
+        ca.div = dv;
     }
     if (mask & OFDFT_WGC99_NL) {
         const double al = c->params[OFDFT_P_WGC_ALPHA], be = c->params[OFDFT_P_WGC_BETA];
