@@ -27,12 +27,94 @@ struct BsIo {
     real* rout[kBsBatch];
 };
 
-template <int M>
-__global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
-                                                                    const cplx* __restrict__ chirp,   // w_n, n < N
-                                                                    const cplx* __restrict__ filt,    // FFT_M(b) / M
-                                                                    const cplx* __restrict__ twM) {
-    constexpr int P = PassCfg<M>::P, E = PassCfg<M>::E, LPW = PassCfg<M>::LPW;
+// Round 3 (second half): the kernel was rewritten around two findings (tools/isa_stats.py on the first version: 584 fp64
+// instructions per wave and line against 595 integer / move VALU instructions, 577 scalar ones and 41 exec-mask branches):
+//  * a line is owned by the lanes of ONE wavefront (8 points per lane, 64 lanes for M = 512), so the two M-point transforms
+//    exchange through LDS without an s_barrier (the first version dealt consecutive lanes to consecutive LINES and paid 16
+//    workgroup barriers per tile -- measured alone that change was neutral: the kernel is bound by its instruction count);
+//  * every access is a buffer access: ONE 32-bit byte offset per lane and slot, elements past the end of the line (the
+//    zero padding of the convolution) and lines past the end of the launch get an offset beyond the descriptor's range --
+//    such loads return zero and such stores are dropped by the hardware, so the loops carry no branches and no 64-bit
+//    address arithmetic; the transform direction and the kind of line are template parameters; the stage twiddles W^(t k)
+//    are read from the LDS copy of the table instead of being formed from W^k by a product tree (24 fp64 instructions per
+//    radix-8 butterfly).
+#ifndef OFDFT_BS_TPB
+#define OFDFT_BS_TPB 256
+#endif
+#ifndef OFDFT_BS_WGS
+#define OFDFT_BS_WGS 8            // persistent workgroups per CU and array
+#endif
+#ifndef OFDFT_BS_WAVES
+#define OFDFT_BS_WAVES 4          // waves per SIMD the register allocation aims at (M = 1024 keeps 16 points per lane: 2)
+#endif
+// The kernel is bound by LDS time (SQ counters at 255^3: 8-15 % of a wave's cycles issue VALU work, 40-46 % of the z rows' wait
+// for the LDS; 52 % of the LDS-array cycles were bank conflicts of the padded line layout): XOR layouts per length and
+// precision, position i ^ ((XMUL ((i >> XS) & XM)) & 31) ^ (LMUL line & 31), found by enumerating the exchanges of these plans
+// against the bank rules of MI355X_MICROARCH.md with a line's lanes CONSECUTIVE in the wave (tools/lds_conflicts.py blocked):
+// every read and write group conflict-free (fp64 M = 128: writes 1.125 cycles per group).
+template <int M, bool F32 = (sizeof(real) == 4)> struct BsLds { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = LineBuf<M>::STRIDE; };
+template <> struct BsLds<64, false> { static constexpr int XS = 2, XM = 15, XMUL = 1, LMUL = 1, RS = 72; };
+template <> struct BsLds<128, false> { static constexpr int XS = 4, XM = 7, XMUL = 3, LMUL = 0, RS = 144; };
+template <> struct BsLds<256, false> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 256; };
+template <> struct BsLds<512, false> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 512; };
+template <> struct BsLds<64, true> { static constexpr int XS = 1, XM = 31, XMUL = 1, LMUL = 1, RS = 72; };
+template <> struct BsLds<128, true> { static constexpr int XS = 2, XM = 31, XMUL = 1, LMUL = 1, RS = 144; };
+template <> struct BsLds<256, true> { static constexpr int XS = 3, XM = 31, XMUL = 1, LMUL = 0, RS = 256; };
+template <> struct BsLds<512, true> { static constexpr int XS = 3, XM = 31, XMUL = 1, LMUL = 0, RS = 512; };
+#ifndef OFDFT_BS_TWTAB
+#define OFDFT_BS_TWTAB 0          // 1: stage twiddles W^(t k) read from the LDS table (fewer fp64 instructions, more LDS time)
+#endif
+#ifndef OFDFT_BS_XOR
+#define OFDFT_BS_XOR 1
+#endif
+template <int M> struct BsPlan : ZPlan<M, 8> {};
+template <int M> struct LdsLayout<BsPlan<M>> : LdsLayoutDefault {
+    static constexpr int XS = OFDFT_BS_XOR ? BsLds<M>::XS : 0, XM = OFDFT_BS_XOR ? BsLds<M>::XM : 0, XMUL = OFDFT_BS_XOR ? BsLds<M>::XMUL : 0;
+};
+template <int M> struct BsPlanPick { using type = BsPlan<M>; };
+template <> struct BsPlanPick<1024> { using type = Plan<1024>; };
+template <int M> struct BsCfg {
+    using PL = typename BsPlanPick<M>::type;
+    static constexpr int TPB = OFDFT_BS_TPB;
+    static constexpr int STRIDE = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::RS : LineBuf<M>::STRIDE;
+    static constexpr int LMUL = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::LMUL : 0;
+    static constexpr int P = PL::P, E = PL::E, LPW = TPB / P;
+    static constexpr int WAVES = M >= 1024 ? 2 : OFDFT_BS_WAVES;
+    static_assert(PL::EXACT, "element j + P q in slot q");
+    static constexpr size_t LDS = sizeof(real) * LPW * STRIDE + 2 * sizeof(cplx) * M;   // line buffers + the staged twiddle and filter tables
+};
+constexpr unsigned kBsOob = 0xffffff00u;      // a byte offset no buffer descriptor of this engine covers (make_rsrc: 2 GiB)
+
+// kinds of line (template parameter KIND)
+constexpr int BS_CPLX = 0;      // complex lines along x (axis 0) or y (axis 1) of the internal half-spectrum layout, in place
+constexpr int BS_R2C = 1;       // real rows -> half spectrum along z
+constexpr int BS_C2R = 2;       // half spectrum -> real rows along z (times `scale`)
+
+// the convolution itself: v (element j + P q in slot q, zero beyond the line) -> its N-point DFT, same slots
+template <class PL, int M, bool INV>
+__device__ __forceinline__ void chirpz_line(cplx (&v)[PL::E], const cplx (&wch)[(PL::E + 1) / 2], int j, real* mine,
+                                            const cplx* tw_l, const cplx* fl_l, int lx) {
+    constexpr int P = PL::P, E = PL::E, EH = (E + 1) / 2;
+#pragma unroll
+    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);       // (slots without an element hold zero)
+    StageP<PL, 0, 1, false, true, OFDFT_BS_TWTAB != 0>::run(v, j, mine, tw_l, lx);
+#pragma unroll
+    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], fl_l[j + P * q]);         // (staged with the direction's sign)
+    exchange_sync<true>();
+    StageP<PL, 0, 1, true, true, OFDFT_BS_TWTAB != 0>::run(v, j, mine, tw_l, lx);
+#pragma unroll
+    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);
+}
+
+template <int M, int KIND, bool INV>
+__global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(BsCfg<M>::WAVES, BsCfg<M>::WAVES))) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
+                                                                  const cplx* __restrict__ chirp,   // w_n, n < N
+                                                                  const cplx* __restrict__ filt,    // FFT_M(b) / M
+                                                                  const cplx* __restrict__ twM) {
+    using Cfg = BsCfg<M>;
+    using PL = typename Cfg::PL;
+    constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, TPB = Cfg::TPB;
+    constexpr int EH = (E + 1) / 2;           // slots that can hold an element e = j + P q < N <= (M + 1) / 2
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
     cplx* __restrict__ spec = io.spec[0];
@@ -45,109 +127,135 @@ __global__ __launch_bounds__(PassCfg<M>::TPB) void bluestein_kernel(BsIo io, Spe
             rin = io.rin[a];
             rout = io.rout[a];
         }
-    // complex lines (mode 0): consecutive lanes take consecutive LINES, enumerated kz-fastest, so that a wave's accesses
-    // for one element index fall on the 8 x 16-B runs of the block-8 layout; z rows (modes 1, 2): consecutive lanes take
-    // consecutive elements of one contiguous row
-    const int j = b.mode == 0 ? tid / LPW : tid % P;
-    const int l = b.mode == 0 ? tid % LPW : tid / P;
-    const long long L = (long long)blockIdx.x * LPW + l;
-    const bool valid = L < b.nlines;
+    const int j = tid % P, l = tid / P;
     const int N = b.N;
-    // line coordinates
-    int x = 0, y = 0, kz = 0;
-    if (valid) {
-        if (b.mode == 0) {
-            kz = (int)(L % g.nzc);
-            if (b.axis == 0) y = (int)(L / g.nzc);
-            else x = (int)(L / g.nzc);
-        } else {
-            x = (int)(L / g.n1);
-            y = (int)(L % g.n1);
-        }
+    // ---- once per workgroup: twiddles and the filter spectrum (with the direction's sign) into LDS, this lane's chirp values
+    // into registers (slot q of lane j holds element j + P q of EVERY line).  The filter used to be requested from global
+    // memory between the two transforms -- an L2 round trip in the middle of each line's dependent chain.
+    cplx* tw_l = reinterpret_cast<cplx*>(lds + LPW * Cfg::STRIDE);
+    cplx* fl_l = tw_l + M;
+    for (int i = tid; i < M; i += TPB) {
+        tw_l[i] = buf_load_c(twM, (unsigned)i * kCB);
+        cplx f = buf_load_c(filt, (unsigned)i * kCB);
+        if (INV) f.y = -f.y;                            // inverse transform = conjugated chirps and filter
+        fl_l[i] = f;
     }
-    const bool conj_in = b.inv != 0;      // inverse transform = conjugated chirps and filter
-    // Round 3: the kernel sat 60 % of its wave cycles waiting (profiles/r03_sq_chirpz_255.md): of its 30 loads per wave only 8
-    // fetch data -- chirp (twice), filter and the stage twiddles were requested one by one where they were used, each a
-    // dependent L2 round trip between barrier-separated phases.  Now every table value a lane needs is requested up front
-    // with its data (the chirp once: it serves the pre- AND the post-multiplication; M >= 2 N - 1 means only the lower half
-    // of the register slots ever holds data) and the M twiddles are staged in LDS behind the line buffers.
-    constexpr int EH = (E + 1) / 2;           // slots that can hold an element e = j + P q < N <= (M + 1) / 2
-    cplx v[E], wch[EH], fl[E];
-    cplx* tw_l = reinterpret_cast<cplx*>(lds + LPW * LineBuf<M>::STRIDE);
-    constexpr int TWC = (M + PassCfg<M>::TPB - 1) / PassCfg<M>::TPB;
-    cplx twr[TWC];
+    cplx wch[EH];
 #pragma unroll
-    for (int t = 0; t < TWC; ++t) {
-        const int i = tid + t * PassCfg<M>::TPB;
-        twr[t] = twM[i < M ? i : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
+    for (int q = 0; q < EH; ++q) {
         const int e = j + P * q;
-        cplx a = mkc(0.0, 0.0);
-        if (q < EH && valid && e < N) {
-            if (b.mode == 0) {
-                a = spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)];
-            } else if (b.mode == 1) {
-                a = mkc(rin[((long long)x * g.n1 + y) * g.n2 + e], 0.0);
-            } else {            // rebuild the Hermitian line; imaginary parts of k = 0 (and Nyquist) are ignored like irfftn
-                const int k = (e < g.nzc) ? e : N - e;
-                a = spec[spec_index(g, x, y, k)];
-                if (e >= g.nzc) a.y = -a.y;
-                if (e == 0 || (2 * e == N)) a.y = 0.0;
+        wch[q] = buf_load_c(chirp, e < N ? (unsigned)e * kCB : kBsOob);
+        if (INV) wch[q].y = -wch[q].y;
+    }
+    real* mine = lds + l * Cfg::STRIDE;
+    __syncthreads();
+    // ---- persistent workgroups: tiles of LPW lines, no workgroup barrier inside the loop
+    const long long ntiles = (b.nlines + LPW - 1) / LPW;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long L = tile * LPW + l;
+        const bool valid = L < b.nlines;
+        // element offsets (bytes, 32 bit: the engine takes this path up to 512 points per axis, 1.1 GB per spectrum); complex
+        // lines are enumerated kz-fastest: the waves of a workgroup take the kz neighbours of one 128-B run
+        unsigned base = 0, stride = 0;              // BS_CPLX: first element and element stride of this lane's line
+        // rows: TWO real rows per complex transform, z = a + i b (rows 2 L and 2 L + 1: the convolution costs the same for a
+        // complex line, so pairing halves the z passes; the two spectra are separated with one more wave-local exchange)
+        const unsigned row = (unsigned)(2 * L);     // x n1 + y of the first row
+        const bool valid1 = 2 * L + 1 < g.nrows;
+        if (KIND == BS_CPLX) {
+            const int kz = (int)(L % g.nzc), r = (int)(L / g.nzc);       // r = y (x lines) or x (y lines)
+            const unsigned rowbase = b.axis == 0 ? (unsigned)r : (unsigned)r * (unsigned)g.n1;
+            const unsigned rowstep = b.axis == 0 ? (unsigned)g.n1 : 1u;
+            if (kz < g.nzm) {
+                base = (((unsigned)(kz >> 3) * (unsigned)g.nrows + rowbase) * 8u + (unsigned)(kz & 7)) * kCB;
+                stride = rowstep * 8u * kCB;
+            } else {
+                base = ((unsigned)g.main_count + (unsigned)(kz - g.nzm) * (unsigned)g.nrows + rowbase) * kCB;
+                stride = rowstep * kCB;
             }
         }
-        v[q] = a;
-    }
+        cplx v[E];
+        unsigned off[EH];
 #pragma unroll
-    for (int q = 0; q < EH; ++q) {
-        const int e = j + P * q;
-        wch[q] = chirp[e < N ? e : 0];
-        if (conj_in) wch[q].y = -wch[q].y;
-    }
-    // (the filter values: up front for the short transforms; for M >= 256 the 2 E more registers cost more occupancy than the
-    // one round trip they save -- 255^3 11.4 -> 13.2 ms with them prefetched -- so there they are requested after the first FFT)
-    constexpr bool PREF = M <= 128;
-    if constexpr (PREF) {
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-            fl[q] = filt[j + P * q];
-            if (conj_in) fl[q].y = -fl[q].y;
+        for (int q = 0; q < EH; ++q) {
+            const int e = j + P * q;
+            const bool in = valid && e < N;
+            if (KIND == BS_CPLX) {
+                off[q] = in ? base + (unsigned)e * stride : kBsOob;
+                v[q] = buf_load_c(spec, off[q]);
+            } else if (KIND == BS_R2C) {
+                off[q] = in ? (row * (unsigned)g.n2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
+                v[q] = mkc(buf_load_d(rin, off[q]), buf_load_d(rin, in && valid1 ? off[q] + (unsigned)g.n2 * (unsigned)sizeof(real) : kBsOob));
+            } else {            // rebuild the Hermitian lines; imaginary parts of k = 0 (and Nyquist) are ignored like irfftn
+                const int k = (e < g.nzc) ? e : N - e;
+                const unsigned idx = k < g.nzm ? ((unsigned)(k >> 3) * (unsigned)g.nrows + row) * 8u + (unsigned)(k & 7)
+                                               : (unsigned)g.main_count + (unsigned)(k - g.nzm) * (unsigned)g.nrows + row;
+                const unsigned step = k < g.nzm ? 8u : 1u;           // the next row's element
+                cplx a = buf_load_c(spec, in ? idx * kCB : kBsOob);
+                cplx bb = buf_load_c(spec, in && valid1 ? (idx + step) * kCB : kBsOob);
+                if (e >= g.nzc) { a.y = -a.y; bb.y = -bb.y; }
+                if (e == 0 || 2 * e == N) { a.y = 0.0; bb.y = 0.0; }
+                v[q] = mkc(a.x - bb.y, a.y + bb.x);                  // A + i B
+                off[q] = in ? (row * (unsigned)g.n2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
+            }
         }
-    }
 #pragma unroll
-    for (int t = 0; t < TWC; ++t) {
-        const int i = tid + t * PassCfg<M>::TPB;
-        if (i < M) tw_l[i] = twr[t];
-    }
+        for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+        chirpz_line<PL, M, INV>(v, wch, j, mine, tw_l, fl_l, (l * Cfg::LMUL) & 31);
+        if (KIND == BS_R2C) {
+            // Z = A + i B with A, B Hermitian: A_k = (Z_k + conj Z_{N-k}) / 2, B_k = (Z_k - conj Z_{N-k}) / 2i -- the partner
+            // element comes through the line buffer (real parts, then imaginary parts; N <= M / 2 entries)
+            cplx p[EH];
+            exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);       // (slots without an element hold zero)
-    real* mine = lds + l * LineBuf<M>::STRIDE;
-    __syncthreads();                                               // the staged twiddles
-    line_fft<M, false>(v, j, mine, tw_l);
-    if constexpr (!PREF) {
+            for (int q = 0; q < EH; ++q)
+                if (j + P * q < N) mine[j + P * q] = v[q].x;
+            exchange_sync<true>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) {
-            fl[q] = filt[j + P * q];
-            if (conj_in) fl[q].y = -fl[q].y;
-        }
-    }
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                p[q].x = mine[e == 0 || e >= N ? 0 : N - e];
+            }
+            exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], fl[q]);
-    __syncthreads();
-    line_fft<M, true>(v, j, mine, tw_l);
+            for (int q = 0; q < EH; ++q)
+                if (j + P * q < N) mine[j + P * q] = v[q].y;
+            exchange_sync<true>();
 #pragma unroll
-    for (int q = 0; q < EH; ++q) {
-        const int e = j + P * q;
-        if (!valid || e >= N) continue;
-        const cplx r = cmul(v[q], wch[q]);
-        if (b.mode == 0) {
-            spec[b.axis == 0 ? spec_index(g, e, y, kz) : spec_index(g, x, e, kz)] = r;
-        } else if (b.mode == 1) {
-            if (e < g.nzc) spec[spec_index(g, x, y, e)] = r;
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                p[q].y = mine[e == 0 || e >= N ? 0 : N - e];
+            }
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                const bool in = valid && e < g.nzc;
+                const unsigned idx = e < g.nzm ? ((unsigned)(e >> 3) * (unsigned)g.nrows + row) * 8u + (unsigned)(e & 7)
+                                               : (unsigned)g.main_count + (unsigned)(e - g.nzm) * (unsigned)g.nrows + row;
+                const unsigned step = e < g.nzm ? 8u : 1u;
+                const cplx za = mkc((real)0.5 * (v[q].x + p[q].x), (real)0.5 * (v[q].y - p[q].y));
+                const cplx zb = mkc((real)0.5 * (v[q].y + p[q].y), (real)-0.5 * (v[q].x - p[q].x));
+                buf_store_c(spec, in ? idx * kCB : kBsOob, za);
+                buf_store_c(spec, in && valid1 ? (idx + step) * kCB : kBsOob, zb);
+            }
         } else {
-            rout[((long long)x * g.n1 + y) * g.n2 + e] = r.x * b.scale;
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                if (KIND == BS_CPLX) {
+                    buf_store_c(spec, off[q], v[q]);
+                } else {
+                    const real r0 = v[q].x * b.scale, r1 = v[q].y * b.scale;
+                    const unsigned o1 = (off[q] != kBsOob && valid1) ? off[q] + (unsigned)g.n2 * (unsigned)sizeof(real) : kBsOob;
+                    if constexpr (sizeof(real) == 8) {
+                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&r0), make_rsrc(rout), (int)off[q], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&r1), make_rsrc(rout), (int)o1, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(&r0), make_rsrc(rout), (int)off[q], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(&r1), make_rsrc(rout), (int)o1, 0, 0);
+                    }
+                }
+            }
         }
+        exchange_sync<true>();          // the line buffer is reused by the next tile
     }
 }
 

@@ -416,7 +416,9 @@ template <bool WAVE> __device__ __forceinline__ void exchange_sync() {
     }
 }
 
-template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
+// TWTAB: `tw` is a copy of the table in LDS and every power W^(t k) is READ from it (R - 1 ds_read_b128) instead of being formed
+// from W^k by the product tree (24 fp64 instructions per radix-8 butterfly): for kernels bound by their instruction count
+template <class PL, int S, int NS, bool INV, bool WAVE, bool TWTAB = false> struct StageP {
     static constexpr int LEN = PL::LEN;
     static constexpr int R = PL::radix(S);
     static constexpr int E = PL::E;
@@ -441,12 +443,20 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
                     const int k = (j + b * P) % NS;
                     constexpr int TSTEP = LEN / (NS * R);
                     cplx w[R];
-                    w[1] = tw[k * TSTEP];
-                    if (INV) w[1].y = -w[1].y;
+                    if constexpr (TWTAB) {
 #pragma unroll
-                    for (int t = 2; t < R; ++t) {
-                        const int hi = (t >= 8) ? 8 : ((t >= 4) ? 4 : 2);   // largest power of two <= t
-                        w[t] = (t == hi) ? cmul(w[t / 2], w[t / 2]) : cmul(w[hi], w[t - hi]);
+                        for (int t = 1; t < R; ++t) {
+                            w[t] = tw[k * (TSTEP * t)];
+                            if (INV) w[t].y = -w[t].y;
+                        }
+                    } else {
+                        w[1] = tw[k * TSTEP];
+                        if (INV) w[1].y = -w[1].y;
+#pragma unroll
+                        for (int t = 2; t < R; ++t) {
+                            const int hi = (t >= 8) ? 8 : ((t >= 4) ? 4 : 2);   // largest power of two <= t
+                            w[t] = (t == hi) ? cmul(w[t / 2], w[t / 2]) : cmul(w[hi], w[t - hi]);
+                        }
                     }
 #pragma unroll
                     for (int t = 1; t < R; ++t) a[t] = cmul(a[t], w[t]);
@@ -496,7 +506,7 @@ template <class PL, int S, int NS, bool INV, bool WAVE> struct StageP {
 #pragma unroll
                     for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpos<PL>(j + b * P + t * NBF2) ^ lx]);
                 }
-            StageP<PL, S + 1, NS * R, INV, WAVE>::run(v, j, line, tw, lx);
+            StageP<PL, S + 1, NS * R, INV, WAVE, TWTAB>::run(v, j, line, tw, lx);
         }
     }
 };

@@ -263,16 +263,34 @@ int get_bluestein(ofdft_ctx* c, int N, BsTables* out) {
     return 0;
 }
 
+static int device_cus(const ofdft_ctx* c) {
+    static int cus[64] = {0};
+    const int d = c->device >= 0 && c->device < 64 ? c->device : 0;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+
 template <int M>
 int launch_bluestein_t(ofdft_ctx* c, const BsIo& io, int narr, const BsArgs& b, const BsTables& t, hipStream_t st) {
     cplx* tw;
     if (int rc = get_twiddle(c, M, &tw)) return rc;
-    using Cfg = PassCfg<M>;
-    const int blocks = (int)((b.nlines + Cfg::LPW - 1) / Cfg::LPW);
-    // line buffers + the staged twiddle table (M = 8 has a one-stage plan and no line buffers: Cfg::LDS is 0 there)
-    const size_t lds = sizeof(real) * Cfg::LPW * LineBuf<M>::STRIDE + sizeof(cplx) * M;
-    OFDFT_LAUNCH(c, st, "bluestein", (bluestein_kernel<M>), dim3(blocks, narr), dim3(Cfg::TPB), lds, io, c->g, b,
-                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);
+    using Cfg = BsCfg<M>;
+    // persistent workgroups (the tables are staged once per workgroup): at most OFDFT_BS_WGS per CU and array
+    const long long tiles = (b.nlines + Cfg::LPW - 1) / Cfg::LPW;
+    const int blocks = (int)std::min<long long>(tiles, (long long)device_cus(c) * OFDFT_BS_WGS);
+    const char* nm = b.mode ? "bluestein_z" : (b.axis ? "bluestein_y" : "bluestein_x");
+#define OFDFT_BS(KIND_, INV_)                                                                                                       \
+    OFDFT_LAUNCH(c, st, nm, (bluestein_kernel<M, KIND_, INV_>), dim3(blocks, narr), dim3(Cfg::TPB), Cfg::LDS, io, c->g, b, \
+                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw)
+    if (b.mode == 1) OFDFT_BS(BS_R2C, false);
+    else if (b.mode == 2) OFDFT_BS(BS_C2R, true);
+    else if (b.inv) OFDFT_BS(BS_CPLX, true);
+    else OFDFT_BS(BS_CPLX, false);
+#undef OFDFT_BS
     return 0;
 }
 
@@ -287,7 +305,7 @@ int bluestein_pass_multi(ofdft_ctx* c, int mode, int axis, int inv, const BsIo& 
     b.axis = axis;
     b.inv = inv;
     b.scale = scale;
-    b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : c->g.nrows;
+    b.nlines = mode == 0 ? (long long)(axis == 0 ? c->n1 : c->n0) * c->g.nzc : (c->g.nrows + 1) / 2;      // (z rows go in pairs)
     switch (t.M) {
         case 8: return launch_bluestein_t<8>(c, io, narr, b, t, st);
         case 16: return launch_bluestein_t<16>(c, io, narr, b, t, st);

@@ -651,9 +651,10 @@ def test_stress_of_laplacian_dependent_pauli_gaussian_and_wt_style(case):
         assert np.abs(s - ref).max() <= 2e-10 * np.abs(ref).max(), key
 
 
-def test_generic_extent_paths_agree():
-    """non power-of-two grids: the chirp-z (Bluestein) line transforms against the plain DFT kernels and numpy"""
-    shape = (17, 18, 15)
+@pytest.mark.parametrize('shape', [(17, 18, 15), (5, 7, 9), (33, 35, 31), (3, 5, 255), (255, 3, 5), (2, 257, 6), (7, 129, 67)])
+def test_generic_extent_paths_agree(shape):
+    """non power-of-two grids: the chirp-z (Bluestein) line transforms against the plain DFT kernels and numpy (odd and even
+    row counts -- the z passes transform rows in pairs --, every padded length 16 ... 1024, remainder planes of the layout)"""
     rng = np.random.default_rng(4)
     x = rng.standard_normal(shape)
     eng = Engine(shape, DEV)
