@@ -39,10 +39,16 @@ struct BsIo {
 //    are read from the LDS copy of the table instead of being formed from W^k by a product tree (24 fp64 instructions per
 //    radix-8 butterfly).
 #ifndef OFDFT_BS_TPB
-#define OFDFT_BS_TPB 256
+#define OFDFT_BS_TPB 512
 #endif
 #ifndef OFDFT_BS_WGS
-#define OFDFT_BS_WGS 8            // persistent workgroups per CU and array
+#define OFDFT_BS_WGS 4            // persistent workgroups per CU and array
+#endif
+#ifndef OFDFT_BS_ZTPB
+#define OFDFT_BS_ZTPB 256
+#endif
+#ifndef OFDFT_BS_ZWAVES
+#define OFDFT_BS_ZWAVES 3
 #endif
 #ifndef OFDFT_BS_WAVES
 #define OFDFT_BS_WAVES 4          // waves per SIMD the register allocation aims at (M = 1024 keeps 16 points per lane: 2)
@@ -52,7 +58,7 @@ struct BsIo {
 // precision, position i ^ ((XMUL ((i >> XS) & XM)) & 31) ^ (LMUL line & 31), found by enumerating the exchanges of these plans
 // against the bank rules of MI355X_MICROARCH.md with a line's lanes CONSECUTIVE in the wave (tools/lds_conflicts.py blocked):
 // every read and write group conflict-free (fp64 M = 128: writes 1.125 cycles per group).
-template <int M, bool F32 = (sizeof(real) == 4)> struct BsLds { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = LineBuf<M>::STRIDE; };
+template <int M, bool F32 = (sizeof(real) == 4)> struct BsLds { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = (LineBuf<M>::STRIDE + 1) & ~1; };
 template <> struct BsLds<64, false> { static constexpr int XS = 2, XM = 15, XMUL = 1, LMUL = 1, RS = 72; };
 template <> struct BsLds<128, false> { static constexpr int XS = 4, XM = 7, XMUL = 3, LMUL = 0, RS = 144; };
 template <> struct BsLds<256, false> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 256; };
@@ -64,6 +70,12 @@ template <> struct BsLds<512, true> { static constexpr int XS = 3, XM = 31, XMUL
 #ifndef OFDFT_BS_TWTAB
 #define OFDFT_BS_TWTAB 0          // 1: stage twiddles W^(t k) read from the LDS table (fewer fp64 instructions, more LDS time)
 #endif
+#ifndef OFDFT_BS_TRANSPOSE
+#define OFDFT_BS_TRANSPOSE 1
+#endif
+#ifndef OFDFT_BS_TRANSPOSE_MINP
+#define OFDFT_BS_TRANSPOSE_MINP 64          // lines of one wave (M >= 512); shorter lines share waves and gain nothing (129 x 135 x 127)
+#endif
 #ifndef OFDFT_BS_XOR
 #define OFDFT_BS_XOR 1
 #endif
@@ -73,13 +85,13 @@ template <int M> struct LdsLayout<BsPlan<M>> : LdsLayoutDefault {
 };
 template <int M> struct BsPlanPick { using type = BsPlan<M>; };
 template <> struct BsPlanPick<1024> { using type = Plan<1024>; };
-template <int M> struct BsCfg {
+template <int M, bool ROWS> struct BsCfg {        // ROWS: the z passes (real rows in pairs); else complex lines
     using PL = typename BsPlanPick<M>::type;
-    static constexpr int TPB = OFDFT_BS_TPB;
-    static constexpr int STRIDE = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::RS : LineBuf<M>::STRIDE;
+    static constexpr int TPB = ROWS ? OFDFT_BS_ZTPB : OFDFT_BS_TPB;
+    static constexpr int STRIDE = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::RS : ((LineBuf<M>::STRIDE + 1) & ~1);      // (even: the buffers also hold complex entries)
     static constexpr int LMUL = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::LMUL : 0;
     static constexpr int P = PL::P, E = PL::E, LPW = TPB / P;
-    static constexpr int WAVES = M >= 1024 ? 2 : OFDFT_BS_WAVES;
+    static constexpr int WAVES = M >= 1024 ? 2 : (ROWS ? OFDFT_BS_ZWAVES : OFDFT_BS_WAVES);
     static_assert(PL::EXACT, "element j + P q in slot q");
     static constexpr size_t LDS = sizeof(real) * LPW * STRIDE + 2 * sizeof(cplx) * M;   // line buffers + the staged twiddle and filter tables
 };
@@ -107,11 +119,12 @@ __device__ __forceinline__ void chirpz_line(cplx (&v)[PL::E], const cplx (&wch)[
 }
 
 template <int M, int KIND, bool INV>
-__global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(BsCfg<M>::WAVES, BsCfg<M>::WAVES))) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
+__global__ __launch_bounds__((BsCfg<M, KIND != BS_CPLX>::TPB))
+__attribute__((amdgpu_waves_per_eu(BsCfg<M, KIND != BS_CPLX>::WAVES, BsCfg<M, KIND != BS_CPLX>::WAVES))) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
                                                                   const cplx* __restrict__ chirp,   // w_n, n < N
                                                                   const cplx* __restrict__ filt,    // FFT_M(b) / M
                                                                   const cplx* __restrict__ twM) {
-    using Cfg = BsCfg<M>;
+    using Cfg = BsCfg<M, KIND != BS_CPLX>;
     using PL = typename Cfg::PL;
     constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, TPB = Cfg::TPB;
     constexpr int EH = (E + 1) / 2;           // slots that can hold an element e = j + P q < N <= (M + 1) / 2
@@ -152,7 +165,15 @@ __global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(B
     // ---- persistent workgroups: tiles of LPW lines, no workgroup barrier inside the loop
     const long long ntiles = (b.nlines + LPW - 1) / LPW;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long L = tile * LPW + l;
+        // complex lines (OFDFT_BS_TRANSPOSE): a thread LOADS and STORES for line `lsel`, element es + P q -- consecutive lanes take
+        // consecutive lines (kz-fastest), so one instruction of a wave covers whole 128-B runs of the block-8 layout -- and hands the
+        // elements to the line's owner wave through that wave's line buffer (N <= M / 2 complex entries, slot e ^ line so that the
+        // 8 or 16 lanes of a write group hit distinct banks).  With the owner lanes loading their own line every cache line was
+        // requested by 8 waves, 16 bytes each (x pass 2.2 TB/s, y pass 3.1 TB/s at 255^3).
+        constexpr bool TR = KIND == BS_CPLX && OFDFT_BS_TRANSPOSE != 0 && P >= OFDFT_BS_TRANSPOSE_MINP;
+        constexpr int XMASK = (M / 2 >= 16) ? ((sizeof(real) == 4 && LPW >= 16) ? 15 : 7) : 0;
+        const int lg = TR ? tid % LPW : l, jg = TR ? tid / LPW : j;      // line and lane slot of the global accesses
+        const long long L = tile * LPW + lg;
         const bool valid = L < b.nlines;
         // element offsets (bytes, 32 bit: the engine takes this path up to 512 points per axis, 1.1 GB per spectrum); complex
         // lines are enumerated kz-fastest: the waves of a workgroup take the kz neighbours of one 128-B run
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(B
         unsigned off[EH];
 #pragma unroll
         for (int q = 0; q < EH; ++q) {
-            const int e = j + P * q;
+            const int e = jg + P * q;
             const bool in = valid && e < N;
             if (KIND == BS_CPLX) {
                 off[q] = in ? base + (unsigned)e * stride : kBsOob;
@@ -198,9 +219,27 @@ __global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(B
                 off[q] = in ? (row * (unsigned)g.n2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
             }
         }
+        if (TR) {
+            cplx* theirs = reinterpret_cast<cplx*>(lds + lg * Cfg::STRIDE);
+#pragma unroll
+            for (int q = 0; q < EH; ++q) theirs[(jg + P * q) ^ (lg & XMASK)] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) v[q] = reinterpret_cast<cplx*>(mine)[(j + P * q) ^ (l & XMASK)];
+            exchange_sync<true>();
+        }
 #pragma unroll
         for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
         chirpz_line<PL, M, INV>(v, wch, j, mine, tw_l, fl_l, (l * Cfg::LMUL) & 31);
+        if (TR) {
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) reinterpret_cast<cplx*>(mine)[(j + P * q) ^ (l & XMASK)] = v[q];
+            __syncthreads();
+            const cplx* theirs = reinterpret_cast<const cplx*>(lds + lg * Cfg::STRIDE);
+#pragma unroll
+            for (int q = 0; q < EH; ++q) v[q] = theirs[(jg + P * q) ^ (lg & XMASK)];
+        }
         if (KIND == BS_R2C) {
             // Z = A + i B with A, B Hermitian: A_k = (Z_k + conj Z_{N-k}) / 2, B_k = (Z_k - conj Z_{N-k}) / 2i -- the partner
             // element comes through the line buffer (real parts, then imaginary parts; N <= M / 2 entries)
@@ -255,7 +294,8 @@ __global__ __launch_bounds__(BsCfg<M>::TPB) __attribute__((amdgpu_waves_per_eu(B
                 }
             }
         }
-        exchange_sync<true>();          // the line buffer is reused by the next tile
+        if (TR) __syncthreads();        // the line buffers are rewritten by other waves in the next tile
+        else exchange_sync<true>();     // the line buffer is reused by the next tile
     }
 }
 

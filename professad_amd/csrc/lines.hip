@@ -278,14 +278,16 @@ template <int M>
 int launch_bluestein_t(ofdft_ctx* c, const BsIo& io, int narr, const BsArgs& b, const BsTables& t, hipStream_t st) {
     cplx* tw;
     if (int rc = get_twiddle(c, M, &tw)) return rc;
-    using Cfg = BsCfg<M>;
-    // persistent workgroups (the tables are staged once per workgroup): at most OFDFT_BS_WGS per CU and array
-    const long long tiles = (b.nlines + Cfg::LPW - 1) / Cfg::LPW;
-    const int blocks = (int)std::min<long long>(tiles, (long long)device_cus(c) * OFDFT_BS_WGS);
     const char* nm = b.mode ? "bluestein_z" : (b.axis ? "bluestein_y" : "bluestein_x");
+    // persistent workgroups (the tables are staged once per workgroup): at most OFDFT_BS_WGS per CU and array
 #define OFDFT_BS(KIND_, INV_)                                                                                                       \
-    OFDFT_LAUNCH(c, st, nm, (bluestein_kernel<M, KIND_, INV_>), dim3(blocks, narr), dim3(Cfg::TPB), Cfg::LDS, io, c->g, b, \
-                 (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw)
+    do {                                                                                                                            \
+        using Cfg = BsCfg<M, KIND_ != BS_CPLX>;                                                                                     \
+        const long long tiles = (b.nlines + Cfg::LPW - 1) / Cfg::LPW;                                                               \
+        const int blocks = (int)std::min<long long>(tiles, (long long)device_cus(c) * OFDFT_BS_WGS);                                \
+        OFDFT_LAUNCH(c, st, nm, (bluestein_kernel<M, KIND_, INV_>), dim3(blocks, narr), dim3(Cfg::TPB), Cfg::LDS, io, c->g, b,      \
+                     (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw);                                                   \
+    } while (0)
     if (b.mode == 1) OFDFT_BS(BS_R2C, false);
     else if (b.mode == 2) OFDFT_BS(BS_C2R, true);
     else if (b.inv) OFDFT_BS(BS_CPLX, true);
