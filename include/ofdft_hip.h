@@ -316,6 +316,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_TEST_FAULT 11   /* test hook, never set in production: 1 = the NEXT persistent-kernel launch is one workgroup short (its grid
                                      barriers time out -> the call must still return the right numbers through the staged path and switch the
                                      kernel off); 2 = the co-residency check of the persistent kernel reports "does not fit" */
+#define OFDFT_OPT_BS_FUSED 15     /* chirp-z path (extents without a line-transform plan, i.e. what the reference's System.ecut2shape, system.py:74-89, gives):
+                                     1 (default) = forward-x, spectral multiply and inverse-x of every convolution in ONE kernel (x extents up to 256);
+                                     0 = three passes per transform and separate multiply kernels */
 #define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
                                      registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
                                      group-parallel kernel that trades spectra through LDS */

@@ -44,6 +44,12 @@ struct BsIo {
 #ifndef OFDFT_BS_WGS
 #define OFDFT_BS_WGS 4            // persistent workgroups per CU and array
 #endif
+#ifndef OFDFT_BS_XTPB
+#define OFDFT_BS_XTPB 512
+#endif
+#ifndef OFDFT_BS_XWAVES
+#define OFDFT_BS_XWAVES 2
+#endif
 #ifndef OFDFT_BS_ZTPB
 #define OFDFT_BS_ZTPB 256
 #endif
@@ -85,13 +91,15 @@ template <int M> struct LdsLayout<BsPlan<M>> : LdsLayoutDefault {
 };
 template <int M> struct BsPlanPick { using type = BsPlan<M>; };
 template <> struct BsPlanPick<1024> { using type = Plan<1024>; };
-template <int M, bool ROWS> struct BsCfg {        // ROWS: the z passes (real rows in pairs); else complex lines
+// CLS 0: complex lines, 1: the z passes (real rows in pairs), 2: the fused forward-x / mix / inverse-x kernel (up to three
+// spectra of a line in registers)
+template <int M, int CLS> struct BsCfg {
     using PL = typename BsPlanPick<M>::type;
-    static constexpr int TPB = ROWS ? OFDFT_BS_ZTPB : OFDFT_BS_TPB;
+    static constexpr int TPB = CLS == 1 ? OFDFT_BS_ZTPB : (CLS == 2 ? OFDFT_BS_XTPB : OFDFT_BS_TPB);
     static constexpr int STRIDE = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::RS : ((LineBuf<M>::STRIDE + 1) & ~1);      // (even: the buffers also hold complex entries)
     static constexpr int LMUL = (OFDFT_BS_XOR && M <= 512) ? BsLds<M>::LMUL : 0;
     static constexpr int P = PL::P, E = PL::E, LPW = TPB / P;
-    static constexpr int WAVES = M >= 1024 ? 2 : (ROWS ? OFDFT_BS_ZWAVES : OFDFT_BS_WAVES);
+    static constexpr int WAVES = M >= 1024 ? 2 : (CLS == 1 ? OFDFT_BS_ZWAVES : (CLS == 2 ? OFDFT_BS_XWAVES : OFDFT_BS_WAVES));
     static_assert(PL::EXACT, "element j + P q in slot q");
     static constexpr size_t LDS = sizeof(real) * LPW * STRIDE + 2 * sizeof(cplx) * M;   // line buffers + the staged twiddle and filter tables
 };
@@ -102,29 +110,40 @@ constexpr int BS_CPLX = 0;      // complex lines along x (axis 0) or y (axis 1) 
 constexpr int BS_R2C = 1;       // real rows -> half spectrum along z
 constexpr int BS_C2R = 2;       // half spectrum -> real rows along z (times `scale`)
 
-// the convolution itself: v (element j + P q in slot q, zero beyond the line) -> its N-point DFT, same slots
-template <class PL, int M, bool INV>
+__device__ __forceinline__ cplx cmul_cj(cplx a, cplx b) {      // a * conj(b)
+    return mkc(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// the convolution itself: v (element j + P q in slot q, zero beyond the line) -> its N-point DFT, same slots.  The chirp (wch)
+// and the filter spectrum (fl_l, in LDS) are in their FORWARD form; the inverse transform conjugates them where they are used
+// (PRE / POST = false skip the chirp multiplication before / after the convolution: in the fused x pass the forward transform's
+// post-multiplication w_k and the inverse transform's pre-multiplication conj(w_k) cancel, |w_k| = 1, around a mix that is
+// diagonal in k)
+template <class PL, int M, bool INV, bool PRE = true, bool POST = true>
 __device__ __forceinline__ void chirpz_line(cplx (&v)[PL::E], const cplx (&wch)[(PL::E + 1) / 2], int j, real* mine,
                                             const cplx* tw_l, const cplx* fl_l, int lx) {
     constexpr int P = PL::P, E = PL::E, EH = (E + 1) / 2;
+    if constexpr (PRE) {
 #pragma unroll
-    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);       // (slots without an element hold zero)
+        for (int q = 0; q < EH; ++q) v[q] = INV ? cmul_cj(v[q], wch[q]) : cmul(v[q], wch[q]);       // (slots without an element hold zero)
+    }
     StageP<PL, 0, 1, false, true, OFDFT_BS_TWTAB != 0>::run(v, j, mine, tw_l, lx);
 #pragma unroll
-    for (int q = 0; q < E; ++q) v[q] = cmul(v[q], fl_l[j + P * q]);         // (staged with the direction's sign)
+    for (int q = 0; q < E; ++q) v[q] = INV ? cmul_cj(v[q], fl_l[j + P * q]) : cmul(v[q], fl_l[j + P * q]);
     exchange_sync<true>();
     StageP<PL, 0, 1, true, true, OFDFT_BS_TWTAB != 0>::run(v, j, mine, tw_l, lx);
+    if constexpr (POST) {
 #pragma unroll
-    for (int q = 0; q < EH; ++q) v[q] = cmul(v[q], wch[q]);
+        for (int q = 0; q < EH; ++q) v[q] = INV ? cmul_cj(v[q], wch[q]) : cmul(v[q], wch[q]);
+    }
 }
 
 template <int M, int KIND, bool INV>
-__global__ __launch_bounds__((BsCfg<M, KIND != BS_CPLX>::TPB))
-__attribute__((amdgpu_waves_per_eu(BsCfg<M, KIND != BS_CPLX>::WAVES, BsCfg<M, KIND != BS_CPLX>::WAVES))) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
+__global__ __launch_bounds__((BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>::TPB))
+__attribute__((amdgpu_waves_per_eu(BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>::WAVES, BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>::WAVES))) void bluestein_kernel(BsIo io, SpecGeom g, BsArgs b,
                                                                   const cplx* __restrict__ chirp,   // w_n, n < N
                                                                   const cplx* __restrict__ filt,    // FFT_M(b) / M
                                                                   const cplx* __restrict__ twM) {
-    using Cfg = BsCfg<M, KIND != BS_CPLX>;
+    using Cfg = BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>;
     using PL = typename Cfg::PL;
     constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, TPB = Cfg::TPB;
     constexpr int EH = (E + 1) / 2;           // slots that can hold an element e = j + P q < N <= (M + 1) / 2
@@ -142,23 +161,20 @@ __attribute__((amdgpu_waves_per_eu(BsCfg<M, KIND != BS_CPLX>::WAVES, BsCfg<M, KI
         }
     const int j = tid % P, l = tid / P;
     const int N = b.N;
-    // ---- once per workgroup: twiddles and the filter spectrum (with the direction's sign) into LDS, this lane's chirp values
+    // ---- once per workgroup: twiddles and the filter spectrum into LDS, this lane's chirp values
     // into registers (slot q of lane j holds element j + P q of EVERY line).  The filter used to be requested from global
     // memory between the two transforms -- an L2 round trip in the middle of each line's dependent chain.
     cplx* tw_l = reinterpret_cast<cplx*>(lds + LPW * Cfg::STRIDE);
     cplx* fl_l = tw_l + M;
     for (int i = tid; i < M; i += TPB) {
         tw_l[i] = buf_load_c(twM, (unsigned)i * kCB);
-        cplx f = buf_load_c(filt, (unsigned)i * kCB);
-        if (INV) f.y = -f.y;                            // inverse transform = conjugated chirps and filter
-        fl_l[i] = f;
+        fl_l[i] = buf_load_c(filt, (unsigned)i * kCB);
     }
     cplx wch[EH];
 #pragma unroll
     for (int q = 0; q < EH; ++q) {
         const int e = j + P * q;
         wch[q] = buf_load_c(chirp, e < N ? (unsigned)e * kCB : kBsOob);
-        if (INV) wch[q].y = -wch[q].y;
     }
     real* mine = lds + l * Cfg::STRIDE;
     __syncthreads();
@@ -296,6 +312,131 @@ __attribute__((amdgpu_waves_per_eu(BsCfg<M, KIND != BS_CPLX>::WAVES, BsCfg<M, KI
         }
         if (TR) __syncthreads();        // the line buffers are rewritten by other waves in the next tile
         else exchange_sync<true>();     // the line buffer is reused by the next tile
+    }
+}
+
+// ---- forward-x, k-space mix, inverse-x of the unfused pipeline in ONE kernel (the chirp-z counterpart of xfused_kernel):
+// NIN spectra that have been through their z and y passes -> NOUT spectra ready for the inverse y and z passes, out_o =
+// sum_i c_oi(k) in_i with the coefficient functors of the fused x pass (pointwise_kernels.h: MixDensity, MixScale, MixDiv,
+// MixWgc).  Per convolution this saves one x pass' load + store and the separate spectral multiply kernel (a read and a
+// write of every spectrum involved); the four M-point transforms per line and spectrum pair remain.
+struct BsMixIo { const cplx* in[4]; cplx* out[4]; };
+template <int M, int NIN, int NOUT, class Mix>
+__global__ __launch_bounds__((BsCfg<M, 2>::TPB))
+__attribute__((amdgpu_waves_per_eu(BsCfg<M, 2>::WAVES, BsCfg<M, 2>::WAVES))) void bluestein_xmix_kernel(
+    BsMixIo io, SpecGeom g, int N, long long nlines, const cplx* __restrict__ chirp, const cplx* __restrict__ filt,
+    const cplx* __restrict__ twM, Mix mix) {
+    using Cfg = BsCfg<M, 2>;
+    using PL = typename Cfg::PL;
+    constexpr int P = Cfg::P, E = Cfg::E, LPW = Cfg::LPW, TPB = Cfg::TPB;
+    constexpr int EH = (E + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    const int tid = threadIdx.x;
+    const int j = tid % P, l = tid / P;
+    cplx* tw_l = reinterpret_cast<cplx*>(lds + LPW * Cfg::STRIDE);
+    cplx* fl_l = tw_l + M;
+    for (int i = tid; i < M; i += TPB) {
+        tw_l[i] = buf_load_c(twM, (unsigned)i * kCB);
+        fl_l[i] = buf_load_c(filt, (unsigned)i * kCB);
+    }
+    cplx wch[EH];
+#pragma unroll
+    for (int q = 0; q < EH; ++q) {
+        const int e = j + P * q;
+        wch[q] = buf_load_c(chirp, e < N ? (unsigned)e * kCB : kBsOob);
+    }
+    real* mine = lds + l * Cfg::STRIDE;
+    cplx* minec = reinterpret_cast<cplx*>(mine);
+    constexpr int XMASK = (M / 2 >= 16) ? ((sizeof(real) == 4 && LPW >= 16) ? 15 : 7) : 0;
+    const int lg = tid % LPW, jg = tid / LPW;       // line and lane slot of the global accesses (see bluestein_kernel)
+    cplx* theirs = reinterpret_cast<cplx*>(lds + lg * Cfg::STRIDE);
+    const int lx = (l * Cfg::LMUL) & 31;
+    const long long ntiles = (nlines + LPW - 1) / LPW;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // x lines, enumerated kz-fastest: line L = (y, kz)
+        unsigned off[EH];
+        {
+            const long long L = tile * LPW + lg;
+            const int kz = (int)(L % g.nzc), y = (int)(L / g.nzc);
+            unsigned base, stride;
+            if (kz < g.nzm) {
+                base = (((unsigned)(kz >> 3) * (unsigned)g.nrows + (unsigned)y) * 8u + (unsigned)(kz & 7)) * kCB;
+                stride = (unsigned)g.n1 * 8u * kCB;
+            } else {
+                base = ((unsigned)g.main_count + (unsigned)(kz - g.nzm) * (unsigned)g.nrows + (unsigned)y) * kCB;
+                stride = (unsigned)g.n1 * kCB;
+            }
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = jg + P * q;
+                off[q] = (L < nlines && e < N) ? base + (unsigned)e * stride : kBsOob;
+            }
+        }
+        // the line this wave transforms (its k-space coordinates and table offsets for the mix)
+        const long long Lo = tile * LPW + l;
+        const bool valid_o = Lo < nlines;
+        const int kzo = (int)(Lo % g.nzc), yo = (int)(Lo / g.nzc);
+        cplx X[NIN][EH];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) v[q] = buf_load_c(io.in[i], off[q]);
+            if (i) __syncthreads();             // the other waves are done with their line buffers
+#pragma unroll
+            for (int q = 0; q < EH; ++q) theirs[(jg + P * q) ^ (lg & XMASK)] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) v[q] = minec[(j + P * q) ^ (l & XMASK)];
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, false, true, false>(v, wch, j, mine, tw_l, fl_l, lx);
+#pragma unroll
+            for (int q = 0; q < EH; ++q) X[i][q] = v[q];
+        }
+        cplx Y[NOUT][EH];
+#pragma unroll
+        for (int q = 0; q < EH; ++q) {
+            const int e = j + P * q;
+            const bool in = valid_o && e < N;
+            const unsigned idx = kzo < g.nzm ? ((unsigned)(kzo >> 3) * (unsigned)g.nrows + (unsigned)e * (unsigned)g.n1 + (unsigned)yo) * 8u + (unsigned)(kzo & 7)
+                                             : (unsigned)g.main_count + (unsigned)(kzo - g.nzm) * (unsigned)g.nrows + (unsigned)e * (unsigned)g.n1 + (unsigned)yo;
+            static_for<NOUT>([&](auto oc) {
+                constexpr int O = decltype(oc)::value;
+                cplx acc = mkc(0.0, 0.0);
+                static_for<NIN>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    if constexpr (Mix::template present<O, I>()) {
+                        const real cf = in ? mix.template coef<O, I>(e, yo, kzo, 0LL, idx) : (real)0.0;
+                        if constexpr (Mix::template imag_oi<O, I>()) {
+                            acc.x -= cf * X[I][q].y;
+                            acc.y += cf * X[I][q].x;
+                        } else {
+                            acc.x += cf * X[I][q].x;
+                            acc.y += cf * X[I][q].y;
+                        }
+                    }
+                });
+                Y[O][q] = acc;
+            });
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) v[q] = Y[o][q];
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, true, false, true>(v, wch, j, mine, tw_l, fl_l, lx);
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) minec[(j + P * q) ^ (l & XMASK)] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) buf_store_c(io.out[o], off[q], theirs[(jg + P * q) ^ (lg & XMASK)]);
+            __syncthreads();                    // before the line buffers are used again
+        }
     }
 }
 

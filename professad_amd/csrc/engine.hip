@@ -411,6 +411,9 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
     real *vh = nullptr, *gx = nullptr, *gy = nullptr, *gz = nullptr, *dfdn = nullptr, *dv = nullptr, *lapn = nullptr, *lap = nullptr,
          *cb = nullptr, *cva = nullptr;
     const bool lapl = has_g && gga_needs_laplacian(c);
+    // chirp-z path: the x transforms and the spectral multiplies of every convolution below run as ONE kernel per convolution
+    // (bluestein_xmix); the Laplacian-dependent GGA members keep the three-pass form
+    const bool xm = bluestein_xmix_ok(c) && !lapl;
     // ---- A: forward batch
     {
         const real* fin[4];
@@ -442,7 +445,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             }
         }
         if (nf)
-            if (int rc = rfftn_internal_multi(c, fin, fout, nf, st)) return rc;
+            if (int rc = (xm ? bluestein_fwd_zy_multi(c, fin, fout, nf, st) : rfftn_internal_multi(c, fin, fout, nf, st))) return rc;
     }
     // ---- B: spectral multiplies; C: inverse batches (at most kBsBatch arrays each)
     {
@@ -465,13 +468,29 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             if (has_g)
                 if (int rc = spec_ws(c, "svh", &svh)) return rc;       // (s1 carries a gradient component then)
             if (int rc = real_ws(c, "vh", &vh)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, svh, c->kg, 0.0, 0.0);
+            if (!xm)
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_HARTREE>), dim3(sp_grid), dim3(256), 0, s0, svh, c->kg, 0.0, 0.0);
+            else if (!has_g) {
+                const cplx* xi[1] = {s0};
+                cplx* xo[1] = {svh};
+                if (int rc = bluestein_xmix<1, 1>(c, xi, xo, MixScale<SPEC_HARTREE>{c->kg, (real)0.0, (real)0.0}, st)) return rc;
+            }
             iin[ni] = svh;
             iout[ni++] = vh;
             ca.vh = vh;
         }
         if (has_g) {
-            OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
+            if (!xm)
+                OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
+            else if (has_h) {          // n^ -> v_H^ and the three gradient components: one forward-x, four inverse-x
+                const cplx* xi[1] = {s0};
+                cplx* xo[4] = {iin[ni - 1], s1, s2, s3};
+                if (int rc = bluestein_xmix<1, 4>(c, xi, xo, MixDensity<true, true>{c->kg}, st)) return rc;
+            } else {
+                const cplx* xi[1] = {s0};
+                cplx* xo[3] = {s1, s2, s3};
+                if (int rc = bluestein_xmix<1, 3>(c, xi, xo, MixDensity<false, true>{c->kg}, st)) return rc;
+            }
             iin[ni] = s1; iout[ni++] = gx;
             iin[ni] = s2; iout[ni++] = gy;
             iin[ni] = s3; iout[ni++] = gz;
@@ -484,7 +503,13 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         }
         if (has_vw) {
             if (int rc = real_ws(c, "lap", &lap)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s_vw, s_vw, c->kg, 0.0, 0.0);
+            if (!xm)
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LAPLACE>), dim3(sp_grid), dim3(256), 0, s_vw, s_vw, c->kg, 0.0, 0.0);
+            else {
+                const cplx* xi[1] = {s_vw};
+                cplx* xo[1] = {s_vw};
+                if (int rc = bluestein_xmix<1, 1>(c, xi, xo, MixScale<SPEC_LAPLACE>{c->kg, (real)0.0, (real)0.0}, st)) return rc;
+            }
             iin[ni] = s_vw; iout[ni++] = lap;
             ca.lap_s = lap;
         }
@@ -493,15 +518,27 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             const double kf = std::cbrt(3.0 * kPi * kPi * nbar);
             const double pref = 5.0 / (9.0 * wal * wbe * std::pow(nbar, wal + wbe - kFiveThirds));
             if (int rc = real_ws(c, "conv_b", &cb)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wb, s_wb, c->kg, pref,
-                               1.0 / (2.0 * kf));
+            if (!xm)
+                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wb, s_wb, c->kg, pref,
+                                   1.0 / (2.0 * kf));
+            else {
+                const cplx* xi[1] = {s_wb};
+                cplx* xo[1] = {s_wb};
+                if (int rc = bluestein_xmix<1, 1>(c, xi, xo, MixScale<SPEC_LINDHARD>{c->kg, (real)pref, (real)(1.0 / (2.0 * kf))}, st)) return rc;
+            }
             iin[ni] = s_wb; iout[ni++] = cb;
             ca.conv_b = cb;
             ca.conv_a = nullptr;
             if (wt2) {
                 if (int rc = real_ws(c, "conv_a", &cva)) return rc;
-                OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wa, s_wa, c->kg, pref,
-                                   1.0 / (2.0 * kf));
+                if (!xm)
+                    OFDFT_LAUNCH(c, st, "spec_scale", (spec_scale_kernel<SPEC_LINDHARD>), dim3(sp_grid), dim3(256), 0, s_wa, s_wa, c->kg, pref,
+                                       1.0 / (2.0 * kf));
+                else {
+                    const cplx* xi[1] = {s_wa};
+                    cplx* xo[1] = {s_wa};
+                    if (int rc = bluestein_xmix<1, 1>(c, xi, xo, MixScale<SPEC_LINDHARD>{c->kg, (real)pref, (real)(1.0 / (2.0 * kf))}, st)) return rc;
+                }
                 iin[ni] = s_wa; iout[ni++] = cva;
                 ca.conv_a = cva;
             }
@@ -511,7 +548,9 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             ca.wt_is_56 = (wal == kFiveSixths && wbe == kFiveSixths) ? 1 : 0;
         }
         for (int b0 = 0; b0 < ni; b0 += 4)
-            if (int rc = irfftn_internal_multi(c, iin + b0, iout + b0, std::min(4, ni - b0), inv_n, st)) return rc;
+            if (int rc = (xm ? bluestein_inv_yz_multi(c, iin + b0, iout + b0, std::min(4, ni - b0), inv_n, st)
+                             : irfftn_internal_multi(c, iin + b0, iout + b0, std::min(4, ni - b0), inv_n, st)))
+                return rc;
     }
     // ---- D: GGA mid stage (needs grad n [, lap n] in real space), flux forward batch, divergence inverse
     if (has_g) {
@@ -522,12 +561,20 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         {
             cplx* sg[4] = {s1, s2, s3, s4};
             const real* rg[4] = {gx, gy, gz, lapn};
-            if (int rc = rfftn_internal_multi(c, rg, sg, lapl ? 4 : 3, st)) return rc;
+            if (int rc = (xm ? bluestein_fwd_zy_multi(c, rg, sg, 3, st) : rfftn_internal_multi(c, rg, sg, lapl ? 4 : 3, st))) return rc;
         }
+        if (xm) {
+            const cplx* xi[3] = {s1, s2, s3};
+            cplx* xo[1] = {s0};
+            real* dvo[1] = {dv};
+            if (int rc = bluestein_xmix<3, 1>(c, xi, xo, MixDiv{c->kg}, st)) return rc;
+            if (int rc = bluestein_inv_yz_multi(c, xo, dvo, 1, inv_n, st)) return rc;
+        } else {
         OFDFT_LAUNCH(c, st, "spec_div", spec_div_kernel, dim3(sp_grid), dim3(256), 0, s1, s2, s3, s0, c->kg);
         if (lapl)        // v += lap(df/dL): the combine forms v += df/dn - 2 div, so div -= lap(df/dL) / 2, i.e. s0 += k^2 (df/dL)^ / 2
             OFDFT_LAUNCH(c, st, "spec_scale", spec_add_lap_kernel, dim3(sp_grid), dim3(256), 0, (const cplx*)s4, s0, c->kg, 0.5);
         if (int rc = irfftn_internal(c, s0, dv, inv_n, st)) return rc;
+        }
         ca.dfdn = dfdn;
         ca.div = dv;
     }
@@ -551,6 +598,12 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
                                nref);
             cplx* sw[3] = {s0, s1, s2};
             const real* tw3[3] = {t0, t1, t2};
+            if (xm) {
+                if (int rc = bluestein_fwd_zy_multi(c, tw3, sw, 3, st)) return rc;
+                if (int rc = bluestein_xmix<3, 3>(c, sw, sw, MixWgc{w0}, st)) return rc;
+                if (int rc = bluestein_inv_yz_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
+                continue;
+            }
             if (int rc = rfftn_internal_multi(c, tw3, sw, 3, st)) return rc;
             OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, w0, K1, K2, K3, c->g.total);
             if (int rc = irfftn_internal_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
@@ -1455,6 +1508,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             return OFDFT_OK;
         case OFDFT_OPT_BLUESTEIN:
             c->use_bluestein = value != 0.0;
+            return OFDFT_OK;
+        case OFDFT_OPT_BS_FUSED:
+            c->bs_fused = value != 0.0;
             return OFDFT_OK;
         case OFDFT_OPT_GGA_SPLIT:
             c->gga_split = value != 0.0;

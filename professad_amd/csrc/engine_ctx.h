@@ -82,6 +82,7 @@ struct ofdft_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;
     bool use_side_stream = true;
+    bool bs_fused = true;        // chirp-z path: forward-x, spectral multiply and inverse-x in one kernel (OFDFT_OPT_BS_FUSED)
     bool use_bluestein = true;   // non power-of-two extents <= 512: chirp-z line transforms (else the plain O(N^2) DFT kernels)
     bool gga_split = true;       // GGA chain in split-derivative form: only the x index-derivative visits the x pass
     bool split_combine = true;   // WGC99 part of the combine as its own kernel on the nonlocal chain's stream (forked runs)
@@ -297,6 +298,12 @@ template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list,
 int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st);
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
 int rfftn_internal_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st);
+// chirp-z path with the fused x pass (lines.hip): z + y passes | forward-x, mix, inverse-x | y + z passes
+bool bluestein_xmix_ok(const ofdft_ctx* c);
+template <int NIN, int NOUT, class Mix>
+int bluestein_xmix(ofdft_ctx* c, const cplx* const* in, cplx* const* out, const Mix& mix, hipStream_t st);
+int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st);
+int bluestein_inv_yz_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st);
 int irfftn_internal_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st);
 int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);
 int fwd_zy(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);

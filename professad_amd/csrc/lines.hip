@@ -282,7 +282,7 @@ int launch_bluestein_t(ofdft_ctx* c, const BsIo& io, int narr, const BsArgs& b, 
     // persistent workgroups (the tables are staged once per workgroup): at most OFDFT_BS_WGS per CU and array
 #define OFDFT_BS(KIND_, INV_)                                                                                                       \
     do {                                                                                                                            \
-        using Cfg = BsCfg<M, KIND_ != BS_CPLX>;                                                                                     \
+        using Cfg = BsCfg<M, (KIND_ != BS_CPLX ? 1 : 0)>;                                                                                     \
         const long long tiles = (b.nlines + Cfg::LPW - 1) / Cfg::LPW;                                                               \
         const int blocks = (int)std::min<long long>(tiles, (long long)device_cus(c) * OFDFT_BS_WGS);                                \
         OFDFT_LAUNCH(c, st, nm, (bluestein_kernel<M, KIND_, INV_>), dim3(blocks, narr), dim3(Cfg::TPB), Cfg::LDS, io, c->g, b,      \
@@ -294,6 +294,70 @@ int launch_bluestein_t(ofdft_ctx* c, const BsIo& io, int narr, const BsArgs& b, 
     else OFDFT_BS(BS_CPLX, false);
 #undef OFDFT_BS
     return 0;
+}
+
+int bluestein_pass_multi(ofdft_ctx* c, int mode, int axis, int inv, const BsIo& io, int narr, double scale, hipStream_t st);
+bool bluestein_ok(const ofdft_ctx* c);
+// forward-x, mix, inverse-x in one chirp-z kernel (bluestein.h: bluestein_xmix_kernel); x extents up to 256 (M <= 512)
+template <int M, int NIN, int NOUT, class Mix>
+static int launch_xmix_t(ofdft_ctx* c, const BsMixIo& io, const Mix& mix, const BsTables& t, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, M, &tw)) return rc;
+    using Cfg = BsCfg<M, 2>;
+    const long long nlines = (long long)c->n1 * c->g.nzc;
+    const long long tiles = (nlines + Cfg::LPW - 1) / Cfg::LPW;
+    const int blocks = (int)std::min<long long>(tiles, (long long)device_cus(c) * OFDFT_BS_WGS);
+    OFDFT_LAUNCH(c, st, "bluestein_xmix", (bluestein_xmix_kernel<M, NIN, NOUT, Mix>), dim3(blocks), dim3(Cfg::TPB), Cfg::LDS, io, c->g,
+                 c->n0, nlines, (const cplx*)t.chirp, (const cplx*)t.filt, (const cplx*)tw, mix);
+    return 0;
+}
+bool bluestein_xmix_ok(const ofdft_ctx* c) { return c->bs_fused && bluestein_ok(c) && c->nranks == 1 && !c->fast && c->n0 <= 256; }
+template <int NIN, int NOUT, class Mix>
+int bluestein_xmix(ofdft_ctx* c, const cplx* const* in, cplx* const* out, const Mix& mix, hipStream_t st) {
+    BsTables t;
+    if (int rc = get_bluestein(c, c->n0, &t)) return rc;
+    BsMixIo io{};
+    for (int i = 0; i < NIN; ++i) io.in[i] = in[i];
+    for (int o = 0; o < NOUT; ++o) io.out[o] = out[o];
+    switch (t.M) {
+        case 8: return launch_xmix_t<8, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 16: return launch_xmix_t<16, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 32: return launch_xmix_t<32, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 64: return launch_xmix_t<64, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 128: return launch_xmix_t<128, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 256: return launch_xmix_t<256, NIN, NOUT, Mix>(c, io, mix, t, st);
+        case 512: return launch_xmix_t<512, NIN, NOUT, Mix>(c, io, mix, t, st);
+    }
+    return fail(c, OFDFT_EINVAL, "no fused chirp-z x pass for length %d", c->n0);
+}
+template int bluestein_xmix<1, 1, MixScale<SPEC_HARTREE>>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixScale<SPEC_HARTREE>&, hipStream_t);
+template int bluestein_xmix<1, 1, MixScale<SPEC_LAPLACE>>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixScale<SPEC_LAPLACE>&, hipStream_t);
+template int bluestein_xmix<1, 1, MixScale<SPEC_LINDHARD>>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixScale<SPEC_LINDHARD>&, hipStream_t);
+template int bluestein_xmix<1, 3, MixDensity<false, true>>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixDensity<false, true>&, hipStream_t);
+template int bluestein_xmix<1, 4, MixDensity<true, true>>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixDensity<true, true>&, hipStream_t);
+template int bluestein_xmix<3, 1, MixDiv>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixDiv&, hipStream_t);
+template int bluestein_xmix<3, 3, MixWgc>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixWgc&, hipStream_t);
+
+// the z and y passes of `n` (<= kBsBatch) transforms, one launch per pass: the halves of a 3-D transform around the fused x pass
+int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st) {
+    BsIo io{};
+    for (int a = 0; a < n; ++a) {
+        io.spec[a] = spec[a];
+        io.rin[a] = in[a];
+    }
+    c->fft_count += n;
+    if (int rc = bluestein_pass_multi(c, 1, 2, 0, io, n, 1.0, st)) return rc;
+    return bluestein_pass_multi(c, 0, 1, 0, io, n, 1.0, st);
+}
+int bluestein_inv_yz_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st) {
+    BsIo io{};
+    for (int a = 0; a < n; ++a) {
+        io.spec[a] = spec[a];
+        io.rout[a] = out[a];
+    }
+    c->fft_count += n;
+    if (int rc = bluestein_pass_multi(c, 0, 1, 1, io, n, 1.0, st)) return rc;
+    return bluestein_pass_multi(c, 2, 2, 1, io, n, scale, st);
 }
 
 // one generic-length pass over `narr` (<= kBsBatch) arrays: mode 0 (complex, axis 0/1), 1 (r2c along z), 2 (c2r along z)

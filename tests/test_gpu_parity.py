@@ -1256,6 +1256,48 @@ def test_mixed_radix_extents_run_the_fused_pipelines(shape):
     eng.close()
 
 
+def test_odd_grid_fused_chirpz_x_pass_matches_the_three_pass_form_and_the_oracle():
+    """extents as the reference's System.ecut2shape gives them (system.py:74-89: always odd; here 27 x 35 x 33, triclinic): the
+    chirp-z path with forward-x / multiply / inverse-x in one kernel (OFDFT_OPT_BS_FUSED, default) against its three-pass form
+    with separate multiply kernels, and config 3 against the pinned CPU oracle"""
+    shape = (27, 35, 33)
+    box = cases.make_cell(('tri', 1.3))
+    den = synth.random_density(shape, seed=91)
+    vext = synth.random_potential(shape, seed=92)
+    chi = np.sqrt(den) * (1 + 0.1 * np.random.default_rng(93).random(shape))
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.3)
+    eng = Engine(shape, DEV).set_cell(dev(box))
+    assert not eng.fast_path
+    sets = [(F.NativeTerms(names).names, None) for names in _CFG_TERMS.values()]
+    sets.append((('hartree', 'vw', 'wt_nl', 'pbe_x', 'pbe_c'), {'wt_alpha': 0.7, 'wt_beta': 0.9}))
+    sets.append((('vw', 'pbe_x'), None))                      # gradient without Hartree
+    sets.append((('hartree', 'vw', 'gga_k', 'pbe_x', 'pbe_c'), {'ggak_kind': 1.0, 'ggak_beta': 0.25, 'ggak_lambda': 0.4, 'ggak_sigma': 0.2}))
+    for names, params in sets:
+        eng.set_terms(names, params)
+        res = {}
+        for fused in (1, 0):
+            eng.set_option(15, fused)
+            E, v = eng.energy_potential(dev(den), dev(vext))
+            Ec, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+            res[fused] = (E, v.cpu().numpy(), Ec, mu, g.cpu().numpy(), int(eng.query(4)))
+        a, b = res[1], res[0]
+        for k in b[0]:
+            assert abs(a[0][k] - b[0][k]) <= 1e-11 * max(1.0, abs(b[0][k])), (names, k, a[0][k], b[0][k])
+            assert abs(a[2][k] - b[2][k]) <= 1e-11 * max(1.0, abs(b[2][k])), (names, k)
+        assert relerr(a[1], b[1]) < 1e-10 and relerr(a[4], b[4]) < 1e-10 and abs(a[3] - b[3]) < 1e-11 * max(1.0, abs(b[3])), names
+        if 'gga_k' not in names:
+            assert a[5] < b[5], (names, a[5], b[5])       # the fused x pass really ran (fewer launches)
+    eng.set_option(15, 1)
+    ev = cf.Evaluator(cf.Grid(box, shape))
+    Eo, go, muo = ev.closure(['ion_electron', 'hartree', 'wgc99', 'pbe_x', 'pbe_c'], chi, n_elec, vext)
+    eng.set_terms(F.NativeTerms(_CFG_TERMS['cfg3']).names)
+    E, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+    assert abs(sum(E.values()) - Eo) <= E_RTOL * abs(Eo)
+    assert abs(mu - muo) <= 1e-9 * max(1.0, abs(muo))
+    assert relerr(g.cpu().numpy(), go) < V_RTOL
+    eng.close()
+
+
 def test_mixed_radix_grid_matches_the_oracle():
     """config 3 on a 48 x 96 x 120 triclinic grid against the pinned CPU oracle (closed forms on numpy FFTs)"""
     shape = (48, 96, 120)
