@@ -321,10 +321,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # (a collective that a failed rank never joins must not hold the job for the backend's default ten minutes)
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get('OFDFT_BENCH_COLL_TIMEOUT_S', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
