@@ -558,23 +558,82 @@ OFDFT_ZPLAN(256, 4, 4, 4, 4, 4, 4)
 template <int M, int WANT> struct ZPick { static constexpr int E = (M / WANT <= 64) ? WANT : 8; };
 // rows whose half length M = n2 / 2 has factors 3 and 5: one plan per M (P a power of two <= 64, E as small as the
 // factorisation allows), whatever lane width the kernel asked for
+#ifndef OFDFT_Z120_STAGES4
+#define OFDFT_Z120_STAGES4 1       // (240^3: zpbe2 40.2 -> 30.4 ps per point, zi_combine 22.6 -> 18.3, evaluation 3.12 -> 2.91 ms)
+#endif
+// Round 3, second half: stage ORDER chosen for the entry / exit patterns -- the fused z kernels do their pointwise physics (pow, PBE,
+// the combine) in the register pattern of the first stage (rows going INTO a forward transform) or of the last one (rows coming OUT
+// of an inverse), so a stage that leaves 16-20 butterflies over 32 lanes makes that part run with half the lanes masked.  A/B per
+// extent (tools/shape_ab.sh, ms per evaluation of the bench's term set): 120^3 0.521 -> 0.50, 160^3 1.065 -> 1.04, 192^3 1.53 -> 1.50,
+// 240^3 3.12 -> 2.91, 270^3 5.00 -> 4.92, 480^3 26.6 -> 25.4; 288^3 (3 x 4 x 4 x 3) measured 1.5 % slower and keeps its order.
+#ifndef OFDFT_ZALT
+#define OFDFT_ZALT 1
+#endif
+#ifndef OFDFT_Z60_ALT
+#define OFDFT_Z60_ALT OFDFT_ZALT
+#endif
+#ifndef OFDFT_Z80_ALT
+#define OFDFT_Z80_ALT OFDFT_ZALT
+#endif
+#ifndef OFDFT_Z96_ALT
+#define OFDFT_Z96_ALT OFDFT_ZALT
+#endif
+#ifndef OFDFT_Z135_ALT
+#define OFDFT_Z135_ALT OFDFT_ZALT
+#endif
+#ifndef OFDFT_Z144_ALT
+#define OFDFT_Z144_ALT 0
+#endif
+#ifndef OFDFT_Z240_ALT
+#define OFDFT_Z240_ALT OFDFT_ZALT
+#endif
 #define OFDFT_ZGPLAN(M_, P_, NST_, R0_, R1_, R2_, R3_)                                                               \
     template <> struct ZPlan<M_, PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E> : PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_> {}; \
     template <> struct ZPick<M_, 4> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };   \
     template <> struct ZPick<M_, 8> { static constexpr int E = PlanBase<M_, P_, NST_, R0_, R1_, R2_, R3_>::E; };
 OFDFT_ZGPLAN(24, 8, 3, 4, 3, 2, 1)        // E = 4
 OFDFT_ZGPLAN(48, 16, 3, 4, 4, 3, 1)       // E = 4
+#if OFDFT_Z60_ALT
+OFDFT_ZGPLAN(60, 32, 4, 2, 5, 3, 2)       // E = 5: entry and exit stages leave 30 butterflies over 32 lanes (2 slots)
+#else
 OFDFT_ZGPLAN(60, 16, 3, 4, 5, 3, 1)       // E = 6
+#endif
 OFDFT_ZGPLAN(72, 32, 3, 4, 6, 3, 1)       // E = 6 (4 x 3 x 3 x 2 with E = 4 measured 4 % slower at 144^3)
+#if OFDFT_Z80_ALT
+OFDFT_ZGPLAN(80, 32, 3, 4, 5, 4, 1)       // E = 5: exit stage 20 butterflies x 4 slots (62 % of the lanes; 4 x 4 x 5: 16 x 5, 50 %)
+#else
 OFDFT_ZGPLAN(80, 32, 3, 4, 4, 5, 1)       // E = 5
+#endif
+#if OFDFT_Z96_ALT
+OFDFT_ZGPLAN(96, 32, 4, 4, 4, 2, 3)       // E = 4: exit stage 32 butterflies x 3 slots (every lane)
+#else
 OFDFT_ZGPLAN(96, 32, 4, 4, 4, 3, 2)       // E = 4 (was 4 x 4 x 6, E = 6: 192^3 1.81 -> 1.51 ms)
+#endif
+#if OFDFT_Z120_STAGES4
+// 4 x 5 x 3 x 2: one more exchange, but the LAST stage leaves 60 butterflies over the 32 lanes (4 slots, 94 % of the lanes) where
+// the radix-6 stage leaves 20 (6 slots, 62 %): the fused z kernels do their pointwise physics in the exit pattern of the inverses
+OFDFT_ZGPLAN(120, 32, 4, 4, 5, 3, 2)      // E = 6
+#else
 OFDFT_ZGPLAN(120, 32, 3, 4, 5, 6, 1)      // E = 6
+#endif
 OFDFT_ZGPLAN(125, 32, 3, 5, 5, 5, 1)      // E = 5
+#if OFDFT_Z135_ALT
+OFDFT_ZGPLAN(135, 32, 4, 3, 3, 3, 5)      // E = 6 over 32 lanes: two waves per SIMD for every fused z kernel
+#else
 OFDFT_ZGPLAN(135, 32, 3, 3, 9, 5, 1)      // E = 9 (3 x 3 x 3 x 5 over 64 lanes, E = 5: 270^3 11 % slower)
+#endif
+#if OFDFT_Z144_ALT
+OFDFT_ZGPLAN(144, 64, 4, 3, 4, 4, 3)      // E = 4: entry stage 48 butterflies x 3 slots (75 % of the lanes; 4 first: 36 x 4, 56 %)
+#else
 OFDFT_ZGPLAN(144, 64, 4, 4, 4, 3, 3)      // E = 4 (was 4 x 6 x 6, E = 6: 288^3 8.34 -> 6.14 ms)
+#endif
 OFDFT_ZGPLAN(160, 32, 3, 4, 8, 5, 1)      // E = 8 (4 x 4 x 2 x 5 over 64 lanes, E = 5: 320^3 12 % slower)
 OFDFT_ZGPLAN(192, 64, 4, 4, 4, 4, 3)      // E = 4
+#if OFDFT_Z240_ALT
+OFDFT_ZGPLAN(240, 64, 4, 4, 5, 3, 4)      // E = 6: exit stage 60 butterflies x 4 slots (94 % of the lanes; 5 last: 48 x 5, 75 %)
+#else
 OFDFT_ZGPLAN(240, 64, 4, 4, 4, 3, 5)      // E = 6
+#endif
 #undef OFDFT_ZGPLAN
 
 template <int LEN, int E, bool INV>

@@ -25,8 +25,8 @@ else
   echo "two-rank rehearsal rc=$?"
   bash tools/ipc_timeline.sh ${TAG}_ipctl 256 > gpurun_out/${TAG}_ipctl.log 2>&1
   echo "ipc timeline rc=$?"
-  timeout -k 10 300 python tools/latency_probe.py 16 32 64 > gpurun_out/${TAG}_lat.jsonl 2> gpurun_out/${TAG}_lat.err
+  timeout -k 10 300 python tools/latency_probe.py 16 32 53 64 > gpurun_out/${TAG}_lat.jsonl 2> gpurun_out/${TAG}_lat.err
   echo "latency rc=$?"
-  timeout -k 10 300 python tools/shape_probe.py 256x256x256 240x240x240 120x120x120 270x270x270 255x255x255 53x53x53 > gpurun_out/${TAG}_shapes.jsonl 2> gpurun_out/${TAG}_shapes.err
+  timeout -k 10 300 python tools/shape_probe.py 256x256x256 240x240x240 120x120x120 270x270x270 255x255x255 129x135x127 53x53x53 > gpurun_out/${TAG}_shapes.jsonl 2> gpurun_out/${TAG}_shapes.err
   echo "shapes rc=$?"
 fi
