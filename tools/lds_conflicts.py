@@ -9,6 +9,9 @@ elements.  Bank rules: fp64 -- ds_read_b64 two 32-lane groups over 64 dword bank
 fp32 -- ds_read_b32 / ds_write_b32 two 32-lane groups over 32 banks.  Cost of a group = the largest number of distinct
 addresses on one bank (1 = conflict-free).
 
+(The "blocked" variant -- a line's lanes consecutive in the wave, as in the chirp-z kernels of csrc/bluestein.h -- is
+tools/bs_lds_search.py.)
+
 usage: lds_conflicts.py          # the table of csrc/xwave.h (XwSwz) and the padded layout it replaces
        lds_conflicts.py search   # best layouts per length and precision
 """
