@@ -38,7 +38,7 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize('shape', [(8, 8, 16), (16, 32, 64), (64, 64, 64), (256, 8, 32), (8, 1024, 16), (8, 8, 2048),
-                                   (128, 128, 128), (18, 20, 16), (5, 6, 7), (17, 17, 17),
+                                   (128, 128, 128), (18, 20, 16), (5, 6, 7), (17, 17, 17), (3, 5, 255), (255, 3, 5), (7, 129, 67),
                                    (48, 96, 120), (144, 160, 192), (240, 250, 270), (288, 48, 320), (384, 96, 480), (96, 480, 144)])
 def test_rfftn_irfftn_match_numpy_f32(shape):
     rng = np.random.default_rng(sum(shape))
