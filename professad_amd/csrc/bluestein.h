@@ -440,4 +440,190 @@ __attribute__((amdgpu_waves_per_eu(BsCfg<M, 2>::WAVES, BsCfg<M, 2>::WAVES))) voi
     }
 }
 
+// ---- small grids: the z rows and the y lines of one x plane in ONE kernel.  Grids of 30 ... 64 points per axis -- what the
+// reference's ecut2shape gives its own test systems -- are bound by their chain of dependent launches (~30 per evaluation at 53^3,
+// 8-12 us each), not by work; a (y, kz) plane of such a grid fits LDS (64 x 33 complex = 34 KB), so the forward half of a 3-D
+// transform is: row pairs -> chirp-z along z -> plane in LDS -> chirp-z along y -> the spectrum (x still in real space), and the
+// inverse half the reverse.  Both padded lengths must be the same M <= 128 (one plan, one twiddle table).
+template <int M> struct BsZyCfg {
+    using PL = typename BsPlanPick<M>::type;
+    static constexpr int TPB = 512, P = PL::P, E = PL::E, G = TPB / P;      // G lines / row pairs in flight
+    static constexpr int STRIDE = BsCfg<M, 0>::STRIDE, LMUL = BsCfg<M, 0>::LMUL;
+    static constexpr size_t lds_bytes(int n1, int nzc) {
+        return sizeof(real) * G * STRIDE + 3 * sizeof(cplx) * M + sizeof(cplx) * (size_t)n1 * (size_t)(nzc | 1);
+    }
+};
+template <int M, bool INV>
+__global__ __launch_bounds__(512) void bluestein_zy_kernel(BsIo io, SpecGeom g, real scale, const cplx* __restrict__ chirp_z,
+                                                           const cplx* __restrict__ filt_z, const cplx* __restrict__ chirp_y,
+                                                           const cplx* __restrict__ filt_y, const cplx* __restrict__ twM) {
+    using Cfg = BsZyCfg<M>;
+    using PL = typename Cfg::PL;
+    constexpr int P = Cfg::P, E = Cfg::E, G = Cfg::G, TPB = Cfg::TPB, EH = (E + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    const int tid = threadIdx.x;
+    cplx* __restrict__ spec = io.spec[0];
+    const real* __restrict__ rin = io.rin[0];
+    real* __restrict__ rout = io.rout[0];
+#pragma unroll
+    for (int a = 1; a < kBsBatch; ++a)
+        if ((int)blockIdx.y == a) {
+            spec = io.spec[a];
+            rin = io.rin[a];
+            rout = io.rout[a];
+        }
+    const int j = tid % P, grp = tid / P;
+    const int x = blockIdx.x, N1 = g.n1, N2 = g.n2, nzc = g.nzc, PS = nzc | 1;
+    cplx* tw_l = reinterpret_cast<cplx*>(lds + G * Cfg::STRIDE);
+    cplx* flz_l = tw_l + M;
+    cplx* fly_l = flz_l + M;
+    cplx* plane = fly_l + M;                       // [y][PS] complex
+    for (int i = tid; i < M; i += TPB) {
+        tw_l[i] = buf_load_c(twM, (unsigned)i * kCB);
+        flz_l[i] = buf_load_c(filt_z, (unsigned)i * kCB);
+        fly_l[i] = buf_load_c(filt_y, (unsigned)i * kCB);
+    }
+    cplx wz[EH], wy[EH];
+#pragma unroll
+    for (int q = 0; q < EH; ++q) {
+        const int e = j + P * q;
+        wz[q] = buf_load_c(chirp_z, e < N2 ? (unsigned)e * kCB : kBsOob);
+        wy[q] = buf_load_c(chirp_y, e < N1 ? (unsigned)e * kCB : kBsOob);
+    }
+    real* mine = lds + grp * Cfg::STRIDE;
+    const int lx = (grp * Cfg::LMUL) & 31;
+    const unsigned rowx = (unsigned)x * (unsigned)N1;
+    const int npair = (N1 + 1) / 2;
+    __syncthreads();
+    if (!INV) {
+        // ---- z: row pairs (y0, y0 + 1) of this plane -> their half spectra, into the LDS plane
+        for (int p = grp; p < npair; p += G) {
+            const int y0 = 2 * p;
+            const bool valid1 = y0 + 1 < N1;
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                const unsigned o = e < N2 ? ((rowx + (unsigned)y0) * (unsigned)N2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
+                v[q] = mkc(buf_load_d(rin, o), buf_load_d(rin, (e < N2 && valid1) ? o + (unsigned)N2 * (unsigned)sizeof(real) : kBsOob));
+            }
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, false>(v, wz, j, mine, tw_l, flz_l, lx);
+            cplx pr[EH];
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q)
+                if (j + P * q < N2) mine[j + P * q] = v[q].x;
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                pr[q].x = mine[e == 0 || e >= N2 ? 0 : N2 - e];
+            }
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q)
+                if (j + P * q < N2) mine[j + P * q] = v[q].y;
+            exchange_sync<true>();
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                pr[q].y = mine[e == 0 || e >= N2 ? 0 : N2 - e];
+            }
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                if (e < nzc) {
+                    plane[y0 * PS + e] = mkc((real)0.5 * (v[q].x + pr[q].x), (real)0.5 * (v[q].y - pr[q].y));
+                    if (valid1) plane[(y0 + 1) * PS + e] = mkc((real)0.5 * (v[q].y + pr[q].y), (real)-0.5 * (v[q].x - pr[q].x));
+                }
+            }
+            exchange_sync<true>();
+        }
+        __syncthreads();
+        // ---- y: lines (x, kz) of the plane -> the spectrum
+        for (int kz = grp; kz < nzc; kz += G) {
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                v[q] = e < N1 ? plane[e * PS + kz] : mkc(0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, false>(v, wy, j, mine, tw_l, fly_l, lx);
+            const unsigned kb = kz < g.nzm ? (unsigned)(kz >> 3) * (unsigned)g.nrows * 8u + (unsigned)(kz & 7)
+                                           : (unsigned)g.main_count + (unsigned)(kz - g.nzm) * (unsigned)g.nrows;
+            const unsigned ks = kz < g.nzm ? 8u : 1u;
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                buf_store_c(spec, e < N1 ? (kb + (rowx + (unsigned)e) * ks) * kCB : kBsOob, v[q]);
+            }
+            exchange_sync<true>();
+        }
+    } else {
+        // ---- y inverse: lines (x, kz) of the spectrum -> the LDS plane
+        for (int kz = grp; kz < nzc; kz += G) {
+            const unsigned kb = kz < g.nzm ? (unsigned)(kz >> 3) * (unsigned)g.nrows * 8u + (unsigned)(kz & 7)
+                                           : (unsigned)g.main_count + (unsigned)(kz - g.nzm) * (unsigned)g.nrows;
+            const unsigned ks = kz < g.nzm ? 8u : 1u;
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                v[q] = buf_load_c(spec, e < N1 ? (kb + (rowx + (unsigned)e) * ks) * kCB : kBsOob);
+            }
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, true>(v, wy, j, mine, tw_l, fly_l, lx);
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                if (e < N1) plane[e * PS + kz] = v[q];
+            }
+            exchange_sync<true>();
+        }
+        __syncthreads();
+        // ---- z inverse: row pairs rebuilt as A + i B from the plane -> two real rows
+        for (int p = grp; p < npair; p += G) {
+            const int y0 = 2 * p;
+            const bool valid1 = y0 + 1 < N1;
+            cplx v[E];
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                cplx a = mkc(0.0, 0.0), bb = mkc(0.0, 0.0);
+                if (e < N2) {
+                    const int k = (e < nzc) ? e : N2 - e;
+                    a = plane[y0 * PS + k];
+                    if (valid1) bb = plane[(y0 + 1) * PS + k];
+                    if (e >= nzc) { a.y = -a.y; bb.y = -bb.y; }
+                    if (e == 0 || 2 * e == N2) { a.y = 0.0; bb.y = 0.0; }
+                }
+                v[q] = mkc(a.x - bb.y, a.y + bb.x);
+            }
+#pragma unroll
+            for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);
+            chirpz_line<PL, M, true>(v, wz, j, mine, tw_l, flz_l, lx);
+#pragma unroll
+            for (int q = 0; q < EH; ++q) {
+                const int e = j + P * q;
+                const unsigned o = e < N2 ? ((rowx + (unsigned)y0) * (unsigned)N2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
+                const unsigned o1 = (e < N2 && valid1) ? o + (unsigned)N2 * (unsigned)sizeof(real) : kBsOob;
+                const real r0 = v[q].x * scale, r1 = v[q].y * scale;
+                if constexpr (sizeof(real) == 8) {
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&r0), make_rsrc(rout), (int)o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&r1), make_rsrc(rout), (int)o1, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(&r0), make_rsrc(rout), (int)o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const unsigned*>(&r1), make_rsrc(rout), (int)o1, 0, 0);
+                }
+            }
+            exchange_sync<true>();
+        }
+    }
+}
+
 }  // namespace ofdft

@@ -338,7 +338,42 @@ template int bluestein_xmix<1, 4, MixDensity<true, true>>(ofdft_ctx*, const cplx
 template int bluestein_xmix<3, 1, MixDiv>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixDiv&, hipStream_t);
 template int bluestein_xmix<3, 3, MixWgc>(ofdft_ctx*, const cplx* const*, cplx* const*, const MixWgc&, hipStream_t);
 
-// the z and y passes of `n` (<= kBsBatch) transforms, one launch per pass: the halves of a 3-D transform around the fused x pass
+// small grids: z rows and y lines of an x plane in one kernel (bluestein.h: bluestein_zy_kernel) -- both padded lengths equal and
+// <= 128, the (y, kz) plane in LDS
+static bool bluestein_zy_ok(const ofdft_ctx* c, int* M_out) {
+    if (!c->bs_fused) return false;
+    const int M1 = bluestein_pad(c->n1), M2 = bluestein_pad(c->n2);
+    if (M1 != M2 || M1 > 128) return false;
+    *M_out = M1;
+    return true;
+}
+template <int M, bool INV>
+static int launch_zy_t(ofdft_ctx* c, const BsIo& io, int narr, double scale, hipStream_t st) {
+    cplx* tw;
+    if (int rc = get_twiddle(c, M, &tw)) return rc;
+    BsTables ty, tz;
+    if (int rc = get_bluestein(c, c->n1, &ty)) return rc;
+    if (int rc = get_bluestein(c, c->n2, &tz)) return rc;
+    const size_t lds = BsZyCfg<M>::lds_bytes(c->n1, c->g.nzc);
+    if (lds > 160 * 1024) return fail(c, OFDFT_EINVAL, "fused z / y chirp-z pass: plane too large for LDS");
+    OFDFT_LAUNCH(c, st, INV ? "bluestein_yz" : "bluestein_zy", (bluestein_zy_kernel<M, INV>), dim3(c->n0, narr), dim3(BsZyCfg<M>::TPB), lds, io,
+                 c->g, (real)scale, (const cplx*)tz.chirp, (const cplx*)tz.filt, (const cplx*)ty.chirp, (const cplx*)ty.filt, (const cplx*)tw);
+    return 0;
+}
+template <bool INV>
+static int bluestein_zy(ofdft_ctx* c, int M, const BsIo& io, int narr, double scale, hipStream_t st) {
+    switch (M) {
+        case 8: return launch_zy_t<8, INV>(c, io, narr, scale, st);
+        case 16: return launch_zy_t<16, INV>(c, io, narr, scale, st);
+        case 32: return launch_zy_t<32, INV>(c, io, narr, scale, st);
+        case 64: return launch_zy_t<64, INV>(c, io, narr, scale, st);
+        case 128: return launch_zy_t<128, INV>(c, io, narr, scale, st);
+    }
+    return fail(c, OFDFT_EINVAL, "no fused z / y chirp-z pass for padded length %d", M);
+}
+
+// the z and y passes of `n` (<= kBsBatch) transforms, one launch per pass (small grids: ONE launch for both): the halves of a 3-D
+// transform around the fused x pass
 int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st) {
     BsIo io{};
     for (int a = 0; a < n; ++a) {
@@ -346,6 +381,8 @@ int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spe
         io.rin[a] = in[a];
     }
     c->fft_count += n;
+    int M;
+    if (bluestein_zy_ok(c, &M)) return bluestein_zy<false>(c, M, io, n, 1.0, st);
     if (int rc = bluestein_pass_multi(c, 1, 2, 0, io, n, 1.0, st)) return rc;
     return bluestein_pass_multi(c, 0, 1, 0, io, n, 1.0, st);
 }
@@ -356,6 +393,8 @@ int bluestein_inv_yz_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, in
         io.rout[a] = out[a];
     }
     c->fft_count += n;
+    int M;
+    if (bluestein_zy_ok(c, &M)) return bluestein_zy<true>(c, M, io, n, scale, st);
     if (int rc = bluestein_pass_multi(c, 0, 1, 1, io, n, 1.0, st)) return rc;
     return bluestein_pass_multi(c, 2, 2, 1, io, n, scale, st);
 }
