@@ -27,17 +27,23 @@ struct BsIo {
     real* rout[kBsBatch];
 };
 
-// Round 3 (second half): the kernel was rewritten around two findings (tools/isa_stats.py on the first version: 584 fp64
-// instructions per wave and line against 595 integer / move VALU instructions, 577 scalar ones and 41 exec-mask branches):
-//  * a line is owned by the lanes of ONE wavefront (8 points per lane, 64 lanes for M = 512), so the two M-point transforms
-//    exchange through LDS without an s_barrier (the first version dealt consecutive lanes to consecutive LINES and paid 16
-//    workgroup barriers per tile -- measured alone that change was neutral: the kernel is bound by its instruction count);
-//  * every access is a buffer access: ONE 32-bit byte offset per lane and slot, elements past the end of the line (the
-//    zero padding of the convolution) and lines past the end of the launch get an offset beyond the descriptor's range --
-//    such loads return zero and such stores are dropped by the hardware, so the loops carry no branches and no 64-bit
-//    address arithmetic; the transform direction and the kind of line are template parameters; the stage twiddles W^(t k)
-//    are read from the LDS copy of the table instead of being formed from W^k by a product tree (24 fp64 instructions per
-//    radix-8 butterfly).
+// Design of the kernels (round 3, second half; the steps and their A/B measurements: DESIGN.md section 13a):
+//  * a line is owned by the lanes of ONE wavefront (ZPlan<M, 8>: 8 points per lane, 64 lanes for M = 512), so the two M-point
+//    transforms of a line exchange through LDS without an s_barrier;
+//  * persistent workgroups: the twiddle table and the filter spectrum are staged in LDS once per workgroup, a lane's chirp values
+//    sit in registers for all of its lines (slot q of lane j holds element j + P q of EVERY line);
+//  * every global access is a buffer access with ONE 32-bit byte offset per lane and slot; elements past the end of the line (the
+//    zero padding of the convolution) and lines past the end of the launch get an offset beyond the descriptor's range -- such
+//    loads return zero and such stores are dropped by the hardware, so the loops carry no branches and no 64-bit address
+//    arithmetic; direction and kind of line are template parameters;
+//  * z rows go through in PAIRS (z = a + i b: one complex convolution for two real rows, the spectra separate with one more
+//    wave-local exchange); complex lines are loaded and stored by consecutive lanes for consecutive LINES (whole 128-B runs of
+//    the block-8 layout) and handed to the owner wave through its line buffer;
+//  * the x transforms and the spectral multiply of a convolution are one kernel (bluestein_xmix_kernel), and on grids of up to
+//    64 points per axis so are the z and y passes of an x plane (bluestein_zy_kernel).
+// What bounds them: the fp64 arithmetic of 2 M >= 4 N points per N-point line (~660 VALU instructions per line at M = 512) and the
+// LDS store rate (a ds_write_b64 costs ~6 cycles per wave); hence the conflict-free line layouts below and the twiddle powers
+// formed by a product tree rather than read from the LDS table (OFDFT_BS_TWTAB).
 #ifndef OFDFT_BS_TPB
 #define OFDFT_BS_TPB 512
 #endif
@@ -59,11 +65,11 @@ struct BsIo {
 #ifndef OFDFT_BS_WAVES
 #define OFDFT_BS_WAVES 4          // waves per SIMD the register allocation aims at (M = 1024 keeps 16 points per lane: 2)
 #endif
-// The kernel is bound by LDS time (SQ counters at 255^3: 8-15 % of a wave's cycles issue VALU work, 40-46 % of the z rows' wait
-// for the LDS; 52 % of the LDS-array cycles were bank conflicts of the padded line layout): XOR layouts per length and
-// precision, position i ^ ((XMUL ((i >> XS) & XM)) & 31) ^ (LMUL line & 31), found by enumerating the exchanges of these plans
-// against the bank rules of MI355X_MICROARCH.md with a line's lanes CONSECUTIVE in the wave (tools/lds_conflicts.py blocked):
-// every read and write group conflict-free (fp64 M = 128: writes 1.125 cycles per group).
+// LDS line layouts.  With the padded layout of the other kernels 52 % of the LDS-array cycles of these kernels were bank conflicts
+// (SQ counters at 255^3, profiles/r03_sq_chirpz_255_before.md).  XOR layouts per length and precision, position
+// i ^ ((XMUL ((i >> XS) & XM)) & 31) ^ (LMUL line & 31), found by enumerating the exchanges of these plans against the bank rules of
+// MI355X_MICROARCH.md with a line's lanes CONSECUTIVE in the wave (tools/bs_lds_search.py): every read and write group
+// conflict-free (fp64 M = 128: writes 1.125 cycles per group); on hardware 5-7 % conflicts.
 template <int M, bool F32 = (sizeof(real) == 4)> struct BsLds { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = (LineBuf<M>::STRIDE + 1) & ~1; };
 template <> struct BsLds<64, false> { static constexpr int XS = 2, XM = 15, XMUL = 1, LMUL = 1, RS = 72; };
 template <> struct BsLds<128, false> { static constexpr int XS = 4, XM = 7, XMUL = 3, LMUL = 0, RS = 144; };

@@ -463,8 +463,9 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             if (int rc = real_ws(c, "dfdn", &dfdn)) return rc;
             if (int rc = real_ws(c, "div", &dv)) return rc;
         }
+        cplx* svh = nullptr;            // spectrum of the Hartree potential (its own array when s1 carries a gradient component)
         if (has_h) {
-            cplx* svh = s1;
+            svh = s1;
             if (has_g)
                 if (int rc = spec_ws(c, "svh", &svh)) return rc;       // (s1 carries a gradient component then)
             if (int rc = real_ws(c, "vh", &vh)) return rc;
@@ -484,7 +485,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
                 OFDFT_LAUNCH(c, st, "spec_grad", spec_grad_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, s3, c->kg);
             else if (has_h) {          // n^ -> v_H^ and the three gradient components: one forward-x, four inverse-x
                 const cplx* xi[1] = {s0};
-                cplx* xo[4] = {iin[ni - 1], s1, s2, s3};
+                cplx* xo[4] = {svh, s1, s2, s3};
                 if (int rc = bluestein_xmix<1, 4>(c, xi, xo, MixDensity<true, true>{c->kg}, st)) return rc;
             } else {
                 const cplx* xi[1] = {s0};
