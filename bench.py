@@ -211,28 +211,44 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
     256^3 energy to round-off -- checked).  Both transports when both work.  Per-link rate = bytes one rank sends to one peer
     per evaluation / time per evaluation: what the links sustain if the exchange were spread over the whole evaluation (a lower bound of
     the rate while an exchange is in flight)."""
-    n = 512
+    base = int(np.asarray(chi256).shape[0])          # 256 in the driver's run (a smaller base only in the rehearsal test)
+    n = 2 * base
     word = 8 if tdtype == torch.double else 4
     box = torch.as_tensor(box256) * 2.0
     nel = n_elec256 * 8.0
     xs256 = None
-    out = {'grid': [n, n, n], 'steps': steps, 'ms_Ngpu': {}, 'inputs': 'the 256^3 bench inputs tiled 2x2x2 on the device'}
+    out = {'grid': [n, n, n], 'steps': steps, 'ms_Ngpu': {}, 'inputs': 'the %d^3 bench inputs tiled 2x2x2 on the device' % base}
 
     def fence():
         torch.cuda.synchronize(device)
         dist.barrier()
         torch.cuda.synchronize(device)
 
+    def agree(ok):          # every rank learns whether ALL ranks got through a set-up step: nobody is left alone in a collective
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    tol = 1e-10 if tdtype == torch.double else 5e-6
     chi_d = torch.as_tensor(chi256, dtype=tdtype, device=device)
     vext_d = torch.as_tensor(vext256, dtype=tdtype, device=device)
     for tr in transports:
-        eng = DistEngine((n, n, n), device, dtype=tdtype, transport=tr,
-                         xchg_chunks=int(os.environ['OFDFT_XCHG_CHUNKS']) if os.environ.get('OFDFT_XCHG_CHUNKS') else None)
-        eng.set_cell(box).set_terms(names)
-        xs = eng.plan.x_range()
-        idx = torch.arange(xs.start, xs.stop, device=device) % 256          # this rank's x planes of the tiled grid
-        chi = chi_d[idx].repeat(1, 2, 2).contiguous()
-        vext = vext_d[idx].repeat(1, 2, 2).contiguous()
+        eng, err = None, None
+        try:        # everything that can fail on ONE rank only (memory, ipc attach is guarded inside) happens before the ranks meet
+            eng = DistEngine((n, n, n), device, dtype=tdtype, transport=tr,
+                             xchg_chunks=int(os.environ['OFDFT_XCHG_CHUNKS']) if os.environ.get('OFDFT_XCHG_CHUNKS') else None)
+            eng.set_cell(box).set_terms(names)
+            xs = eng.plan.x_range()
+            idx = torch.arange(xs.start, xs.stop, device=device) % base          # this rank's x planes of the tiled grid
+            chi = chi_d[idx].repeat(1, 2, 2).contiguous()
+            vext = vext_d[idx].repeat(1, 2, 2).contiguous()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not agree(err is None):
+            out.setdefault('errors', {})[tr] = 'set-up failed on some rank (%r on rank %d)' % (err, rank)
+            if eng is not None:
+                eng.close()
+            continue
         for _ in range(2):
             E, mu, g = eng.energy_grad_chi(chi, nel, vext)
         fence()
@@ -247,23 +263,29 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
         out['rel_dE_vs_8x_256'] = abs(sum(E.values()) - 8.0 * E256) / abs(8.0 * E256)
         eng.close()
         del chi, vext, g
-    if rank == 0:          # the one-GPU leg: this rank alone on the whole 512^3 grid
-        one = Engine((n, n, n), device, dtype=tdtype).set_cell(box).set_terms(names)
-        chi = chi_d.repeat(2, 2, 2).contiguous()
-        vext = vext_d.repeat(2, 2, 2).contiguous()
-        for _ in range(2):
-            one.energy_grad_chi(chi, nel, vext)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            E1, _, _ = one.energy_grad_chi(chi, nel, vext)
-        torch.cuda.synchronize(device)
-        out['ms_1gpu'] = round((time.perf_counter() - t0) / steps * 1e3, 4)
-        out['rel_dE_1gpu_vs_8x_256'] = abs(sum(E1.values()) - 8.0 * E256) / abs(8.0 * E256)
-        one.close()
-        del chi, vext
+    if rank == 0:          # the one-GPU leg: this rank alone on the whole 512^3 grid (the others wait at the barrier below)
+        try:
+            one = Engine((n, n, n), device, dtype=tdtype).set_cell(box).set_terms(names)
+            chi = chi_d.repeat(2, 2, 2).contiguous()
+            vext = vext_d.repeat(2, 2, 2).contiguous()
+            for _ in range(2):
+                one.energy_grad_chi(chi, nel, vext)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                E1, _, _ = one.energy_grad_chi(chi, nel, vext)
+            torch.cuda.synchronize(device)
+            out['ms_1gpu'] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+            out['rel_dE_1gpu_vs_8x_256'] = abs(sum(E1.values()) - 8.0 * E256) / abs(8.0 * E256)
+            one.close()
+            del chi, vext
+        except Exception as e:  # noqa: BLE001  (rank 0 alone: it must still reach the barrier)
+            out.setdefault('errors', {})['1gpu'] = repr(e)[:300]
     dist.barrier()
-    if rank == 0 and out['ms_Ngpu']:
+    if rank == 0:          # the tiled problem's energy is 8 x the 256^3 energy: asserted, not only reported
+        out['ok'] = bool(out['ms_Ngpu']) and 'ms_1gpu' in out and max(out.get('rel_dE_vs_8x_256', 1.0), out.get('rel_dE_1gpu_vs_8x_256', 1.0)) < tol
+        out['tol'] = tol
+    if rank == 0 and out['ms_Ngpu'] and 'ms_1gpu' in out:
         best = min(out['ms_Ngpu'], key=out['ms_Ngpu'].get)
         out['speedup'] = round(out['ms_1gpu'] / out['ms_Ngpu'][best], 3)
         out['speedup_transport'] = best
@@ -571,11 +593,14 @@ def main():
         del g1, gs
     if world > 1:
         out['exchange']['xchg_chunks'] = eng.stages.nchunks
-    if world > 1 and n == 256 and a.cfg == 'cfg3' and os.environ.get('OFDFT_BENCH_NO_SCALE512') != '1':
+    if world > 1 and (n == 256 or os.environ.get('OFDFT_BENCH_SCALE_ANY_GRID') == '1') and a.cfg == 'cfg3' and os.environ.get('OFDFT_BENCH_NO_SCALE512') != '1':
         # the 512^3 one-GPU / N-GPU pair of the north star, inside this very command (the driver passes no --grid)
         working = [tr for tr, v in (transport_probe or {}).items() if not v.get('failed') and not v.get('disagrees_with_collective')]
         eng.close()
         del g
+        if rank == 0:       # the primary line survives whatever happens in the optional block (a copy on stderr; stdout stays ONE line)
+            sys.stderr.write('bench.py: 256^3 line before the optional scale_512 block: %s\n' % json.dumps(out))
+            sys.stderr.flush()
         try:
             sc = scale_512_block(dist, device, backend, rank, world, tdtype, names, box, chi_full, vext_full, n_elec, E_tot, working)
         except Exception as e:  # noqa: BLE001  (a failure every rank shares, e.g. memory: the 256^3 line above must survive it)

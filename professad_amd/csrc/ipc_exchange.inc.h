@@ -98,14 +98,15 @@ __global__ void ipc_wait_kernel(const unsigned* flags, const unsigned* abort_wor
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
     while ((int)(__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == eval_id) {
+        // (monotone word: a rank that aborted evaluation N and N + 1 before a late rank reaches N must still fail N there)
+        if ((int)(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - eval_id) >= 0) {
             __hip_atomic_store(err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
             __hip_atomic_store(err, 1 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int q = 0; q < P; ++q)
-                __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox.p[q]) + 48, eval_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(mailbox.p[q]) + 48, eval_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
     }
@@ -114,7 +115,7 @@ __global__ void ipc_wait_kernel(const unsigned* flags, const unsigned* abort_wor
 }
 // end of an evaluation (after the last reduction, i.e. after every rank's last stamp): did anybody abort it?
 __global__ void ipc_abort_check_kernel(const unsigned* abort_word, unsigned eval_id, int* err) {
-    if (threadIdx.x == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == eval_id &&
+    if (threadIdx.x == 0 && (int)(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - eval_id) >= 0 &&
         __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         __hip_atomic_store(err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -125,14 +126,17 @@ __global__ __launch_bounds__(256) void ipc_scatter_kernel(const u32x4* __restric
     u32x4* dst = reinterpret_cast<u32x4*>(recv.p[peer]) + (long long)me * vec_per_peer;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_peer; i += (long long)gridDim.x * blockDim.x)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
-    // (No fence here.  A system-scope release per thread was tried as insurance for the first run on separate GPUs: it is an L2
-    // write-back per wave on this multi-XCD part -- the scatter kernels ran 10 x longer and dragged the kernels beside them along,
-    // 5.1 -> 22.5 ms per evaluation for two ranks at 256^3.  The stores target the peer's fine-grained arena, which the local L2
-    // does not hold dirty; the kernel's completion orders them before the stamp kernel's system-scope store.)
+    // (No fence here.  A system-scope release per thread was tried: it is an L2 write-back per wave on this multi-XCD part --
+    // the scatter kernels ran 10 x longer and dragged the kernels beside them along, 5.1 -> 22.5 ms per evaluation for two
+    // ranks at 256^3.  The release that orders these stores before the stamp is ONE fence in the one-wave stamp kernel, which
+    // runs behind this kernel on the same stream.)
 }
 // lane p: epoch -> word `word` of rank p's mailbox (system scope: another agent polls it)
 __global__ void ipc_stamp_kernel(IpcPeers mailbox, int P, int me, int word, unsigned epoch) {
     const int p = threadIdx.x;
+    // system-scope release: everything the kernels before this one (same stream: the scatter) stored is visible to the peers
+    // before the stamp is -- one L2 write-back per chunk, not per scatter wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if (p < P && p != me) __hip_atomic_store(reinterpret_cast<unsigned*>(mailbox.p[p]) + word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // lane (p, i): this rank's i-th number -> its slot in rank p's mailbox

@@ -57,9 +57,17 @@ class SlabPlan:
 
 
 class Comm:
-    """The two collectives the path needs, over a torch.distributed group (or trivially for one rank)."""
+    """The two collectives the path needs, over a torch.distributed group (or trivially for one rank).
 
-    def __init__(self, group=None):
+    The evaluation is two independent chains whose exchanges must not queue behind each other: a process group owns ONE
+    communicator (under nccl = RCCL: one internal stream per device), so asynchronous all-to-alls issued on the same group
+    execute in host-issue order, and chain 1's chunk would wait for chain 0's previously issued message -- which in turn
+    waits for chain 0's kernels.  `groups[c]` is therefore the group chain c's all-to-alls are issued on: two groups over
+    the same ranks (second communicator, second stream).  The small all-reduces stay on `groups[0]`.  Every rank issues
+    the exchanges of both groups in the same order (`_run_exchanges` is deterministic), which is what concurrent
+    communicators on one device require."""
+
+    def __init__(self, group=None, chain1_group=None):
         # (OFDFT_COMM_ONE_RANK=1: also route a ONE-rank group's exchanges through the backend -- on a one-GPU box that is the
         # only way to drive the whole staged evaluation through RCCL: tests/test_dist_gpu.py)
         import os
@@ -69,6 +77,13 @@ class Comm:
         self.nranks = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.backend = dist.get_backend(group) if self.active else None
+        # second group for chain 1.  `dist.new_group` is collective over the WORLD, so it is created here only when this
+        # Comm spans the world (every process constructs it); a caller that passes a sub-group creates the second group
+        # itself (all world ranks calling new_group) and hands it in as `chain1_group` -- else both chains share `group`.
+        if chain1_group is None and self.active and group is None and os.environ.get('OFDFT_COMM_ONE_GROUP') != '1':
+            chain1_group = dist.new_group(ranks=list(range(dist.get_world_size())), backend=self.backend)
+        self.groups = (group, chain1_group if chain1_group is not None else group)
+        self.issued = [0, 0]          # all-to-alls issued per chain group (tests assert the chains use different groups)
 
     def all_reduce_sum(self, vec, device):
         """vec: 1-D numpy fp64 -> summed over ranks (numpy)"""
@@ -89,14 +104,17 @@ class Comm:
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
 
-    def all_to_all(self, send_t, recv_t):
-        """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo).
+    def all_to_all(self, send_t, recv_t, chain=0):
+        """equal-split all-to-all between flat byte tensors (device tensors; staged through host under gloo), issued on
+        the group of `chain` (0: density / Hartree / vW / GGA and everything else, 1: the nonlocal KEDF chain).
         Returns None when complete on return, else a work handle whose .wait() orders the current stream after it."""
         if not self.active:
             recv_t.copy_(send_t)
             return None
+        group = self.groups[1 if chain else 0]
+        self.issued[1 if chain else 0] += 1
         if self.backend == 'nccl':
-            return dist.all_to_all_single(recv_t, send_t, group=self.group, async_op=True)
+            return dist.all_to_all_single(recv_t, send_t, group=group, async_op=True)
         else:
             # gloo has no all-to-all: host-staged pairwise exchange (test / fallback transport only)
             hs = send_t.cpu()
@@ -108,8 +126,8 @@ class Comm:
                 if p == self.rank:
                     outs[p].copy_(ins[p])
                 else:
-                    reqs.append(dist.isend(ins[p].contiguous(), p, group=self.group))
-                    reqs.append(dist.irecv(outs[p], p, group=self.group))
+                    reqs.append(dist.isend(ins[p].contiguous(), p, group=group))
+                    reqs.append(dist.irecv(outs[p], p, group=group))
             for r in reqs:
                 r.wait()
             recv_t.copy_(hr)
@@ -343,7 +361,7 @@ def _run_exchanges(stages, comm):
                         pending[chain][k] = None
                     ex = stages.step(step, chain, k)
                     if ex is not None:
-                        pending[chain][k] = comm.all_to_all(ex[0], ex[1])
+                        pending[chain][k] = comm.all_to_all(ex[0], ex[1], chain)
     if side is not None:
         torch.cuda.current_stream(dev).wait_stream(side)           # the combine needs both chains
 
@@ -396,16 +414,18 @@ class DistEngine:
     """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
     as `Engine`, on this rank's slab."""
 
-    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective', xchg_chunks=None):
+    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective', xchg_chunks=None, chain1_group=None):
         """dtype=torch.float32 runs the slab-decomposed hot path on the fp32 build (half the bytes on every link);
         stress and ion forces are then formed by the fp64 routines on fp64 slabs.
         transport: 'collective' = the host issues an all-to-all per stage through torch.distributed (RCCL under nccl);
         'ipc' = the library maps the peers' buffers (hipIpc) and moves the spectra itself, one call per evaluation.
-        xchg_chunks: kz chunks the exchange is pipelined by inside each chain (both transports; None = automatic, 1 = off)."""
+        xchg_chunks: kz chunks the exchange is pipelined by inside each chain (both transports; None = automatic, 1 = off).
+        chain1_group: second process group over the same ranks for the nonlocal chain's all-to-alls (see `Comm`; created
+        automatically when `group` is the world)."""
         if transport not in ('collective', 'ipc'):
             raise ValueError("transport must be 'collective' or 'ipc'")
         self.transport = transport
-        self.comm = Comm(group)
+        self.comm = Comm(group, chain1_group)
         self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
         self.stages.enable_collectives(self.comm)
         if xchg_chunks is not None:             # kz chunks of the exchange (None: the engine's automatic choice)

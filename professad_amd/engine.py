@@ -95,14 +95,16 @@ class Engine:
 
     # -- configuration
     def set_cell(self, box_vecs):
-        if box_vecs is getattr(self, '_box_obj', None) and isinstance(box_vecs, np.ndarray):
-            return self           # the very (host) array of the last call: the drop-in terms pass one cached array per cell
-        box = np.ascontiguousarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64).reshape(9)
+        # a host array is compared by its 72 bytes (no device sync; a caller may rescale its box array IN PLACE between
+        # calls, so object identity says nothing); anything else goes through torch first
+        if isinstance(box_vecs, np.ndarray):
+            box = np.ascontiguousarray(box_vecs, dtype=np.float64).reshape(9)
+        else:
+            box = np.ascontiguousarray(torch.as_tensor(box_vecs).detach().cpu().numpy(), dtype=np.float64).reshape(9)
         key = box.tobytes()
         if key != self._box_key:
             self._check(self.lib.ofdft_set_cell(self._ctx, box.ctypes.data_as(C.POINTER(C.c_double))), 'ofdft_set_cell')
             self._box_key = key
-        self._box_obj = box_vecs if isinstance(box_vecs, np.ndarray) else None
         return self
 
     def set_terms(self, names, params=None):
@@ -204,7 +206,7 @@ class Engine:
             if self._box_key is None or self._terms_key is None:
                 raise RuntimeError('Engine.stress: set_cell and set_terms must be called first')
             sib = engine_for(self.global_shape, self.device)
-            sib._box_key, sib._terms_key, sib._box_obj = None, None, None          # the sibling is shared: always (re)configure it
+            sib._box_key, sib._terms_key = None, None          # the sibling is shared: always (re)configure it
             sib._check(sib.lib.ofdft_set_cell(sib._ctx, np.frombuffer(self._box_key, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))),
                        'ofdft_set_cell')
             sib._check(sib.lib.ofdft_set_terms(sib._ctx, self._terms_key[0],

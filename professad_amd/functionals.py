@@ -14,6 +14,8 @@ handed to professad's ``System`` unchanged, and ``get_functional_derivative(box_
 Gradients w.r.t. ``box_vecs`` come from the engine's analytic per-term stress (ofdft_stress), so the reference's
 ``get_stress(box_vecs, den, f)`` (functional_tools.py:73-101) works on these terms too.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -23,21 +25,32 @@ from .engine import engine_for
 _S5 = np.sqrt(5.0)
 
 
-_BOX_SLOT = [None, -1, None, 0.0]       # tensor, its version counter, host copy (3x3 float64), cell volume
+_BOX_CACHE = {}       # id(tensor) -> (weakref, version counter, data_ptr, host copy (3x3 float64), cell volume); a few Systems
+_BOX_CACHE_MAX = 8
 
 
 def _host_box(box_vecs):
     """Lattice vectors on the host + the cell volume.  professad's System hands its own ``box_vecs`` attribute to every term of
-    every iteration (system.py:771): when the caller passes the very tensor object it passed last time, unmodified (same
-    version counter), nothing crosses the device boundary -- a device->host copy of 72 bytes is a stream synchronisation,
-    as long as a small-grid evaluation itself.  Tensors that require grad (stress paths) are never cached."""
-    s = _BOX_SLOT
-    if s[0] is box_vecs and s[1] == box_vecs._version:
-        return s[2], s[3]
+    every iteration (system.py:771): when the caller passes a tensor object it passed before, unmodified (same version
+    counter, same storage), nothing crosses the device boundary -- a device->host copy of 72 bytes is a stream
+    synchronisation, as long as a small-grid evaluation itself.  The cache holds weak references only (no device tensor is
+    kept alive), tensors that require grad (stress paths) or have no version counter (inference mode) are never cached."""
+    try:
+        ver = box_vecs._version
+    except Exception:  # noqa: BLE001  (inference-mode tensors have no version counter)
+        ver = None
+    key = id(box_vecs)
+    if ver is not None:
+        hit = _BOX_CACHE.get(key)
+        if hit is not None and hit[0]() is box_vecs and hit[1] == ver and hit[2] == box_vecs.data_ptr():
+            return hit[3], hit[4]
     box = np.ascontiguousarray(box_vecs.detach().double().cpu().numpy()).reshape(3, 3)
     vol = float(torch.abs(torch.linalg.det(torch.from_numpy(box))))
-    if not box_vecs.requires_grad:
-        s[0], s[1], s[2], s[3] = box_vecs, box_vecs._version, box, vol
+    if ver is not None and not box_vecs.requires_grad:
+        if len(_BOX_CACHE) >= _BOX_CACHE_MAX:
+            for k in [k for k, h in _BOX_CACHE.items() if h[0]() is None] or list(_BOX_CACHE)[:1]:
+                del _BOX_CACHE[k]
+        _BOX_CACHE[key] = (weakref.ref(box_vecs), ver, box_vecs.data_ptr(), box, vol)
     return box, vol
 
 

@@ -49,9 +49,20 @@ class NumpyStages:
 
     def step(self, step, chain, k):
         """the product's step protocol (ofdft_dist_step): steps 1 / 2 send chunk k, steps 3 / 6 consume, 4 / 5 idle here"""
-        if chain == 1:       # the double has no nonlocal-KEDF chain
-            return None
         p = self.plan
+        if chain == 1:       # no nonlocal-KEDF physics in the double: a tagged message per chunk, checked on arrival (step 2),
+            P = p.nranks     # so that the second chain's exchanges (own process group, Comm.groups[1]) are exercised too
+            if step == 1:
+                send = np.array([[1000.0 * p.rank + 10.0 * q + k] * 4 for q in range(P)])
+                self.recv1 = getattr(self, 'recv1', {})
+                self.recv1[k] = torch.empty(send.nbytes, dtype=torch.uint8)
+                return self._bytes(send), self.recv1[k]
+            if step == 2:
+                got = self.recv1.pop(k).numpy().view(np.float64).reshape(P, 4)
+                want = np.array([[1000.0 * q + 10.0 * p.rank + k] * 4 for q in range(P)])
+                assert np.array_equal(got, want), (got, want)
+                self.chain1_ok = getattr(self, 'chain1_ok', 0) + 1
+            return None
         K = self.nchunks
         assert (step, k) == ((self.k[0], self.k[1] + 1) if self.k[1] + 1 < K and self.k[0] > 0 else (self.k[0] + 1, 0)), (step, k, self.k)
         self.k = (step, k)

@@ -313,3 +313,23 @@ def test_whole_staged_evaluation_through_rccl_with_one_rank(shape, dtype, tmp_pa
     res = _run_workers(1, shape, dtype, str(tmp_path / 'res.json'), {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_COMM_ONE_RANK': '1'},
                        timeout=400)
     _check_worker_results(res, dtype)
+
+
+def test_bench_scale_pair_rehearsal_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` end to end (self-launched workers, transport probe, timed region, then the one-GPU / N-GPU pair of
+    the north star appended by `scale_512_block`) at a reduced grid: 64^3 bench inputs, the pair on 128^3.  The driver's
+    round-end run on a real multi-GPU node is the same command with nccl and one GPU per rank."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, OFDFT_BENCH_SHARE_GPU='1', OFDFT_BENCH_BACKEND='gloo', OFDFT_BENCH_SCALE_ANY_GRID='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--grid', '64', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors='replace')[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['reference_check']['ok'], line
+    sc = line['scale_512']
+    assert sc.get('ok') and sc['grid'] == [128, 128, 128] and 'errors' not in sc, sc
+    assert 'collective' in sc['ms_Ngpu'] and sc['ms_1gpu'] > 0 and sc['speedup'] > 0, sc
+    assert b'256^3 line before the optional scale_512 block' in p.stderr
