@@ -319,9 +319,14 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_BS_FUSED 15     /* chirp-z path (extents without a line-transform plan, i.e. what the reference's System.ecut2shape, system.py:74-89, gives):
                                      1 (default) = forward-x, spectral multiply and inverse-x of every convolution in ONE kernel (x extents up to 256);
                                      0 = three passes per transform and separate multiply kernels */
-#define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the wave-local kernel (a line of every spectrum in the lanes of one wavefront, mixing in
-                                     registers; x extents up to 512) for passes over three or more spectra, 2 = for every pass, 0 = always the
-                                     group-parallel kernel that trades spectra through LDS */
+#define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the cross-wave kernel (whole runs of memory-adjacent lines per access, the
+                                     radix-4 / -8 step of the line transform across the waves of a workgroup) for 256- and 512-point lines
+                                     and, for passes over three or more spectra, 1024-point lines; elsewhere the wave-local kernel (a line of
+                                     every spectrum in the lanes of one wavefront, mixing in registers; x extents up to 512) for passes over
+                                     three or more spectra and the group-parallel kernel (spectra traded through LDS) for the rest.
+                                     0 = always the group-parallel kernel, 2 = the wave-local kernel for every pass, 5 = the cross-wave
+                                     kernel wherever it exists (128..1024 points), 6 = ... for passes over >= 3 spectra only, 7 = the
+                                     round-3 choice (no cross-wave kernel) */
 int  ofdft_set_option(ofdft_ctx* ctx, int option, double value);
 
 /* Measurement support (bench.py): when on, every kernel launch of the energy calls is bracketed by HIP

@@ -1,0 +1,217 @@
+// Cross-wave fused x pass (gfx950):  forward x-FFT of NIN spectra -> k-space mixing -> inverse x-FFT of NOUT spectra,
+// with every global access a whole run of memory-adjacent lines.
+//
+// Third design of the fused x pass.  The wave-local kernel (xwave.h) gives a line to LEN/8 lanes of one wavefront; its
+// lanes therefore touch LEN/8 different x planes per load instruction -- 32 cache lines with 32 useful bytes each at 256
+// points per line, 64 cache lines with 16 useful bytes at 512 (one line per wave): the texture path looks up one cache
+// line per cycle, so the pass is bound by cache-line look-ups, not by bytes (4.0 TB/s at 256^3, 2.7 TB/s at 512^3 where
+// the y pass streams 5.4-5.9; profiles/r03_shape_probe_per_kernel.jsonl).
+// Here the LEN-point transform is split as LEN = A x S (four-step form, A = waves per workgroup):
+//     x = A b + a,   k = b' + S a'
+//     X[b' + S a'] = sum_a W_A^(a a') [ W_LEN^(a b') sum_b f[A b + a] W_S^(b b') ]
+//   * wave a of the workgroup loads the residue class x = a (mod A) of ALL the tile's lines: its lanes are
+//     (line l fastest, b) -- a load instruction covers S/8 x planes x (512/S) memory-adjacent lines, i.e. whole 128-byte
+//     (S = 64) or 64-byte (S = 128) runs: 8 (16) cache-line look-ups per instruction instead of 32 (64);
+//   * the S-point sub-transforms over b are wave-local (the wave-local kernel's own plan, layout and swizzle: XwPlan<S>);
+//   * the radix-A step over a runs ACROSS the waves through LDS -- the exchange a Stockham stage needs anyway, so the
+//     LDS traffic equals the wave-local kernel's (two exchanges per line transform); afterwards thread t owns the
+//     k-points k = J + (LEN/8) m, m < 8, of one line of EVERY spectrum (J = t / lines-per-tile): the mix is register
+//     arithmetic with one table entry per k-point, exactly as in the wave-local kernel;
+//   * the inverse mirrors it (inverse radix-A step, conj twiddles, cross exchange, wave-local inverse sub-transforms) and
+//     wave a stores its residue class in the same whole runs.
+// One workgroup barrier per spectrum and direction: two cross buffers alternate (A x 512 complex each), and the wave-local
+// line buffers of a step live inside the wave's own region of that step's buffer, which nobody else touches before the
+// step's barrier -- 64 KB (fp64) + tables per workgroup, two workgroups per CU.
+#pragma once
+#include "xwave.h"
+
+namespace ofdft {
+
+#ifndef OFDFT_XC_A512
+#define OFDFT_XC_A512 8       // (512^3, WGC99 pair: A = 4, 64-byte runs: 4.95 ms; A = 8, whole lines, one 512-thread workgroup per CU: 3.8 ms)
+#endif
+template <int LEN> struct XcWaves { static constexpr int A = 4; };
+template <> struct XcWaves<512> { static constexpr int A = OFDFT_XC_A512; };
+template <> struct XcWaves<1024> { static constexpr int A = 8; };
+
+template <int LEN> struct XcCfg {
+    static constexpr int A = XcWaves<LEN>::A;         // waves per workgroup = radix of the cross-wave step
+    static constexpr int S = LEN / A;                 // length of the wave-local sub-transforms
+    static constexpr int E = 8;
+    static constexpr int P = S / E;                   // lanes per line in a sub-transform
+    static constexpr int LPWV = 64 / P;               // lines per tile (every wave works on all of them)
+    static constexpr int LPB = LPWV;
+    static constexpr int TPB = 64 * A;
+    static constexpr int PP = TPB / LPWV;             // threads per line in the mix phase (= LEN / 8)
+    static constexpr int RR = E / A;                  // radix-A butterflies per thread in the cross step
+    static constexpr int WREG = 64 * E;               // complex elements of one wave's region of a cross buffer
+    static constexpr int XB = A * WREG;               // complex elements of a cross buffer (= lines per tile x LEN)
+    static constexpr int RS = XwSwz<S>::RS;           // reals per wave-local line buffer
+    static_assert(S >= 16 && P <= 64 && E % A == 0, "split");
+    static_assert(LPWV * RS * sizeof(real) <= WREG * sizeof(cplx), "the wave's line buffers live inside its region of a cross buffer");
+    static constexpr size_t LDS = sizeof(cplx) * (2 * XB + LEN + S);     // two cross buffers + W_LEN + W_S
+};
+
+#ifndef OFDFT_XC_WAVES
+#define OFDFT_XC_WAVES 2
+#endif
+// cache policy of the data loads: a tile of whole 128-byte runs is read once by ONE wave -> nt (256^3: the WGC99 pair 452 -> 405 us);
+// narrower tiles (64-byte runs: the partner workgroup reads the other half of every cache line) keep the lines cached
+// (512^3 with A = 4: nt 4.95 -> 5.26 ms)
+#ifndef OFDFT_XC_LD_AUX
+#define OFDFT_XC_LD_AUX 2
+#endif
+#ifndef OFDFT_XC_ST_AUX
+#define OFDFT_XC_ST_AUX 2
+#endif
+
+template <int LEN, int NIN, int NOUT, class Mix>
+__global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfIo io, LineMap m_main, LineMap m_rem, int main_blocks,
+                                                                              SpecGeom g, const cplx* __restrict__ tw_g, Mix mix,
+                                                                              XfStride xs) {
+    using Cfg = XcCfg<LEN>;
+    constexpr int A = Cfg::A, S = Cfg::S, E = Cfg::E, P = Cfg::P, LPWV = Cfg::LPWV, LPB = Cfg::LPB, PP = Cfg::PP, RR = Cfg::RR,
+                  TPB = Cfg::TPB, WREG = Cfg::WREG, G = NIN > NOUT ? NIN : NOUT;
+    extern __shared__ __attribute__((aligned(16))) real lds[];
+    cplx* xb = reinterpret_cast<cplx*>(lds);
+    cplx* twN = xb + 2 * Cfg::XB;         // W_LEN^m
+    cplx* twS = twN + LEN;                // W_S^m = W_LEN^(A m)
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int a = __builtin_amdgcn_readfirstlane(t >> 6);       // residue class of this wave
+    const int l = lane % LPWV;            // lines fastest over the lanes: the memory-contiguous direction
+    const int j = lane / LPWV;            // b = j + P q in the load / store phases
+    const int J = t / LPWV;               // k = J + PP m in the mix phase (J = a P + j)
+    // ---- twiddle tables: requested now, written to LDS after the data loads have been issued
+    constexpr int TWC = (LEN + TPB - 1) / TPB;
+    cplx twr[TWC];
+#pragma unroll
+    for (int c = 0; c < TWC; ++c) {
+        const int i = t + c * TPB;
+        twr[c] = tw_g[i < LEN ? i : 0];
+    }
+    const cplx tws = tw_g[(t < S ? t : 0) * A];
+    const bool is_rem = (int)blockIdx.x >= main_blocks;    // one grid: the block-8 main part, then the remainder planes
+    const LineMap m = is_rem ? m_rem : m_main;
+    int bid = is_rem ? (int)blockIdx.x - main_blocks : (int)blockIdx.x;
+    if (LPB * sizeof(cplx) < 128 && !is_rem && bid < (main_blocks & ~15)) {
+        // tiles narrower than a 128-B line: the two workgroups that share every line go to ONE XCD (blocks are dealt
+        // round-robin over the 8 XCDs) -- speed only, never correctness
+        bid = (bid & ~15) + ((bid & 7) << 1) + ((bid >> 3) & 1);
+    }
+    if (!is_rem) bid += m.blk0;           // launch over a range of kz blocks
+    const long long L0 = (long long)bid * LPB;
+    const long long L = L0 + l;
+    const bool valid = L < m.nlines;
+    const long long base = valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0;
+    int y, kz;                            // k-point coordinates of this line
+    if (is_rem) {
+        y = (int)(L % g.n1);
+        kz = g.nzm + (int)(L / g.n1);
+    } else {
+        const int c = (int)(L % m.d);
+        y = c >> 3;
+        kz = m.kz0 + (int)(L / m.d) * 8 + (c & 7);
+    }
+    const long long region = is_rem ? g.main_count : 0;
+    const long long lb0 = line_base(m, L0);
+    const long long b0 = uniform64(region + lb0);                               // workgroup-uniform
+    const long long se_o = xs.se_out ? xs.se_out : m.se, se_t = xs.tse ? xs.tse : m.se;
+    const int xa = A * j + a;             // x of register slot 0 in the load / store phases (slot q: x = xa + PP q)
+    const unsigned voff = valid ? (unsigned)((base - lb0 + (long long)xa * m.se) * kCB) : 0u;
+    const unsigned voff_o = valid ? (unsigned)((base - lb0 + (long long)xa * se_o) * kCB) : 0u;
+    const unsigned tloff = valid ? (unsigned)(base - lb0 + (long long)J * se_t) : 0u;
+    const long long qstep = uniform64((long long)PP * m.se), qstep_o = uniform64((long long)PP * se_o),
+                    tqstep = uniform64((long long)PP * se_t);
+
+    cplx v[G][E];
+    static_for<NIN>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        const cplx* ub = io.in[I] + b0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[I][q] = valid ? buf_load_c_aux<(LPWV * sizeof(cplx) >= 128 ? OFDFT_XC_LD_AUX : 0)>(ub + q * qstep, voff) : mkc(0.0, 0.0);
+    });
+    // table-driven mixes: the k-point entries of the MIX phase's slots are requested with the data
+    constexpr int NC = OFDFT_XW_PREFETCH ? mix_coef_count<Mix>::N : 0;
+    real cfs[E][NC > 0 ? NC : 1];
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) mix.fetch(cfs[q], b0 + q * tqstep, tloff, valid);
+    }
+    // ---- publish the twiddles
+#pragma unroll
+    for (int c = 0; c < TWC; ++c) {
+        const int i = t + c * TPB;
+        if (i < LEN) twN[i] = twr[c];
+    }
+    if (t < S) twS[t] = tws;
+    __syncthreads();
+    const int lx = (l * XwSwz<S>::LMUL) & 31;       // line-dependent part of the wave-local LDS swizzle
+    // cross-step twiddles W_LEN^(aa b'), b' = J + PP r: the same for every spectrum and (conjugated) for the inverse
+    static_for<NIN>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        cplx* buf = xb + (I & 1) * Cfg::XB;
+        real* mine = reinterpret_cast<real*>(buf + a * WREG) + l * Cfg::RS;
+        xw_line_fft<S, false>(v[I], j, mine, twS, lx);          // G_a[b' = j + P q] of line l
+        exchange_sync<true>();
+#pragma unroll
+        for (int q = 0; q < E; ++q) buf[a * WREG + lane + 64 * q] = v[I][q];      // index (b' LPWV + l) of region a
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const int bp = J + PP * r;
+            cplx c[A];
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa) c[aa] = buf[aa * WREG + t + TPB * r];
+#pragma unroll
+            for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], twN[aa * bp]);
+            Dft<A, false>::run(c);
+#pragma unroll
+            for (int ap = 0; ap < A; ++ap) v[I][r + RR * ap] = c[ap];               // X[b' + S a'] = X[J + PP (r + RR a')]
+        }
+    });
+    // ---- mix, in registers: the thread owns k-points x = J + PP m of its line in every spectrum
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        cplx in[NIN], out[NOUT];
+#pragma unroll
+        for (int I = 0; I < NIN; ++I) in[I] = v[I][q];
+        if constexpr (NC > 0) mix.apply(out, in, cfs[q]);
+        else xw_outputs<NIN, NOUT, 0, Mix>(out, in, mix, J + PP * q, y, kz, b0 + q * tqstep, tloff);
+#pragma unroll
+        for (int O = 0; O < NOUT; ++O) v[O][q] = out[O];
+    }
+    static_for<NOUT>([&](auto oc) {
+        constexpr int O = decltype(oc)::value;
+        cplx* buf = xb + ((NIN + O) & 1) * Cfg::XB;
+        real* mine = reinterpret_cast<real*>(buf + a * WREG) + l * Cfg::RS;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const int bp = J + PP * r;
+            cplx c[A];
+#pragma unroll
+            for (int ap = 0; ap < A; ++ap) c[ap] = v[O][r + RR * ap];
+            Dft<A, true>::run(c);
+#pragma unroll
+            for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], cconj(twN[aa * bp]));
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa) buf[aa * WREG + t + TPB * r] = c[aa];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < E; ++q) v[O][q] = buf[a * WREG + lane + 64 * q];
+        exchange_sync<true>();
+        xw_line_fft<S, true>(v[O], j, mine, twS, lx);
+        exchange_sync<true>();
+        if (valid) {
+            cplx* ub = io.out[O] + b0;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                if (xs.se_out) buf_store_c(ub + q * qstep_o, voff_o, v[O][q]);
+                else buf_store_c_aux<OFDFT_XC_ST_AUX>(ub + q * qstep_o, voff_o, v[O][q]);
+            }
+        }
+    });
+}
+
+}  // namespace ofdft
