@@ -63,7 +63,7 @@ def class_alg_bytes(cfg, n, word, n_ypass):
                   'yderiv': 2 * 2 * Cc,                 # D_b n (out of place) and D_b G_b (in place)
                   'xfused_n': 3 * Cc,                   # n^ -> vH^, i f_a n^
                   'xfused_div': 2 * Cc,
-                  'xfused_wgc': 2 * 6 * Cc,             # two 3 -> 3 launches; their (w0,K1,K2,K3) kernel tables are NOT algorithmic
+                  'xfused_wgc': 2 * 6 * Cc,             # two 3 -> 3 launches; their (w0,K1 | K2) kernel tables are NOT algorithmic
                                                         # bytes (k-dependent kernels earn none) -- see `table_MB_per_eval`
                   'zpbe': 4 * Cc + 3 * R,               # A, B in/out; D_c n, chi in; df/dn - 2 D_c G_c out
                   'zf_powers': R + 6 * Cc,

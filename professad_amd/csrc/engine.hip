@@ -291,19 +291,18 @@ int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, doubl
     if (c->wgc_valid && c->wgc_key_nel == nel_rounded) return 0;
     WgcSeries s{};
     if (int rc = wgc_series_setup(c, nel_rounded, st, &s)) return rc;
-    real *w0, *K1, *K2, *K3;
+    cplx* t01;
     const size_t tb = sizeof(real) * (size_t)c->g.total;
-    if (int rc = get_ws(c, "t:wgc", 4 * tb, (void**)&w0)) return rc;      // interleaved (w0,K1,K2,K3) per k-point
-    K1 = w0 + 1;
-    K2 = w0 + 2;
-    K3 = w0 + 3;
+    if (int rc = get_ws(c, "t:wgc", 3 * tb, (void**)&t01)) return rc;      // (w0, K1) per k-point, then K2 per k-point (wgc_tab)
+    real* t2 = reinterpret_cast<real*>(t01 + c->g.total);
     TabMap tm{c->nranks > 1 ? 1 : 0, c->xg.nyl, c->g.nzm, c->xg.arr_sz};
     tm.nch = c->xc.n;
     tm.n0g = c->n0g;
     tm.nrem = c->xg.nrem;
     for (int k = 0; k <= c->xc.n; ++k) tm.kb[k] = c->xc.kb[k];
     if (c->xc.n <= 1) tm.kb[1] = c->xg.nb;
-    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, w0, K1, K2, K3, c->kg, s, tm);
+    OFDFT_LAUNCH(c, st, "wgc_table", wgc_table_kernel, dim3(grid_for(c->g.total, 256, 4096)), dim3(256), 0, t01, t2, c->kg, s, tm);
+    c->wgc_ck = (3.0 - c->params[OFDFT_P_WGC_GAMMA]) / (3.0 * nref);
     c->wgc_key_nel = nel_rounded;
     c->wgc_valid = true;
     return 0;
@@ -593,7 +592,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         if (int rc = spec_ws(c, "s1", &s1)) return rc;
         if (int rc = spec_ws(c, "s2", &s2)) return rc;
-        const real *w0 = (real*)c->ws["t:wgc"].p, *K1 = w0 + 1, *K2 = w0 + 2, *K3 = w0 + 3;
+        const MixWgc wmix = wgc_tab(c);
         for (int pass = 0; pass < 2; ++pass) {
             OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
                                nref);
@@ -601,12 +600,12 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
             const real* tw3[3] = {t0, t1, t2};
             if (xm) {
                 if (int rc = bluestein_fwd_zy_multi(c, tw3, sw, 3, st)) return rc;
-                if (int rc = bluestein_xmix<3, 3>(c, sw, sw, MixWgc{w0}, st)) return rc;
+                if (int rc = bluestein_xmix<3, 3>(c, sw, sw, wmix, st)) return rc;
                 if (int rc = bluestein_inv_yz_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
                 continue;
             }
             if (int rc = rfftn_internal_multi(c, tw3, sw, 3, st)) return rc;
-            OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, w0, K1, K2, K3, c->g.total);
+            OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, wmix.t01, wmix.t2, wmix.ck, c->g.total);
             if (int rc = irfftn_internal_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
         }
         ca.u0 = o[0]; ca.u1 = o[1]; ca.u2 = o[2];
@@ -757,7 +756,7 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
             if (int rc = real_ws(c, names[i], &o[i])) return rc;
         for (int i = 1; i < 3; ++i)
             if (int rc = spec_ws(c, sn[i], &s[i])) return rc;
-        const MixWgc mix{(real*)c->ws["t:wgc"].p};
+        const MixWgc mix = wgc_tab(c);
         XfIo io{};
         for (int i = 0; i < 3; ++i) {
             io.in[i] = s[i];
@@ -1023,17 +1022,16 @@ void resident_give_up(ofdft_ctx* c) {
 int closure_enqueue(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st) {
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
-    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
-                 c->d_reduced + kSumsqSlot);
-    OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, nel,
-                 c->vol / (double)c->npts);
+    OFDFT_LAUNCH(c, st, "reduce", closure_scale_reduce_kernel, dim3(1), dim3(kRedThreads), 0, (const acc_t*)c->d_partial, blocks,
+                 c->d_reduced + kSumsqSlot, c->d_scal, nel, c->vol / (double)c->npts);
     const DenSrc ds{chi, 0.0, 1, c->d_scal};
     if (int rc = zfused_enqueue(c, ds, nel, vext, v, c->h_partial /* any non-null: host copy wanted */, st, true)) return rc;
     if (grad) {
         const ZRun& zr = zrun(c);
         OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v, grad,
                      c->npts, 0.0, (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV, nel,
-                     zr.vpart_deferred ? zr.za.v_part : (const real*)nullptr);
+                     zr.vpart_deferred ? zr.za.v_part : (const real*)nullptr,
+                     zr.late_join ? (const acc_t*)(c->d_scal + 3) : (const acc_t*)nullptr);
     }
     return 0;
 }
@@ -1084,7 +1082,7 @@ int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, r
             graph_drop(c);
             return 0;
         }
-        ge->wgc_split = zrun(c).wgc_split;
+        ge->collect = collect_flags(zrun(c), zrun(c).late_join);
         ge->fft_count = c->fft_count;
         ge->launch_count = c->launch_count;
         ge->ypass_count = c->ypass_count;
@@ -1094,7 +1092,7 @@ int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, r
     c->ypass_count = ge->ypass_count;
     HIP_TRY(c, hipGraphLaunch(ge->exec, st));
     if (int rc = end_call(c, st)) return rc;
-    zfused_collect(c, ge->wgc_split, sums);
+    zfused_collect(c, ge->collect, sums);
     c->graph_replays++;
     *done = true;
     return 0;
@@ -1165,7 +1163,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
         if (!done) {
             if (int rc = closure_enqueue(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st)) return rc;
             if (int rc = end_call(c, st)) return rc;
-            zfused_collect(c, zrun(c).wgc_split, sums);
+            zfused_collect(c, collect_flags(zrun(c), zrun(c).late_join), sums);
         }
         double vn;
         for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;

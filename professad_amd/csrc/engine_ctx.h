@@ -74,6 +74,7 @@ struct ofdft_ctx {
     double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
     long long wgc_key_nel = -1;
     bool wgc_valid = false;
+    double wgc_ck = 0.0;           // K3 = K2 + wgc_ck K1 for the tables in "t:wgc" ((3 - gamma) / (3 n_ref))
     // stats
     int fft_count = 0, launch_count = 0;
     double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
@@ -111,7 +112,7 @@ struct ofdft_ctx {
         unsigned long long version = 0;      // configuration the graph was captured under
         int seen = 0;                        // calls with these arguments so far (the first one runs uncaptured: it allocates)
         hipGraphExec_t exec = nullptr;
-        bool wgc_split = false;
+        int collect = 0;                     // zfused_collect flags of the captured evaluation
         int fft_count = 0, launch_count = 0;
         double ypass_count = 0.0;
     };
@@ -327,6 +328,11 @@ int launch_zf_density(ofdft_ctx* c, const DenSrc& ds, cplx* out_n, cplx* out_s, 
                       real* dzn = nullptr);
 // WGC99 kernel tables (w0, K1, K2, K3 interleaved per k-point, spectrum order) for round(N_e) = nel_rounded; *nref_out = kappa n0
 int ensure_wgc_tables(ofdft_ctx* c, long long nel_rounded, hipStream_t st, double* nref_out);
+// the tables as the mix functor of the fused x passes sees them, from element `off` (a kz chunk of a chunk-major table)
+inline MixWgc wgc_tab(ofdft_ctx* c, long long off = 0) {
+    const cplx* t01 = (const cplx*)c->ws["t:wgc"].p;
+    return MixWgc{t01 + off, reinterpret_cast<const real*>(t01 + c->g.total) + off, (real)c->wgc_ck};
+}
 bool resident_serves(const ofdft_ctx* c);
 constexpr int kResidentDeclined = 1;       // resident_closure: not an error -- the caller takes the graph / staged path instead
 // chi -> (sums, v, chi.grad) -- or, with from_den, density -> (sums, v) -- by the persistent small-grid kernel (resident.hip)

@@ -56,6 +56,7 @@ struct ZRun {
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     bool closure = false;          // single-GPU closure evaluation: only chi.grad leaves the call, so v may stay in two parts
+    bool late_join = false;        // host-bound sums of a closure evaluation: the share of sum(v n) of the deferred part is added by chi_grad / the host
     bool vpart_deferred = false;   // ... and does: zi_combine does not wait for zi_wgc, chi_grad adds v_part (zstage5)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
     int stage[2] = {0, 0};
@@ -322,7 +323,7 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
             }
         }
         if (r.has_wgc) {
-            const MixWgc mix{(real*)c->ws["t:wgc"].p + (dx ? 4 * xv.base1 : 0)};    // (the table is chunk-major like the buffers)
+            const MixWgc mix = wgc_tab(c, dx ? xv.base1 : 0);    // (the table is chunk-major like the buffers)
             // kz-chunked form (one GPU): the fused x pass of a range of kz blocks is followed at once by the y-inverse
             // of the same range, which then reads the x pass' output from the Infinity Cache
             const int nb = c->g.nzm / 8;
@@ -426,7 +427,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
             }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
             OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 2,
-                         c->d_scal + 2);                       // [2] energy sum, [3] this part's sum(v n)
+                         c->d_scal + 2, c->h_partial + kNSums);        // [2] energy sum, [3] this part's sum(v n); host mirror
             r.za.v_part = vp;
             r.wgc_split = true;
             // closure evaluations leave v in two parts: the combine kernel then has nothing to wait for on this stream
@@ -444,7 +445,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
         if ((rc = launch_zpbe2(c, r.ds, r.s_g[0], r.s_g[1], r.dzn, r.dfdn, r.za.inv_n, &r.pbe_blocks, st, r.lapl ? r.s_l : nullptr)))
             return rc;
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
-                     kPbeScalars, c->d_reduced + kCombineScalars);
+                     kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
         // D_b G_b in one y pass, in place (scaled like B); only G_a goes on to the x pass
         if ((rc = yderiv(c, r.s_g[1], r.s_g[1], (double)c->n0g, st))) return rc;
         if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[0], st))) return rc;
@@ -469,7 +470,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
         }
         // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
         OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
-                     kPbeScalars, c->d_reduced + kCombineScalars);
+                     kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
             if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             xl.push_back(r.s_g[k]);
@@ -536,9 +537,19 @@ int zstage4(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
 }
 
 // the local sums of an evaluation from the pinned host mirror (after the stream that copied them has been drained)
-void zfused_collect(const ofdft_ctx* c, bool wgc_split, double* sums) {
+// what the host has to fold when it reads the pinned mirror of an evaluation's sums (the reducing kernels write it directly)
+constexpr int kCollectWgcSplit = 1;     // the split WGC99 kernel's energy sum sits in slot kNSums
+constexpr int kCollectVnShare = 2;      // ... and its share of sum(v n) in slot kNSums + 1 (closure form: chi_grad added it on the device)
+constexpr int kCollectNoGga = 4;        // no GGA term: the three GGA slots are not written
+int collect_flags(const ZRun& r, bool late_join) {
+    return (r.wgc_split ? kCollectWgcSplit : 0) | (late_join ? kCollectVnShare : 0) | (r.has_g ? 0 : kCollectNoGga);
+}
+void zfused_collect(const ofdft_ctx* c, int flags, double* sums) {
     for (int i = 0; i < kNSums; ++i) sums[i] = c->h_partial[i];
-    if (wgc_split) sums[5] += c->h_partial[kNSums];
+    if (flags & kCollectNoGga)
+        for (int i = kCombineScalars; i < kNSums; ++i) sums[i] = 0.0;
+    if (flags & kCollectWgcSplit) sums[5] += c->h_partial[kNSums];
+    if (flags & kCollectVnShare) sums[8] += c->h_partial[kNSums + 1];
 }
 
 // local sums: sums[0..8] combine scalars, sums[9..10] PBE x / c
@@ -608,15 +619,20 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false, int 
     } else if ((rc = launch_zi_combine(c, r.za, &r.combine_blocks, st))) {
         return rc;
     }
+    // (host-bound sums: the reduce kernel writes the pinned mirror itself -- no copy command behind it; the stabilised
+    // WT-style functional rewrites two of the sums afterwards and keeps the copy)
     OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
-                 r.combine_blocks, kCombineScalars, c->d_reduced);
+                 r.combine_blocks, kCombineScalars, c->d_reduced, (sums && !wts) ? c->h_partial : (acc_t*)nullptr);
     if (wts) OFDFT_LAUNCH(c, st, "reduce", wts_finalize_kernel, dim3(1), dim3(64), 0, c->d_reduced, (const acc_t*)(c->d_scal + 4));
     if (late_join) {      // now the nonlocal chain: its share of sum(v n) joins the combine's (mu is formed from the total)
         HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        OFDFT_LAUNCH(c, st, "reduce", (axpy_kernel<acc_t>), dim3(1), dim3(64), 0, (const acc_t*)(c->d_scal + 3), c->d_reduced + 8,
-                     (long long)1, 1);
+        // host-bound sums: chi_grad and the host each add the share (slot 3 of the device scalars / its pinned mirror) themselves
+        if (!sums)
+            OFDFT_LAUNCH(c, st, "reduce", (axpy_kernel<acc_t>), dim3(1), dim3(64), 0, (const acc_t*)(c->d_scal + 3), c->d_reduced + 8,
+                         (long long)1, 1);
     }
+    r.late_join = late_join && sums != nullptr;
     if (!r.has_g) HIP_TRY(c, hipMemsetAsync(c->d_reduced + kCombineScalars, 0, kPbeScalars * sizeof(double), st));
     r.stage[0] = r.stage[1] = 5;
     if (!sums) {                  // the caller reduces the device-resident sums (c->d_reduced) itself
@@ -625,12 +641,10 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false, int 
                          (long long)1, 1);
         return 0;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
-    if (r.wgc_split)       // energy sum of the split WGC99 kernel (its stream was joined above)
-        HIP_TRY(c, hipMemcpyAsync(c->h_partial + kNSums, c->d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (wts) HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * kCombineScalars, hipMemcpyDeviceToHost, st));
     if (defer) return 0;
     HIP_TRY(c, hipStreamSynchronize(st));
-    zfused_collect(c, r.wgc_split, sums);
+    zfused_collect(c, collect_flags(r, r.late_join), sums);
     return 0;
 }
 

@@ -18,13 +18,22 @@
 namespace ofdft {
 namespace fm {
 
-// ---- reciprocal: hardware seed (~2^-23 relative) + two Newton steps; no scaling / fix-up (normal-range arguments)
+// ---- reciprocal: hardware seed (~2^-23 relative) + ONE third-order step r (1 + e + e^2), e = 1 - x r: the error after it is
+// e^3 ~ 2^-69, below the rounding of the last fma (round 4; was two Newton steps = one fma more); no scaling / fix-up
+// (normal-range arguments).  OFDFT_RCP_NEWTON2=1 restores the two-step form.
+#ifndef OFDFT_RCP_NEWTON2
+#define OFDFT_RCP_NEWTON2 0
+#endif
 __device__ __forceinline__ double rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
+#if OFDFT_RCP_NEWTON2
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
+#else
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+#endif
 }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

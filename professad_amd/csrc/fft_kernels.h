@@ -71,7 +71,8 @@ template <int LEN> struct PassCfg {
     static constexpr int E = Plan<LEN>::E;
     static constexpr int TPB = (8 * P > OFDFT_CPASS_TPB) ? 8 * P : OFDFT_CPASS_TPB;
     static constexpr int LPW = TPB / P;
-    static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(real) * LPW * LineBuf<LEN>::STRIDE : 0;
+    static constexpr int LSTR = kCXMul * LineBuf<LEN>::STRIDE;      // reals per line buffer (fp32 build: complex elements, StageP CX)
+    static constexpr size_t LDS = (Plan<LEN>::NST > 1) ? sizeof(real) * LPW * LSTR : 0;
 };
 
 // uniform base of a tile (first line of the workgroup) and the per-lane byte offset of line L, element j
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void cpass_kernel(ArrList arrs, 
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if (t > 0) __syncthreads();                             // the line buffers are reused
-        line_fft<LEN, INV>(v[t], js[t], lds + ls[t] * LineBuf<LEN>::STRIDE, tw);
+        line_fft<LEN, INV, kCX>(v[t], js[t], lds + ls[t] * PassCfg<LEN>::LSTR, tw);
         if (valids[t]) {
 #pragma unroll
             for (int q = 0; q < E; ++q)
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* _
 #pragma unroll
     for (int q = 0; q < E; ++q)
         v[q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c(in + roff + b0 + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
-    real* mine = lds + l * LineBuf<LEN>::STRIDE;
-    line_fft<LEN, false>(v, j, mine, tw);
+    real* mine = lds + l * PassCfg<LEN>::LSTR;
+    line_fft<LEN, false, kCX>(v, j, mine, tw);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = j + PL::cout(q);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* _
     }
     __syncthreads();
     repattern_out_to_in<PL, false>(v, j, mine);
-    line_fft<LEN, true>(v, j, mine, tw);
+    line_fft<LEN, true, kCX>(v, j, mine, tw);
     if (valid) {
 #pragma unroll
         for (int q = 0; q < E; ++q)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void ypass_xchg_kernel(ArrList a
         if (INV) v[q] = on ? nt_load_c(buf + bpos(j + PL::cin(q))) : mkc(0.0, 0.0);
         else v[q] = on ? buf_load_c_aux<OFDFT_CPASS_LD_AUX>(ub + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
     }
-    line_fft<LEN, INV>(v, j, lds + l * LineBuf<LEN>::STRIDE, tw);
+    line_fft<LEN, INV, kCX>(v, j, lds + l * PassCfg<LEN>::LSTR, tw);
     if (valid) {
 #pragma unroll
         for (int q = 0; q < E; ++q) {

@@ -43,6 +43,16 @@ typedef double real;
 typedef double2 cplx;
 #endif
 typedef double acc_t;
+// fp32 build: the LDS exchange of a line transform moves whole complex numbers (8-byte accesses, one write + one read per
+// element and stage) instead of real and imaginary parts separately (4-byte accesses, two of each, and twice the wave
+// synchronisations): ds_write_b32 sustains 64 B/clk/CU where ds_write_b64 sustains ~85, and a b32 read half a b64 read's
+// bytes per LDS cycle (MI355X_MICROARCH.md, LDS).  Kernels that opt in (StageP<..., CX = true>) give every line buffer
+// twice the reals; element positions and bank behaviour are then those of the fp64 build's 8-byte accesses.
+#ifndef OFDFT_F32_CX
+#define OFDFT_F32_CX 1
+#endif
+constexpr bool kCX = sizeof(real) == 4 && OFDFT_F32_CX != 0;
+constexpr int kCXMul = kCX ? 2 : 1;          // reals per element of a CX line buffer
 __host__ __device__ __forceinline__ cplx mkc(real x, real y) {
     cplx c;
     c.x = x;
@@ -418,7 +428,7 @@ template <bool WAVE> __device__ __forceinline__ void exchange_sync() {
 
 // TWTAB: `tw` is a copy of the table in LDS and every power W^(t k) is READ from it (R - 1 ds_read_b128) instead of being formed
 // from W^k by the product tree (24 fp64 instructions per radix-8 butterfly): for kernels bound by their instruction count
-template <class PL, int S, int NS, bool INV, bool WAVE, bool TWTAB = false> struct StageP {
+template <class PL, int S, int NS, bool INV, bool WAVE, bool TWTAB = false, bool CX = false> struct StageP {
     static constexpr int LEN = PL::LEN;
     static constexpr int R = PL::radix(S);
     static constexpr int E = PL::E;
@@ -477,36 +487,54 @@ template <class PL, int S, int NS, bool INV, bool WAVE, bool TWTAB = false> stru
                 const int jb = j + b * P;
                 base[b] = (jb / NS) * (NS * R) + (jb % NS);
             }
-            exchange_sync<WAVE>();
+            if constexpr (CX) {          // whole complex numbers through a buffer of complex elements (fp32 build)
+                cplx* cl = reinterpret_cast<cplx*>(line);
+                exchange_sync<WAVE>();
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                if (FULL || j + b * P < NBF) {
+                for (int b = 0; b < NB; ++b)
+                    if (FULL || j + b * P < NBF) {
 #pragma unroll
-                    for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS) ^ lx] = v[b + u * NB].x;
-                }
-            exchange_sync<WAVE>();
-            real re[E];
+                        for (int u = 0; u < R; ++u) cl[lpos<PL>(base[b] + u * NS) ^ lx] = v[b + u * NB];
+                    }
+                exchange_sync<WAVE>();
 #pragma unroll
-            for (int b = 0; b < NB2; ++b)
-                if (FULL2 || j + b * P < NBF2) {
+                for (int b = 0; b < NB2; ++b)
+                    if (FULL2 || j + b * P < NBF2) {
 #pragma unroll
-                    for (int t = 0; t < R2; ++t) re[b + t * NB2] = line[lpos<PL>(j + b * P + t * NBF2) ^ lx];
-                }
-            exchange_sync<WAVE>();
+                        for (int t = 0; t < R2; ++t) v[b + t * NB2] = cl[lpos<PL>(j + b * P + t * NBF2) ^ lx];
+                    }
+            } else {
+                exchange_sync<WAVE>();
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                if (FULL || j + b * P < NBF) {
+                for (int b = 0; b < NB; ++b)
+                    if (FULL || j + b * P < NBF) {
 #pragma unroll
-                    for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS) ^ lx] = v[b + u * NB].y;
-                }
-            exchange_sync<WAVE>();
+                        for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS) ^ lx] = v[b + u * NB].x;
+                    }
+                exchange_sync<WAVE>();
+                real re[E];
 #pragma unroll
-            for (int b = 0; b < NB2; ++b)
-                if (FULL2 || j + b * P < NBF2) {
+                for (int b = 0; b < NB2; ++b)
+                    if (FULL2 || j + b * P < NBF2) {
 #pragma unroll
-                    for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpos<PL>(j + b * P + t * NBF2) ^ lx]);
-                }
-            StageP<PL, S + 1, NS * R, INV, WAVE, TWTAB>::run(v, j, line, tw, lx);
+                        for (int t = 0; t < R2; ++t) re[b + t * NB2] = line[lpos<PL>(j + b * P + t * NBF2) ^ lx];
+                    }
+                exchange_sync<WAVE>();
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (FULL || j + b * P < NBF) {
+#pragma unroll
+                        for (int u = 0; u < R; ++u) line[lpos<PL>(base[b] + u * NS) ^ lx] = v[b + u * NB].y;
+                    }
+                exchange_sync<WAVE>();
+#pragma unroll
+                for (int b = 0; b < NB2; ++b)
+                    if (FULL2 || j + b * P < NBF2) {
+#pragma unroll
+                        for (int t = 0; t < R2; ++t) v[b + t * NB2] = mkc(re[b + t * NB2], line[lpos<PL>(j + b * P + t * NBF2) ^ lx]);
+                    }
+            }
+            StageP<PL, S + 1, NS * R, INV, WAVE, TWTAB, CX>::run(v, j, line, tw, lx);
         }
     }
 };
@@ -514,9 +542,9 @@ template <class PL, int S, int NS, bool INV, bool WAVE, bool TWTAB = false> stru
 // Full line transform.  `line` = this line's LDS buffer (LineBuf<LEN>::STRIDE doubles; unused when
 // the plan has one stage).  `tw` = forward table W_LEN^m, m = 0..LEN-1 (global memory).
 // Every thread of the workgroup must call this (it contains __syncthreads()).
-template <int LEN, bool INV>
+template <int LEN, bool INV, bool CX = false>
 __device__ __forceinline__ void line_fft(cplx (&v)[Plan<LEN>::E], int j, real* line, const cplx* __restrict__ tw) {
-    StageP<Plan<LEN>, 0, 1, INV, false>::run(v, j, line, tw);
+    StageP<Plan<LEN>, 0, 1, INV, false, false, CX>::run(v, j, line, tw);
 }
 
 // ---- small-footprint plans for the z kernels: E = 8 or 4 complex points per lane.  A line's P = LEN/E
@@ -636,10 +664,15 @@ OFDFT_ZGPLAN(240, 64, 4, 4, 4, 3, 5)      // E = 6
 #endif
 #undef OFDFT_ZGPLAN
 
+// (OFDFT_Z_TWTAB=1: every twiddle power read from the table -- the z kernels keep it in LDS -- instead of formed by the product
+// tree: fewer fp64 instructions, more LDS reads; A/B knob for the instruction-bound GGA mid stage)
+#ifndef OFDFT_Z_TWTAB
+#define OFDFT_Z_TWTAB 0
+#endif
 template <int LEN, int E, bool INV>
 __device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {
     static_assert(ZPlan<LEN, E>::P <= 64, "a line must fit one wavefront");
-    StageP<ZPlan<LEN, E>, 0, 1, INV, true>::run(v, j, line, tw);
+    StageP<ZPlan<LEN, E>, 0, 1, INV, true, OFDFT_Z_TWTAB != 0>::run(v, j, line, tw);
 }
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1

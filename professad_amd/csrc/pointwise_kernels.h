@@ -62,8 +62,9 @@ __device__ __forceinline__ void block_reduce_store(acc_t (&acc)[NS], acc_t* __re
 }
 
 // second level: partial[rows][ns] -> out[ns], fixed summation order (bitwise reproducible)
+// (host_out: optional pinned, device-visible mirror -- the numbers reach the host without a copy command behind the kernel)
 static __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const acc_t* __restrict__ partial, int rows, int ns,
-                                                                      acc_t* __restrict__ out) {
+                                                                      acc_t* __restrict__ out, acc_t* __restrict__ host_out = nullptr) {
     const int s = blockIdx.x;
     acc_t acc[1] = {0.0};
     for (int r = threadIdx.x; r < rows; r += kRedThreads) acc[0] += partial[(long long)r * ns + s];
@@ -74,7 +75,10 @@ static __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(con
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[s] = red[0];
+    if (threadIdx.x == 0) {
+        out[s] = red[0];
+        if (host_out) host_out[s] = red[0];
+    }
 }
 
 // sum(a) or sum(a^2)
@@ -211,11 +215,11 @@ static __global__ void spec_div_kernel(const cplx* __restrict__ fx, const cplx* 
 
 // WGC99 spectral mixing, in place: (A,B,C) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A)   SURVEY §8a-8
 static __global__ void spec_wgc_mix_kernel(cplx* __restrict__ A, cplx* __restrict__ B, cplx* __restrict__ C,
-                                    const real* __restrict__ w0, const real* __restrict__ K1,
-                                    const real* __restrict__ K2, const real* __restrict__ K3, long long total) {
+                                    const cplx* __restrict__ t01, const real* __restrict__ t2v, real ck, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const cplx a = A[i], b = B[i], c = C[i];
-        const real t0 = w0[4 * i], t1 = K1[4 * i], t2 = K2[4 * i], t3 = K3[4 * i];   // interleaved (w0,K1,K2,K3) per k-point
+        const cplx p = t01[i];                                    // (w0, K1) per k-point; K2 in its own array; K3 = K2 + ck K1
+        const real t0 = p.x, t1 = p.y, t2 = t2v[i], t3 = t2 + ck * t1;
         A[i] = mkc(t0 * a.x + t1 * b.x + t2 * c.x, t0 * a.y + t1 * b.y + t2 * c.y);
         B[i] = mkc(t1 * a.x + t3 * b.x, t1 * a.y + t3 * b.y);
         C[i] = mkc(t2 * a.x, t2 * a.y);
@@ -313,8 +317,10 @@ __device__ __forceinline__ void wgc_series(double eta, const WgcSeries& s, doubl
     w3 = THIRD ? H3 + P3 / (eta * eta * eta) : 0.0;
 }
 
-static __global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict__ K1o, real* __restrict__ K2o,
-                                 real* __restrict__ K3o, KGeom kg, WgcSeries s, TabMap tm) {
+// Table layout (round 4): (w0, K1) as one 2-real entry per k-point + K2 in a second array -- 3 reals per k-point.  The
+// fourth coefficient of functionals.py:968-972 is not independent: K3 = K2 + ((3 - gamma) / (3 n_ref)) K1 exactly (from the
+// definitions below), so the mixes form it in registers (-25 % of the table bytes every fused x pass of the nonlocal chain reads).
+static __global__ void wgc_table_kernel(cplx* __restrict__ t01, real* __restrict__ t2, KGeom kg, WgcSeries s, TabMap tm) {
     for (long long ii = (long long)blockIdx.x * blockDim.x + threadIdx.x; ii < kg.g.total; ii += (long long)gridDim.x * blockDim.x) {
         real kx, ky, kz, k2;
         kvec(kg, ii, kx, ky, kz, k2);
@@ -330,11 +336,10 @@ static __global__ void wgc_table_kernel(real* __restrict__ w0o, real* __restrict
         w0 *= s.pref;
         w1 *= s.pref;
         w2 *= s.pref;
-        // interleaved per k-point (32 B): a 4-line x tile then reads whole 128-B lines of the table
-        w0o[4 * i] = w0;
-        K1o[4 * i] = -eta * w1 / (6.0 * s.nref);
-        K2o[4 * i] = (eta * eta * w2 + (7.0 - s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
-        K3o[4 * i] = (eta * eta * w2 + (1.0 + s.gamma) * eta * w1) / (36.0 * s.nref * s.nref);
+        // K1 = -eta w' / (6 n_ref), K2 = (eta^2 w'' + (7 - gamma) eta w') / (36 n_ref^2);
+        // (K3 = (eta^2 w'' + (1 + gamma) eta w') / (36 n_ref^2) = K2 + (3 - gamma) K1 / (3 n_ref))
+        t01[i] = mkc((real)w0, (real)(-eta * w1 / (6.0 * s.nref)));
+        t2[i] = (real)((eta * eta * w2 + (7.0 - s.gamma) * eta * w1) / (36.0 * s.nref * s.nref));
     }
 }
 
@@ -447,29 +452,41 @@ struct MixDiv {
 // WGC99: (A^,B^,C^) -> (w0 A + K1 B + K2 C, K1 A + K3 B, K2 A) with tables in the spectrum layout
 struct MixWgc {
     static constexpr bool kTables = true;     // coef() is a load: the fused x pass requests a half's worth in one batch
-    const real* tab;     // interleaved (w0, K1, K2, K3) per k-point, spectrum order
+    const cplx* t01;     // (w0, K1) per k-point, spectrum order
+    const real* t2;      // K2 per k-point
+    real ck;             // K3 = K2 + ck K1, ck = (3 - gamma) / (3 n_ref)
     static __device__ __forceinline__ constexpr bool imag(int) { return false; }
     // symmetric pattern: (0,0) w0; O+I=1 K1; (0,2),(2,0) K2; (1,1) K3; the rest absent
     template <int O, int I> static __device__ __forceinline__ constexpr bool present() { return O + I <= 2; }
     template <int O, int I> static __device__ __forceinline__ constexpr bool imag_oi() { return false; }
     template <int O, int I>
     __device__ __forceinline__ real coef(int, int, int, long long uoff, unsigned loff) const {
-        // 16-byte loads of (w0,K1) or (K2,K3): identical loads of one k-point are merged by the compiler
-        const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff + ((O + I == 2) ? 1 : 0);
-        const cplx pr = buf_load_c(t2, loff * (unsigned)(4 * sizeof(real)));
-        return (O + I == 0) ? pr.x : ((O + I == 1) ? pr.y : ((O == 1) ? pr.y : pr.x));
+        // identical loads of one k-point are merged by the compiler
+        if constexpr (O + I <= 1) {
+            const cplx pr = buf_load_c(t01 + uoff, loff * (unsigned)sizeof(cplx));
+            return (O + I == 0) ? pr.x : pr.y;
+        } else {
+            const real k2 = buf_load_d(t2 + uoff, loff * (unsigned)sizeof(real));
+            if constexpr (O == 1) {
+                const cplx pr = buf_load_c(t01 + uoff, loff * (unsigned)sizeof(cplx));
+                return k2 + ck * pr.y;
+            } else {
+                return k2;
+            }
+        }
     }
-    // wave-local x pass (xwave.h): all four entries of a k-point by two 16-byte loads, requested with the data
-    static constexpr int kTableReals = 4;
-    __device__ __forceinline__ void fetch(real (&cf)[4], long long uoff, unsigned loff, bool valid) const {
-        const cplx* t2 = reinterpret_cast<const cplx*>(tab) + 2 * uoff;
-        const unsigned bo = loff * (unsigned)(4 * sizeof(real));
-        const cplx p0 = valid ? buf_load_c(t2, bo) : mkc(0.0, 0.0), p1 = valid ? buf_load_c(t2 + 1, bo) : mkc(0.0, 0.0);
-        cf[0] = p0.x; cf[1] = p0.y; cf[2] = p1.x; cf[3] = p1.y;       // w0, K1, K2, K3
+    // wave-local / cross-wave x pass (xwave.h, xcross.h): the three entries of a k-point by one 2-real and one 1-real load,
+    // requested with the data
+    static constexpr int kTableReals = 3;
+    __device__ __forceinline__ void fetch(real (&cf)[3], long long uoff, unsigned loff, bool valid) const {
+        const cplx p0 = valid ? buf_load_c(t01 + uoff, loff * (unsigned)sizeof(cplx)) : mkc(0.0, 0.0);
+        const real k2 = valid ? buf_load_d(t2 + uoff, loff * (unsigned)sizeof(real)) : (real)0.0;
+        cf[0] = p0.x; cf[1] = p0.y; cf[2] = k2;       // w0, K1, K2
     }
-    static __device__ __forceinline__ void apply(cplx (&o)[3], const cplx (&in)[3], const real (&cf)[4]) {
+    __device__ __forceinline__ void apply(cplx (&o)[3], const cplx (&in)[3], const real (&cf)[3]) const {
+        const real k3 = cf[2] + ck * cf[1];
         o[0] = mkc(cf[0] * in[0].x + cf[1] * in[1].x + cf[2] * in[2].x, cf[0] * in[0].y + cf[1] * in[1].y + cf[2] * in[2].y);
-        o[1] = mkc(cf[1] * in[0].x + cf[3] * in[1].x, cf[1] * in[0].y + cf[3] * in[1].y);
+        o[1] = mkc(cf[1] * in[0].x + k3 * in[1].x, cf[1] * in[0].y + k3 * in[1].y);
         o[2] = mkc(cf[2] * in[0].x, cf[2] * in[0].y);
     }
 };
@@ -609,7 +626,8 @@ __device__ __forceinline__ PbePoint pbe_point(real n, real gn2, const GgaSel& se
         const real dAdn = A * A * (1.0 / beta) * ee * deps_dn;
         const real ct = (1.0 / 16.0) * kCbrtPiOver3;
         const real n43 = n13 * n;
-        const real in73 = fm::rcp(n43 * n + 1e-30);
+        // n^(-7/3) from the roots already at hand (was a reciprocal of n^(7/3) + 1e-30: the guard's cap kept, one min instead of 5 fmas)
+        const real in73 = fmin(inv_n * inv_n * q.inv13, (real)1e30);
         const real t2 = ct * gn2 * in73;
         const real dt2dn = -(7.0 / 3.0) * ct * gn2 * n43 * in73 * in73;
         const real dt2dg = ct * in73;
@@ -863,6 +881,24 @@ static __global__ void closure_scale_kernel(const acc_t* __restrict__ sumsq, acc
                                      acc_t vol_over_npts) {
     if (threadIdx.x == 0 && blockIdx.x == 0) cscale[0] = n_elec / (sumsq[0] * vol_over_npts);
 }
+// the two steps in ONE launch (one block): sum chi^2 from the partials (the order of reduce_partials_kernel), then c
+static __global__ __launch_bounds__(kRedThreads) void closure_scale_reduce_kernel(const acc_t* __restrict__ partial, int rows,
+                                                                           acc_t* __restrict__ sumsq, acc_t* __restrict__ cscale,
+                                                                           acc_t n_elec, acc_t vol_over_npts) {
+    acc_t acc = 0.0;
+    for (int r = threadIdx.x; r < rows; r += kRedThreads) acc += partial[r];
+    __shared__ acc_t red[kRedThreads];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kRedThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sumsq[0] = red[0];
+        cscale[0] = n_elec / (red[0] * vol_over_npts);
+    }
+}
 
 // Stabilised Wang-Teter style functional T_TF f(X), X = T_NL / T_TF, f = exp (functionals.py:771-782): weights of the two
 // potentials from the reduced sums of a first (energy-only) combine pass ...
@@ -885,11 +921,12 @@ static __global__ void wts_finalize_kernel(acc_t* __restrict__ sums, const acc_t
 static __global__ void chi_grad_kernel(const real* __restrict__ chi, const real* __restrict__ v, real* __restrict__ g,
                                 long long npts, real c2dV_host, const acc_t* __restrict__ cscale_dev, real two_dV,
                                 real mu_host, const acc_t* __restrict__ vn_dev = nullptr, acc_t dV = 0.0, acc_t n_elec = 1.0,
-                                const real* __restrict__ v2 = nullptr) {
+                                const real* __restrict__ v2 = nullptr, const acc_t* __restrict__ vn2_dev = nullptr) {
     const real c2dV = cscale_dev ? (real)(cscale_dev[0] * two_dV) : c2dV_host;
     // mu = (sum(v n) dV) / N_e: from the host, or formed here from the device-resident sum (no host round trip: the
     // graph-captured evaluation); same operations in the same order as the host form
-    const real mu = vn_dev ? (real)((vn_dev[0] * dV) / n_elec) : mu_host;
+    // (vn2_dev: the share of sum(v n) of a part of the potential formed on another stream -- added here in the order the host adds it)
+    const real mu = vn_dev ? (real)(((vn2_dev ? vn_dev[0] + vn2_dev[0] : vn_dev[0]) * dV) / n_elec) : mu_host;
     const long long n2 = npts >> 1;
     // v2: a part of the potential kept in its own array (the WGC99 part formed beside the combine kernel)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {

@@ -52,7 +52,7 @@ struct ResArgs {
                              // closure scale: n^e theta^m / m!, e = beta | alpha, theta = n - n_ref) and the slot of its spectrum
     int need_c;              // WGC99 present: sum chi^2 is reduced before phase A (one more barrier)
     int nw;                  // WGC99 triples mixed in phase B (0 or 2: slots 9-11 and 12-14, in place)
-    const real* wtab;        // its kernel tables (w0, K1, K2, K3 per k-point, the staged pipeline's spectrum order)
+    MixWgc wtab;             // its kernel tables ((w0, K1) and K2 per k-point, the staged pipeline's spectrum order)
     SpecGeom wg;             // ... and that order
     ResOp bop[8];            // phase B work list
     int nb;
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(kResThreads, 1) void resident_closure_kernel(ResArg
 #pragma unroll
             for (int q = 0; q < EL; ++q) {
                 const long long ti = spec_index(A.wg, lj + PL * q, ky, kz);
-                const cplx t01 = reinterpret_cast<const cplx*>(A.wtab)[2 * ti], t23 = reinterpret_cast<const cplx*>(A.wtab)[2 * ti + 1];
-                const real w0 = t01.x, K1 = t01.y, K2 = t23.x, K3 = t23.y;
+                const cplx t01 = A.wtab.t01[ti];
+                const real w0 = t01.x, K1 = t01.y, K2 = A.wtab.t2[ti], K3 = K2 + A.wtab.ck * K1;
                 const cplx a0 = u[0][q], a1 = u[1][q], a2 = u[2][q];
                 u[0][q] = mkc(w0 * a0.x + K1 * a1.x + K2 * a2.x, w0 * a0.y + K1 * a1.y + K2 * a2.y);
                 u[1][q] = mkc(K1 * a0.x + K3 * a1.x, K1 * a0.y + K3 * a1.y);
@@ -769,7 +769,7 @@ int resident_closure(ofdft_ctx* c, const real* chi, const real* vext, double nel
         const double wal = c->params[OFDFT_P_WGC_ALPHA], wbe = c->params[OFDFT_P_WGC_BETA];
         double nref;
         if (int rc = ensure_wgc_tables(c, std::llround(nel), st, &nref)) return rc;     // functionals.py:952 (rounded N_e)
-        a.wtab = (const real*)c->ws["t:wgc"].p;
+        a.wtab = wgc_tab(c);
         a.wg = c->g;
         a.ca.wgc_alpha = wal;
         a.ca.wgc_beta = wbe;

@@ -31,6 +31,14 @@ namespace ofdft {
 #define OFDFT_XC_A512 8       // (512^3, WGC99 pair: A = 4, 64-byte runs: 4.95 ms; A = 8, whole lines, one 512-thread workgroup per CU: 3.8 ms)
 #endif
 template <int LEN> struct XcWaves { static constexpr int A = 4; };
+#ifndef OFDFT_XC_A256
+#ifdef OFDFT_REAL_F32
+#define OFDFT_XC_A256 4
+#else
+#define OFDFT_XC_A256 4
+#endif
+#endif
+template <> struct XcWaves<256> { static constexpr int A = OFDFT_XC_A256; };
 template <> struct XcWaves<512> { static constexpr int A = OFDFT_XC_A512; };
 template <> struct XcWaves<1024> { static constexpr int A = 8; };
 
@@ -44,9 +52,12 @@ template <int LEN> struct XcCfg {
     static constexpr int TPB = 64 * A;
     static constexpr int PP = TPB / LPWV;             // threads per line in the mix phase (= LEN / 8)
     static constexpr int RR = E / A;                  // radix-A butterflies per thread in the cross step
-    static constexpr int WREG = 64 * E;               // complex elements of one wave's region of a cross buffer
-    static constexpr int XB = A * WREG;               // complex elements of a cross buffer (= lines per tile x LEN)
-    static constexpr int RS = XwSwz<S>::RS;           // reals per wave-local line buffer
+    static constexpr int RS = kCXMul * XwSwz<S>::RS;  // reals per wave-local line buffer
+    // complex elements of one wave's region of a cross buffer: its 64 E points -- or its line buffers, which live there too
+    // (fp32 build with complex-element exchange: 8 x 72 x 8 B = 4.5 KB of line buffers against 4 KB of points)
+    static constexpr int WLB = (int)((LPWV * RS * sizeof(real) + sizeof(cplx) - 1) / sizeof(cplx));
+    static constexpr int WREG = ((64 * E > WLB ? 64 * E : WLB) + 15) / 16 * 16;
+    static constexpr int XB = A * WREG;               // complex elements of a cross buffer (>= lines per tile x LEN)
     static_assert(S >= 16 && P <= 64 && E % A == 0, "split");
     static_assert(LPWV * RS * sizeof(real) <= WREG * sizeof(cplx), "the wave's line buffers live inside its region of a cross buffer");
     static constexpr size_t LDS = sizeof(cplx) * (2 * XB + LEN + S);     // two cross buffers + W_LEN + W_S

@@ -28,7 +28,7 @@ namespace ofdft {
 #endif
 template <int LEN> struct XwSwz { static constexpr int XS = 0, XM = 0, XMUL = 0, LMUL = 0, RS = LineBuf<LEN>::STRIDE; };
 #if OFDFT_XW_SWIZZLE
-#ifdef OFDFT_REAL_F32
+#if defined(OFDFT_REAL_F32) && !OFDFT_F32_CX
 // (b32 accesses: reads and writes in two 32-lane groups over 32 banks)
 template <> struct XwSwz<32> { static constexpr int XS = 3, XM = 1, XMUL = 1, LMUL = 0, RS = 34; };
 template <> struct XwSwz<64> { static constexpr int XS = 3, XM = 3, XMUL = 1, LMUL = 0, RS = 68; };
@@ -36,7 +36,8 @@ template <> struct XwSwz<128> { static constexpr int XS = 3, XM = 7, XMUL = 1, L
 template <> struct XwSwz<256> { static constexpr int XS = 3, XM = 15, XMUL = 1, LMUL = 0, RS = 272; };
 template <> struct XwSwz<512> { static constexpr int XS = 3, XM = 31, XMUL = 1, LMUL = 0, RS = 512; };
 #else
-// (b64 accesses: reads in two 32-lane groups over 64 banks, writes in four 16-lane groups over 32 banks -- the two rules ask
+// (b64 accesses -- fp64, and the fp32 build's complex-element exchange, OFDFT_F32_CX: reads in two 32-lane groups over 64 banks,
+// writes in four 16-lane groups over 32 banks -- the two rules ask
 // for different strides between the interleaved lines, which the line-dependent XOR (LMUL * line) & 31 reconciles)
 template <> struct XwSwz<32> { static constexpr int XS = 1, XM = 1, XMUL = 1, LMUL = 1, RS = 48; };
 template <> struct XwSwz<64> { static constexpr int XS = 1, XM = 1, XMUL = 1, LMUL = 1, RS = 72; };
@@ -51,7 +52,7 @@ template <int LEN> struct LdsLayout<XwPlan<LEN>> : LdsLayoutDefault {
 };
 template <int LEN, bool INV>
 __device__ __forceinline__ void xw_line_fft(cplx (&v)[8], int j, real* line, const cplx* __restrict__ tw, int lx) {
-    StageP<XwPlan<LEN>, 0, 1, INV, true>::run(v, j, line, tw, lx);
+    StageP<XwPlan<LEN>, 0, 1, INV, true, false, kCX>::run(v, j, line, tw, lx);
 }
 
 template <int LEN> struct XwCfg {
@@ -72,7 +73,7 @@ template <int LEN> struct XwCfg {
     static constexpr int TPB = (P == 64 && OFDFT_XW_TPB512) ? 512 : 256;
 #endif
     static constexpr int LPB = LPWV * (TPB / 64);     // lines per workgroup
-    static constexpr int RS = XwSwz<LEN>::RS;         // LDS reals per line buffer
+    static constexpr int RS = kCXMul * XwSwz<LEN>::RS;         // LDS reals per line buffer (XwSwz counts elements: fp32 CX = complex)
     static constexpr int ROWS = LPB * RS;
     static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * LEN;     // line buffers + the staged twiddle table
 };
