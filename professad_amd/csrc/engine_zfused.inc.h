@@ -56,6 +56,7 @@ struct ZRun {
     bool wgc_yinv_done = false;    // kz-chunked form: the y-inverse of the WGC99 results already ran next to the x pass
     bool wgc_split = false;        // the WGC99 potential was formed by zi_wgc_kernel (za.v_part)
     bool closure = false;          // single-GPU closure evaluation: only chi.grad leaves the call, so v may stay in two parts
+    bool setup_done = false;       // zsetup ran for the evaluation being enqueued (zstage1 of chain 0 consumes it)
     bool late_join = false;        // host-bound sums of a closure evaluation: the share of sum(v n) of the deferred part is added by chi_grad / the host
     bool vpart_deferred = false;   // ... and does: zi_combine does not wait for zi_wgc, chi_grad adds v_part (zstage5)
     std::vector<cplx*> deferred;   // x-chunked pipeline: spectra whose y-inverse runs inside the combine loop
@@ -94,6 +95,33 @@ int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
 // Stage 1: z-forward (with the pointwise pre-ops) and y-forward of the chain's input spectra.
 // (xk: chunk of the kz-chunked exchange -- the z kernels run with chunk 0, every call y-transforms its chunk into the send
 // buffer; -1 = all chunks)
+// host-side state of an evaluation that both chains read (term flags, the combine kernel's arguments): first thing of stage 1
+// of chain 0 -- or, when the nonlocal chain's first kernels are enqueued first (zfused_enqueue), before either
+int zsetup(ofdft_ctx* c) {
+    ZRun& r = zrun(c);
+    const unsigned mask = c->mask;
+    r.has_h = mask & OFDFT_HARTREE;
+    r.has_g = mask & kGgaAny;
+    r.has_vw = mask & OFDFT_VW;
+    r.has_wt = mask & OFDFT_WT_NL;
+    r.has_wgc = mask & OFDFT_WGC99_NL;
+    r.za = ZCombineArgs{};
+    r.za.ds = r.ds;
+    r.za.vext = r.vext;
+    r.za.v_out = r.v_out;
+    r.za.mask = mask;
+    r.za.inv_n = 1.0 / (double)c->npts_g;
+    r.za.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
+    r.za.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(r.nel) : 0.0;   // functionals.py:268-270
+    r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
+    r.wgc_yinv_done = false;
+    r.s_g[0] = r.s_g[1] = r.s_g[2] = nullptr;
+    r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
+    if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+    r.setup_done = true;
+    return 0;
+}
+
 int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
@@ -104,24 +132,8 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     if (xk <= 0) {
     xl.clear();
     if (chain == 0) {
-        r.has_h = mask & OFDFT_HARTREE;
-        r.has_g = mask & kGgaAny;
-        r.has_vw = mask & OFDFT_VW;
-        r.has_wt = mask & OFDFT_WT_NL;
-        r.has_wgc = mask & OFDFT_WGC99_NL;
-        r.za = ZCombineArgs{};
-        r.za.ds = r.ds;
-        r.za.vext = r.vext;
-        r.za.v_out = r.v_out;
-        r.za.mask = mask;
-        r.za.inv_n = 1.0 / (double)c->npts_g;
-        r.za.gtf_kind = (int)c->params[OFDFT_P_VWGTF_KIND];
-        r.za.gtf_inv_n0 = (mask & OFDFT_VWGTF) ? c->vol / (double)std::llround(r.nel) : 0.0;   // functionals.py:268-270
-        r.pbe_sums[0] = r.pbe_sums[1] = r.pbe_sums[2] = 0.0;
-        r.wgc_yinv_done = false;
-        r.s_g[0] = r.s_g[1] = r.s_g[2] = nullptr;
-        r.s_n = r.s_s = r.s_vh = r.s_b = r.s_a = nullptr;
-        if ((mask & OFDFT_ION_ELECTRON) && !r.vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
+        if (!r.setup_done && (rc = zsetup(c))) return rc;
+        r.setup_done = false;         // (consumed: the next evaluation sets up again)
         if (r.has_h || r.has_g)
             if ((rc = spec_ws(c, "zn", &r.s_n))) return rc;
         if (r.has_vw)
@@ -675,8 +687,12 @@ int zfused_enqueue(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext,
         HIP_TRY(c, hipStreamWaitEvent(r.sb, c->ev_fork, 0));
         HIP_TRY(c, hipStreamWaitEvent(r.sc, c->ev_fork, 0));
     }
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage1(c, st, chain))) return rc;
+    // one GPU, forked: the nonlocal chain's first kernels go to the device BEFORE the other chain's four launches (its stream
+    // sat idle for ~30 us of host enqueue time at the head of every evaluation; profiles/r04_timeline_*.md)
+    if ((rc = zsetup(c))) return rc;
+    const bool nl_first = r.forked && c->nranks == 1;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = zstage1(c, st, nl_first ? 1 - i : i))) return rc;
     for (int chain = 0; chain < 2; ++chain)
         if ((rc = zstage2(c, st, chain))) return rc;
     for (int chain = 0; chain < 2; ++chain)

@@ -135,7 +135,8 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
     //   1024 x 128 x 128: 920 -> 670 / 197 -> 140 but 90-94 -> 101-106 for the 1 -> 1 passes;  128^3: neutral to 3 % slower.
     // option 1 (default): 256- and 512-point lines always, 1024-point lines for passes over >= 3 spectra;
     // 5 = wherever it exists (128..1024), 6 = passes over >= 3 spectra only, 7 = the round-3 choice (no cross-wave kernel)
-    const bool xc_len = c->n0g == 256 || c->n0g == 512;
+    // (fp32 build, 256-point lines: the 1 -> 1 passes measured 36-37 us in the group-parallel kernel against 39-40 here)
+    const bool xc_len = (c->n0g == 256 && !(sizeof(real) == 4 && NIN + NOUT == 2)) || c->n0g == 512;
     if (c->use_xwave == 5 || (c->use_xwave == 6 && NIN + NOUT >= 3) ||
         (c->use_xwave == 1 && (xc_len || (c->n0g == 1024 && NIN + NOUT >= 3)))) {
         switch (c->n0g) {

@@ -58,7 +58,14 @@ template <int M, int E_> struct ZW {
 #ifndef OFDFT_Z_EMAX_PBE
 #define OFDFT_Z_EMAX_PBE 9      // ... for the GGA mid stage (zpbe2)
 #endif
-template <int M, int E, int EMAX = OFDFT_Z_EMAX> constexpr int z_waves(int want) { return (M >= 512 || E > EMAX) ? (want > 2 ? 2 : 1) : want; }
+// (fp32 build: half the registers per point -- rows of 1024 keep the wanted waves, OFDFT_Z_F32_BIG_WAVES; config 5's grid)
+#ifndef OFDFT_Z_F32_BIG_WAVES
+#define OFDFT_Z_F32_BIG_WAVES 1
+#endif
+template <int M, int E, int EMAX = OFDFT_Z_EMAX> constexpr int z_waves(int want) {
+    if (sizeof(real) == 4 && OFDFT_Z_F32_BIG_WAVES && M >= 512 && E <= 8) return want > 2 ? 2 : want;
+    return (M >= 512 || E > EMAX) ? (want > 2 ? 2 : 1) : want;
+}
 
 // lane geometry of the z kernels
 template <int M, int E> struct ZLane {
