@@ -18,6 +18,10 @@
 namespace ofdft {
 namespace fm {
 
+// (Round 4, measured negative: a Horner step p = fma(p, z, C) compiles to v_mov_b32 x 2 (C into a VGPR pair) + v_fmac_f64, and 204 of
+// the 1 453 vector instructions of one point pair of the GGA mid stage are such moves.  Forcing C into an SGPR operand of v_fma_f64
+// by inline asm removed 72 of them -- zpbe2 0.338 -> 0.338 ms, it is not bound by its instruction count -- and made the
+// register-heavy WGC99 combine kernel 0.25 -> 0.36-0.39 ms slower (the asm operands lengthen its live ranges).  Not kept.)
 // ---- reciprocal: hardware seed (~2^-23 relative) + ONE third-order step r (1 + e + e^2), e = 1 - x r: the error after it is
 // e^3 ~ 2^-69, below the rounding of the last fma (round 4; was two Newton steps = one fma more); no scaling / fix-up
 // (normal-range arguments).  OFDFT_RCP_NEWTON2=1 restores the two-step form.
@@ -83,7 +87,7 @@ __device__ __forceinline__ double exp(double x) {
     p = __builtin_fma(p, r, 1.0 / 120.0);
     p = __builtin_fma(p, r, 1.0 / 24.0);
     p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 0.5);          // (inline constants: no operand to place)
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)k);

@@ -185,14 +185,14 @@ template <int M, int E, int Q> __device__ __forceinline__ long long z_spec_ubase
 }
 
 // forward: real pairs in v -> half-spectrum row written to `spec` (block-8 layout + Nyquist plane)
-template <int M, int E>
+template <int M, int E, bool TT = (OFDFT_Z_TWTAB != 0)>
 __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>& z, cplx* __restrict__ spec,
                                                 const SpecGeom& g, const cplx* __restrict__ twM,
                                                 const cplx* __restrict__ twN) {
     using W = ZW<M, E>;
     using PL = typename W::PL;
     constexpr int P = W::P;
-    wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
     if constexpr (PL::EXACT) {
@@ -271,12 +271,12 @@ __device__ __forceinline__ void z_issue_row(cplx (&v)[E], real& nyq, const ZLane
 // ---- row transforms that stay on chip (the spectrum lives in registers) -----------------------------------------
 // forward: real pairs in v (entry pattern) -> v[q] = coefficient k = j + cout(q) (k < M) of the row's half spectrum; nyq
 // (lane j == 0) = coefficient M (real)
-template <int M, int E>
+template <int M, int E, bool TT = (OFDFT_Z_TWTAB != 0)>
 __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                                const cplx* __restrict__ twN, real& nyq) {
     using W = ZW<M, E>;
     using PL = typename W::PL;
-    wave_line_fft<M, E, false>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
@@ -306,7 +306,7 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
 
 // inverse of the above: v[q] = coefficient k = j + cin(q), nyq = coefficient M -> unscaled real pairs (exit pattern);
 // imaginary parts of the kz = 0 / Nyquist coefficients are ignored, as irfftn does
-template <int M, int E>
+template <int M, int E, bool TT = (OFDFT_Z_TWTAB != 0)>
 __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                                const cplx* __restrict__ twN, real nyq) {
     using W = ZW<M, E>;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
         }
     }
     exchange_sync<true>();
-    wave_line_fft<M, E, true>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, true, TT>(v, z.j, z.mine, twM);
     exchange_sync<true>();
     if constexpr (!PL::EXACT) {      // slots no butterfly of the last stage wrote: keep them out of every sum downstream
 #pragma unroll
@@ -350,7 +350,7 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
 }
 
 // inverse: half-spectrum row of `spec` -> unscaled real pairs in v (imaginary parts of kz = 0 / Nyquist ignored)
-template <int M, int E>
+template <int M, int E, bool TT = (OFDFT_Z_TWTAB != 0)>
 __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ spec,
                                                const SpecGeom& g, const cplx* __restrict__ twM,
                                                const cplx* __restrict__ twN) {
@@ -360,25 +360,25 @@ __device__ __forceinline__ void z_load_inverse(cplx (&v)[E], const ZLane<M, E>& 
     __builtin_amdgcn_sched_barrier(0);
     real nyq;
     z_issue_row<M, E>(v, nyq, z, spec, g);
-    z_inverse_regs<M, E>(v, z, twM, twN, nyq);
+    z_inverse_regs<M, E, TT>(v, z, twM, twN, nyq);
 }
 
 // index derivative along the row, D_c f = F^-1[i f_c F[f]] with the integer frequency f_c = k (rfftfreq,
 // functional_tools.py:155): real pairs in (entry pattern) -> N2 x (derivative) out (exit pattern).  The k = 0 and Nyquist
 // terms are purely imaginary after the multiplication and drop out of the real inverse, as they do in the reference's irfftn.
-template <int M, int E>
+template <int M, int E, bool TT = (OFDFT_Z_TWTAB != 0)>
 __device__ __forceinline__ void z_deriv_row(cplx (&v)[E], const ZLane<M, E>& z, const cplx* __restrict__ twM,
                                             const cplx* __restrict__ twN) {
     using PL = typename ZW<M, E>::PL;
     real nyq;
-    z_forward_regs<M, E>(v, z, twM, twN, nyq);
+    z_forward_regs<M, E, TT>(v, z, twM, twN, nyq);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const real k = (real)(z.j + PL::cout(q));
         v[q] = mkc(-k * v[q].y, k * v[q].x);
     }
     repattern_out_to_in<PL, true>(v, z.j, z.mine);
-    z_inverse_regs<M, E>(v, z, twM, twN, 0.0);
+    z_inverse_regs<M, E, TT>(v, z, twM, twN, 0.0);
 }
 
 // x^y for x > 0 as exp(y log x) with the lean log / exp of fastmath.h: a few ulp for the |y log x| = O(1..10) met here,
@@ -590,6 +590,14 @@ struct Bmat { real b[9]; };
 // LAPL: the Laplacian-dependent Pauli-Gaussian members (functionals.py:336-403).  Lsp holds, on entry, the rows of
 // (lap n)^ = -k^2 n^ (x and y already back in real space); on exit the rows of the spectrum of df/d(lap n), whose
 // Laplacian joins the divergence in the next x pass (MixDerivAL).
+// The GGA mid stage is bound by fp64 instruction issue (35 % VALU-busy, 3 700 vector instructions per wave of which ~1 400 are
+// its six row transforms): its transforms read every twiddle power from the LDS table (StageP TWTAB) instead of forming
+// W^2k, W^3k by complex products -- 8 fp64 instructions less per radix-4 butterfly for two more ds_read_b128
+// (256^3, A/B on one box: 0.332 / 0.342 -> 0.323 / 0.319 ms).  OFDFT_ZPBE_TWTAB=0: the product tree as in the other z kernels.
+#ifndef OFDFT_ZPBE_TWTAB
+#define OFDFT_ZPBE_TWTAB 1
+#endif
+constexpr bool kZpbeTT = OFDFT_ZPBE_TWTAB != 0;
 template <int M, int E, bool LAPL>
 __global__ __launch_bounds__(256, (z_waves<M, E, OFDFT_Z_EMAX_PBE>(2))) void zpbe2_kernel(DenSrc ds, cplx* __restrict__ A, cplx* __restrict__ B,
                                                                       const real* __restrict__ dzn,
@@ -611,35 +619,44 @@ __global__ __launch_bounds__(256, (z_waves<M, E, OFDFT_Z_EMAX_PBE>(2))) void zpb
         z_issue_row<M, E>(a, nyq_a, z, A, g);
         z_issue_row<M, E>(b, nyq_b, z, B, g);
         z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
-        z_inverse_regs<M, E>(a, z, twM, twN, nyq_a);
+        z_inverse_regs<M, E, kZpbeTT>(a, z, twM, twN, nyq_a);
         if constexpr (LAPL) {
             real nyq_l;
             z_issue_row<M, E>(lp, nyq_l, z, Lsp, g);
-            z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
-            z_inverse_regs<M, E>(lp, z, twM, twN, nyq_l);
+            z_inverse_regs<M, E, kZpbeTT>(b, z, twM, twN, nyq_b);
+            z_inverse_regs<M, E, kZpbeTT>(lp, z, twM, twN, nyq_l);
         } else {
-            z_inverse_regs<M, E>(b, z, twM, twN, nyq_b);
+            z_inverse_regs<M, E, kZpbeTT>(b, z, twM, twN, nyq_b);
         }
     }
 #else
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
-    z_load_inverse<M, E>(a, z, A, g, twM, twN);
-    z_load_inverse<M, E>(b, z, B, g, twM, twN);
-    if constexpr (LAPL) z_load_inverse<M, E>(lp, z, Lsp, g, twM, twN);
+    z_load_inverse<M, E, kZpbeTT>(a, z, A, g, twM, twN);
+    z_load_inverse<M, E, kZpbeTT>(b, z, B, g, twM, twN);
+    if constexpr (LAPL) z_load_inverse<M, E, kZpbeTT>(lp, z, Lsp, g, twM, twN);
 #endif
     z_load_real<M, E, true>(c, z, dzn);
     z_load_real<M, E, true>(n, z, ds.src);
     acc_t acc[kPbeScalars] = {0.0, 0.0, 0.0};
     cplx d[E];
+    const bool diag = bm.b[1] == 0.0 && bm.b[2] == 0.0 && bm.b[3] == 0.0 && bm.b[5] == 0.0 && bm.b[6] == 0.0 && bm.b[7] == 0.0;   // (uniform)
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         const real da0 = a[q].x * inv_n, db0 = b[q].x * inv_n, dc0 = c[q].x;
         const real da1 = a[q].y * inv_n, db1 = b[q].y * inv_n, dc1 = c[q].y;
-        // Cartesian gradient g_j = b[0][j] D_a n + b[1][j] D_b n + b[2][j] D_c n
-        const real gx0 = bm.b[0] * da0 + bm.b[3] * db0 + bm.b[6] * dc0, gx1 = bm.b[0] * da1 + bm.b[3] * db1 + bm.b[6] * dc1;
-        const real gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0, gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
-        const real gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0, gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
+        // Cartesian gradient g_j = b[0][j] D_a n + b[1][j] D_b n + b[2][j] D_c n (orthorhombic cells: the diagonal only -- the
+        // same numbers, 24 fp64 instructions less per point pair in a kernel bound by their issue)
+        real gx0, gx1, gy0, gy1, gz0, gz1;
+        if (diag) {
+            gx0 = bm.b[0] * da0; gx1 = bm.b[0] * da1;
+            gy0 = bm.b[4] * db0; gy1 = bm.b[4] * db1;
+            gz0 = bm.b[8] * dc0; gz1 = bm.b[8] * dc1;
+        } else {
+            gx0 = bm.b[0] * da0 + bm.b[3] * db0 + bm.b[6] * dc0; gx1 = bm.b[0] * da1 + bm.b[3] * db1 + bm.b[6] * dc1;
+            gy0 = bm.b[1] * da0 + bm.b[4] * db0 + bm.b[7] * dc0; gy1 = bm.b[1] * da1 + bm.b[4] * db1 + bm.b[7] * dc1;
+            gz0 = bm.b[2] * da0 + bm.b[5] * db0 + bm.b[8] * dc0; gz1 = bm.b[2] * da1 + bm.b[5] * db1 + bm.b[8] * dc1;
+        }
         PbePoint p0 = {0, 0, 0, 0, 0}, p1 = {0, 0, 0, 0, 0};
         if constexpr (LAPL) {
             real dl0 = 0.0, dl1 = 0.0;
@@ -662,24 +679,30 @@ __global__ __launch_bounds__(256, (z_waves<M, E, OFDFT_Z_EMAX_PBE>(2))) void zpb
         acc[2] += p0.fk + p1.fk;
         d[q] = mkc(p0.dfdn, p1.dfdn);
         // contravariant components of the flux F = df/dg grad n:  G_axis = sum_j b[axis][j] F_j
-        a[q] = mkc(p0.dfdg * (bm.b[0] * gx0 + bm.b[1] * gy0 + bm.b[2] * gz0),
-                            p1.dfdg * (bm.b[0] * gx1 + bm.b[1] * gy1 + bm.b[2] * gz1));
-        b[q] = mkc(p0.dfdg * (bm.b[3] * gx0 + bm.b[4] * gy0 + bm.b[5] * gz0),
-                            p1.dfdg * (bm.b[3] * gx1 + bm.b[4] * gy1 + bm.b[5] * gz1));
-        c[q] = mkc(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
-                            p1.dfdg * (bm.b[6] * gx1 + bm.b[7] * gy1 + bm.b[8] * gz1));
+        if (diag) {
+            a[q] = mkc(p0.dfdg * (bm.b[0] * gx0), p1.dfdg * (bm.b[0] * gx1));
+            b[q] = mkc(p0.dfdg * (bm.b[4] * gy0), p1.dfdg * (bm.b[4] * gy1));
+            c[q] = mkc(p0.dfdg * (bm.b[8] * gz0), p1.dfdg * (bm.b[8] * gz1));
+        } else {
+            a[q] = mkc(p0.dfdg * (bm.b[0] * gx0 + bm.b[1] * gy0 + bm.b[2] * gz0),
+                       p1.dfdg * (bm.b[0] * gx1 + bm.b[1] * gy1 + bm.b[2] * gz1));
+            b[q] = mkc(p0.dfdg * (bm.b[3] * gx0 + bm.b[4] * gy0 + bm.b[5] * gz0),
+                       p1.dfdg * (bm.b[3] * gx1 + bm.b[4] * gy1 + bm.b[5] * gz1));
+            c[q] = mkc(p0.dfdg * (bm.b[6] * gx0 + bm.b[7] * gy0 + bm.b[8] * gz0),
+                       p1.dfdg * (bm.b[6] * gx1 + bm.b[7] * gy1 + bm.b[8] * gz1));
+        }
     }
     using PL = typename ZW<M, E>::PL;      // (rows with factors 3 / 5: pointwise results sit in the exit pattern of the inverses)
     repattern_out_to_in<PL, true>(a, z.j, z.mine);
-    z_forward_store<M, E>(a, z, A, g, twM, twN);
+    z_forward_store<M, E, kZpbeTT>(a, z, A, g, twM, twN);
     repattern_out_to_in<PL, true>(b, z.j, z.mine);
-    z_forward_store<M, E>(b, z, B, g, twM, twN);
+    z_forward_store<M, E, kZpbeTT>(b, z, B, g, twM, twN);
     if constexpr (LAPL) {
         repattern_out_to_in<PL, true>(lp, z.j, z.mine);
-        z_forward_store<M, E>(lp, z, Lsp, g, twM, twN);
+        z_forward_store<M, E, kZpbeTT>(lp, z, Lsp, g, twM, twN);
     }
     repattern_out_to_in<PL, true>(c, z.j, z.mine);
-    z_deriv_row<M, E>(c, z, twM, twN);               // N2 x D_c G_c
+    z_deriv_row<M, E, kZpbeTT>(c, z, twM, twN);               // N2 x D_c G_c
 #pragma unroll
     for (int q = 0; q < E; ++q) d[q] = mkc(d[q].x - 2.0 * inv_nz * c[q].x, d[q].y - 2.0 * inv_nz * c[q].y);
     z_store_real<M, E>(d, z, dfdn);
