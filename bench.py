@@ -60,7 +60,9 @@ def class_alg_bytes(cfg, n, word, n_ypass):
          'resident': (3 + 6 + 1 + 2 + 1) * R + 4 * 3 * Cc}
     if cfg == 'cfg3':
         t.update({'zf_density': 2 * R + 2 * Cc,         # chi -> n^, (sqrt n)^, D_c n
-                  'yderiv': 2 * 2 * Cc,                 # D_b n (out of place) and D_b G_b (in place)
+                  # D_b n (out of place) and D_b G_b (in place); on one GPU the y-forward of n^ rides in the first launch (1C -> 2C:
+                  # one y pass less in `n_ypass`, one more C written here)
+                  'yderiv': (4 + max(0.0, 19.0 - n_ypass)) * Cc,
                   'xfused_n': 3 * Cc,                   # n^ -> vH^, i f_a n^
                   'xfused_div': 2 * Cc,
                   'xfused_wgc': 2 * 6 * Cc,             # two 3 -> 3 launches; their (w0,K1 | K2) kernel tables are NOT algorithmic

@@ -73,6 +73,7 @@ struct ofdft_ctx {
     // WGC tables
     double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
     long long wgc_key_nel = -1;
+    int fft_passes_fused = 0;      // y-forward passes that rode inside a yderiv launch (diagnostics)
     bool wgc_valid = false;
     double wgc_ck = 0.0;           // K3 = K2 + wgc_ck K1 for the tables in "t:wgc" ((3 - gamma) / (3 n_ref))
     // stats
@@ -296,7 +297,8 @@ int fast_axis_pass_multi(ofdft_ctx* c, int axis, cplx* const* specs, int narr, h
 template <bool INV> int fast_axis_pass(ofdft_ctx* c, int axis, cplx* spec, hipStream_t st);
 // xk: chunk of the exchange layout (-1: every chunk, one launch each; kWholeXchg: the unchunked layout)
 template <bool INV> int ypass_xchg(ofdft_ctx* c, const std::vector<cplx*>& list, cplx* buf, hipStream_t st, int xk = -1);
-int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st);
+// (fwd: also store the y-forward transform of `in` there -- in place when fwd == in; fft_kernels.h: yderiv_kernel)
+int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st, cplx* fwd = nullptr);
 int rfftn_internal(ofdft_ctx* c, const real* in, cplx* spec, hipStream_t st);
 int rfftn_internal_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st);
 // chirp-z path with the fused x pass (lines.hip): z + y passes | forward-x, mix, inverse-x | y + z passes

@@ -97,6 +97,9 @@ int chunks_for(const ofdft_ctx* c, int narr, int which = 15) {
 // buffer; -1 = all chunks)
 // host-side state of an evaluation that both chains read (term flags, the combine kernel's arguments): first thing of stage 1
 // of chain 0 -- or, when the nonlocal chain's first kernels are enqueued first (zfused_enqueue), before either
+#ifndef OFDFT_YDERIV_FWD
+#define OFDFT_YDERIV_FWD 1
+#endif
 int zsetup(ofdft_ctx* c) {
     ZRun& r = zrun(c);
     const unsigned mask = c->mask;
@@ -162,12 +165,14 @@ int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
                 return rc;
             }
             // D_b n from the (kz; y, x) spectrum before its in-place y-forward; scaled so that the consumer's 1/N fits
-            if (r.gsplit && (rc = yderiv(c, r.s_n, r.s_g[1], (double)c->n0g, st))) return rc;
+            // (one GPU: the y-forward of n^ rides in the same pass -- both read the same array; OFDFT_YDERIV_FWD=0: two passes)
+            const bool yfwd = OFDFT_YDERIV_FWD && r.gsplit && !dx && nch == 1;
+            if (r.gsplit && (rc = yderiv(c, r.s_n, r.s_g[1], (double)c->n0g, st, yfwd ? r.s_n : nullptr))) return rc;
             if (r.forked && r.s_s) {          // the vW chain continues on the second side stream
                 HIP_TRY(c, hipEventRecord(c->ev_a, st));
                 HIP_TRY(c, hipStreamWaitEvent(sc, c->ev_a, 0));
             }
-            if (!dx && nch == 1 && r.s_n && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
+            if (!dx && nch == 1 && r.s_n && !yfwd && (rc = fast_axis_pass<false>(c, 1, r.s_n, st))) return rc;
             if (!dx && nch == 1 && r.s_s && (rc = fast_axis_pass<false>(c, 1, r.s_s, sc))) return rc;
             if (r.s_n) xl.push_back(r.s_n);
             if (r.s_s) xl.push_back(r.s_s);

@@ -206,11 +206,13 @@ __device__ __forceinline__ void repattern_out_to_in(cplx (&v)[PL::E], int j, rea
 // ----------------------------------------------------------------------------------------------
 // index derivative along y in ONE pass: forward FFT of the line, times i f_b (integer frequency, Nyquist positive as in
 // functional_tools.py:152-154) times `scale`, inverse FFT.  Out of place or in place (in == out).
+// fwd != nullptr (round 4): the forward transform of the line is stored there as well (in place: fwd == in) -- the density
+// spectrum needs BOTH its y-forward (for the x pass) and D_b n, which were two passes reading the same array.
 template <int LEN>
-__global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* __restrict__ in, cplx* __restrict__ out,
+__global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* in, cplx* out,
                                                                    LineMap m_main, LineMap m_rem, int main_blocks,
                                                                    long long rem_offset, const cplx* __restrict__ tw,
-                                                                   real scale) {
+                                                                   real scale, cplx* fwd) {
     constexpr int P = PassCfg<LEN>::P, E = PassCfg<LEN>::E, LPW = PassCfg<LEN>::LPW;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const int tid = threadIdx.x;
@@ -234,6 +236,11 @@ __global__ __launch_bounds__(PassCfg<LEN>::TPB) void yderiv_kernel(const cplx* _
         v[q] = (PL::slot_in(q) && valid && PL::lane_in(j, q)) ? buf_load_c(in + roff + b0 + PL::cin(q) * se_u, voff) : mkc(0.0, 0.0);
     real* mine = lds + l * PassCfg<LEN>::LSTR;
     line_fft<LEN, false, kCX>(v, j, mine, tw);
+    if (fwd && valid) {       // (every load of the workgroup's lines precedes the transform's barriers: in place is safe)
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (PL::slot_out(q) && PL::lane_out(j, q)) buf_store_c_aux<OFDFT_CPASS_ST_AUX>(fwd + roff + b0 + PL::cout(q) * se_u, voff, v[q]);
+    }
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = j + PL::cout(q);

@@ -595,7 +595,7 @@ static int dist_irfftn(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStr
 
 // index derivative along y of an x-slab spectrum in (kz; y, x) form, in one pass (fft_kernels.h: yderiv_kernel)
 template <int LEN>
-int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st, cplx* fwd) {
     cplx* tw;
     if (int rc = get_twiddle(c, LEN, &tw)) return rc;
     using Cfg = PassCfg<LEN>;
@@ -603,20 +603,21 @@ int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipSt
     pass_maps(c, 1, main, rem);
     const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
     OFDFT_LAUNCH(c, st, "yderiv", (yderiv_kernel<LEN>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, in, out, main, rem, mb,
-                 c->g.main_count, (const cplx*)tw, scale);
+                 c->g.main_count, (const cplx*)tw, (real)scale, fwd);
+    if (fwd) c->fft_passes_fused++;
     return 0;
 }
-int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st) {
+int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st, cplx* fwd) {
     switch (c->n1) {
-        case 8: return launch_yderiv_t<8>(c, in, out, scale, st);
-        case 16: return launch_yderiv_t<16>(c, in, out, scale, st);
-        case 32: return launch_yderiv_t<32>(c, in, out, scale, st);
-        case 64: return launch_yderiv_t<64>(c, in, out, scale, st);
-        case 128: return launch_yderiv_t<128>(c, in, out, scale, st);
-        case 256: return launch_yderiv_t<256>(c, in, out, scale, st);
-        case 512: return launch_yderiv_t<512>(c, in, out, scale, st);
-        case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st);
-#define X(L) case L: return launch_yderiv_t<L>(c, in, out, scale, st);
+        case 8: return launch_yderiv_t<8>(c, in, out, scale, st, fwd);
+        case 16: return launch_yderiv_t<16>(c, in, out, scale, st, fwd);
+        case 32: return launch_yderiv_t<32>(c, in, out, scale, st, fwd);
+        case 64: return launch_yderiv_t<64>(c, in, out, scale, st, fwd);
+        case 128: return launch_yderiv_t<128>(c, in, out, scale, st, fwd);
+        case 256: return launch_yderiv_t<256>(c, in, out, scale, st, fwd);
+        case 512: return launch_yderiv_t<512>(c, in, out, scale, st, fwd);
+        case 1024: return launch_yderiv_t<1024>(c, in, out, scale, st, fwd);
+#define X(L) case L: return launch_yderiv_t<L>(c, in, out, scale, st, fwd);
         OFDFT_MIXED_LINES(X)
 #undef X
     }

@@ -126,7 +126,9 @@ def test_lds_layout_table_of_the_wave_local_x_pass_is_a_conflict_free_permutatio
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import lds_conflicts as lc
     src = open(os.path.join(ROOT, 'professad_amd', 'csrc', 'xwave.h')).read()
-    f32_part, f64_part = src.split('#ifdef OFDFT_REAL_F32', 1)[1].split('#else', 1)
+    # (the b32 table serves the fp32 build only when its exchange moves re / im separately, OFDFT_F32_CX=0; by default the fp32
+    # build exchanges whole complex numbers -- 8-byte accesses -- and uses the b64 table like the fp64 build)
+    f32_part, f64_part = src.split('#if defined(OFDFT_REAL_F32) && !OFDFT_F32_CX', 1)[1].split('#else', 1)
     f64_part = f64_part.split('#endif', 1)[0]
     pat = re.compile(r'XwSwz<(\d+)> \{ static constexpr int XS = (\d+), XM = (\d+), XMUL = (\d+), LMUL = (\d+), RS = (\d+); \}')
     for prec, part in (('f32', f32_part), ('f64', f64_part)):
