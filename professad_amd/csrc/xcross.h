@@ -42,24 +42,32 @@ template <> struct XcWaves<256> { static constexpr int A = OFDFT_XC_A256; };
 template <> struct XcWaves<512> { static constexpr int A = OFDFT_XC_A512; };
 template <> struct XcWaves<1024> { static constexpr int A = 8; };
 
+// lines per lane (round 4, fp32 build): a tile of the fp32 kernel carried half the bytes of the fp64 tile behind the same seven
+// barriers and the same per-tile address / twiddle work, and streamed 3.6 TB/s where the fp64 kernel reaches 5.2 (SQ counters:
+// 62 % of its wave cycles waiting).  With NL = 2 a lane owns the same points of TWO memory-adjacent lines -- one 16-byte access
+// per point pair, 128-byte runs, the fp64 tile's bytes per barrier and per byte in flight.
+#ifndef OFDFT_XC_NL_F32
+#define OFDFT_XC_NL_F32 2
+#endif
 template <int LEN> struct XcCfg {
     static constexpr int A = XcWaves<LEN>::A;         // waves per workgroup = radix of the cross-wave step
     static constexpr int S = LEN / A;                 // length of the wave-local sub-transforms
     static constexpr int E = 8;
+    static constexpr int NL = (sizeof(real) == 4 && LEN <= 512) ? OFDFT_XC_NL_F32 : 1;      // memory-adjacent lines per lane
     static constexpr int P = S / E;                   // lanes per line in a sub-transform
-    static constexpr int LPWV = 64 / P;               // lines per tile (every wave works on all of them)
-    static constexpr int LPB = LPWV;
+    static constexpr int LPWV = 64 / P;               // line groups per tile (every wave works on all of them)
+    static constexpr int LPB = NL * LPWV;             // lines per tile
     static constexpr int TPB = 64 * A;
     static constexpr int PP = TPB / LPWV;             // threads per line in the mix phase (= LEN / 8)
-    static constexpr int RR = E / A;                  // radix-A butterflies per thread in the cross step
+    static constexpr int RR = E / A;                  // radix-A butterflies per thread and line in the cross step
     static constexpr int RS = kCXMul * XwSwz<S>::RS;  // reals per wave-local line buffer
-    // complex elements of one wave's region of a cross buffer: its 64 E points -- or its line buffers, which live there too
-    // (fp32 build with complex-element exchange: 8 x 72 x 8 B = 4.5 KB of line buffers against 4 KB of points)
-    static constexpr int WLB = (int)((LPWV * RS * sizeof(real) + sizeof(cplx) - 1) / sizeof(cplx));
-    static constexpr int WREG = ((64 * E > WLB ? 64 * E : WLB) + 15) / 16 * 16;
+    static constexpr int WPT = 64 * E;                // points of one line group in a wave's region
+    // complex elements of one wave's region of a cross buffer: its NL x 64 E points -- or its line buffers, which live there too
+    // (fp32 build with complex-element exchange: 8 x 72 x 8 B = 4.5 KB of line buffers per 4 KB of points)
+    static constexpr int WLB = (int)((NL * LPWV * RS * sizeof(real) + sizeof(cplx) - 1) / sizeof(cplx));
+    static constexpr int WREG = ((NL * WPT > WLB ? NL * WPT : WLB) + 15) / 16 * 16;
     static constexpr int XB = A * WREG;               // complex elements of a cross buffer (>= lines per tile x LEN)
-    static_assert(S >= 16 && P <= 64 && E % A == 0, "split");
-    static_assert(LPWV * RS * sizeof(real) <= WREG * sizeof(cplx), "the wave's line buffers live inside its region of a cross buffer");
+    static_assert(S >= 16 && P <= 64 && E % A == 0 && (NL == 1 || NL == 2), "split");
     static constexpr size_t LDS = sizeof(cplx) * (2 * XB + LEN + S);     // two cross buffers + W_LEN + W_S
 };
 
@@ -76,13 +84,41 @@ template <int LEN> struct XcCfg {
 #define OFDFT_XC_ST_AUX 2
 #endif
 
+// NL complex elements that are adjacent in memory by one access (NL = 2: 16 bytes in the fp32 build)
+template <int NL, int AUX> __device__ __forceinline__ void buf_load_cn(cplx (&o)[NL], const cplx* ubase, unsigned voff_bytes) {
+    if constexpr (NL == 1) {
+        o[0] = buf_load_c_aux<AUX>(ubase, voff_bytes);
+    } else if constexpr (sizeof(cplx) == 8) {
+        u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+        o[0] = *reinterpret_cast<cplx*>(&t);
+        o[1] = *(reinterpret_cast<cplx*>(&t) + 1);
+    } else {
+        o[0] = buf_load_c_aux<AUX>(ubase, voff_bytes);
+        o[1] = buf_load_c_aux<AUX>(ubase + 1, voff_bytes);
+    }
+}
+template <int NL, int AUX> __device__ __forceinline__ void buf_store_cn(cplx* ubase, unsigned voff_bytes, const cplx (&v)[NL]) {
+    if constexpr (NL == 1) {
+        buf_store_c_aux<AUX>(ubase, voff_bytes, v[0]);
+    } else if constexpr (sizeof(cplx) == 8) {
+        u32x4 t;
+        *reinterpret_cast<cplx*>(&t) = v[0];
+        *(reinterpret_cast<cplx*>(&t) + 1) = v[1];
+        __builtin_amdgcn_raw_buffer_store_b128(t, make_rsrc(ubase), (int)voff_bytes, 0, AUX);
+    } else {
+        buf_store_c_aux<AUX>(ubase, voff_bytes, v[0]);
+        buf_store_c_aux<AUX>(ubase + 1, voff_bytes, v[1]);
+    }
+}
+
 template <int LEN, int NIN, int NOUT, class Mix>
 __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfIo io, LineMap m_main, LineMap m_rem, int main_blocks,
                                                                               SpecGeom g, const cplx* __restrict__ tw_g, Mix mix,
                                                                               XfStride xs) {
     using Cfg = XcCfg<LEN>;
     constexpr int A = Cfg::A, S = Cfg::S, E = Cfg::E, P = Cfg::P, LPWV = Cfg::LPWV, LPB = Cfg::LPB, PP = Cfg::PP, RR = Cfg::RR,
-                  TPB = Cfg::TPB, WREG = Cfg::WREG, G = NIN > NOUT ? NIN : NOUT;
+                  TPB = Cfg::TPB, WREG = Cfg::WREG, WPT = Cfg::WPT, NL = Cfg::NL, G = NIN > NOUT ? NIN : NOUT;
+    constexpr int LDA = (LPB * sizeof(cplx) >= 128) ? OFDFT_XC_LD_AUX : 0;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     cplx* xb = reinterpret_cast<cplx*>(lds);
     cplx* twN = xb + 2 * Cfg::XB;         // W_LEN^m
@@ -90,7 +126,7 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int a = __builtin_amdgcn_readfirstlane(t >> 6);       // residue class of this wave
-    const int l = lane % LPWV;            // lines fastest over the lanes: the memory-contiguous direction
+    const int l = lane % LPWV;            // line groups fastest over the lanes: the memory-contiguous direction
     const int j = lane / LPWV;            // b = j + P q in the load / store phases
     const int J = t / LPWV;               // k = J + PP m in the mix phase (J = a P + j)
     // ---- twiddle tables: requested now, written to LDS after the data loads have been issued
@@ -112,17 +148,21 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
     }
     if (!is_rem) bid += m.blk0;           // launch over a range of kz blocks
     const long long L0 = (long long)bid * LPB;
-    const long long L = L0 + l;
+    const long long L = L0 + NL * l;      // first line of this lane's group (the launcher guarantees whole groups: nlines % NL == 0)
     const bool valid = L < m.nlines;
     const long long base = valid ? (L / m.d) * m.sb + (L % m.d) * (long long)m.sl : 0;
-    int y, kz;                            // k-point coordinates of this line
-    if (is_rem) {
-        y = (int)(L % g.n1);
-        kz = g.nzm + (int)(L / g.n1);
-    } else {
-        const int c = (int)(L % m.d);
-        y = c >> 3;
-        kz = m.kz0 + (int)(L / m.d) * 8 + (c & 7);
+    int y[NL], kz[NL];                    // k-point coordinates of the group's lines
+#pragma unroll
+    for (int nl = 0; nl < NL; ++nl) {
+        const long long Ln = L + nl;
+        if (is_rem) {
+            y[nl] = (int)(Ln % g.n1);
+            kz[nl] = g.nzm + (int)(Ln / g.n1);
+        } else {
+            const int c = (int)(Ln % m.d);
+            y[nl] = c >> 3;
+            kz[nl] = m.kz0 + (int)(Ln / m.d) * 8 + (c & 7);
+        }
     }
     const long long region = is_rem ? g.main_count : 0;
     const long long lb0 = line_base(m, L0);
@@ -135,19 +175,31 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
     const long long qstep = uniform64((long long)PP * m.se), qstep_o = uniform64((long long)PP * se_o),
                     tqstep = uniform64((long long)PP * se_t);
 
-    cplx v[G][E];
+    cplx v[G][NL][E];
     static_for<NIN>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         const cplx* ub = io.in[I] + b0;
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[I][q] = valid ? buf_load_c_aux<(LPWV * sizeof(cplx) >= 128 ? OFDFT_XC_LD_AUX : 0)>(ub + q * qstep, voff) : mkc(0.0, 0.0);
+        for (int q = 0; q < E; ++q) {
+            cplx pr[NL];
+            if (valid) {
+                buf_load_cn<NL, LDA>(pr, ub + q * qstep, voff);
+            } else {
+#pragma unroll
+                for (int nl = 0; nl < NL; ++nl) pr[nl] = mkc(0.0, 0.0);
+            }
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl) v[I][nl][q] = pr[nl];
+        }
     });
     // table-driven mixes: the k-point entries of the MIX phase's slots are requested with the data
     constexpr int NC = OFDFT_XW_PREFETCH ? mix_coef_count<Mix>::N : 0;
-    real cfs[E][NC > 0 ? NC : 1];
+    real cfs[NL][E][NC > 0 ? NC : 1];
     if constexpr (NC > 0) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) mix.fetch(cfs[q], b0 + q * tqstep, tloff, valid);
+        for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+            for (int q = 0; q < E; ++q) mix.fetch(cfs[nl][q], b0 + q * tqstep, tloff + nl, valid);
     }
     // ---- publish the twiddles
 #pragma unroll
@@ -158,68 +210,86 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
     if (t < S) twS[t] = tws;
     __syncthreads();
     const int lx = (l * XwSwz<S>::LMUL) & 31;       // line-dependent part of the wave-local LDS swizzle
-    // cross-step twiddles W_LEN^(aa b'), b' = J + PP r: the same for every spectrum and (conjugated) for the inverse
     static_for<NIN>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
         cplx* buf = xb + (I & 1) * Cfg::XB;
-        real* mine = reinterpret_cast<real*>(buf + a * WREG) + l * Cfg::RS;
-        xw_line_fft<S, false>(v[I], j, mine, twS, lx);          // G_a[b' = j + P q] of line l
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            real* mine = reinterpret_cast<real*>(buf + a * WREG) + (nl * LPWV + l) * Cfg::RS;
+            xw_line_fft<S, false>(v[I][nl], j, mine, twS, lx);          // G_a[b' = j + P q] of line (l, nl)
+        }
         exchange_sync<true>();
 #pragma unroll
-        for (int q = 0; q < E; ++q) buf[a * WREG + lane + 64 * q] = v[I][q];      // index (b' LPWV + l) of region a
+        for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+            for (int q = 0; q < E; ++q) buf[a * WREG + nl * WPT + lane + 64 * q] = v[I][nl][q];      // index (b' LPWV + l) of region a
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-            const int bp = J + PP * r;
-            cplx c[A];
+        for (int nl = 0; nl < NL; ++nl)
 #pragma unroll
-            for (int aa = 0; aa < A; ++aa) c[aa] = buf[aa * WREG + t + TPB * r];
+            for (int r = 0; r < RR; ++r) {
+                const int bp = J + PP * r;
+                cplx c[A];
 #pragma unroll
-            for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], twN[aa * bp]);
-            Dft<A, false>::run(c);
+                for (int aa = 0; aa < A; ++aa) c[aa] = buf[aa * WREG + nl * WPT + t + TPB * r];
 #pragma unroll
-            for (int ap = 0; ap < A; ++ap) v[I][r + RR * ap] = c[ap];               // X[b' + S a'] = X[J + PP (r + RR a')]
-        }
+                for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], twN[aa * bp]);
+                Dft<A, false>::run(c);
+#pragma unroll
+                for (int ap = 0; ap < A; ++ap) v[I][nl][r + RR * ap] = c[ap];           // X[b' + S a'] = X[J + PP (r + RR a')]
+            }
     });
-    // ---- mix, in registers: the thread owns k-points x = J + PP m of its line in every spectrum
+    // ---- mix, in registers: the thread owns k-points x = J + PP m of its lines in every spectrum
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-        cplx in[NIN], out[NOUT];
+    for (int nl = 0; nl < NL; ++nl)
 #pragma unroll
-        for (int I = 0; I < NIN; ++I) in[I] = v[I][q];
-        if constexpr (NC > 0) mix.apply(out, in, cfs[q]);
-        else xw_outputs<NIN, NOUT, 0, Mix>(out, in, mix, J + PP * q, y, kz, b0 + q * tqstep, tloff);
+        for (int q = 0; q < E; ++q) {
+            cplx in[NIN], out[NOUT];
 #pragma unroll
-        for (int O = 0; O < NOUT; ++O) v[O][q] = out[O];
-    }
+            for (int I = 0; I < NIN; ++I) in[I] = v[I][nl][q];
+            if constexpr (NC > 0) mix.apply(out, in, cfs[nl][q]);
+            else xw_outputs<NIN, NOUT, 0, Mix>(out, in, mix, J + PP * q, y[nl], kz[nl], b0 + q * tqstep, tloff + nl);
+#pragma unroll
+            for (int O = 0; O < NOUT; ++O) v[O][nl][q] = out[O];
+        }
     static_for<NOUT>([&](auto oc) {
         constexpr int O = decltype(oc)::value;
         cplx* buf = xb + ((NIN + O) & 1) * Cfg::XB;
-        real* mine = reinterpret_cast<real*>(buf + a * WREG) + l * Cfg::RS;
 #pragma unroll
-        for (int r = 0; r < RR; ++r) {
-            const int bp = J + PP * r;
-            cplx c[A];
+        for (int nl = 0; nl < NL; ++nl)
 #pragma unroll
-            for (int ap = 0; ap < A; ++ap) c[ap] = v[O][r + RR * ap];
-            Dft<A, true>::run(c);
+            for (int r = 0; r < RR; ++r) {
+                const int bp = J + PP * r;
+                cplx c[A];
 #pragma unroll
-            for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], cconj(twN[aa * bp]));
+                for (int ap = 0; ap < A; ++ap) c[ap] = v[O][nl][r + RR * ap];
+                Dft<A, true>::run(c);
 #pragma unroll
-            for (int aa = 0; aa < A; ++aa) buf[aa * WREG + t + TPB * r] = c[aa];
-        }
+                for (int aa = 1; aa < A; ++aa) c[aa] = cmul(c[aa], cconj(twN[aa * bp]));
+#pragma unroll
+                for (int aa = 0; aa < A; ++aa) buf[aa * WREG + nl * WPT + t + TPB * r] = c[aa];
+            }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < E; ++q) v[O][q] = buf[a * WREG + lane + 64 * q];
+        for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+            for (int q = 0; q < E; ++q) v[O][nl][q] = buf[a * WREG + nl * WPT + lane + 64 * q];
         exchange_sync<true>();
-        xw_line_fft<S, true>(v[O], j, mine, twS, lx);
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            real* mine = reinterpret_cast<real*>(buf + a * WREG) + (nl * LPWV + l) * Cfg::RS;
+            xw_line_fft<S, true>(v[O][nl], j, mine, twS, lx);
+        }
         exchange_sync<true>();
         if (valid) {
             cplx* ub = io.out[O] + b0;
 #pragma unroll
             for (int q = 0; q < E; ++q) {
-                if (xs.se_out) buf_store_c(ub + q * qstep_o, voff_o, v[O][q]);
-                else buf_store_c_aux<OFDFT_XC_ST_AUX>(ub + q * qstep_o, voff_o, v[O][q]);
+                cplx pr[NL];
+#pragma unroll
+                for (int nl = 0; nl < NL; ++nl) pr[nl] = v[O][nl][q];
+                if (xs.se_out) buf_store_cn<NL, 0>(ub + q * qstep_o, voff_o, pr);
+                else buf_store_cn<NL, OFDFT_XC_ST_AUX>(ub + q * qstep_o, voff_o, pr);
             }
         }
     });

@@ -98,6 +98,10 @@ int launch_xc_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
         pass_maps(c, 0, main, rem);
     }
     main.lf = rem.lf = Cfg::LPB;
+    if constexpr (Cfg::NL > 1) {          // lanes own groups of memory-adjacent lines: whole groups only, else the wave-local kernel
+        if (main.sl != 1 || rem.sl != 1 || main.d % Cfg::NL || rem.d % Cfg::NL || main.nlines % Cfg::NL || rem.nlines % Cfg::NL)
+            return launch_xw_t<LEN, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+    }
     int line0 = 0;
     if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
         const int per_block = c->gx.n1 * 8;

@@ -80,10 +80,18 @@ class Comm:
         # second group for chain 1.  `dist.new_group` is collective over the WORLD, so it is created here only when this
         # Comm spans the world (every process constructs it); a caller that passes a sub-group creates the second group
         # itself (all world ranks calling new_group) and hands it in as `chain1_group` -- else both chains share `group`.
+        self._own_group = None
         if chain1_group is None and self.active and group is None and os.environ.get('OFDFT_COMM_ONE_GROUP') != '1':
-            chain1_group = dist.new_group(ranks=list(range(dist.get_world_size())), backend=self.backend)
+            chain1_group = self._own_group = dist.new_group(ranks=list(range(dist.get_world_size())), backend=self.backend)
         self.groups = (group, chain1_group if chain1_group is not None else group)
         self.issued = [0, 0]          # all-to-alls issued per chain group (tests assert the chains use different groups)
+
+    def close(self):
+        """release the communicator this object created for chain 1 (every rank calls it, in the same order)"""
+        if self._own_group is not None and dist.is_initialized():
+            g, self._own_group = self._own_group, None
+            self.groups = (self.group, self.group)
+            dist.destroy_process_group(g)
 
     def all_reduce_sum(self, vec, device):
         """vec: 1-D numpy fp64 -> summed over ranks (numpy)"""
@@ -527,3 +535,4 @@ class DistEngine:
         self.stages.close()
         if getattr(self, '_f64', None) is not None:
             self._f64.close()
+        self.comm.close()
