@@ -57,11 +57,17 @@ def main():
     # overlap of a rank's scatter kernels with compute kernels of the same rank
     def overlap(a, b):
         return max(0, min(a[1], b[1]) - max(a[0], b[0]))
-    print('# Slab ranks over the ipc transport with the kz-chunked exchange, sharing ONE GPU: kernels of one evaluation, all ranks merged by time')
-    print()
-    print("rocprofv3 --kernel-trace of each rank (`tools/ipc_timeline.sh`), evaluation %d of the run.  The ranks share the device, so nothing here "
-          "measures xGMI; the table is protocol evidence: a chain's `ipc_scatter_kernel` of chunk k (its communication stream) runs while the SAME "
-          "chain's next y pass / fused x pass (its compute stream) is in flight." % which)
+    if len(ranks) > 1:
+        print('# Slab ranks over the ipc transport with the kz-chunked exchange, sharing ONE GPU: kernels of one evaluation, all ranks merged by time')
+        print()
+        print("rocprofv3 --kernel-trace of each rank (`tools/ipc_timeline.sh`), evaluation %d of the run.  The ranks share the device, so nothing here "
+              "measures xGMI; the table is protocol evidence: a chain's `ipc_scatter_kernel` of chunk k (its communication stream) runs while the SAME "
+              "chain's next y pass / fused x pass (its compute stream) is in flight." % which)
+    else:
+        print('# One single-GPU closure evaluation on its three streams: begin / end of every kernel')
+        print()
+        print('rocprofv3 --kernel-trace of `python3 bench.py --steps 6 --warmup 2` (`tools/timeline.sh`), evaluation %d of the run; streams NOT '
+              'serialised.  The profiler inflates short kernels by a few microseconds each.' % which)
     print()
     for r in range(len(ranks)):
         sc = [e for e in ev if e[2] == r and e[4].startswith('ipc_scatter_kernel')]

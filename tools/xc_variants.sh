@@ -4,7 +4,7 @@ SHAPES=$1; OPTS=$2; shift 2
 fmt='
 import sys,json
 for l in sys.stdin:
-    d=json.loads(l); print(d["shape"][0], d["xwave"], d["ms"], d["x_ms"], "%.1e"%d["dgrad_rel"])'
+    d=json.loads(l); print(d["shape"][0], d["xwave"], d["ms"], d["x_us"], "%.1e"%d["dgrad_rel"])'
 for r in 1 2; do
   echo "== default"; timeout -k 10 200 python tools/xpass_ab.py opts=$OPTS $SHAPES 2>/dev/null | python -c "$fmt"
   for lib in "$@"; do

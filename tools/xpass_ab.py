@@ -50,6 +50,6 @@ for arg in [a for a in sys.argv[1:] if a[0].isdigit()]:
         print(json.dumps({'shape': shape, 'dtype': str(DT), 'xwave': opt, 'ms': round(ms, 3),
                           'rel_dE': abs(Et - ref[0]) / abs(ref[0]), 'rel_dmu': abs(mu - ref[1]) / abs(ref[1]),
                           'dgrad_rel': float((gr - ref[2]).abs().max() / ref[2].abs().max()),
-                          'x_ms': {k: round(v[0] / 3 * 1e3, 4) for k, v in sorted(prof.items()) if k.startswith('xfused')}}), flush=True)
+                          'x_us': {k: round(v[0] / 3 * 1e3, 1) for k, v in sorted(prof.items()) if k.startswith('xfused')}}), flush=True)
         eng.close()
     del chi, vext, ref
