@@ -75,7 +75,9 @@ def test_eval_roofline_fraction_is_formed_from_real_hbm_bytes_and_never_exceeds_
 
 def test_committed_bench_lines_of_this_round_carry_no_fraction_above_one():
     import glob
-    for fn in glob.glob(os.path.join(ROOT, 'profiles', 'bench_r03*.json')):
+    files = glob.glob(os.path.join(ROOT, 'profiles', 'bench_r03*.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'bench_r04*.json'))
+    assert len(files) >= 10
+    for fn in files:
         with open(fn) as fh:
             line = json.loads(fh.read().strip().splitlines()[-1])
 
@@ -86,6 +88,21 @@ def test_committed_bench_lines_of_this_round_carry_no_fraction_above_one():
                         assert v <= 1.0, (fn, path + k, v)
                     walk(v, path + k + '.')
         walk(line)
+
+
+def test_round4_bench_lines_carry_roofline_and_baseline_blocks():
+    """the committed default lines of this round: `roofline` (dominant kernel, live HIP-event time, counter traffic of the very build),
+    `eval_roofline` formed from counter bytes, `cpu_baseline` on the fp64 line, the energy pinned to the reference's"""
+    for fn, need_cpu in (('bench_r04_final_256.json', True), ('bench_r04_final_256_f32.json', False)):
+        with open(os.path.join(ROOT, 'profiles', fn)) as fh:
+            d = json.loads(fh.read().strip().splitlines()[-1])
+        r = d['roofline']
+        assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic']
+        assert 0.9 < r['traffic'] / r['alg_bytes_per_launch'] < 1.1                 # nothing re-read
+        assert 'rocprofv3' in d['eval_roofline']['hbm_bytes_basis'] and 0.5 < d['eval_roofline']['frac'] < 1.0
+        assert d['reference_check']['ok'] and d['n_gpus'] == 1 and d['vs_baseline'] is None
+        if need_cpu:
+            assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['cores'] >= 1 and d['cpu_baseline']['value'] > 0
 
 
 def test_bench_workload_is_pinned_to_the_reference():

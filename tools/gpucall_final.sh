@@ -29,7 +29,7 @@ else
   timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench_256.json 2> gpurun_out/${TAG}_bench_256.err || exit 1
   echo "bench 256 done"
   timeout -k 10 300 python bench.py --dtype f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_256_f32.json 2> gpurun_out/${TAG}_bench_256_f32.err || exit 1
-  timeout -k 10 300 python bench.py --grid 512 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_512.json 2> gpurun_out/${TAG}_bench_512.err || exit 1
+  timeout -k 10 300 python bench.py --grid 512 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_512.json 2> gpurun_out/${TAG}_bench_512.err || exit 1
   echo "bench 512 done"
   timeout -k 10 300 python bench.py --grid 64 --cfg cfg2 --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_64_cfg2.json 2> gpurun_out/${TAG}_bench_64_cfg2.err
   echo "bench 64 rc=$?"
