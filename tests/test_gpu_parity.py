@@ -1162,7 +1162,7 @@ def test_wave_local_x_pass_matches_the_group_parallel_kernel(shape):
     for ts, params in term_sets:
         names = F.NativeTerms(ts).names
         out = {}
-        for xw in (2, 1, 0):
+        for xw in (2, 1, 0, 5, 7):      # wave-local, default (cross-wave at 256 / 512 points), group-parallel, cross-wave wherever it exists, round-3 choice
             for gsplit in (1, 0):
                 eng = Engine(shape, DEV).set_cell(box).set_terms(names, params)
                 eng.set_option(8, xw).set_option(6, gsplit)
@@ -1315,3 +1315,21 @@ def test_mixed_radix_grid_matches_the_oracle():
     assert abs(mu - muo) <= 1e-9 * max(1.0, abs(muo))
     assert relerr(g.cpu().numpy(), go) < V_RTOL
     eng.close()
+
+
+def test_set_cell_sees_a_box_array_that_was_changed_in_place():
+    """round-3 advice: Engine.set_cell compares a host array by its bytes, not by object identity -- a geometry / stress loop that
+    rescales its box array in place and hands it over again must get the new cell"""
+    shape = (16, 16, 16)
+    box = np.ascontiguousarray(cases.make_cell(('tri', 1.0)))
+    den = dev(synth.random_density(shape, seed=71))
+    eng = engine_for(shape, DEV)
+    eng.set_cell(box).set_terms(('hartree', 'tf'))
+    E1, _ = eng.energy_potential(den)
+    box *= 1.1                                                   # the same ndarray object
+    eng.set_cell(box)
+    E2, _ = eng.energy_potential(den)
+    fresh = engine_for(shape, DEV).set_cell(box.copy()).set_terms(('hartree', 'tf'))
+    E3, _ = fresh.energy_potential(den)
+    assert abs(sum(E2.values()) - sum(E3.values())) <= 1e-13 * abs(sum(E3.values()))
+    assert abs(sum(E2.values()) - sum(E1.values())) > 1e-3 * abs(sum(E1.values()))

@@ -143,3 +143,37 @@ def test_lds_layout_table_of_the_wave_local_x_pass_is_a_conflict_free_permutatio
             assert rd == 1.0 and wr == 1.0, (prec, LEN, rd, wr)
             old = lc.conflicts(LEN, lc.PLANS[LEN], lambda i: i + (i >> 4), LEN + (LEN >> 4) + 2, prec == 'f32')
             assert old[0] >= 2.0, (prec, LEN, old)
+
+
+def test_host_box_cache_follows_the_tensor_and_keeps_nothing_alive():
+    """professad_amd.functionals._host_box (round-3 advice): a hit needs the same tensor object, version counter and storage; an
+    in-place change misses; tensors that require grad or have no version counter (inference mode) are never cached; only weak
+    references are held"""
+    import gc
+    import weakref
+
+    import numpy as np
+    import torch
+    from professad_amd import functionals as F
+    F._BOX_CACHE.clear()
+    box = torch.eye(3, dtype=torch.double) * 7.5
+    b1, v1 = F._host_box(box)
+    b2, v2 = F._host_box(box)
+    assert b2 is b1 and v1 == v2 == 7.5 ** 3 and len(F._BOX_CACHE) == 1
+    box *= 2.0                                                   # in place: the version counter moves
+    b3, v3 = F._host_box(box)
+    assert b3 is not b1 and abs(v3 - 15.0 ** 3) < 1e-9 and np.allclose(b3, np.eye(3) * 15.0)
+    g = torch.eye(3, dtype=torch.double, requires_grad=True)
+    F._host_box(g)
+    assert id(g) not in F._BOX_CACHE                            # stress paths: never cached
+    with torch.inference_mode():
+        inf = torch.eye(3, dtype=torch.double) * 3.0
+    bi, vi = F._host_box(inf)                                    # no version counter: works, uncached
+    assert abs(vi - 27.0) < 1e-12
+    ref = weakref.ref(box)
+    del box
+    gc.collect()
+    assert ref() is None                                         # the cache did not keep the caller's tensor alive
+    for i in range(3 * F._BOX_CACHE_MAX):                        # bounded
+        F._host_box(torch.eye(3, dtype=torch.double) * (1.0 + i))
+    assert len(F._BOX_CACHE) <= F._BOX_CACHE_MAX

@@ -43,6 +43,20 @@ def test_wgc99_kernel_matches_reference():
     assert relerr(k, gold['kernel']) < 1e-13
 
 
+def test_wgc99_fourth_table_is_a_combination_of_two_others():
+    """the engine stores (w0, K1 | K2) and forms K3 = K2 + ((3 - gamma) / (3 n_ref)) K1 in registers (csrc/pointwise_kernels.h: MixWgc,
+    wgc_table_kernel): the identity on the REFERENCE's own kernel derivatives (functionals.py:968-972 on the golden w, w', w'')"""
+    gold = load('wgc99_kernel_g16r.npz')
+    eta = gold['eta']
+    w0, w1, w2 = gold['kernel']
+    for ga, nref in ((2.7, 0.03), (2.2, 0.17), (4.2, 1.3)):
+        K1 = -eta * w1 / (6 * nref)
+        K2 = (eta ** 2 * w2 + (7 - ga) * eta * w1) / (36 * nref ** 2)
+        K3 = (eta ** 2 * w2 + (1 + ga) * eta * w1) / (36 * nref ** 2)
+        ck = (3 - ga) / (3 * nref)
+        assert np.abs(K3 - (K2 + ck * K1)).max() <= 1e-14 * max(np.abs(K3).max(), np.abs(K2).max(), np.abs(ck * K1).max())
+
+
 @pytest.mark.parametrize('case', cases.PER_TERM_CASES)
 def test_per_term_energy_and_potential(case):
     gold = load('terms_%s.npz' % case)
