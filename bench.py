@@ -343,6 +343,10 @@ def main():
     if os.environ.get('OFDFT_BENCH_SHARE_GPU') == '1':
         local_rank = 0
     if world > 1:
+        # A slab rank runs three compute streams, two RCCL communicators (one per chain) or two communication streams of the ipc
+        # transport: more streams than the runtime's default of four hardware queues per process, and streams that share a queue
+        # serialise -- which would couple the chains' exchanges again.  Must be set before the first HIP call of the process.
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # (a collective that a failed rank never joins must not hold the job for the backend's default ten minutes)

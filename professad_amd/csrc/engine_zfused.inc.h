@@ -127,7 +127,6 @@ int zsetup(ofdft_ctx* c) {
 
 int zstage1(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
     ZRun& r = zrun(c);
-    const unsigned mask = c->mask;
     int rc;
     hipStream_t sb = r.forked ? r.sb : st, sc = r.forked ? r.sc : st;
     const bool dx = c->nranks > 1;

@@ -669,10 +669,10 @@ OFDFT_ZGPLAN(240, 64, 4, 4, 4, 3, 5)      // E = 6
 #ifndef OFDFT_Z_TWTAB
 #define OFDFT_Z_TWTAB 0
 #endif
-template <int LEN, int E, bool INV, bool TT = (OFDFT_Z_TWTAB != 0)>
+template <int LEN, int E, bool INV, bool TT = (OFDFT_Z_TWTAB != 0), bool CX = false>
 __device__ __forceinline__ void wave_line_fft(cplx (&v)[E], int j, real* line, const cplx* __restrict__ tw) {
     static_assert(ZPlan<LEN, E>::P <= 64, "a line must fit one wavefront");
-    StageP<ZPlan<LEN, E>, 0, 1, INV, true, TT>::run(v, j, line, tw);
+    StageP<ZPlan<LEN, E>, 0, 1, INV, true, TT, CX>::run(v, j, line, tw);
 }
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1

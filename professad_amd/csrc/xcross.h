@@ -53,7 +53,7 @@ template <int LEN> struct XcCfg {
     static constexpr int A = XcWaves<LEN>::A;         // waves per workgroup = radix of the cross-wave step
     static constexpr int S = LEN / A;                 // length of the wave-local sub-transforms
     static constexpr int E = 8;
-    static constexpr int NL = (sizeof(real) == 4 && LEN <= 512) ? OFDFT_XC_NL_F32 : 1;      // memory-adjacent lines per lane
+    static constexpr int NL = (sizeof(real) == 4 && LEN <= 1024) ? OFDFT_XC_NL_F32 : 1;     // memory-adjacent lines per lane
     static constexpr int P = S / E;                   // lanes per line in a sub-transform
     static constexpr int LPWV = 64 / P;               // line groups per tile (every wave works on all of them)
     static constexpr int LPB = NL * LPWV;             // lines per tile
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
                                                                               SpecGeom g, const cplx* __restrict__ tw_g, Mix mix,
                                                                               XfStride xs) {
     using Cfg = XcCfg<LEN>;
-    constexpr int A = Cfg::A, S = Cfg::S, E = Cfg::E, P = Cfg::P, LPWV = Cfg::LPWV, LPB = Cfg::LPB, PP = Cfg::PP, RR = Cfg::RR,
+    constexpr int A = Cfg::A, S = Cfg::S, E = Cfg::E, LPWV = Cfg::LPWV, LPB = Cfg::LPB, PP = Cfg::PP, RR = Cfg::RR,
                   TPB = Cfg::TPB, WREG = Cfg::WREG, WPT = Cfg::WPT, NL = Cfg::NL, G = NIN > NOUT ? NIN : NOUT;
     constexpr int LDA = (LPB * sizeof(cplx) >= 128) ? OFDFT_XC_LD_AUX : 0;
     extern __shared__ __attribute__((aligned(16))) real lds[];

@@ -100,7 +100,10 @@ int launch_xc_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
     main.lf = rem.lf = Cfg::LPB;
     if constexpr (Cfg::NL > 1) {          // lanes own groups of memory-adjacent lines: whole groups only, else the wave-local kernel
         if (main.sl != 1 || rem.sl != 1 || main.d % Cfg::NL || rem.d % Cfg::NL || main.nlines % Cfg::NL || rem.nlines % Cfg::NL)
-            return launch_xw_t<LEN, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        {
+            if constexpr (LEN <= 512) return launch_xw_t<LEN, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+            else return launch_xfused_t<LEN, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
+        }
     }
     int line0 = 0;
     if (lay.kb1 > lay.kb0 && !lay.se_in) {              // a range of kz blocks; the remainder planes ride with the last one
@@ -140,9 +143,12 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
     // option 1 (default): 256- and 512-point lines always, 1024-point lines for passes over >= 3 spectra;
     // 5 = wherever it exists (128..1024), 6 = passes over >= 3 spectra only, 7 = the round-3 choice (no cross-wave kernel)
     // (fp32 build, 256-point lines: the 1 -> 1 passes measured 36-37 us in the group-parallel kernel against 39-40 here)
+    // (fp32 build, 1024-point lines -- config 5 -- with two lines per lane: every pass, 1 -> 1 included: 205-220 us against 264-272 in
+    // the group-parallel kernel at 1024 x 256 x 256, the Lindhard mix 5.8 against 5.9 ms at 1024^3; profiles/r04_x_stride_probe.jsonl)
+    constexpr bool xc_1024_f32 = sizeof(real) == 4;
     const bool xc_len = (c->n0g == 256 && !(sizeof(real) == 4 && NIN + NOUT == 2)) || c->n0g == 512;
     if (c->use_xwave == 5 || (c->use_xwave == 6 && NIN + NOUT >= 3) ||
-        (c->use_xwave == 1 && (xc_len || (c->n0g == 1024 && NIN + NOUT >= 3)))) {
+        (c->use_xwave == 1 && (xc_len || (c->n0g == 1024 && (NIN + NOUT >= 3 || xc_1024_f32))))) {
         switch (c->n0g) {
             case 128: return launch_xc_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
             case 256: return launch_xc_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);

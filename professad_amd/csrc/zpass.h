@@ -29,6 +29,13 @@ namespace ofdft {
 #define OFDFT_Z_LDS_TWIDDLES 1
 #endif
 
+// (round 4, measured negative: whole-complex LDS exchange in the fp32 z kernels, as in the y / x passes -- zpbe2 0.154 -> 0.168 ms,
+// zi_combine 0.142 -> 0.149, zf_powers 0.099 -> 0.106, only the 8-point zf_density gains, 0.068 -> 0.062: the radix-4 rows' XOR
+// layout is tuned to the b32 bank rules.  Knob kept, default off.)
+#ifndef OFDFT_Z_CX
+#define OFDFT_Z_CX 0
+#endif
+constexpr bool kZCX = OFDFT_Z_CX && kCX;
 template <int M, int E_> struct ZW {
     using PL = ZPlan<M, E_>;
     static constexpr int E = E_;
@@ -36,7 +43,8 @@ template <int M, int E_> struct ZW {
     static constexpr int RPWV = 64 / P;             // rows per wave
     static constexpr int TPB = 256;
     static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
-    static constexpr int RS = line_stride<PL>();    // LDS doubles per row
+    // LDS reals per row (fp32 build, OFDFT_Z_CX: the row transforms exchange whole complex numbers -- twice the reals per row)
+    static constexpr int RS = (OFDFT_Z_CX ? kCXMul : 1) * line_stride<PL>();
     static constexpr int ROWS = RPB * RS;           // reals of the row buffers; the staged twiddle tables follow them
 #if OFDFT_Z_LDS_TWIDDLES
     static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * 2 * M;
@@ -192,7 +200,7 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     using W = ZW<M, E>;
     using PL = typename W::PL;
     constexpr int P = W::P;
-    wave_line_fft<M, E, false, TT>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT, kZCX>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
     if constexpr (PL::EXACT) {
@@ -276,7 +284,7 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
                                                const cplx* __restrict__ twN, real& nyq) {
     using W = ZW<M, E>;
     using PL = typename W::PL;
-    wave_line_fft<M, E, false, TT>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT, kZCX>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
@@ -340,7 +348,7 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
         }
     }
     exchange_sync<true>();
-    wave_line_fft<M, E, true, TT>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, true, TT, kZCX>(v, z.j, z.mine, twM);
     exchange_sync<true>();
     if constexpr (!PL::EXACT) {      // slots no butterfly of the last stage wrote: keep them out of every sum downstream
 #pragma unroll
