@@ -491,9 +491,11 @@ def main():
     # rocprofv3 FETCH_SIZE / WRITE_SIZE of the same command, committed under profiles/ by tools/profile.sh and stamped
     # with the hash of the sources it profiled: used only when it belongs to THIS build (else traffic = null)
     pmc, pmc_name, stamp = None, None, source_stamp()
-    if n == 256 and a.cfg == 'cfg3' and world == 1:
+    if world == 1:
         import glob
-        suffix = '' if a.dtype == 'f64' else '_f32'
+        # pmc_traffic_rNN[_<grid>][_f32][_cfg2].json: the default workload has no tag; other single-GPU workloads that were profiled
+        # (tools/profile.sh <dir> --grid 512, ... --dtype f32 --grid 1024 --cfg cfg2) carry theirs
+        suffix = ('' if n == 256 else '_%d' % n) + ('' if a.dtype == 'f64' else '_f32') + ('' if a.cfg == 'cfg3' else '_' + a.cfg)
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_traffic_r[0-9][0-9]%s.json' % suffix)), reverse=True):
             with open(fn) as fh:
                 cand = json.load(fh)
