@@ -1150,7 +1150,8 @@ def test_lean_transcendentals_are_accurate_to_a_few_ulp():
     assert err < 2e-15, err
 
 
-@pytest.mark.parametrize('shape', [(8, 8, 16), (16, 32, 64), (32, 16, 32), (64, 32, 128), (128, 8, 16), (256, 64, 32), (512, 16, 32)])
+@pytest.mark.parametrize('shape', [(8, 8, 16), (16, 32, 64), (32, 16, 32), (64, 32, 128), (128, 8, 16), (256, 64, 32), (512, 16, 32),
+                                   (256, 48, 16), (512, 8, 48), (1024, 8, 16), (256, 120, 48)])      # (cross-wave kernel: thin / mixed-radix neighbours, 1 024 points)
 def test_wave_local_x_pass_matches_the_group_parallel_kernel(shape):
     """the two fused x-pass kernels (xwave.h: a line of every spectrum in one wavefront, mix in registers; fft_kernels.h:
     one wave group per spectrum, mix through LDS) on every x extent and every mix functor of configs 1-3 + GGA kinetic"""
