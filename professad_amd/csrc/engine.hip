@@ -312,8 +312,12 @@ namespace {
 
 // ---------------------------------------------------------------------------------- combine / energies
 // launch the combine kernel and turn its partial sums into per-term energies
+// defer (the closure of the unfused / chirp-z pipelines, round 4): nothing waits here -- the sums are reduced on the device in a fixed
+// order (c->d_reduced, mirrored into the pinned host block by the reduce kernel), chi_grad forms mu from them on the device and the
+// caller turns the mirror into energies after ITS one synchronisation (an evaluation used to wait four times: sum chi^2, the GGA
+// sums, the combine sums, the end).  Not for the two-pass stabilised WT-style functional, whose weights pass through the host.
 int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, double* E_terms, double* vn_int,
-                 hipStream_t st) {
+                 hipStream_t st, bool defer = false) {
     const unsigned mask = c->mask;
     const long long npts = c->npts;
     const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
@@ -338,6 +342,11 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
         cb.w_nl = (real)wts_f;
     }
     OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, cb, c->d_partial);
+    if (defer && !wts_active(c)) {
+        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial, blocks,
+                     kCombineScalars, c->d_reduced, c->h_partial);
+        return 0;
+    }
     if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
     if (wts_active(c)) {
         sums[2] *= wts_f;
@@ -369,8 +378,10 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
 
 // ---------------------------------------------------------------------------------- the energy pipeline
 // den: density on device.  Fills E_terms (host), writes v_out (device, may be NULL), returns sum(v n) dV.
+// nel_known > 0: the caller knows N_e = int n (the closure: n = N_e chi^2 / int chi^2) -- no device sum of the density;
+// defer: see finish_terms (the GGA sums are reduced on the device as well)
 int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E_terms, real* v_out,
-                      double* vn_int, hipStream_t st) {
+                      double* vn_int, hipStream_t st, double nel_known = 0.0, bool defer = false) {
     const unsigned mask = c->mask;
     const long long npts = c->npts;
     const double inv_n = 1.0 / (double)npts;
@@ -379,10 +390,11 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
     for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
     if ((mask & OFDFT_ION_ELECTRON) && !vext) return fail(c, OFDFT_EINVAL, "IonElectron term needs vext");
 
+    defer = defer && !wts_active(c);
     double nsum = 0.0;
-    if (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF))
+    if (nel_known <= 0.0 && (mask & (OFDFT_WT_NL | OFDFT_WGC99_NL | OFDFT_VWGTF)))
         if (int rc = device_sum(c, den, false, &nsum, st)) return rc;
-    const double nel = nsum * inv_n * c->vol;       // mean(den) * vol   functionals.py:634,646,952
+    const double nel = nel_known > 0.0 ? nel_known : nsum * inv_n * c->vol;       // mean(den) * vol   functionals.py:634,646,952
 
     CombineArgs ca{};
     ca.n = den;
@@ -557,7 +569,12 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         const int blocks = grid_for(npts / 2 + 1, kRedThreads, kRedBlocks);
         OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
                            gga_sel(c), c->d_partial, lapn);
-        if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) return rc;
+        if (defer) {
+            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, blocks,
+                         kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
+        } else if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) {
+            return rc;
+        }
         {
             cplx* sg[4] = {s1, s2, s3, s4};
             const real* rg[4] = {gx, gy, gz, lapn};
@@ -615,7 +632,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         ca.nref = nref;
         ca.wgc_sum_53 = (std::fabs(al + be - kFiveThirds) < 4e-16) ? 1 : 0;
     }
-    return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
+    return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st, defer);
 }
 
 
@@ -781,10 +798,14 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
     return finish_terms(c, ca, pbe_sums, E_terms, vn_int, st);
 }
 
+// *deferred (out): the unfused pipeline ran in the host-free form (finish_terms: defer) -- E_terms / vn_int are NOT filled yet
 int run_terms(ofdft_ctx* c, const real* den, const real* vext, double* E_terms, real* v_out, double* vn_int,
-              hipStream_t st) {
+              hipStream_t st, double nel_known = 0.0, bool* deferred = nullptr) {
+    if (deferred) *deferred = false;
     if (c->fast && !c->force_unfused && !gga_needs_laplacian(c)) return run_terms_fast(c, den, vext, E_terms, v_out, vn_int, st);
-    return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st);
+    const bool defer = deferred && !wts_active(c);
+    if (deferred) *deferred = defer;
+    return run_terms_unfused(c, den, vext, E_terms, v_out, vn_int, st, nel_known, defer);
 }
 
 
@@ -1042,12 +1063,54 @@ void graph_drop(ofdft_ctx* c) {
     c->graphs.clear();
 }
 
+// the unfused / chirp-z closure can run without touching the host (finish_terms: defer): not the two-pass WT-style functional,
+// and not the configurations run_terms hands to the x-fused pipeline
+bool unfused_deferrable(const ofdft_ctx* c) {
+    return !wts_active(c) && !(c->fast && !c->force_unfused && !gga_needs_laplacian(c));
+}
+
+// chi -> (sums in the pinned mirror, grad) for extents without a plan, enqueued on ONE stream without a host synchronisation when
+// *deferred comes back true: sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device (system.py:833-834), n = c chi^2 is formed
+// from it, the sums are reduced on the device in a fixed order, chi_grad forms mu on the device (system.py:851).  An evaluation
+// used to wait four times (sum chi^2, the GGA sums, the combine sums, the end): 53^3 WT + PBE 0.247 -> 0.186 ms.
+int closure_enqueue_unfused(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st,
+                            double* E_terms, double* mu_host, bool* deferred) {
+    real* den;
+    {
+        const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
+        OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
+        OFDFT_LAUNCH(c, st, "reduce", closure_scale_reduce_kernel, dim3(1), dim3(kRedThreads), 0, (const acc_t*)c->d_partial, blocks,
+                     c->d_reduced + kSumsqSlot, c->d_scal, nel, c->vol / (double)c->npts);
+    }
+    if (int rc = real_ws(c, "den", &den)) return rc;
+    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, den, c->npts, 0.0,
+                 (const acc_t*)c->d_scal);
+    double vn = 0.0;
+    double E_tmp[OFDFT_NTERMS];
+    if (int rc = run_terms(c, den, vext, E_terms ? E_terms : E_tmp, v, &vn, st, nel, deferred)) return rc;
+    if (!*deferred) {          // (the x-fused pipeline with the z-fused stage off, or the two-pass WT-style functional: sums via the host)
+        double cfac;
+        HIP_TRY(c, hipMemcpyAsync(&cfac, c->d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const double mu = vn / nel;                                                   // system.py:851
+        if (mu_host) *mu_host = mu;
+        if (grad)
+            OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v, grad, c->npts,
+                         cfac * 2.0 * c->dV, (const acc_t*)nullptr, 0.0, mu);
+        return 0;
+    }
+    if (grad)
+        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, chi, (const real*)v, grad, c->npts, 0.0,
+                     (const acc_t*)c->d_scal, 2.0 * c->dV, 0.0, (const acc_t*)(c->d_reduced + 8), c->dV, nel);
+    return 0;
+}
+
 // Serve the call from a captured graph when one exists for exactly these arguments; capture one on the second call
 // with the same arguments (the first call runs kernel by kernel: workspaces and tables are allocated there, which a
 // capture may not do).  *done = false -> the caller runs the ordinary path.  Any capture failure disables the feature
 // for this context (results never depend on it).
 int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, real* v, real* grad, hipStream_t st, double* sums,
-                  bool* done) {
+                  bool* done, bool unfused = false) {
     *done = false;
     if (!graph_eligible(c) || c->profiling) return 0;
     ofdft_ctx::GraphEntry* ge = nullptr;
@@ -1070,8 +1133,10 @@ int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, r
         hipGraph_t graph = nullptr;
         bool ok = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
-            const int rc = closure_enqueue(c, chi, vext, nel, v, grad, c->cap_stream);
-            ok = hipStreamEndCapture(c->cap_stream, &graph) == hipSuccess && rc == 0 && graph;
+            bool deferred = true;
+            const int rc = unfused ? closure_enqueue_unfused(c, chi, vext, nel, v, grad, c->cap_stream, nullptr, nullptr, &deferred)
+                                   : closure_enqueue(c, chi, vext, nel, v, grad, c->cap_stream);
+            ok = hipStreamEndCapture(c->cap_stream, &graph) == hipSuccess && rc == 0 && graph && deferred;
         }
         if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) (void)hipGraphDestroy(graph);
@@ -1082,7 +1147,7 @@ int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, r
             graph_drop(c);
             return 0;
         }
-        ge->collect = collect_flags(zrun(c), zrun(c).late_join);
+        ge->collect = unfused ? ((c->mask & kGgaAny) ? 0 : kCollectNoGga) : collect_flags(zrun(c), zrun(c).late_join);
         ge->fft_count = c->fft_count;
         ge->launch_count = c->launch_count;
         ge->ypass_count = c->ypass_count;
@@ -1112,7 +1177,7 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
     if (!c->mask) return fail(c, OFDFT_ESTATE, "ofdft_set_terms has not been called");
     if (c->nranks > 1) return fail(c, OFDFT_ESTATE, "slab-decomposed context: use the staged ofdft_dist_* calls");
     if (!(n_electrons > 0.0)) return fail(c, OFDFT_EINVAL, "n_electrons must be positive");
-    real *den, *v;
+    real* v;
     if (int rc = real_ws(c, "v", &v)) return rc;
     if (zfused_serves(c)) {
         // sum chi^2 -> c = N_e / (mean(chi^2) vol) stays on the device; n = c chi^2 is formed on the fly inside the
@@ -1171,22 +1236,28 @@ int ofdft_energy_grad_chi(ofdft_ctx* c, const void* chi, const void* vext, doubl
         if (mu_host) *mu_host = vn / n_electrons;
         return OFDFT_OK;
     }
-    double s2;
-    if (int rc = device_sum(c, (const real*)chi, true, &s2, st)) return rc;
-    const double ntilde = s2 / (double)c->npts * c->vol;                              // system.py:833
-    const double cfac = n_electrons / ntilde;                                         // system.py:834
-    if (int rc = real_ws(c, "den", &den)) return rc;
-    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SCALE_SQ>), dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi, den,
-                       c->npts, cfac);
-    double vn;
-    if (int rc = run_terms(c, den, (const real*)vext, E_terms, v, &vn, st)) return rc;
-    const double mu = vn / n_electrons;                                               // system.py:851
-    if (mu_host) *mu_host = mu;
-    if (grad) {
-        OFDFT_LAUNCH(c, st, "chi_grad", chi_grad_kernel, dim3(grid_for(c->npts / 2 + 1)), dim3(256), 0, (const real*)chi, v, (real*)grad,
-                           c->npts, cfac * 2.0 * c->dV, (const acc_t*)nullptr, 0.0, mu);
+    // Unfused / chirp-z pipelines (extents without a plan -- the reference's own odd grids): host-free like the fused form,
+    // and replayed from a captured graph on small grids (closure_enqueue_unfused, closure_graph)
+    {
+        double sums[kNSums];
+        bool done = false;
+        if (unfused_deferrable(c))
+            if (int rc = closure_graph(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, sums, &done, true)) return rc;
+        if (!done) {
+            bool deferred = false;
+            if (int rc = closure_enqueue_unfused(c, (const real*)chi, (const real*)vext, n_electrons, v, (real*)grad, st, E_terms,
+                                                  mu_host, &deferred))
+                return rc;
+            if (int rc = end_call(c, st)) return rc;
+            if (!deferred) return OFDFT_OK;        // (E_terms / mu were filled on the way)
+            zfused_collect(c, (c->mask & kGgaAny) ? 0 : kCollectNoGga, sums);
+        }
+        double vn;
+        for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+        energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
+        if (mu_host) *mu_host = vn / n_electrons;
     }
-    return end_call(c, st);
+    return OFDFT_OK;
 }
 
 int ofdft_rfftn(ofdft_ctx* c, const void* real_dev, void* spec_dev, void* stream) {

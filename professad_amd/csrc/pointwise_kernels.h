@@ -103,8 +103,10 @@ template <int OP> __device__ __forceinline__ real map_op(real x, real p) {
     if (OP == MAP_POW) return pow(x, p);
     return p * x * x;                                               // n = c chi^2, system.py:834
 }
+// (p_dev: the parameter read from device memory -- the closure scale c of n = c chi^2 left there by closure_scale_reduce_kernel)
 template <int OP>
-__global__ void map_kernel(const real* __restrict__ a, real* __restrict__ out, long long n, real p) {
+__global__ void map_kernel(const real* __restrict__ a, real* __restrict__ out, long long n, real p, const acc_t* __restrict__ p_dev = nullptr) {
+    if (p_dev) p = (real)p_dev[0];
     const long long n2 = n >> 1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
         const cplx x = reinterpret_cast<const cplx*>(a)[i];

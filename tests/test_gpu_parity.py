@@ -897,7 +897,8 @@ def test_pme_and_exact_structure_factors_give_the_same_physics():
 
 # ------------------------------------------------------------------------------- hipGraph replay of the closure
 @pytest.mark.parametrize('shape,cfg', [((32, 32, 32), 'cfg1'), ((64, 64, 64), 'cfg3'), ((16, 32, 64), 'cfg2'),
-                                       ((256, 32, 64), 'cfg3')])        # (256-point x lines: the cross-wave x pass inside a captured graph)
+                                       ((256, 32, 64), 'cfg3'),         # (256-point x lines: the cross-wave x pass inside a captured graph)
+                                       ((15, 17, 19), 'cfg3'), ((53, 53, 53), 'cfg2')])      # (odd extents: the host-free chirp-z closure, round 4)
 def test_graph_replay_is_bitwise_the_kernel_by_kernel_path(shape, cfg):
     """ofdft_energy_grad_chi captures a hipGraph on the second call with the same arguments and replays it afterwards:
     same bits as launching kernel by kernel, tracks in-place changes of chi, and is dropped when the configuration changes"""
