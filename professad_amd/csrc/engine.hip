@@ -1020,8 +1020,18 @@ int ofdft_energy_potential(ofdft_ctx* c, const void* den, const void* vext, doub
         if (int rc = run_terms_zfused(c, ds, nel, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
         return end_call(c, st);
     }
-    if (int rc = run_terms(c, (const real*)den, (const real*)vext, E_terms, (real*)dEdn, &vn, st)) return rc;
-    return end_call(c, st);
+    // unfused / chirp-z pipelines: the sums are reduced on the device and read from the pinned mirror after the ONE wait at the end
+    // (finish_terms: defer; the GGA terms used to wait for their own sums in the middle of the call)
+    bool deferred = false;
+    if (int rc = run_terms(c, (const real*)den, (const real*)vext, E_terms, (real*)dEdn, &vn, st, 0.0, &deferred)) return rc;
+    if (int rc = end_call(c, st)) return rc;
+    if (deferred) {
+        double sums[kNSums];
+        zfused_collect(c, (c->mask & kGgaAny) ? 0 : kCollectNoGga, sums);
+        for (int i = 0; i < OFDFT_NTERMS; ++i) E_terms[i] = 0.0;
+        energies_from_sums(c, sums, sums + kCombineScalars, E_terms, &vn);
+    }
+    return OFDFT_OK;
 }
 
 // ---- the closure evaluation chi -> (sums, grad) as ONE host-free enqueue, and its hipGraph replay --------------------
