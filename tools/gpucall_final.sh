@@ -1,5 +1,6 @@
 # final measurement artefacts of a round (run on the GPU box from the repository root, in two calls: gpurun's limit is 20 minutes):
 #   bash tools/gpucall_final.sh a <tag>   serialised rocprof + PMC traffic (fp64, fp32), SQ counters
+#   bash tools/gpucall_final.sh big <tag> rocprofv3 + PMC at 512^3 fp64 and 1024^3 fp32 cfg2 (install them before part c)
 #   bash tools/gpucall_final.sh c <tag>   8-rank emulation probes (512^3, 256^3), x-stride probe, single-GPU timelines (fp64, fp32), 1024^3 fp32 cfg2 bench
 #   bash tools/gpucall_final.sh b <tag>   bench lines (256^3 fp64 with the CPU baseline, fp32, 512^3, 64^3 cfg2), two-rank rehearsal of
 #                                         `bench.py --gpus 2` (scale_512 block, both transports), two-rank ipc timeline, small-grid latencies
@@ -14,6 +15,10 @@ if [ "$PART" = a ]; then
   bash tools/profile_sq.sh ${TAG}_sq > gpurun_out/${TAG}_sq.log 2>&1 || exit 1
   bash tools/profile_sq.sh ${TAG}_sq_f32 --dtype f32 > gpurun_out/${TAG}_sq_f32.log 2>&1 || exit 1
   echo "sq done"
+elif [ "$PART" = big ]; then      # rocprofv3 + PMC of the two big single-GPU workloads (before the bench lines of part c: they look the PMC files up)
+  bash tools/profile.sh ${TAG}_prof_512 --grid 512 > gpurun_out/${TAG}_prof_512.log 2>&1 || exit 1
+  bash tools/profile.sh ${TAG}_prof_1024_f32_cfg2 --dtype f32 --grid 1024 --cfg cfg2 > gpurun_out/${TAG}_prof_1024.log 2>&1 || exit 1
+  echo "big profiles done"
 elif [ "$PART" = c ]; then
   timeout -k 10 300 python tools/scale_probe.py 512 8 > gpurun_out/${TAG}_scale_probe.jsonl 2> gpurun_out/${TAG}_scale_probe_512.err || exit 1
   timeout -k 10 200 python tools/scale_probe.py 256 8 >> gpurun_out/${TAG}_scale_probe.jsonl 2> gpurun_out/${TAG}_scale_probe_256.err || exit 1
@@ -25,6 +30,8 @@ elif [ "$PART" = c ]; then
   echo "timelines rc=$?"
   timeout -k 10 280 python bench.py --dtype f32 --grid 1024 --cfg cfg2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_1024_f32_cfg2.json 2> gpurun_out/${TAG}_bench_1024_f32_cfg2.err
   echo "bench 1024 rc=$?"
+  timeout -k 10 300 python bench.py --grid 512 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_512.json 2> gpurun_out/${TAG}_bench_512.err
+  echo "bench 512 rc=$?"
 else
   timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench_256.json 2> gpurun_out/${TAG}_bench_256.err || exit 1
   echo "bench 256 done"

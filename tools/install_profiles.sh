@@ -22,3 +22,7 @@ cpif $G/${T}_x_stride_probe.jsonl $P/${T}_x_stride_probe.jsonl
 cpif $G/${T}_tl64/timeline.md $P/${T}_timeline_f64.md
 cpif $G/${T}_tl32/timeline.md $P/${T}_timeline_f32.md
 cpif $G/${T}_bench_1024_f32_cfg2.json $P/bench_${T}_1024_f32_cfg2.json
+cpif $G/${T}_prof_512/summary.md $P/${T}_512_rocprof_serialised.md
+cpif $G/${T}_prof_512/pmc_traffic.json $P/pmc_traffic_${T}_512.json
+cpif $G/${T}_prof_1024_f32_cfg2/summary.md $P/${T}_1024_f32_cfg2_rocprof_serialised.md
+cpif $G/${T}_prof_1024_f32_cfg2/pmc_traffic.json $P/pmc_traffic_${T}_1024_f32_cfg2.json
