@@ -43,7 +43,7 @@ def algorithmic_bytes(n, cfg, word=8):
     return n_fft * (R + 5 * Cc) + n_pw * R, R, Cc
 
 
-def class_alg_bytes(cfg, n, word, n_ypass):
+def class_alg_bytes(cfg, n, word, n_ypass, n_yfwd_fused=0):
     """ALGORITHMIC bytes per evaluation of every kernel class of the default (z-fused, split-derivative) pipeline: what
     the class must read + write once, whatever the launch granularity (a class may run as several x- or kz-chunked
     launches).  R = one real grid, C = one half spectrum; DESIGN.md section 4 lists the arrays behind each entry.
@@ -61,8 +61,8 @@ def class_alg_bytes(cfg, n, word, n_ypass):
     if cfg == 'cfg3':
         t.update({'zf_density': 2 * R + 2 * Cc,         # chi -> n^, (sqrt n)^, D_c n
                   # D_b n (out of place) and D_b G_b (in place); on one GPU the y-forward of n^ rides in the first launch (1C -> 2C:
-                  # one y pass less in `n_ypass`, one more C written here)
-                  'yderiv': (4 + max(0.0, 19.0 - n_ypass)) * Cc,
+                  # one y pass less in `n_ypass`, one more C written here -- counted by the engine, OFDFT_Q_YFWD_FUSED)
+                  'yderiv': (4 + n_yfwd_fused) * Cc,
                   'xfused_n': 3 * Cc,                   # n^ -> vH^, i f_a n^
                   'xfused_div': 2 * Cc,
                   'xfused_wgc': 2 * 6 * Cc,             # two 3 -> 3 launches; their (w0,K1 | K2) kernel tables are NOT algorithmic
@@ -299,9 +299,30 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
     return out
 
 
-def reference_check(n, cfg, dtype, E, mu):
+def grad_stats(g, dist=None, x0=0, npts=None):
+    """sum, L2 norm and the eight fixed probes of chi.grad (tests/golden/cases.py: probe_stats) from the device tensor; on
+    slabs (`dist` given): g is this rank's x-slab starting at plane x0 of a grid of npts points -- one small all-reduce"""
+    import torch
+    flat = g.reshape(-1).double()
+    npts = npts or flat.numel()
+    idx = [int(i * 2654435761 % npts) for i in range(8)]
+    off = x0 * (flat.numel() // g.shape[0])
+    mine = [(k, i - off) for k, i in enumerate(idx) if 0 <= i - off < flat.numel()]
+    acc = torch.zeros(10, dtype=torch.double, device=flat.device)
+    acc[0] = flat.sum()
+    acc[1] = (flat * flat).sum()
+    if mine:
+        acc[torch.as_tensor([2 + k for k, _ in mine], device=flat.device)] = flat[torch.as_tensor([j for _, j in mine], device=flat.device)]
+    if dist is not None:
+        dist.all_reduce(acc)
+    acc = acc.cpu()
+    return {'sum': float(acc[0]), 'l2': float(acc[1].sqrt()), 'probes': [float(x) for x in acc[2:]], 'probe_idx': idx}
+
+
+def reference_check(n, cfg, dtype, E, mu, grad=None):
     """The bench workload pinned to the reference (tests/golden/bench_scalars.json, written by make_golden.py --bench
-    from the reference's own closure on these inputs).  Outside the timed region."""
+    from the reference's own closure on these inputs): energy, mu and -- when `grad` (grad_stats of the timed call's
+    chi.grad) is given -- the L2 norm, the sum and eight probes of chi.grad (system.py:850-853).  Outside the timed region."""
     fn = os.path.join(ROOT, 'tests', 'golden', 'bench_scalars.json')
     if cfg != 'cfg3' or not os.path.exists(fn):
         return None
@@ -312,8 +333,19 @@ def reference_check(n, cfg, dtype, E, mu):
     tol = 1e-10 if dtype == 'f64' else 5e-6
     dE = abs(E - ref['E']) / abs(ref['E'])
     dmu = abs(mu - ref['mu']) / max(abs(ref['mu']), 1e-300)
-    return {'E_ref_Ha': ref['E'], 'rel_dE': dE, 'mu_ref': ref['mu'], 'rel_dmu': dmu, 'tol': tol,
-            'ok': bool(dE < tol and dmu < max(tol, 1e-9)), 'source': 'tests/golden/bench_scalars.json (reference closure, system.py:830-838)'}
+    out = {'E_ref_Ha': ref['E'], 'rel_dE': dE, 'mu_ref': ref['mu'], 'rel_dmu': dmu, 'tol': tol,
+           'ok': bool(dE < tol and dmu < max(tol, 1e-9)), 'source': 'tests/golden/bench_scalars.json (reference closure, system.py:830-838)'}
+    if grad is not None and ref.get('grad'):
+        rg = ref['grad']
+        gtol = 1e-9 if dtype == 'f64' else 5e-4          # of the gradient's scale (max-norm bar of the parity tests)
+        scale = max(abs(p) for p in rg['probes'])
+        assert list(grad['probe_idx']) == list(rg['probe_idx'])
+        d_l2 = abs(grad['l2'] - rg['l2']) / rg['l2']
+        d_sum = abs(grad['sum'] - rg['sum']) / (rg['l2'] * float(n) ** 1.5)       # |sum| <= l2 sqrt(N^3)
+        d_probe = max(abs(a - b) for a, b in zip(grad['probes'], rg['probes'])) / scale
+        out.update(grad_rel_dl2=d_l2, grad_rel_dsum=d_sum, grad_probe_max_rel=d_probe, grad_tol=gtol)
+        out['ok'] = bool(out['ok'] and d_l2 < gtol and d_sum < gtol and d_probe < gtol)
+    return out
 
 
 def main():
@@ -467,6 +499,7 @@ def main():
     n_fft = int(eng.query(0))
     n_launch = int(eng.query(4))
     n_ypass = float(eng.query(5))          # whole-spectrum y line passes actually executed
+    n_yfwd = int(eng.query(10))            # y-forward transforms that rode inside a yderiv launch
     dev_ms = raw.query(3) or None          # begin .. end of the last evaluation on this rank's stream (HIP events); the
                                            # persistent small-grid kernel's calls are not bracketed by events (reads 0)
 
@@ -487,7 +520,7 @@ def main():
         ys = [prof.pop(k) for k in ('ypass_send', 'ypass_recv') if k in prof]
         prof['cpass_y'] = (sum(v[0] for v in ys), sum(v[1] for v in ys))
     tot_ms = sum(v[0] for v in prof.values()) or 1.0
-    cab = class_alg_bytes(a.cfg, n, word, n_ypass) if default_options else {}
+    cab = class_alg_bytes(a.cfg, n, word, n_ypass, n_yfwd) if default_options else {}
     # rocprofv3 FETCH_SIZE / WRITE_SIZE of the same command, committed under profiles/ by tools/profile.sh and stamped
     # with the hash of the sources it profiled: used only when it belongs to THIS build (else traffic = null)
     pmc, pmc_name, stamp = None, None, source_stamp()
@@ -586,7 +619,9 @@ def main():
                       scatter_GBs_per_link=round(sent / (world - 1) / (ms * 1e-3) / 1e9, 1) if ms else None,
                       wait_ms_per_eval=kernels.get('ipc_sync', {}).get('ms_per_eval'))
         out['exchange'] = ex
-    chk = reference_check(n, a.cfg, a.dtype, E_tot, mu)
+    # (chi.grad of the timed call itself; on slabs every rank contributes its planes' share of the statistics)
+    gst = grad_stats(g) if world == 1 else grad_stats(g, dist, eng.plan.x_range().start, n ** 3)
+    chk = reference_check(n, a.cfg, a.dtype, E_tot, mu, gst)
     out['reference_check'] = chk
     if world > 1 and rank == 0 and os.environ.get('OFDFT_BENCH_NO_PARITY') != '1':
         # the slab-decomposed result against ONE engine on the whole grid of this rank's GPU (outside the timed region)
@@ -637,7 +672,7 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and chk is not None and not chk['ok']:
-        sys.stderr.write('bench.py: energy / mu differ from the reference pin beyond %g: %r\n' % (chk['tol'], chk))
+        sys.stderr.write('bench.py: energy / mu / chi.grad differ from the reference pin beyond %g: %r\n' % (chk['tol'], chk))
         sys.exit(3)
 
 

@@ -104,6 +104,7 @@ typedef struct ofdft_ctx ofdft_ctx;
 #define OFDFT_Q_GRAPH_REPLAYS     6  /* ofdft_energy_grad_chi calls served by a hipGraph replay so far */
 #define OFDFT_Q_RESIDENT_EVALS    7  /* ofdft_energy_grad_chi calls served by the persistent small-grid kernel so far */
 #define OFDFT_Q_XCHG_CHUNKS      9  /* effective number of kz chunks of the slab exchange (OFDFT_OPT_XCHG_CHUNKS)               */
+#define OFDFT_Q_YFWD_FUSED      10  /* y-forward transforms of the last energy call that rode inside a yderiv launch (1C -> 2C in one pass) */
 #define OFDFT_Q_RESIDENT_FALLBACKS 8 /* evaluations re-run on the staged path because a grid barrier of the persistent kernel timed out
                                         (the kernel is switched off for the context after the first one) */
 

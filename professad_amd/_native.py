@@ -27,6 +27,7 @@ NPARAMS = 13
 Q_FFT_COUNT, Q_WORKSPACE_BYTES, Q_FAST_PATH, Q_KERNEL_MS, Q_LAUNCH_COUNT, Q_YPASS_COUNT, Q_GRAPH_REPLAYS, Q_RESIDENT_EVALS = 0, 1, 2, 3, 4, 5, 6, 7
 Q_RESIDENT_FALLBACKS = 8
 Q_XCHG_CHUNKS = 9
+Q_YFWD_FUSED = 10
 OPT_GRAPH = 7
 OPT_XWAVE = 8
 OPT_MIXED_RADIX = 9

@@ -182,8 +182,7 @@ void resident_give_up(ofdft_ctx* c);
 // copy `rows` x `ns` partials to the host and sum them in a fixed order
 int fetch_partials(ofdft_ctx* c, int rows, int ns, double* sums, hipStream_t st) {
     if (rows > kRedBlocks) {     // many rows: reduce on the device first (fixed order), copy ns numbers
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(ns), dim3(kRedThreads), 0, c->d_partial, rows, ns,
-                     c->d_reduced);
+        OFDFT_REDUCE(c, st, c->d_partial, rows, ns, c->d_reduced);
         HIP_TRY(c, hipMemcpyAsync(c->h_partial, c->d_reduced, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         for (int s = 0; s < ns; ++s) sums[s] = c->h_partial[s];
@@ -343,8 +342,7 @@ int finish_terms(ofdft_ctx* c, const CombineArgs& ca, const double* pbe_sums, do
     }
     OFDFT_LAUNCH(c, st, "combine", combine_kernel, dim3(blocks), dim3(kRedThreads), 0, cb, c->d_partial);
     if (defer && !wts_active(c)) {
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial, blocks,
-                     kCombineScalars, c->d_reduced, c->h_partial);
+        OFDFT_REDUCE(c, st, c->d_partial, blocks, kCombineScalars, c->d_reduced, c->h_partial);
         return 0;
     }
     if (int rc = fetch_partials(c, blocks, kCombineScalars, sums, st)) return rc;
@@ -570,8 +568,7 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         OFDFT_LAUNCH(c, st, "pbe", pbe_kernel, dim3(blocks), dim3(kRedThreads), 0, den, gx, gy, gz, dfdn, npts,
                            gga_sel(c), c->d_partial, lapn);
         if (defer) {
-            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, blocks,
-                         kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
+            OFDFT_REDUCE(c, st, c->d_partial, blocks, kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
         } else if (int rc = fetch_partials(c, blocks, kPbeScalars, pbe_sums, st)) {
             return rc;
         }
@@ -875,7 +872,7 @@ int ofdft_create_dist(ofdft_ctx** out, int n0g, int n1g, int n2, int dtype, int 
         const long long zb = (g.nrows + 3) / 4;      // >= blocks of any z kernel (RPB >= 4)
         if (zb > c->partial_rows) c->partial_rows = zb;
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * c->partial_rows * kMaxScalars);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_partial, sizeof(double) * (c->partial_rows + kRedMidRows) * kMaxScalars);   // + the first-level sums of OFDFT_REDUCE
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_reduced, sizeof(double) * kMaxScalars);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_scal, sizeof(double) * 8);    // [0] closure scale, [2] split WGC99 energy, [4..6] WT-style weights
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_partial, sizeof(double) * kRedBlocks * kMaxScalars);
@@ -1161,10 +1158,12 @@ int closure_graph(ofdft_ctx* c, const real* chi, const real* vext, double nel, r
         ge->fft_count = c->fft_count;
         ge->launch_count = c->launch_count;
         ge->ypass_count = c->ypass_count;
+        ge->yfwd_fused = c->yfwd_fused;
     }
     c->fft_count = ge->fft_count;
     c->launch_count = ge->launch_count;
     c->ypass_count = ge->ypass_count;
+    c->yfwd_fused = ge->yfwd_fused;
     HIP_TRY(c, hipGraphLaunch(ge->exec, st));
     if (int rc = end_call(c, st)) return rc;
     zfused_collect(c, ge->collect, sums);
@@ -1346,8 +1345,7 @@ int ofdft_dist_sumsq(ofdft_ctx* c, const void* x_local, int square, double* loca
     else
         OFDFT_LAUNCH(c, st, "sum", (sum_kernel<false>), dim3(blocks), dim3(kRedThreads), 0, (const real*)x_local, c->npts,
                      c->d_partial);
-    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1,
-                 c->d_reduced + kSumsqSlot);
+    OFDFT_REDUCE(c, st, c->d_partial, blocks, 1, c->d_reduced + kSumsqSlot);
     HIP_TRY(c, hipGetLastError());
     return OFDFT_OK;
 }
@@ -1383,6 +1381,7 @@ int ofdft_dist_begin(ofdft_ctx* c, const void* src_local, int from_chi, double c
     r.nel = nel_global;
     r.vext = (const real*)vext_local;
     r.v_out = (real*)v_out_local;
+    r.setup_done = false;          // every evaluation sets up afresh (a failed earlier call must not leave its state behind)
     r.stage[0] = r.stage[1] = 0;
     c->recv_parity[0] = c->recv_parity[1] = 0;
     r.step[0] = r.step[1] = 0;
@@ -1677,6 +1676,7 @@ int ofdft_query(ofdft_ctx* c, int what, double* out) {
         case OFDFT_Q_RESIDENT_EVALS: *out = (double)c->resident_evals; return OFDFT_OK;
         case OFDFT_Q_RESIDENT_FALLBACKS: *out = (double)c->resident_fallbacks; return OFDFT_OK;
         case OFDFT_Q_XCHG_CHUNKS: *out = (double)c->xc.n; return OFDFT_OK;
+        case OFDFT_Q_YFWD_FUSED: *out = (double)c->yfwd_fused; return OFDFT_OK;
         case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27:      // phase clock of the last persistent-kernel evaluation (microseconds)
             *out = c->h_partial[what] * 0.01;
             return OFDFT_OK;

@@ -73,7 +73,8 @@ struct ofdft_ctx {
     // WGC tables
     double* d_wgc_coef = nullptr;   // ca[nt], cb[nt]
     long long wgc_key_nel = -1;
-    int fft_passes_fused = 0;      // y-forward passes that rode inside a yderiv launch (diagnostics)
+    int fft_passes_fused = 0;      // y-forward passes that rode inside a yderiv launch, so far (diagnostics)
+    int yfwd_fused = 0;            // ... of the last energy call (OFDFT_Q_YFWD_FUSED: the byte model of bench.py)
     bool wgc_valid = false;
     double wgc_ck = 0.0;           // K3 = K2 + wgc_ck K1 for the tables in "t:wgc" ((3 - gamma) / (3 n_ref))
     // stats
@@ -114,7 +115,7 @@ struct ofdft_ctx {
         int seen = 0;                        // calls with these arguments so far (the first one runs uncaptured: it allocates)
         hipGraphExec_t exec = nullptr;
         int collect = 0;                     // zfused_collect flags of the captured evaluation
-        int fft_count = 0, launch_count = 0;
+        int fft_count = 0, launch_count = 0, yfwd_fused = 0;
         double ypass_count = 0.0;
     };
     std::vector<GraphEntry> graphs;
@@ -234,6 +235,27 @@ inline int grid_for(long long n, int tpb = 256, int cap = 2048) {
     if (b < 1) b = 1;
     return (int)b;
 }
+
+// partial[rows][ns] -> out[ns] (+ the pinned host mirror): one launch for few rows, two (reduce_rows_kernel, pointwise_kernels.h) for
+// many.  `mid` = room for kRedMidRows x ns doubles that nobody else uses while the launch runs: by default the tail of `partial`
+// itself (every partial buffer is allocated with kRedMidRows x kMaxScalars doubles beyond its rows).
+#define OFDFT_REDUCE(c, st, partial, rows, ns, ...)                                                                          \
+    do {                                                                                                                     \
+        const acc_t* part_ = (partial);                                                                                      \
+        const int rows_ = (rows), ns_ = (ns);                                                                                \
+        if (rows_ > kRedTwoLevelRows) {                                                                                      \
+            acc_t* mid_ = const_cast<acc_t*>(part_) + (size_t)rows_ * ns_;                                                   \
+            int g_ = rows_ / 512;                                                                                            \
+            g_ = g_ < 1 ? 1 : (g_ > kRedMidRows ? kRedMidRows : g_);                                                         \
+            const int per_ = (rows_ + g_ - 1) / g_;                                                                          \
+            g_ = (rows_ + per_ - 1) / per_;                                                                                  \
+            OFDFT_LAUNCH(c, st, "reduce", reduce_rows_kernel, dim3(g_), dim3(kRedThreads), 0, part_, rows_, ns_, per_, mid_); \
+            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(ns_), dim3(kRedThreads), 0, (const acc_t*)mid_, g_, ns_, \
+                         __VA_ARGS__);                                                                                       \
+        } else {                                                                                                             \
+            OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(ns_), dim3(kRedThreads), 0, part_, rows_, ns_, __VA_ARGS__); \
+        }                                                                                                                    \
+    } while (0)
 
 
 // ---- kz-block chunks of the exchange layout

@@ -435,15 +435,14 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
             acc_t* part2;
             int blocks = 0;
             if ((rc = real_ws(c, "vpart", &vp))) return rc;
-            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * 2 * (size_t)c->partial_rows, (void**)&part2))) return rc;
+            if ((rc = get_ws(c, "zwgc:part", sizeof(double) * 2 * (size_t)(c->partial_rows + kRedMidRows), (void**)&part2))) return rc;
             if (r.forked) {
                 // (its own event: one event recorded on two different streams inside a stream capture crashes the runtime)
                 HIP_TRY(c, hipEventRecord(c->ev_c, sc));
                 HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_c, 0));
             }
             if ((rc = launch_zi_wgc(c, r.za, vp, part2, &blocks, sb))) return rc;
-            OFDFT_LAUNCH(c, sb, "reduce", reduce_partials_kernel, dim3(2), dim3(kRedThreads), 0, (const acc_t*)part2, blocks, 2,
-                         c->d_scal + 2, c->h_partial + kNSums);        // [2] energy sum, [3] this part's sum(v n); host mirror
+            OFDFT_REDUCE(c, sb, (const acc_t*)part2, blocks, 2, c->d_scal + 2, c->h_partial + kNSums);        // [2] energy sum, [3] this part's sum(v n); host mirror
             r.za.v_part = vp;
             r.wgc_split = true;
             // closure evaluations leave v in two parts: the combine kernel then has nothing to wait for on this stream
@@ -460,8 +459,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
         if ((rc = real_ws(c, "dfdn", &r.dfdn))) return rc;
         if ((rc = launch_zpbe2(c, r.ds, r.s_g[0], r.s_g[1], r.dzn, r.dfdn, r.za.inv_n, &r.pbe_blocks, st, r.lapl ? r.s_l : nullptr)))
             return rc;
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
-                     kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
+        OFDFT_REDUCE(c, st, c->d_partial, r.pbe_blocks, kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
         // D_b G_b in one y pass, in place (scaled like B); only G_a goes on to the x pass
         if ((rc = yderiv(c, r.s_g[1], r.s_g[1], (double)c->n0g, st))) return rc;
         if (!dx && (rc = fast_axis_pass<false>(c, 1, r.s_g[0], st))) return rc;
@@ -485,8 +483,7 @@ int zstage3(ofdft_ctx* c, hipStream_t st, int chain, int part = 0, int xk = -1) 
             if (pbe_chunked && (rc = fast_axis_pass_multi<false>(c, 1, r.s_g, 3, st, x0, cx))) return rc;
         }
         // no host round trip in the middle of the evaluation: reduce on the device, read with the final sums
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kPbeScalars), dim3(kRedThreads), 0, c->d_partial, r.pbe_blocks,
-                     kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
+        OFDFT_REDUCE(c, st, c->d_partial, r.pbe_blocks, kPbeScalars, c->d_reduced + kCombineScalars, c->h_partial + kCombineScalars);
         for (int k = 0; k < 3; ++k) {
             if (!dx && !pbe_chunked && (rc = fast_axis_pass<false>(c, 1, r.s_g[k], st))) return rc;
             xl.push_back(r.s_g[k]);
@@ -618,8 +615,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false, int 
         ZCombineArgs z1 = r.za;
         z1.v_out = nullptr;
         if ((rc = launch_zi_combine(c, z1, &r.combine_blocks, st))) return rc;
-        OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
-                     r.combine_blocks, kCombineScalars, c->d_reduced);
+        OFDFT_REDUCE(c, st, c->d_partial, r.combine_blocks, kCombineScalars, c->d_reduced);
         OFDFT_LAUNCH(c, st, "reduce", wts_weights_kernel, dim3(1), dim3(64), 0, (const acc_t*)c->d_reduced, c->d_scal + 4);
         r.za.wts_w = c->d_scal + 4;
     }
@@ -637,8 +633,7 @@ int zstage5(ofdft_ctx* c, double* sums, hipStream_t st, bool defer = false, int 
     }
     // (host-bound sums: the reduce kernel writes the pinned mirror itself -- no copy command behind it; the stabilised
     // WT-style functional rewrites two of the sums afterwards and keeps the copy)
-    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(kCombineScalars), dim3(kRedThreads), 0, c->d_partial,
-                 r.combine_blocks, kCombineScalars, c->d_reduced, (sums && !wts) ? c->h_partial : (acc_t*)nullptr);
+    OFDFT_REDUCE(c, st, c->d_partial, r.combine_blocks, kCombineScalars, c->d_reduced, (sums && !wts) ? c->h_partial : (acc_t*)nullptr);
     if (wts) OFDFT_LAUNCH(c, st, "reduce", wts_finalize_kernel, dim3(1), dim3(64), 0, c->d_reduced, (const acc_t*)(c->d_scal + 4));
     if (late_join) {      // now the nonlocal chain: its share of sum(v n) joins the combine's (mu is formed from the total)
         HIP_TRY(c, hipEventRecord(c->ev_join, r.sb));
@@ -693,16 +688,18 @@ int zfused_enqueue(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext,
     }
     // one GPU, forked: the nonlocal chain's first kernels go to the device BEFORE the other chain's four launches (its stream
     // sat idle for ~30 us of host enqueue time at the head of every evaluation; profiles/r04_timeline_*.md)
-    if ((rc = zsetup(c))) return rc;
+    r.setup_done = false;
+    rc = zsetup(c);
     const bool nl_first = r.forked && c->nranks == 1;
-    for (int i = 0; i < 2; ++i)
-        if ((rc = zstage1(c, st, nl_first ? 1 - i : i))) return rc;
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage2(c, st, chain))) return rc;
-    for (int chain = 0; chain < 2; ++chain)
-        if ((rc = zstage3(c, st, chain))) return rc;
-    if ((rc = zstage4(c, st, 0))) return rc;
-    return zstage5(c, sums, st, defer);
+    for (int i = 0; i < 2 && !rc; ++i) rc = zstage1(c, st, nl_first ? 1 - i : i);
+    for (int chain = 0; chain < 2 && !rc; ++chain) rc = zstage2(c, st, chain);
+    for (int chain = 0; chain < 2 && !rc; ++chain) rc = zstage3(c, st, chain);
+    if (!rc) rc = zstage4(c, st, 0);
+    if (!rc) rc = zstage5(c, sums, st, defer);
+    // (a call that failed between zsetup and chain 0's stage 1 -- the nonlocal chain goes first here -- must not leave the
+    // flag set: a later staged evaluation entering through zstage1(chain 0) would skip its own set-up)
+    r.setup_done = false;
+    return rc;
 }
 
 int run_terms_zfused(ofdft_ctx* c, const DenSrc& ds, double nel, const real* vext, double* E_terms, real* v_out,
@@ -727,6 +724,7 @@ int begin_call(ofdft_ctx* c, hipStream_t st, bool timed = true) {
     c->fft_count = 0;
     c->launch_count = 0;
     c->ypass_count = 0.0;
+    c->yfwd_fused = 0;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, st));
     return 0;
 }

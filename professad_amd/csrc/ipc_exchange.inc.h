@@ -382,7 +382,7 @@ int ofdft_dist_closure(ofdft_ctx* c, const void* chi_local, const void* vext_loc
     // ---- sum chi^2 over all ranks -> closure scale on the device
     const int blocks = grid_for(c->npts / 2 + 1, kRedThreads, kRedBlocks);
     OFDFT_LAUNCH(c, st, "sum", (sum_kernel<true>), dim3(blocks), dim3(kRedThreads), 0, chi, c->npts, c->d_partial);
-    OFDFT_LAUNCH(c, st, "reduce", reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, c->d_partial, blocks, 1, c->d_reduced + kSumsqSlot);
+    OFDFT_REDUCE(c, st, c->d_partial, blocks, 1, c->d_reduced + kSumsqSlot);
     if (int rc = ipc_allreduce(c, 0, c->d_reduced + kSumsqSlot, 1, c->d_reduced + kSumsqSlot, st)) return rc;
     OFDFT_LAUNCH(c, st, "reduce", closure_scale_kernel, dim3(1), dim3(64), 0, c->d_reduced + kSumsqSlot, c->d_scal, n_electrons,
                  c->vol / (double)c->npts_g);

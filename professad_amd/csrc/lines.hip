@@ -604,7 +604,7 @@ int launch_yderiv_t(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipSt
     const int mb = (main.nlines + Cfg::LPW - 1) / Cfg::LPW, rb = (rem.nlines + Cfg::LPW - 1) / Cfg::LPW;
     OFDFT_LAUNCH(c, st, "yderiv", (yderiv_kernel<LEN>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, in, out, main, rem, mb,
                  c->g.main_count, (const cplx*)tw, (real)scale, fwd);
-    if (fwd) c->fft_passes_fused++;
+    if (fwd) c->fft_passes_fused++, c->yfwd_fused++;
     return 0;
 }
 int yderiv(ofdft_ctx* c, const cplx* in, cplx* out, double scale, hipStream_t st, cplx* fwd) {

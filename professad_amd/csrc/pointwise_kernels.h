@@ -80,19 +80,74 @@ static __global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(con
         if (host_out) host_out[s] = red[0];
     }
 }
+// Many rows (round 5): the kernel above gives scalar s ONE block that walks its column with a stride of ns doubles -- 80-byte
+// strides for the ten combine sums, 17 us at 256^3 (8 192 rows), 129 us at 512^3, 0.5 ms at 1024^3.  First level instead: block b
+// sums the rows [b per, (b + 1) per), a CONTIGUOUS range read with unit stride (thread t keeps element t of every run of
+// T = ns floor(256 / ns) doubles, i.e. always scalar t mod ns), into mid[b][ns]; the kernel above then reduces the <= 256 rows of
+// `mid`.  Fixed order for a given (rows, ns): bitwise reproducible.
+constexpr int kRedTwoLevelRows = 2048;     // more rows than this take the two-level form
+constexpr int kRedMidRows = 256;           // most first-level blocks (rows of `mid`)
+static __global__ __launch_bounds__(kRedThreads) void reduce_rows_kernel(const acc_t* __restrict__ partial, int rows, int ns, int per,
+                                                                  acc_t* __restrict__ mid) {
+    __shared__ acc_t red[kRedThreads];
+    const int rpt = kRedThreads / ns, T = rpt * ns;
+    const int r0 = blockIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    acc_t a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if ((int)threadIdx.x < T && r1 > r0) {
+        const acc_t* p = partial + (long long)r0 * ns;
+        const long long n = (long long)(r1 - r0) * ns;
+        long long i = threadIdx.x;
+        for (; i + 3LL * T < n; i += 4LL * T) {        // four independent loads in flight per thread
+            a0 += p[i];
+            a1 += p[i + T];
+            a2 += p[i + 2LL * T];
+            a3 += p[i + 3LL * T];
+        }
+        for (; i < n; i += T) a0 += p[i];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if ((int)threadIdx.x < ns) {
+        acc_t t = 0.0;
+        for (int k = 0; k < rpt; ++k) t += red[threadIdx.x + k * ns];
+        mid[(long long)blockIdx.x * ns + threadIdx.x] = t;
+    }
+}
 
-// sum(a) or sum(a^2)
+// sum(a) or sum(a^2).  Round 5: 16-byte accesses, four of them in flight per thread -- with one 8-byte (fp32: a pair) load per
+// thread and iteration a CU of the 1024-block grid had 8 KB in flight and the kernel streamed 4.0 TB/s at 1024^3 fp32 (0.49 of
+// the peak), 5.3 at 256^3 fp64.  (arrays that are not 16-byte aligned -- a view of a larger tensor -- take pairs as before)
 template <bool SQUARE>
 __global__ __launch_bounds__(kRedThreads) void sum_kernel(const real* __restrict__ a, long long n,
                                                           acc_t* __restrict__ partial) {
     acc_t acc[1] = {0.0};
-    const long long n2 = n >> 1;
-    const cplx* a2 = reinterpret_cast<const cplx*>(a);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const cplx t = a2[i];
-        acc[0] += SQUARE ? (t.x * t.x + t.y * t.y) : (t.x + t.y);
+    constexpr int NV = 16 / (int)sizeof(real);                // reals per 16-byte access
+    typedef real vec_t __attribute__((ext_vector_type(NV)));
+    const long long stride = (long long)gridDim.x * blockDim.x, gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto fold = [&](const vec_t& v) {
+        acc_t t = 0.0;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) t += SQUARE ? (acc_t)v[e] * (acc_t)v[e] : (acc_t)v[e];
+        return t;
+    };
+    long long done = 0;
+    if ((reinterpret_cast<unsigned long long>(a) & 15ull) == 0) {
+        const vec_t* av = reinterpret_cast<const vec_t*>(a);
+        const long long nv = n / NV;
+        acc_t b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        long long i = gid;
+        for (; i + 3 * stride < nv; i += 4 * stride) {
+            const vec_t v0 = av[i], v1 = av[i + stride], v2 = av[i + 2 * stride], v3 = av[i + 3 * stride];
+            b0 += fold(v0);
+            b1 += fold(v1);
+            b2 += fold(v2);
+            b3 += fold(v3);
+        }
+        for (; i < nv; i += stride) b0 += fold(av[i]);
+        acc[0] = (b0 + b1) + (b2 + b3);
+        done = nv * NV;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc[0] += SQUARE ? a[n - 1] * a[n - 1] : a[n - 1];
+    for (long long i = done + gid; i < n; i += stride) acc[0] += SQUARE ? (acc_t)a[i] * (acc_t)a[i] : (acc_t)a[i];
     block_reduce_store<1>(acc, partial);
 }
 
@@ -155,14 +210,49 @@ __device__ __forceinline__ void kvec(const KGeom& kg, long long i, real& kx, rea
     k2 = kx * kx + ky * ky + kz * kz;
 }
 
-// 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648).  Always evaluated in fp64: G cancels 0.5 against -0.5 + O(eta^-2)
-// and its reciprocal then cancels against 3 eta^2; in fp32 that left 5e-4 of the Wang-Teter energy of a rough density.
+// 1/G^-1(eta) - 3 eta^2 - 1 (functionals.py:617-628,648), fp64: the reference's own form, with the lean logarithm and
+// reciprocal of fastmath.h (the library log + two IEEE quotients were ~200 fp64 instructions per k-point of the
+// Wang-Teter x pass; this is ~60)
 __device__ __forceinline__ double lindhard_shape(double eta) {
     double ginv;
     if (eta == 0.0) ginv = 1.0;
     else if (eta == 1.0) ginv = 0.5;
-    else ginv = 0.5 + ((1.0 - eta * eta) / (4.0 * eta)) * log(fabs((1.0 + eta) / (1.0 - eta)));
-    return 1.0 / ginv - 3.0 * eta * eta - 1.0;
+    else ginv = 0.5 + ((1.0 - eta * eta) * 0.25 * fm::rcp(eta)) * fm::log(fabs((1.0 + eta) * fm::rcp(1.0 - eta)));
+    return fm::rcp(ginv) - 3.0 * eta * eta - 1.0;
+}
+// fp32 (round 5): the direct form cancels twice -- G = 0.5 + (-0.5 + O(eta^-2)) for large eta, then 1/G against 3 eta^2; for
+// small eta 1/G - 1 against O(eta^2) -- which left 5e-4 of the Wang-Teter energy of a rough density, so rounds 3-4 evaluated
+// the fp64 form at every k-point of the fp32 build: 2.3 of the 5.8 ms of the 1024^3 x pass (538 M k-points) were its issue
+// time.  Cancellation-free instead: with c_j = 1 / (4 j^2 - 1) the logarithm's series gives
+//   eta < 1:  G = 1 - S,  S = sum_{j>=1} c_j eta^(2j)              f = S / (1 - S) - 3 eta^2
+//   eta > 1:  G = sum_{j>=1} c_j eta^(-2j) = (z / 3) T(z), z = eta^-2  f = -3 V / R - 1,  R = sum_j c_(j+1) z^j, V = sum_j c_(j+2) z^j
+// (S = z R with z = eta^2: ONE Horner recursion serves both sides).  12 terms are exact to fp32 rounding for z <= 0.36; in
+// between, 0.6 < eta < 5/3, the direct form loses at most a digit (|G| >= 0.13): max 2e-6, rms 3e-7 relative over the band,
+// 1.5e-7 outside (numpy float32 emulation against 80-bit arithmetic; tests/test_gpu_f32.py pins it on the device).
+__device__ __forceinline__ float lindhard_shape(float eta) {
+    const float e2 = eta * eta;
+    const float z = eta < 1.0f ? e2 : __builtin_amdgcn_rcpf(e2);
+    constexpr float c[14] = {0.0f, 1.0f / 3.0f, 1.0f / 15.0f, 1.0f / 35.0f, 1.0f / 63.0f, 1.0f / 99.0f, 1.0f / 143.0f, 1.0f / 195.0f,
+                             1.0f / 255.0f, 1.0f / 323.0f, 1.0f / 399.0f, 1.0f / 483.0f, 1.0f / 575.0f, 1.0f / 675.0f};
+    float r = c[12], v = c[13];
+#pragma unroll
+    for (int j = 11; j >= 1; --j) {
+        r = __builtin_fmaf(r, z, c[j]);           // R = c_1 + c_2 z + ... + c_12 z^11
+        v = __builtin_fmaf(v, z, c[j + 1]);       // V = c_2 + c_3 z + ... + c_13 z^11
+    }
+    float f;
+    if (eta < 1.0f) {
+        const float s = z * r;
+        f = __builtin_fmaf(s, __builtin_amdgcn_rcpf(1.0f - s), -3.0f * e2);
+    } else {
+        f = __builtin_fmaf(-3.0f * v, __builtin_amdgcn_rcpf(r), -1.0f);
+    }
+    if (eta > 0.6f && eta < (5.0f / 3.0f)) {
+        const float lg = 0.69314718055994530942f * __builtin_amdgcn_logf(fabsf((1.0f + eta) * __builtin_amdgcn_rcpf(1.0f - eta)));
+        const float g = __builtin_fmaf((1.0f - e2) * 0.25f * __builtin_amdgcn_rcpf(eta), lg, 0.5f);
+        f = eta == 1.0f ? -2.0f : __builtin_amdgcn_rcpf(g) - 3.0f * e2 - 1.0f;
+    }
+    return f;
 }
 
 enum { SPEC_HARTREE = 0, SPEC_LAPLACE = 1, SPEC_LINDHARD = 2 };
@@ -929,19 +1019,42 @@ static __global__ void chi_grad_kernel(const real* __restrict__ chi, const real*
     // graph-captured evaluation); same operations in the same order as the host form
     // (vn2_dev: the share of sum(v n) of a part of the potential formed on another stream -- added here in the order the host adds it)
     const real mu = vn_dev ? (real)(((vn2_dev ? vn_dev[0] + vn2_dev[0] : vn_dev[0]) * dV) / n_elec) : mu_host;
-    const long long n2 = npts >> 1;
     // v2: a part of the potential kept in its own array (the WGC99 part formed beside the combine kernel)
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
-        const cplx x = reinterpret_cast<const cplx*>(chi)[i];
-        cplx w = reinterpret_cast<const cplx*>(v)[i];
-        if (v2) {
-            const cplx w2 = reinterpret_cast<const cplx*>(v2)[i];
-            w = mkc(w.x + w2.x, w.y + w2.y);
+    // Round 5: 16-byte accesses, two per array in flight per thread (one 8-byte pair per thread and iteration left the 2 048-block
+    // grid at 4.4 TB/s on 4-GB arrays, 0.55 of the peak; unaligned views take pairs as before)
+    constexpr int NV = 16 / (int)sizeof(real);
+    typedef real vec_t __attribute__((ext_vector_type(NV)));
+    const long long stride = (long long)gridDim.x * blockDim.x, gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long done = 0;
+    const unsigned long long al = reinterpret_cast<unsigned long long>(chi) | reinterpret_cast<unsigned long long>(v) |
+                                  reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(v2);
+    if ((al & 15ull) == 0) {
+        const vec_t* xv = reinterpret_cast<const vec_t*>(chi);
+        const vec_t* wv = reinterpret_cast<const vec_t*>(v);
+        const vec_t* w2v = reinterpret_cast<const vec_t*>(v2);
+        vec_t* gv = reinterpret_cast<vec_t*>(g);
+        const long long nv = npts / NV;
+        auto one = [&](const vec_t& x, vec_t w, const vec_t& w2) {
+            vec_t r;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) r[e] = c2dV * x[e] * ((v2 ? w[e] + w2[e] : w[e]) - mu);
+            return r;
+        };
+        long long i = gid;
+        for (; i + stride < nv; i += 2 * stride) {
+            const vec_t x0 = xv[i], x1 = xv[i + stride], w0 = wv[i], w1 = wv[i + stride];
+            const vec_t u0 = v2 ? w2v[i] : w0, u1 = v2 ? w2v[i + stride] : w1;
+            gv[i] = one(x0, w0, u0);                 // (plain stores: the optimiser's sweeps read g next)
+            gv[i + stride] = one(x1, w1, u1);
         }
-        reinterpret_cast<cplx*>(g)[i] = mkc(c2dV * x.x * (w.x - mu), c2dV * x.y * (w.y - mu));
+        for (; i < nv; i += stride) {
+            const vec_t x0 = xv[i], w0 = wv[i];
+            const vec_t u0 = v2 ? w2v[i] : w0;
+            gv[i] = one(x0, w0, u0);
+        }
+        done = nv * NV;
     }
-    if ((npts & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-        g[npts - 1] = c2dV * chi[npts - 1] * (v[npts - 1] + (v2 ? v2[npts - 1] : (real)0.0) - mu);
+    for (long long i = done + gid; i < npts; i += stride) g[i] = c2dV * chi[i] * (v[i] + (v2 ? v2[i] : (real)0.0) - mu);
 }
 
 }  // namespace ofdft

@@ -50,8 +50,12 @@ int launch_zf_powers(ofdft_ctx* c, const DenSrc& ds, const PowersArgs& pa, hipSt
     case M_: {                                                                                                     \
         const int nb = z_blocks<M_, ZPick<M_, EZP>::E>(c) / nchunks;                                                \
         gz.blk0 = chunk * nb;                                                                                      \
-        OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZP>::E>), dim3(nb), dim3(256),           \
-                     (ZW<M_, ZPick<M_, EZP>::E>::LDS), ds, pa, gz, twM, twN);                                       \
+        if (pa.out[0] && !pa.out[1] && !pa.out[2] && !pa.out[3] && !pa.out[4] && !pa.out[5])                       \
+            OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZP>::E, true>), dim3(nb), dim3(256), \
+                         (ZW<M_, ZPick<M_, EZP>::E>::LDS), ds, pa, gz, twM, twN);                                   \
+        else                                                                                                       \
+            OFDFT_LAUNCH(c, st, "zf_powers", (zf_powers_kernel<M_, ZPick<M_, EZP>::E>), dim3(nb), dim3(256),       \
+                         (ZW<M_, ZPick<M_, EZP>::E>::LDS), ds, pa, gz, twM, twN);                                   \
         return 0;                                                                                                  \
     }
     switch (c->n2 / 2) { OFDFT_ZCASES(X) }

@@ -25,6 +25,9 @@ namespace ofdft {
 #ifndef OFDFT_Z_PREFETCH
 #define OFDFT_Z_PREFETCH 1     // depth-one software pipeline over the spectra a fused z kernel consumes (z_issue_row)
 #endif
+#ifndef OFDFT_Z_PIPE_BIG_F32
+#define OFDFT_Z_PIPE_BIG_F32 1  // fp32 build: the depth-one pipeline of zi_combine also for rows of 1024 points
+#endif
 #ifndef OFDFT_Z_LDS_TWIDDLES
 #define OFDFT_Z_LDS_TWIDDLES 1
 #endif
@@ -73,6 +76,13 @@ template <int M, int E_> struct ZW {
 template <int M, int E, int EMAX = OFDFT_Z_EMAX> constexpr int z_waves(int want) {
     if (sizeof(real) == 4 && OFDFT_Z_F32_BIG_WAVES && M >= 512 && E <= 8) return want > 2 ? 2 : want;
     return (M >= 512 || E > EMAX) ? (want > 2 ? 2 : 1) : want;
+}
+
+// zf_powers: the single-output form holds one row of points and its transform only
+template <int M, int E, bool ONE> constexpr int z_powers_waves() {
+    if (!ONE) return z_waves<M, E>(3);
+    if (M >= 512 || E > OFDFT_Z_EMAX) return (sizeof(real) == 4 && E <= 8) ? 4 : z_waves<M, E>(3);
+    return 4;
 }
 
 // lane geometry of the z kernels
@@ -490,8 +500,11 @@ struct PowersArgs {
     real e0, e1, nref;
     int sum53;       // e0 + e1 == 5/3: n^e1 = n^(5/3) / n^e0
 };
-template <int M, int E>
-__global__ __launch_bounds__(256, (z_waves<M, E>(3))) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
+// ONE: only out[0] is wanted (Wang-Teter with alpha = beta, BASELINE configs 2 and 5): n, its logarithm and the second half are
+// dead after the power is formed -- the general instantiation keeps them (176 VGPRs at 8 points per lane in the fp32 build, two
+// waves per SIMD; this one fits four)
+template <int M, int E, bool ONE = false>
+__global__ __launch_bounds__(256, (z_powers_waves<M, E, ONE>())) void zf_powers_kernel(DenSrc ds, PowersArgs pa, SpecGeom g,
                                                         const cplx* __restrict__ twM_g, const cplx* __restrict__ twN_g) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
@@ -510,6 +523,10 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(3))) void zf_powers_kernel(DenS
         n[q] = mkc(ds(n[q].x), ds(n[q].y));
         l[q] = mkc(fm::log(n[q].x), fm::log(n[q].y));
         a[q] = mkc(fm::exp(pa.e0 * l[q].x), fm::exp(pa.e0 * l[q].y));
+    }
+    if constexpr (ONE) {
+        z_forward_store<M, E>(a, z, pa.out[0], g, twM, twN);
+        return;
     }
     for (int half = 0; half < 2; ++half) {
         if (half == 1) {
@@ -853,7 +870,10 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     // present one before transforming its own (z_issue_row).
     // (not at M = 512 -- rows of 1024 -- where E = 8: the extra row would push the kernel past 256 registers, i.e. from
     // two waves per SIMD to one)
-    constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE && M < 512;
+    // (round 5: the fp32 build keeps the pipeline at M = 512 -- 8 more complex registers are 16 VGPRs there, the kernel stays
+    // at three waves per SIMD, and without it a wave had ONE row of ONE array in flight: 12 waves x 4 KB per CU against the
+    // ~40 KB a CU must keep in flight at 5 TB/s -- zi_combine at 1024-point rows ran at 0.33 of the peak)
+    constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE && (M < 512 || (sizeof(real) == 4 && OFDFT_Z_PIPE_BIG_F32));
     const bool gga = (a.mask & (7u << 10)) != 0;
     const cplx* chain[6] = {(a.mask & 2u) ? a.vh : nullptr,  (a.mask & 8u) ? a.lap : nullptr, (a.mask & 16u) ? a.conv_b : nullptr,
                             (a.mask & 16u) ? a.conv_a : nullptr, gga ? a.div : nullptr, gga ? a.div2 : nullptr};

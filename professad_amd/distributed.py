@@ -56,18 +56,39 @@ class SlabPlan:
         return full[self.x_range()]
 
 
+def _group_timeout():
+    """the timeout the default (world) process group was created with, or None when torch does not tell"""
+    try:
+        from torch.distributed.distributed_c10d import _get_default_group
+        pg = _get_default_group()
+        for attr in ('_timeout', 'timeout'):
+            t = getattr(pg, attr, None)
+            if t is not None:
+                return t() if callable(t) else t
+        opts = getattr(pg, 'options', None)
+        return getattr(opts, '_timeout', None)
+    except Exception:  # noqa: BLE001  (private API: absence is not an error)
+        return None
+
+
 class Comm:
     """The two collectives the path needs, over a torch.distributed group (or trivially for one rank).
 
-    The evaluation is two independent chains whose exchanges must not queue behind each other: a process group owns ONE
-    communicator (under nccl = RCCL: one internal stream per device), so asynchronous all-to-alls issued on the same group
-    execute in host-issue order, and chain 1's chunk would wait for chain 0's previously issued message -- which in turn
-    waits for chain 0's kernels.  `groups[c]` is therefore the group chain c's all-to-alls are issued on: two groups over
-    the same ranks (second communicator, second stream).  The small all-reduces stay on `groups[0]`.  Every rank issues
-    the exchanges of both groups in the same order (`_run_exchanges` is deterministic), which is what concurrent
-    communicators on one device require."""
+    The evaluation is two independent chains.  A process group owns ONE communicator (under nccl = RCCL: one internal
+    stream per device), so asynchronous all-to-alls issued on the same group execute in host-issue order, and chain 1's
+    chunk queues behind chain 0's previously issued message.  `groups[c]` is the group chain c's all-to-alls are issued
+    on.  DEFAULT: both chains on `group` -- the ordering every rank shares by construction.
+    A second communicator for chain 1 (own stream: its exchanges no longer queue behind chain 0's) is OPT-IN
+    (`chain1_group=` or OFDFT_COMM_TWO_GROUPS=1) until it has run on a multi-GPU node: two communicators on one device
+    are only safe when every rank's all-to-all kernels of BOTH can be resident at once.  If a compute stream of one chain
+    shares a hardware queue with the other chain's spinning all-to-all kernel on rank A while rank B is in the mirror
+    state, the ranks wait for each other forever (the runtime maps streams onto 4 hardware queues by default; a slab rank
+    has main + side + ipc + torch streams and one stream per communicator).  So the opt-in also REQUIRES
+    GPU_MAX_HW_QUEUES >= 8 in the environment before HIP initialises (checked here; bench.py sets it for its workers),
+    and every rank must issue the exchanges of both groups in the same order (`_run_exchanges` is deterministic).
+    The small all-reduces stay on `groups[0]`."""
 
-    def __init__(self, group=None, chain1_group=None):
+    def __init__(self, group=None, chain1_group=None, timeout=None):
         # (OFDFT_COMM_ONE_RANK=1: also route a ONE-rank group's exchanges through the backend -- on a one-GPU box that is the
         # only way to drive the whole staged evaluation through RCCL: tests/test_dist_gpu.py)
         import os
@@ -77,14 +98,25 @@ class Comm:
         self.nranks = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.backend = dist.get_backend(group) if self.active else None
-        # second group for chain 1.  `dist.new_group` is collective over the WORLD, so it is created here only when this
-        # Comm spans the world (every process constructs it); a caller that passes a sub-group creates the second group
-        # itself (all world ranks calling new_group) and hands it in as `chain1_group` -- else both chains share `group`.
+        # second group for chain 1 (opt-in, see above).  `dist.new_group` is collective over the WORLD, so it is created here
+        # only when this Comm spans the world (every process constructs it); a caller that passes a sub-group creates the
+        # second group itself (all world ranks calling new_group) and hands it in as `chain1_group`.
         self._own_group = None
-        if chain1_group is None and self.active and group is None and os.environ.get('OFDFT_COMM_ONE_GROUP') != '1':
-            chain1_group = self._own_group = dist.new_group(ranks=list(range(dist.get_world_size())), backend=self.backend)
+        want_two = os.environ.get('OFDFT_COMM_TWO_GROUPS') == '1' and os.environ.get('OFDFT_COMM_ONE_GROUP') != '1'
+        if (chain1_group is not None or want_two) and self.active and self.backend == 'nccl' and self.nranks > 1:
+            if int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) < 8:
+                raise RuntimeError('a second communicator for the nonlocal chain needs GPU_MAX_HW_QUEUES >= 8 in the environment '
+                                   'before HIP initialises (streams that share a hardware queue can deadlock two concurrent '
+                                   'all-to-alls across ranks); set it, or drop chain1_group / OFDFT_COMM_TWO_GROUPS')
+        if chain1_group is None and want_two and self.active and group is None:
+            kw = {}
+            if timeout is None:          # the world group's bound holds for chain 1 too (torch's default would be 10 minutes)
+                timeout = _group_timeout()
+            if timeout is not None:
+                kw['timeout'] = timeout
+            chain1_group = self._own_group = dist.new_group(ranks=list(range(dist.get_world_size())), backend=self.backend, **kw)
         self.groups = (group, chain1_group if chain1_group is not None else group)
-        self.issued = [0, 0]          # all-to-alls issued per chain group (tests assert the chains use different groups)
+        self.issued = [0, 0]          # all-to-alls issued per chain group (tests assert which groups the chains use)
 
     def close(self):
         """release the communicator this object created for chain 1 (every rank calls it, in the same order)"""
@@ -422,22 +454,33 @@ class DistEngine:
     """User-facing slab-decomposed engine: same `set_cell` / `set_terms` / `energy_grad_chi` / `energy_potential`
     as `Engine`, on this rank's slab."""
 
-    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective', xchg_chunks=None, chain1_group=None):
+    def __init__(self, shape, device, group=None, dtype=torch.double, transport='collective', xchg_chunks=None, chain1_group=None,
+                 timeout=None):
         """dtype=torch.float32 runs the slab-decomposed hot path on the fp32 build (half the bytes on every link);
         stress and ion forces are then formed by the fp64 routines on fp64 slabs.
         transport: 'collective' = the host issues an all-to-all per stage through torch.distributed (RCCL under nccl);
         'ipc' = the library maps the peers' buffers (hipIpc) and moves the spectra itself, one call per evaluation.
         xchg_chunks: kz chunks the exchange is pipelined by inside each chain (both transports; None = automatic, 1 = off).
-        chain1_group: second process group over the same ranks for the nonlocal chain's all-to-alls (see `Comm`; created
-        automatically when `group` is the world)."""
+        chain1_group: second process group over the same ranks for the nonlocal chain's all-to-alls (OPT-IN, see `Comm`:
+        needs GPU_MAX_HW_QUEUES >= 8; OFDFT_COMM_TWO_GROUPS=1 creates it when `group` is the world); timeout: of that group."""
         if transport not in ('collective', 'ipc'):
             raise ValueError("transport must be 'collective' or 'ipc'")
         self.transport = transport
-        self.comm = Comm(group, chain1_group)
-        self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
-        self.stages.enable_collectives(self.comm)
-        if xchg_chunks is not None:             # kz chunks of the exchange (None: the engine's automatic choice)
-            self.stages.set_xchg_chunks(xchg_chunks)
+        self.comm = Comm(group, chain1_group, timeout)
+        self.stages = None
+        try:
+            self.stages = HipStages(shape, device, nranks=self.comm.nranks, rank=self.comm.rank, dtype=dtype)
+            self.stages.enable_collectives(self.comm)
+            if xchg_chunks is not None:             # kz chunks of the exchange (None: the engine's automatic choice)
+                self.stages.set_xchg_chunks(xchg_chunks)
+        except BaseException:
+            # a failed set-up must not leak the communicator this object created (callers wrap the constructor in try / except
+            # and would never reach close(): one leaked group per attempt, asymmetric group bookkeeping between the ranks)
+            if self.stages is not None:
+                with contextlib.suppress(Exception):
+                    self.stages.close()
+            self.comm.close()
+            raise
         self.plan = self.stages.plan
         self.npts_global = int(np.prod(self.plan.shape))
         self._vol = None

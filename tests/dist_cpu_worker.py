@@ -37,9 +37,13 @@ def main():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
     vol, npts = abs(np.linalg.det(box)), int(np.prod(shape))
     E, mu, g = run_closure(st, comm, t(pl.scatter(chi)), n_elec, t(pl.scatter(vext)), vol, npts, torch.empty_like)
-    # the chains' exchanges go out on different process groups (one communicator each: under RCCL they do not queue
-    # behind each other), the same number per chain here: one per chunk in steps 1 (both chains) and 2 (chain 0)
-    assert comm.groups[0] is not comm.groups[1] and comm.groups[0] is None, comm.groups
+    # default: both chains on the world group (one communicator: the ordering every rank shares by construction); opt-in
+    # (OFDFT_COMM_TWO_GROUPS=1): the chains' exchanges go out on different process groups (under RCCL: one communicator and
+    # stream each).  Exchanges per chain here: one per chunk in steps 1 (both chains) and 2 (chain 0)
+    if os.environ.get('OFDFT_COMM_TWO_GROUPS') == '1':
+        assert comm.groups[0] is not comm.groups[1] and comm.groups[0] is None, comm.groups
+    else:
+        assert comm.groups[0] is comm.groups[1] and comm._own_group is None, comm.groups
     assert comm.issued == [2 * st.nchunks, st.nchunks] and st.chain1_ok == st.nchunks, (comm.issued, st.chain1_ok)
     E2, v = run_potential(st, comm, t(pl.scatter(den)), t(pl.scatter(vext)), vol, npts, torch.empty_like)
     gs = [torch.empty(pl.local_shape, dtype=torch.double) for _ in range(world)]
@@ -56,6 +60,7 @@ def main():
                    dE2=abs(sum(E2.values()) - Eo) / abs(Eo),
                    dv=float(np.abs(torch.cat(vs).numpy() - vo).max() / np.abs(vo).max()))
         json.dump(res, open(out, 'w'))
+    comm.close()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -24,10 +24,12 @@ def test_slab_plan_bookkeeping():
         SlabPlan((18, 32, 8), 4, 0)
 
 
-@pytest.mark.parametrize('world,shape,chunks', [(2, '8x12x10', 1), (4, '16x8x9', 1), (2, '8x12x10', 3), (4, '16x8x9', 4)])
-def test_multi_rank_host_logic_under_gloo(world, shape, chunks, tmp_path):
+@pytest.mark.parametrize('world,shape,chunks,two_groups', [(2, '8x12x10', 1, 0), (4, '16x8x9', 1, 1), (2, '8x12x10', 3, 1), (4, '16x8x9', 4, 0),
+                                                          (8, '16x8x9', 2, 0), (8, '8x16x6', 1, 1)])
+def test_multi_rank_host_logic_under_gloo(world, shape, chunks, two_groups, tmp_path):
     """chunks > 1: the exchange of every step travels as that many kz chunks, each its own all-to-all, consumed chunk by chunk
-    by the next step (the sequencing of professad_amd.distributed._run_exchanges)"""
+    by the next step (the sequencing of professad_amd.distributed._run_exchanges).  two_groups: the opt-in
+    second process group for the nonlocal chain (Comm).  world 8 = the node size of BASELINE configs 4 / 5."""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -35,7 +37,7 @@ def test_multi_rank_host_logic_under_gloo(world, shape, chunks, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   OMP_NUM_THREADS='1')
+                   OMP_NUM_THREADS='1', OFDFT_COMM_TWO_GROUPS=str(two_groups))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_cpu_worker.py'), shape, out, str(chunks)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=240)[0].decode(errors='replace')[-1500:] for p in procs]

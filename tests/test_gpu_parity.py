@@ -152,6 +152,30 @@ def test_big_scalars_match_reference_golden(fname):
         assert np.allclose(st['probes'], rec['pot']['probes'], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize('n', [64, 128, 256])
+def test_bench_workload_energy_mu_and_gradient_match_the_reference_pin(n):
+    """the TIMED workload of bench.py (its own input recipe) through the closure call: E, mu and chi.grad (L2 norm, sum, eight
+    probes) against the reference's closure on these inputs (tests/golden/bench_scalars.json; system.py:830-853); the same
+    check bench.py runs on its timed call (reference_check: exit code 3 on a mismatch)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    with open(os.path.join(GOLDEN, 'bench_scalars.json')) as fh:
+        ref = json.load(fh)['cfg3_%d' % n]
+    box, chi, vext, n_elec, _ = bench.make_inputs(n)
+    assert abs(cases.checksum(chi[:8, :8, :8], vext[:8, :8, :8]) - ref['input_checksum']) < 1e-12 and n_elec == ref['n_elec']
+    eng = Engine((n, n, n), DEV).set_cell(dev(box)).set_terms(bench.CFG3)
+    Et, mu, g = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+    st = bench.grad_stats(g)
+    chk = bench.reference_check(n, 'cfg3', 'f64', sum(Et.values()), mu, st)
+    assert chk['ok'] and chk['rel_dE'] < 1e-10 and chk['grad_rel_dl2'] < 1e-9 and chk['grad_probe_max_rel'] < 1e-9, chk
+    # a gradient that is off by 1e-6 of its scale does not pass
+    bad = dict(st, probes=[p * (1 + 1e-6) for p in st['probes']])
+    assert not bench.reference_check(n, 'cfg3', 'f64', sum(Et.values()), mu, bad)['ok']
+    eng.close()
+
+
 # ------------------------------------------------------------------------------- oracle on seeded inputs
 @pytest.mark.parametrize('shape,cell', [((64, 64, 64), ('cubic', 64)), ((32, 64, 16), ('tri', 1.3)),
                                         ((24, 20, 18), ('tri', 0.8)), ((33, 32, 31), ('cubic', 32))])

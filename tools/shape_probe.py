@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-kernel-class time per grid point for non-cubic shapes (which axis makes a pass slow?): cfg3 closure, streams serialised.
-usage: python tools/shape_probe.py [f32] [nomixed] 256x256x256 512x256x256 ...   -> one JSON line per shape
-(f32: the fp32 build; nomixed: OFDFT_OPT_MIXED_RADIX off = chirp-z transforms + unfused pipeline on extents with factors 3 / 5)"""
+usage: python tools/shape_probe.py [f32] [cfg2] [nomixed] 256x256x256 512x256x256 ...   -> one JSON line per shape
+(f32: the fp32 build; cfg2: the Wang-Teter + LDA term set of BASELINE configs 2 / 5 instead of the bench's;
+nomixed: OFDFT_OPT_MIXED_RADIX off = chirp-z transforms + unfused pipeline on extents with factors 3 / 5)"""
 import json
 import os
 import sys
@@ -13,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from professad_amd.engine import Engine  # noqa: E402
 
 CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c']
+if 'cfg2' in sys.argv[1:]:
+    CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c']
 DT = torch.float32 if 'f32' in sys.argv[1:] else torch.double
 NOMIXED = 'nomixed' in sys.argv[1:]
 for arg in [a for a in sys.argv[1:] if a[0].isdigit()]:
@@ -41,7 +44,7 @@ for arg in [a for a in sys.argv[1:] if a[0].isdigit()]:
         eng.energy_grad_chi(chi, nel, vext)
     prof = eng.profile()
     npts = float(np.prod(shape))
-    print(json.dumps({'shape': shape, 'dtype': str(DT), 'mixed_radix': not NOMIXED, 'ms': round(ms, 3), 'ns_per_point': round(ms * 1e6 / npts, 4),
+    print(json.dumps({'shape': shape, 'terms': 'cfg2' if 'cfg2' in sys.argv[1:] else 'cfg3', 'dtype': str(DT), 'mixed_radix': not NOMIXED, 'ms': round(ms, 3), 'ns_per_point': round(ms * 1e6 / npts, 4),
                       'ps_per_point': {k: round(v[0] / 3 * 1e9 / npts, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}), flush=True)
     eng.close()
     del chi, vext
