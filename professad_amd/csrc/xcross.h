@@ -68,12 +68,38 @@ template <int LEN> struct XcCfg {
     static constexpr int WREG = ((NL * WPT > WLB ? NL * WPT : WLB) + 15) / 16 * 16;
     static constexpr int XB = A * WREG;               // complex elements of a cross buffer (>= lines per tile x LEN)
     static_assert(S >= 16 && P <= 64 && E % A == 0 && (NL == 1 || NL == 2), "split");
-    static constexpr size_t LDS = sizeof(cplx) * (2 * XB + LEN + S);     // two cross buffers + W_LEN + W_S
+    // entries of W_LEN^m the cross step reads: m = a b' <= (A - 1)(S - 1)
+    static constexpr int TWN = ((A - 1) * (S - 1) + 1 + 15) / 16 * 16;
+    static_assert(TWN <= LEN, "table");
+    // cross buffers (two alternate, or ONE with a second barrier per step: xc_one_buffer) + W_LEN + W_S
+    static constexpr size_t lds_bytes(bool one) { return sizeof(cplx) * ((one ? 1 : 2) * XB + TWN + S); }
+    static constexpr size_t LDS = lds_bytes(false);
 };
+// One cross buffer instead of two (round 5).  Two buffers let step n + 1 write while stragglers still read step n's -- one
+// barrier per step -- but they set the workgroup's LDS footprint, and with it how many workgroups a CU holds: at 1024-point
+// lines in the fp32 build (config 5) 157 KB, ONE 8-wave workgroup per CU, whose waves load, transform and store in lock step,
+// so nothing is in flight while it computes: the 1 -> 1 passes ran at 0.31 of the peak (13.6 us per 128-KB tile, where its loads,
+// its 1.7 us of arithmetic and its stores in sequence take about that long).  With one buffer (a second barrier per step) two
+// workgroups fit (80 KB each at 1024 points, exactly) and one's memory phases overlap the other's arithmetic.
+// Measured (tools/ab_onebuf.sh, one box, ps per grid point, two alternations; profiles/r05_onebuf_ab.jsonl): 1 -> 1 passes at 1024-point
+// lines fp32 3.1 -> 2.0-2.2 (the Lindhard mix 3.9 -> 2.6), at 512 points fp64 4.1-4.4 -> 3.5, at 256 points 3.7 -> 3.6; 1 -> 2 at
+// 512 points 6.1 -> 5.7, neutral at 256.  Compiled for four waves per SIMD the WGC99 pass (3 -> 3) spills: 24 -> 55 ps -- it keeps
+// two buffers unless OFDFT_XC_ONEBUF=2, which leaves its register budget alone.
+// OFDFT_XC_ONEBUF: 0 = never, 1 = passes over at most three spectra (1 -> 1, 1 -> 2, 2 -> 1), 2 = every pass
+#ifndef OFDFT_XC_ONEBUF
+#define OFDFT_XC_ONEBUF 1
+#endif
+template <int LEN, int NIN, int NOUT> constexpr bool xc_one_buffer() {
+    return OFDFT_XC_ONEBUF == 2 || (OFDFT_XC_ONEBUF == 1 && NIN + NOUT <= 3);
+}
 
 #ifndef OFDFT_XC_WAVES
 #define OFDFT_XC_WAVES 2
 #endif
+// waves per SIMD the kernel is compiled for: with one cross buffer twice the workgroups fit the LDS
+template <int LEN, int NIN, int NOUT> constexpr int xc_waves() {
+    return (xc_one_buffer<LEN, NIN, NOUT>() && NIN + NOUT <= 3 && OFDFT_XC_WAVES < 4) ? 2 * OFDFT_XC_WAVES : OFDFT_XC_WAVES;
+}
 // cache policy of the data loads: a tile of whole 128-byte runs is read once by ONE wave -> nt (256^3: the WGC99 pair 452 -> 405 us);
 // narrower tiles (64-byte runs: the partner workgroup reads the other half of every cache line) keep the lines cached
 // (512^3 with A = 4: nt 4.95 -> 5.26 ms)
@@ -112,7 +138,7 @@ template <int NL, int AUX> __device__ __forceinline__ void buf_store_cn(cplx* ub
 }
 
 template <int LEN, int NIN, int NOUT, class Mix>
-__global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfIo io, LineMap m_main, LineMap m_rem, int main_blocks,
+__global__ __launch_bounds__(XcCfg<LEN>::TPB, (xc_waves<LEN, NIN, NOUT>())) void xc_kernel(XfIo io, LineMap m_main, LineMap m_rem, int main_blocks,
                                                                               SpecGeom g, const cplx* __restrict__ tw_g, Mix mix,
                                                                               XfStride xs) {
     using Cfg = XcCfg<LEN>;
@@ -120,9 +146,10 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
                   TPB = Cfg::TPB, WREG = Cfg::WREG, WPT = Cfg::WPT, NL = Cfg::NL, G = NIN > NOUT ? NIN : NOUT;
     constexpr int LDA = (LPB * sizeof(cplx) >= 128) ? OFDFT_XC_LD_AUX : 0;
     extern __shared__ __attribute__((aligned(16))) real lds[];
+    constexpr bool ONEBUF = xc_one_buffer<LEN, NIN, NOUT>();
     cplx* xb = reinterpret_cast<cplx*>(lds);
-    cplx* twN = xb + 2 * Cfg::XB;         // W_LEN^m
-    cplx* twS = twN + LEN;                // W_S^m = W_LEN^(A m)
+    cplx* twN = xb + (ONEBUF ? 1 : 2) * Cfg::XB;         // W_LEN^m, m < TWN
+    cplx* twS = twN + Cfg::TWN;           // W_S^m = W_LEN^(A m)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int a = __builtin_amdgcn_readfirstlane(t >> 6);       // residue class of this wave
@@ -130,12 +157,12 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
     const int j = lane / LPWV;            // b = j + P q in the load / store phases
     const int J = t / LPWV;               // k = J + PP m in the mix phase (J = a P + j)
     // ---- twiddle tables: requested now, written to LDS after the data loads have been issued
-    constexpr int TWC = (LEN + TPB - 1) / TPB;
+    constexpr int TWC = (Cfg::TWN + TPB - 1) / TPB;
     cplx twr[TWC];
 #pragma unroll
     for (int c = 0; c < TWC; ++c) {
         const int i = t + c * TPB;
-        twr[c] = tw_g[i < LEN ? i : 0];
+        twr[c] = tw_g[i < Cfg::TWN ? i : 0];
     }
     const cplx tws = tw_g[(t < S ? t : 0) * A];
     const bool is_rem = (int)blockIdx.x >= main_blocks;    // one grid: the block-8 main part, then the remainder planes
@@ -205,14 +232,15 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
 #pragma unroll
     for (int c = 0; c < TWC; ++c) {
         const int i = t + c * TPB;
-        if (i < LEN) twN[i] = twr[c];
+        if (i < Cfg::TWN) twN[i] = twr[c];
     }
     if (t < S) twS[t] = tws;
     __syncthreads();
     const int lx = (l * XwSwz<S>::LMUL) & 31;       // line-dependent part of the wave-local LDS swizzle
     static_for<NIN>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        cplx* buf = xb + (I & 1) * Cfg::XB;
+        cplx* buf = ONEBUF ? xb : xb + (I & 1) * Cfg::XB;
+        if constexpr (ONEBUF && I > 0) __syncthreads();      // the previous step's cross reads are done: the buffer is free again
 #pragma unroll
         for (int nl = 0; nl < NL; ++nl) {
             real* mine = reinterpret_cast<real*>(buf + a * WREG) + (nl * LPWV + l) * Cfg::RS;
@@ -254,7 +282,8 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, OFDFT_XC_WAVES) void xc_kernel(XfI
         }
     static_for<NOUT>([&](auto oc) {
         constexpr int O = decltype(oc)::value;
-        cplx* buf = xb + ((NIN + O) & 1) * Cfg::XB;
+        cplx* buf = ONEBUF ? xb : xb + ((NIN + O) & 1) * Cfg::XB;
+        if constexpr (ONEBUF) __syncthreads();      // everybody is through with the buffer's previous contents (cross reads / line buffers)
 #pragma unroll
         for (int nl = 0; nl < NL; ++nl)
 #pragma unroll

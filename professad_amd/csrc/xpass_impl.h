@@ -115,16 +115,17 @@ int launch_xc_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
     }
     main.blk0 = line0 / Cfg::LPB;
     const int mb = (main.nlines - line0 + Cfg::LPB - 1) / Cfg::LPB, rb = (rem.nlines + Cfg::LPB - 1) / Cfg::LPB;
-    if constexpr (Cfg::LDS > 64 * 1024) {          // more dynamic LDS than the default limit: declared once per kernel and device
+    constexpr size_t lds = Cfg::lds_bytes(xc_one_buffer<LEN, NIN, NOUT>());
+    if constexpr (lds > 64 * 1024) {          // more dynamic LDS than the default limit: declared once per kernel and device
         static bool declared[64] = {};
         const int dv = c->device & 63;
         if (!declared[dv]) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&xc_kernel<LEN, NIN, NOUT, Mix>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             declared[dv] = true;
         }
     }
-    OFDFT_LAUNCH(c, st, nm, (xc_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), Cfg::LDS, io, main, rem, mb, gk,
+    OFDFT_LAUNCH(c, st, nm, (xc_kernel<LEN, NIN, NOUT, Mix>), dim3(mb + rb), dim3(Cfg::TPB), lds, io, main, rem, mb, gk,
                  (const cplx*)tw, mix, XfStride{lay.se_out, lay.tse});
     return 0;
 }
