@@ -124,6 +124,16 @@ template <class T> struct Roots {
     T n13;      // n^(1/3)
     T inv_n;    // 1 / n
 };
+// ... from an n^(-1/6) the caller already holds (kernels that need the roots in several places form y once per point)
+template <class T> __device__ __forceinline__ Roots<T> roots_from_y(T n, T y) {
+    Roots<T> r;
+    r.y = y;
+    r.inv13 = y * y;
+    const T y4 = r.inv13 * r.inv13;
+    r.n13 = n * y4;
+    r.inv_n = y4 * r.inv13;
+    return r;
+}
 __device__ __forceinline__ Roots<double> roots(double n) {
     Roots<double> r;
     r.y = rsixth(n);

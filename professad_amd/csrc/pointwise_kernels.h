@@ -13,7 +13,9 @@ namespace ofdft {
 // floating literals (-cl-single-precision-constant): long-double literal / integer operands
 constexpr double kPi = (double)3.14159265358979323846264338327950288L;
 constexpr double kFiveThirds = (double)5 / 3, kFiveSixths = (double)5 / 6;
-constexpr real kPiR = (real)kPi;      // pi in the grid precision (device math on `real` operands)
+constexpr real kPiR = (real)kPi;
+      // pi in the grid precision (device math on `real` operands)
+constexpr real kThird = (real)(1.0L / 3.0L);      // (x / 3 as a product: the quotient by a literal is a full IEEE division sequence on the device)
 // Roots and logarithms of constants, spelled out: the device compiler does NOT fold cbrt() / log() / sqrt() of a literal
 // (they are library routines there), so `cbrt(3.0 / kPiR)` inside a pointwise function was evaluated at every grid point
 // -- 4 cube roots, a logarithm, a square root and 2 quotients per PBE point, about 300 of its 650 instructions.
@@ -613,9 +615,8 @@ __device__ __forceinline__ void pw92_roots(real sr, real isr, real& eps, real& d
 struct XcLocal { real ex, vx, ec, vc; };   // energy densities (per volume) and potentials
 
 // LDA exchange + one of PZ / PW / Chachiyo correlation (functionals.py:1510-1537; tools_for_tests.py:121-152)
-__device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
+__device__ __forceinline__ XcLocal lda_point(real n, unsigned mask, const fm::Roots<real>& q) {
     XcLocal r = {0.0, 0.0, 0.0, 0.0};
-    const fm::Roots<real> q = fm::roots(n);
     const real n13 = q.n13;
     if (mask & (1u << 6)) {
         r.ex = kCx * n13 * n;
@@ -629,7 +630,7 @@ __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
             if (rs < 1.0) {
                 const real lr = fm::log(rs);
                 eps = A * lr + B + C * rs * lr + D * rs;
-                v = lr * (A + (2.0 / 3.0) * C * rs) + (B - A / 3.0) + rs / 3.0 * (2.0 * D - C);
+                v = lr * (A + (2.0 / 3.0) * C * rs) + (B - A / 3.0) + rs * ((2.0 * D - C) / 3.0);
             } else {
                 const real sr = kSqrtCrs * q.y, iden = fm::rcp(1.0 + b1 * sr + b2 * rs);
                 eps = gm * iden;
@@ -642,7 +643,7 @@ __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
             real eps, d;
             pw92_roots(kSqrtCrs * q.y, kInvSqrtCrs * (n * q.inv13 * q.inv13 * q.y), eps, d);
             r.ec += eps * n;
-            r.vc += eps - rs / 3.0 * d;
+            r.vc += eps - rs * kThird * d;
         }
         if (mask & (1u << 9)) {
             const real a = (kLn2 - 1.0) / (2.0 * kPiR * kPiR), b = 20.4562557;
@@ -651,11 +652,13 @@ __device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) {
             const real eps = a * fm::log(arg);
             const real d = a * fm::rcp(arg) * (-b * irs * irs - 2.0 * b * irs * irs * irs);
             r.ec += eps * n;
-            r.vc += eps - rs / 3.0 * d;
+            r.vc += eps - rs * kThird * d;
         }
     }
     return r;
 }
+
+__device__ __forceinline__ XcLocal lda_point(real n, unsigned mask) { return lda_point(n, mask, fm::roots(n)); }
 
 struct PbePoint { real fx, fc, fk, dfdn, dfdg; };
 // which GGA pieces a pass evaluates: PBE exchange / correlation, and the Pauli part of a GGA kinetic functional

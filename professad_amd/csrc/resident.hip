@@ -90,7 +90,7 @@ template <int N> struct ResCfg {
     static constexpr int lo(int a, int b) { return a < b ? a : b; }
     static constexpr int ROWS = lo(T / PZ, up(AG * N, RPWV));    // row slots of a pass (whole waves)
     static constexpr int LINES = lo(T / PL, up(4 * NZH, LPWV));  // line slots of a pass
-    static constexpr int RSZ = (kZCX ? 2 : 1) * line_stride<ZPlan<M, EZ>>();     // reals per z-row buffer (layout of that plan; the z helpers of the fp32 build exchange complex elements)
+    static constexpr int RSZ = (z_cx<EZ>() ? 2 : 1) * line_stride<ZPlan<M, EZ>>();     // reals per z-row buffer (layout of that plan; the z helpers of the fp32 build exchange complex elements)
     static constexpr int RB_Z = ROWS * RSZ, RB_L = LINES * LineBuf<N>::STRIDE;
     static constexpr int RB = RB_Z > RB_L ? RB_Z : RB_L;         // reals of the row / line exchange buffers
     static constexpr size_t LDS_FFT = sizeof(real) * RB + sizeof(cplx) * (M + N) + sizeof(cplx) * AG * N * PS;

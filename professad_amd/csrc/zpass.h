@@ -28,6 +28,9 @@ namespace ofdft {
 #ifndef OFDFT_Z_PIPE_BIG_F32
 #define OFDFT_Z_PIPE_BIG_F32 1  // fp32 build: the depth-one pipeline of zi_combine also for rows of 1024 points
 #endif
+#ifndef OFDFT_ZI_ROOTS_ONCE
+#define OFDFT_ZI_ROOTS_ONCE 0   // zi_combine: n^(-1/6) of every point kept in registers for all sections (1) or formed per section (0)
+#endif
 #ifndef OFDFT_Z_LDS_TWIDDLES
 #define OFDFT_Z_LDS_TWIDDLES 1
 #endif
@@ -38,7 +41,10 @@ namespace ofdft {
 #ifndef OFDFT_Z_CX
 #define OFDFT_Z_CX 0
 #endif
-constexpr bool kZCX = OFDFT_Z_CX && kCX;
+
+// OFDFT_Z_CX=2: only the rows with 8 points per lane (radix-8 plans in the padded layout: 31-45 % of their LDS cycles are bank
+// conflicts with 4-byte accesses, profiles/r05_sq_counters_1024_f32_cfg2_before.md) exchange whole complex numbers
+template <int E> constexpr bool z_cx() { return kCX && (OFDFT_Z_CX == 1 || (OFDFT_Z_CX == 2 && E == 8)); }
 template <int M, int E_> struct ZW {
     using PL = ZPlan<M, E_>;
     static constexpr int E = E_;
@@ -47,7 +53,7 @@ template <int M, int E_> struct ZW {
     static constexpr int TPB = 256;
     static constexpr int RPB = RPWV * (TPB / 64);   // rows per block
     // LDS reals per row (fp32 build, OFDFT_Z_CX: the row transforms exchange whole complex numbers -- twice the reals per row)
-    static constexpr int RS = (OFDFT_Z_CX ? kCXMul : 1) * line_stride<PL>();
+    static constexpr int RS = (z_cx<E_>() ? kCXMul : 1) * line_stride<PL>();
     static constexpr int ROWS = RPB * RS;           // reals of the row buffers; the staged twiddle tables follow them
 #if OFDFT_Z_LDS_TWIDDLES
     static constexpr size_t LDS = sizeof(real) * ROWS + sizeof(cplx) * 2 * M;
@@ -210,7 +216,7 @@ __device__ __forceinline__ void z_forward_store(cplx (&v)[E], const ZLane<M, E>&
     using W = ZW<M, E>;
     using PL = typename W::PL;
     constexpr int P = W::P;
-    wave_line_fft<M, E, false, TT, kZCX>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT, z_cx<E>()>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
     if constexpr (PL::EXACT) {
@@ -294,7 +300,7 @@ __device__ __forceinline__ void z_forward_regs(cplx (&v)[E], const ZLane<M, E>& 
                                                const cplx* __restrict__ twN, real& nyq) {
     using W = ZW<M, E>;
     using PL = typename W::PL;
-    wave_line_fft<M, E, false, TT, kZCX>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, false, TT, z_cx<E>()>(v, z.j, z.mine, twM);
     real cr_m[E], c0r;
     exchange_sync<true>();
 #pragma unroll
@@ -358,7 +364,7 @@ __device__ __forceinline__ void z_inverse_regs(cplx (&v)[E], const ZLane<M, E>& 
         }
     }
     exchange_sync<true>();
-    wave_line_fft<M, E, true, TT, kZCX>(v, z.j, z.mine, twM);
+    wave_line_fft<M, E, true, TT, z_cx<E>()>(v, z.j, z.mine, twM);
     exchange_sync<true>();
     if constexpr (!PL::EXACT) {      // slots no butterfly of the last stage wrote: keep them out of every sum downstream
 #pragma unroll
@@ -865,6 +871,27 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     }
     const real sc = a.inv_n;
     const real w_tf = a.wts_w ? (real)a.wts_w[0] : (real)1.0, w_nl = a.wts_w ? (real)a.wts_w[1] : (real)1.0;
+    // ONE n^(-1/6) per point serves every section below (round 5): the vW, Wang-Teter (alpha = 5/6), Thomas-Fermi and local-XC
+    // sections each formed it again -- four times per point in BASELINE configs 2 / 5, a fifth of the kernel's vector instructions
+    // at 1024-point rows, where it is bound by their issue (3 250 per wave: 5.4 of its 8.0 ms at 1024^3).  n == 0 -> 0: the
+    // guard of functionals.py:242-243 (sqrt n and 1 / sqrt n both read as 0 there)
+    constexpr unsigned kRootTerms = 4u | 8u | 16u | (0xFu << 6) | (1u << 13);
+    constexpr bool ROOTS_ONCE = OFDFT_ZI_ROOTS_ONCE != 0;
+    cplx yv[ROOTS_ONCE ? E : 1];
+    if constexpr (ROOTS_ONCE) {
+        if (a.mask & kRootTerms) {
+#pragma unroll
+            for (int q = 0; q < E; ++q)
+                yv[q] = mkc(n[q].x != 0.0 ? fm::rsixth(n[q].x) : (real)0.0, n[q].y != 0.0 ? fm::rsixth(n[q].y) : (real)0.0);
+        }
+    }
+    auto root_y = [&](int q, int c) -> real {          // n^(-1/6) of point (q, c); 0 for n == 0
+        if constexpr (ROOTS_ONCE) return c ? yv[q].y : yv[q].x;
+        else {
+            const real nn = c ? n[q].y : n[q].x;
+            return nn != 0.0 ? fm::rsixth(nn) : (real)0.0;
+        }
+    };
     // Depth-one software pipeline over the spectra this kernel consumes (lean instantiation): chain[i] = the i-th
     // spectrum or null; a section takes its row from the registers filled one section earlier and requests the next
     // present one before transforming its own (z_issue_row).
@@ -920,7 +947,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
             __builtin_amdgcn_sched_barrier(0);
             const real x0 = w[q].x * sc, x1 = w[q].y * sc;
             // sqrt(n) = n y^3 and 1 / sqrt(n) = y^3 with y = n^(-1/6) (one root, no quotient); n == 0 -> 0 (functionals.py:242-243)
-            const real y0 = n[q].x != 0.0 ? fm::roots(n[q].x).y : 0.0, y1 = n[q].y != 0.0 ? fm::roots(n[q].y).y : 0.0;
+            const real y0 = root_y(q, 0), y1 = root_y(q, 1);
             const real r0 = y0 * y0 * y0, r1 = y1 * y1 * y1;
             e += -0.5 * (n[q].x * r0 * x0 + n[q].y * r1 * x1);
             vacc[q].x += -0.5 * x0 * r0;
@@ -936,8 +963,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
         for (int q = 0; q < E; ++q) {
             __builtin_amdgcn_sched_barrier(0);
             const real x0 = w[q].x * sc, x1 = w[q].y * sc;
-            pa1[q] = a.wt_is_56 ? mkc(fm::roots(n[q].x).y, fm::roots(n[q].y).y)
-                                : mkc(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
+            pa1[q] = a.wt_is_56 ? mkc(root_y(q, 0), root_y(q, 1)) : mkc(pow_pos(n[q].x, a.wt_alpha - 1.0), pow_pos(n[q].y, a.wt_alpha - 1.0));
             e += ctf * ((pa1[q].x * n[q].x - a.wt_nbar_pa) * x0 + (pa1[q].y * n[q].y - a.wt_nbar_pa) * x1);
             const real f = w_nl * (a.conv_a ? a.wt_alpha : 2.0 * a.wt_alpha);
             vacc[q].x += ctf * f * pa1[q].x * x0;
@@ -1003,22 +1029,24 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     for (int q = 0; q < E; ++q) {
         __builtin_amdgcn_sched_barrier(0);
         if (!(PL::slot_out(q) && PL::lane_out(z.j, q))) continue;      // (rows with factors 3 / 5: slots without a grid point)
+        // (the local sections of a point share one root in either form)
+        const fm::Roots<real> rt0 = fm::roots_from_y(n[q].x, root_y(q, 0)), rt1 = fm::roots_from_y(n[q].y, root_y(q, 1));
         if (a.mask & 4u) {                               // TF  functionals.py:223
-            const real c0 = fm::roots(n[q].x).n13, c1 = fm::roots(n[q].y).n13;
+            const real c0 = rt0.n13, c1 = rt1.n13;
             acc[2] += ctf * (c0 * c0 * n[q].x + c1 * c1 * n[q].y);
             vacc[q].x += w_tf * (5.0 / 3.0) * ctf * c0 * c0;
             vacc[q].y += w_tf * (5.0 / 3.0) * ctf * c1 * c1;
         }
         if (a.mask & (1u << 13)) {                       // vWGTF1 / 2  functionals.py:251-306
             real e0, v0, e1, v1;
-            vwgtf_point(n[q].x, fm::roots(n[q].x).n13, ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
-            vwgtf_point(n[q].y, fm::roots(n[q].y).n13, ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
+            vwgtf_point(n[q].x, rt0.n13, ctf, a.gtf_inv_n0, a.gtf_kind, e0, v0);
+            vwgtf_point(n[q].y, rt1.n13, ctf, a.gtf_inv_n0, a.gtf_kind, e1, v1);
             acc[9] += e0 + e1;
             vacc[q].x += v0;
             vacc[q].y += v1;
         }
         if (a.mask & (0xFu << 6)) {                      // local XC
-            const XcLocal x0 = lda_point(n[q].x, a.mask), x1 = lda_point(n[q].y, a.mask);
+            const XcLocal x0 = lda_point(n[q].x, a.mask, rt0), x1 = lda_point(n[q].y, a.mask, rt1);
             acc[6] += x0.ex + x1.ex;
             acc[7] += x0.ec + x1.ec;
             vacc[q].x += x0.vx + x0.vc;
