@@ -31,6 +31,7 @@ from professad_amd.engine import Engine  # noqa: E402
 from professad_amd.distributed import DistEngine  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+XGMI_GBS_PER_LINK_DIRECTION = 76.8      # xGMI is point-to-point, 7 links x ~153.6 GB/s (both directions together) per GPU
 CFG3 = ['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c']
 CFG2 = ['ion_electron', 'hartree', 'tf', 'vw', 'wt_nl', 'lda_x', 'pz_c']
 
@@ -260,6 +261,22 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
         fence()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.double, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if 'compute_only_ms' not in out:
+            # a rank's LOCAL wall time per evaluation (kernels, launches, both streams, the small all-reduces; the all-to-alls
+            # skipped): the floor the exchange adds to -- measured here, on this node, not taken from a one-GPU emulation
+            try:
+                for _ in range(2):
+                    eng.compute_only(chi, nel, vext)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    eng.compute_only(chi, nel, vext)
+                fence()
+                tc = torch.tensor([time.perf_counter() - t1], dtype=torch.double, device=device if backend == 'nccl' else 'cpu')
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+                out['compute_only_ms'] = round(float(tc.item()) / steps * 1e3, 4)
+            except Exception as e:  # noqa: BLE001
+                out.setdefault('errors', {})['compute_only'] = repr(e)[:300]
         out['ms_Ngpu'][tr] = round(float(tt[0]) / steps * 1e3, 4)
         out['xchg_chunks'] = eng.stages.nchunks
         out['rel_dE_vs_8x_256'] = abs(sum(E.values()) - 8.0 * E256) / abs(8.0 * E256)
@@ -295,6 +312,14 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
         per_link = 19 * (Cc / world) / world                       # bytes one rank sends to ONE peer per evaluation (19 spectra)
         out['MB_per_link_per_eval'] = round(per_link / 1e6, 1)
         out['GBs_per_link_direction'] = {tr: round(per_link / (ms * 1e-3) / 1e9, 1) for tr, ms in out['ms_Ngpu'].items()}
+        # what this decomposition CAN give on this node: a rank cannot finish before its own kernels (compute_only_ms, measured
+        # above) nor before its bytes have crossed its slowest link (xGMI: 7 links x ~153.6 GB/s bidirectional = ~76.8 GB/s per
+        # link and direction) -- with perfect overlap the evaluation takes the larger of the two
+        link_ms = per_link / XGMI_GBS_PER_LINK_DIRECTION / 1e6
+        out['bound'] = {'link_ms_at_%.1f_GBs_per_link_direction' % XGMI_GBS_PER_LINK_DIRECTION: round(link_ms, 3),
+                        'compute_only_ms': out.get('compute_only_ms'),
+                        'expected_speedup_at_most': round(out['ms_1gpu'] / max(link_ms, out.get('compute_only_ms') or 0.0), 2),
+                        'binding': 'links' if link_ms > (out.get('compute_only_ms') or 0.0) else 'kernels'}
         out['target'] = 'north star: >= 6x at 8 GPUs'
     return out
 

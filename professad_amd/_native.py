@@ -41,7 +41,7 @@ OPT_BS_FUSED = 15
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',
            'ofdft_create_dist', 'ofdft_dist_sumsq', 'ofdft_dist_begin', 'ofdft_dist_stage', 'ofdft_dist_step', 'ofdft_dist_finish', 'ofdft_dist_scalars',
-           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ipc_export', 'ofdft_ipc_attach', 'ofdft_dist_closure', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_direction', 'ofdft_lbfgs_abs_step', 'ofdft_lbfgs_dots',
+           'ofdft_dist_energies', 'ofdft_dist_chi_grad', 'ofdft_ipc_export', 'ofdft_ipc_attach', 'ofdft_ipc_detach', 'ofdft_dist_closure', 'ofdft_ionic_potential', 'ofdft_ion_electron_forces', 'ofdft_stress', 'ofdft_ion_electron_stress', 'ofdft_ion_ion', 'ofdft_lbfgs_create', 'ofdft_lbfgs_destroy', 'ofdft_lbfgs_last_error', 'ofdft_lbfgs_reset', 'ofdft_lbfgs_direction', 'ofdft_lbfgs_abs_step', 'ofdft_lbfgs_dots',
            'ofdft_lbfgs_commit', 'ofdft_lbfgs_update', 'ofdft_set_option', 'ofdft_set_collectives', 'ofdft_set_profiling', 'ofdft_profile_count', 'ofdft_profile_get']
 
 
@@ -122,6 +122,8 @@ def load(dtype=F64):
     lib.ofdft_ipc_export.restype = ip
     lib.ofdft_ipc_attach.argtypes = [vp, ip, vp, C.POINTER(C.c_ulonglong)]
     lib.ofdft_ipc_attach.restype = ip
+    lib.ofdft_ipc_detach.argtypes = [vp]
+    lib.ofdft_ipc_detach.restype = ip
     lib.ofdft_dist_closure.argtypes = [vp, vp, vp, C.c_double, dp, dp, vp, vp, vp]
     lib.ofdft_dist_closure.restype = ip
     lib.ofdft_ionic_potential.argtypes = [vp, dp, ip, dp, dp, ip, C.c_double, ip, vp, ip, vp]

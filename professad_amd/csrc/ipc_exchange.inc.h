@@ -208,8 +208,15 @@ int ipc_arena(ofdft_ctx* c) {
     }
     if (s->arena) HIP_TRY(c, hipFree(s->arena));
     s->arena = nullptr;
-    const size_t need[5] = {dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 1), dist_buffer_bytes(c, 1),
-                            kIpcMailboxBytes};
+    // Sized ONCE for the largest term set the chains can carry (chain 0: Hartree + three gradient components + the Laplacian
+    // pair + vW = 6 spectra, chain 1: two Wang-Teter powers + six WGC99 spectra = 8; dist_buffer_bytes) -- not for the active one:
+    // a later ofdft_set_terms then never rebuilds the arena.  Rebuilding meant freeing device memory that the peer processes
+    // still had open through hipIpc and opening the replacement right after: one run in ~10 of four ranks failed there
+    // ("hipIpcOpenMemHandle: invalid device pointer"), and closing the peers' mappings first made the re-opened ones stale
+    // (deliveries that never arrived) -- round 5.  An arena is now opened once per peer and closed when the context dies.
+    const size_t unit = sizeof(cplx) * (size_t)c->g.total;
+    const size_t need[5] = {std::max(dist_buffer_bytes(c, 0), 6 * unit), std::max(dist_buffer_bytes(c, 0), 6 * unit),
+                            std::max(dist_buffer_bytes(c, 1), 8 * unit), std::max(dist_buffer_bytes(c, 1), 8 * unit), kIpcMailboxBytes};
     size_t tot = 0;
     for (int w = 0; w < 5; ++w) {
         s->off[w] = tot;
@@ -349,6 +356,29 @@ int ofdft_ipc_attach(ofdft_ctx* c, int peer, const void* handle64, const unsigne
         HIP_TRY(c, hipDeviceSynchronize());
     }
     for (int w = 0; w < 5; ++w) s->peer[w][peer] = (char*)s->peer_base[peer] + offsets5[w];
+    return OFDFT_OK;
+}
+
+// close every peer mapping (first step of a new export / attach round, before any rank frees its arena: include/ofdft_hip.h)
+int ofdft_ipc_detach(ofdft_ctx* c) {
+    if (!c) return OFDFT_EINVAL;
+    ofdft_ipc_state* s = c->ipc;
+    if (!s) return OFDFT_OK;
+    OFDFT_ON_DEVICE(c, c->device);
+    HIP_TRY(c, hipDeviceSynchronize());           // nothing of this rank's may still be storing through the mappings
+    for (int p = 0; p < 16; ++p) {
+        if (p == s->me) continue;
+        for (int w = 0; w < 5; ++w) s->peer[w][p] = nullptr;
+        if (s->peer_base[p]) {
+            const hipError_t e = hipIpcCloseMemHandle(s->peer_base[p]);
+            s->peer_base[p] = nullptr;
+            std::memset(&s->peer_handle[p], 0, sizeof(s->peer_handle[p]));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, OFDFT_EHIP, "ipc transport: closing the mapping of rank %d failed: %s", p, hipGetErrorString(e));
+            }
+        }
+    }
     return OFDFT_OK;
 }
 

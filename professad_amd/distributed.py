@@ -174,6 +174,25 @@ class Comm:
             return None
 
 
+class _NoExchange:
+    """Timing aid (bench.py: scale_512.compute_only_ms): a view of a `Comm` whose all-to-alls move nothing -- the ranks' kernels, the
+    step sequence, both streams and the small all-reduces run as in a real evaluation, on whatever the receive buffers hold.  What
+    it times is a rank's LOCAL wall time per evaluation: the floor the exchange adds to.  The numbers it produces mean nothing."""
+
+    def __init__(self, comm):
+        self._c = comm
+        self.active, self.nranks, self.rank, self.backend, self.group = comm.active, comm.nranks, comm.rank, comm.backend, comm.group
+
+    def all_reduce_sum(self, vec, device):
+        return self._c.all_reduce_sum(vec, device)
+
+    def all_reduce_dev(self, t):
+        return self._c.all_reduce_dev(t)
+
+    def all_to_all(self, send_t, recv_t, chain=0):
+        return None
+
+
 class _RawDeviceBuffer:
     """Zero-copy view of engine-owned device memory for torch (``__cuda_array_interface__``)."""
 
@@ -271,6 +290,7 @@ class HipStages(Engine):
         if not agree(err is None):        # (also the barrier: nobody starts writing before everybody has mapped)
             raise RuntimeError('ipc transport: mapping the peers\' buffers failed on some rank (%r here)' % (err,))
         self._ipc_terms = self._terms_key
+        self._ipc_attached = True        # (DistEngine.close: peers hold this rank's arena open)
         return True
 
     def closure_ipc(self, chi, n_elec, vext):
@@ -505,6 +525,12 @@ class DistEngine:
             return self.stages.closure_ipc(chi, n_elec, vext)
         return run_closure(self.stages, self.comm, chi, n_elec, vext, self._vol, self.npts_global, torch.empty_like)
 
+    def compute_only(self, chi, n_elec, vext=None):
+        """one evaluation's LOCAL work with the exchange skipped (timing only: see `_NoExchange`); the collective sequencing"""
+        chi = self.stages._grid_tensor(chi, 'chi')
+        vext = self.stages._grid_tensor(vext, 'v_ext')
+        return run_closure(self.stages, _NoExchange(self.comm), chi, n_elec, vext, self._vol, self.npts_global, torch.empty_like)
+
     def energy_potential(self, den, vext=None):
         den = self.stages._grid_tensor(den, 'den')
         vext = self.stages._grid_tensor(vext, 'v_ext')
@@ -575,6 +601,14 @@ class DistEngine:
                                pme_order).to(self.stages.dtype).contiguous()
 
     def close(self):
+        """collective when the ipc transport was attached: every rank lets go of the peers' arenas, the ranks meet, and only
+        then is any arena freed (see ofdft_ipc_detach)"""
+        if self.comm.active and getattr(self.stages, '_ipc_attached', False) and dist.is_initialized():
+            with contextlib.suppress(Exception):
+                self.stages.lib.ofdft_ipc_detach(self.stages._ctx)
+                t = torch.zeros(1, dtype=torch.int32, device=self.stages.device if self.comm.backend == 'nccl' else 'cpu')
+                dist.all_reduce(t, group=self.comm.group)
+            self.stages._ipc_attached = False
         self.stages.close()
         if getattr(self, '_f64', None) is not None:
             self._f64.close()
