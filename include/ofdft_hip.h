@@ -325,6 +325,9 @@ int  ofdft_lbfgs_update(ofdft_lbfgs* h, const double* coef_s, const double* coef
 #define OFDFT_OPT_BS_FUSED 15     /* chirp-z path (extents without a line-transform plan, i.e. what the reference's System.ecut2shape, system.py:74-89, gives):
                                      1 (default) = forward-x, spectral multiply and inverse-x of every convolution in ONE kernel (x extents up to 256);
                                      0 = three passes per transform and separate multiply kernels */
+#define OFDFT_OPT_WGC_FOLD 28     /* 1 (default): on cells with orthogonal axes the cross-wave x pass reads the WGC99 table entry of x > n0 / 2 at
+                                     n0 - x (|k| is even along a line there; functionals.py:968-972 depends on |k| only): both uses of an entry
+                                     fall into one tile, the second is a cache hit, the pass' table traffic halves.  0: every k-point its own entry */
 #define OFDFT_OPT_XWAVE 8         /* fused x passes: 1 (default) = the cross-wave kernel (whole runs of memory-adjacent lines per access, the
                                      radix-4 / -8 step of the line transform across the waves of a workgroup) for 256- and 512-point lines
                                      and, for passes over three or more spectra, 1024-point lines; elsewhere the wave-local kernel (a line of

@@ -37,6 +37,7 @@ OPT_XCHG_CHUNKS = 12
 OPT_IPC_WAIT_MS = 13
 OPT_YBATCH = 14
 OPT_BS_FUSED = 15
+OPT_WGC_FOLD = 28
 
 EXPORTS = ['ofdft_create', 'ofdft_destroy', 'ofdft_last_error', 'ofdft_set_cell', 'ofdft_set_terms',
            'ofdft_energy_potential', 'ofdft_energy_grad_chi', 'ofdft_rfftn', 'ofdft_irfftn', 'ofdft_debug_math', 'ofdft_query',

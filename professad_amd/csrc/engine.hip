@@ -781,7 +781,7 @@ int run_terms_fast(ofdft_ctx* c, const real* den, const real* vext, double* E_te
                          pass == 0 ? be : al, nref);
             for (int i = 0; i < 3; ++i)
                 if (int rc = fwd_zy(c, t[i], s[i], st)) return rc;
-            if (int rc = xfused<3, 3>(c, io, mix, st, "xfused_wgc")) return rc;
+            if (int rc = xfused_wgc(c, io, mix, st, "xfused_wgc")) return rc;
             for (int i = 0; i < 3; ++i)
                 if (int rc = inv_yz(c, s[i], o[3 * pass + i], inv_n, st)) return rc;
         }
@@ -1621,6 +1621,9 @@ int ofdft_set_option(ofdft_ctx* c, int option, double value) {
             return OFDFT_OK;
         case OFDFT_OPT_YBATCH:
             c->ybatch = (int)value;
+            return OFDFT_OK;
+        case OFDFT_OPT_WGC_FOLD:
+            c->wgc_fold = value != 0.0;
             return OFDFT_OK;
         case OFDFT_OPT_IPC_WAIT_MS:
             if (!(value >= 1.0 && value <= 3.6e6)) return fail(c, OFDFT_EINVAL, "OFDFT_OPT_IPC_WAIT_MS takes 1 .. 3 600 000 ms");

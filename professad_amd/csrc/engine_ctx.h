@@ -77,6 +77,7 @@ struct ofdft_ctx {
     int yfwd_fused = 0;            // ... of the last energy call (OFDFT_Q_YFWD_FUSED: the byte model of bench.py)
     bool wgc_valid = false;
     double wgc_ck = 0.0;           // K3 = K2 + wgc_ck K1 for the tables in "t:wgc" ((3 - gamma) / (3 n_ref))
+    bool wgc_fold = true;          // orthogonal cells: the cross-wave x pass reads the table entry of x > n0 / 2 at n0 - x (OFDFT_OPT_WGC_FOLD)
     // stats
     int fft_count = 0, launch_count = 0;
     double ypass_count = 0.0;   // whole-spectrum y passes executed (fractions for x- / kz-range launches)
@@ -345,6 +346,9 @@ struct XfLayout {
 };
 template <int NIN, int NOUT, class Mix>
 int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{});
+// the WGC99 pass (3 -> 3): with folded table reads (MixWgcFold) where the cell's axes are orthogonal and the cross-wave kernel serves
+// the pass, the plain form everywhere else (xpass_b.hip)
+int xfused_wgc(ofdft_ctx* c, const XfIo& io, const MixWgc& mix, hipStream_t st, const char* nm, const XfLayout& lay = XfLayout{});
 
 // ---- launchers of the fused z kernels (zfused.hip).  (chunk, nchunks): the launch covers that share of the rows, i.e. the
 // x planes [chunk, chunk + 1) * n0 / nchunks (x-chunked pipeline); partial sums land where a full launch would put them.

@@ -354,14 +354,14 @@ int zstage2(ofdft_ctx* c, hipStream_t st, int chain, int xk = -1) {
                 }
                 hipStream_t hs = half == 0 ? sb : sc;
                 if (nkz == 1) {
-                    if ((rc = xfused<3, 3>(c, io, mix, hs, "xfused_wgc", lay))) return rc;
+                    if ((rc = xfused_wgc(c, io, mix, hs, "xfused_wgc", lay))) return rc;
                     continue;
                 }
                 for (int ch = 0; ch < nkz; ++ch) {
                     XfLayout lk = lay;
                     lk.kb0 = ch * (nb / nkz);
                     lk.kb1 = (ch + 1) * (nb / nkz);
-                    if ((rc = xfused<3, 3>(c, io, mix, hs, "xfused_wgc", lk))) return rc;
+                    if ((rc = xfused_wgc(c, io, mix, hs, "xfused_wgc", lk))) return rc;
                     if ((rc = fast_axis_pass_multi<true>(c, 1, r.sw + 3 * half, 3, hs, 0, 0, lk.kb0, lk.kb1))) return rc;
                 }
             }

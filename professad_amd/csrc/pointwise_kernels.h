@@ -573,9 +573,16 @@ struct MixWgc {
     // requested with the data
     static constexpr int kTableReals = 3;
     __device__ __forceinline__ void fetch(real (&cf)[3], long long uoff, unsigned loff, bool valid) const {
+#ifdef OFDFT_WGC_TABLE_PROBE
+        // TIMING PROBE ONLY (tools: ab_generic.sh, profiles/r05_ab_wgc_table_probe.jsonl): no table traffic at all -- the upper bound
+        // of what any cheaper source of the coefficients (an L2-resident |k|^2-class table, an interleaved layout) could buy.  Wrong numbers.
+        cf[0] = (real)1.0; cf[1] = (real)0.5; cf[2] = valid ? (real)0.25 : (real)0.0;
+        (void)uoff; (void)loff;
+#else
         const cplx p0 = valid ? buf_load_c(t01 + uoff, loff * (unsigned)sizeof(cplx)) : mkc(0.0, 0.0);
         const real k2 = valid ? buf_load_d(t2 + uoff, loff * (unsigned)sizeof(real)) : (real)0.0;
         cf[0] = p0.x; cf[1] = p0.y; cf[2] = k2;       // w0, K1, K2
+#endif
     }
     __device__ __forceinline__ void apply(cplx (&o)[3], const cplx (&in)[3], const real (&cf)[3]) const {
         const real k3 = cf[2] + ck * cf[1];
@@ -583,6 +590,16 @@ struct MixWgc {
         o[1] = mkc(cf[1] * in[0].x + k3 * in[1].x, cf[1] * in[0].y + k3 * in[1].y);
         o[2] = mkc(cf[2] * in[0].x, cf[2] * in[0].y);
     }
+};
+
+// Round 5: cells with orthogonal axes have |k|(x) = |k|(n0 - x) along a line, so the entry of x > n0 / 2 is READ at n0 - x (the
+// table keeps its spectrum-order layout; the upper half is simply never touched): both uses of an entry fall into the same
+// tile of the cross-wave x pass, moments apart -- the second is a cache hit, and the pass' table traffic from HBM halves
+// (traffic / algorithmic bytes of xfused_wgc 1.33 -> 1.17; the pass 23.5 -> 22.5 ps per point at 256^3 fp64, 29.5 -> 26.7 at
+// 512-point lines, 17.1 -> 16.4 fp32; upper bound with NO table loads at all: 20.5 / 22.7 / 12.1, profiles/r05_ab_wgc_table_probe.jsonl).
+// Its own type: the kernels that do not fold -- and cells with skewed axes -- keep the plain form and its wave-uniform addressing.
+struct MixWgcFold : MixWgc {
+    int fold_n0;         // n0
 };
 
 // ---- XC pointwise math -------------------------------------------------------------------------

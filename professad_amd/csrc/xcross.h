@@ -199,6 +199,7 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, (xc_waves<LEN, NIN, NOUT>())) void
     const unsigned voff = valid ? (unsigned)((base - lb0 + (long long)xa * m.se) * kCB) : 0u;
     const unsigned voff_o = valid ? (unsigned)((base - lb0 + (long long)xa * se_o) * kCB) : 0u;
     const unsigned tloff = valid ? (unsigned)(base - lb0 + (long long)J * se_t) : 0u;
+    const unsigned tl0 = valid ? (unsigned)(base - lb0) : 0u;      // ... without the x term (folded table reads: MixWgc::fold_n0)
     const long long qstep = uniform64((long long)PP * m.se), qstep_o = uniform64((long long)PP * se_o),
                     tqstep = uniform64((long long)PP * se_t);
 
@@ -226,7 +227,14 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, (xc_waves<LEN, NIN, NOUT>())) void
 #pragma unroll
         for (int nl = 0; nl < NL; ++nl)
 #pragma unroll
-            for (int q = 0; q < E; ++q) mix.fetch(cfs[nl][q], b0 + q * tqstep, tloff + nl, valid);
+            for (int q = 0; q < E; ++q) {
+                if constexpr (mix_has_fold<Mix>::value) {       // the entry of x > n0 / 2 lives at n0 - x too: read it there (MixWgcFold)
+                    const int xq = J + PP * q, xf = 2 * xq > mix.fold_n0 ? mix.fold_n0 - xq : xq;
+                    mix.fetch(cfs[nl][q], b0, tl0 + nl + (unsigned)xf * (unsigned)se_t, valid);
+                } else {
+                    mix.fetch(cfs[nl][q], b0 + q * tqstep, tloff + nl, valid);
+                }
+            }
     }
     // ---- publish the twiddles
 #pragma unroll

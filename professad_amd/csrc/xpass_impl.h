@@ -130,6 +130,15 @@ int launch_xc_t(ofdft_ctx* c, const XfIo& io, const Mix& mix, const XfLayout& la
     return 0;
 }
 
+// does the cross-wave kernel take this pass? (OFDFT_OPT_XWAVE, measured choices: see xfused below)
+template <int NIN, int NOUT> bool xc_serves(const ofdft_ctx* c) {
+    constexpr bool xc_1024_f32 = sizeof(real) == 4;
+    const bool xc_len = (c->n0g == 256 && !(sizeof(real) == 4 && NIN + NOUT == 2)) || c->n0g == 512;
+    const bool len_ok = c->n0g == 128 || c->n0g == 256 || c->n0g == 512 || c->n0g == 1024;
+    return len_ok && (c->use_xwave == 5 || (c->use_xwave == 6 && NIN + NOUT >= 3) ||
+                      (c->use_xwave == 1 && (xc_len || (c->n0g == 1024 && (NIN + NOUT >= 3 || xc_1024_f32)))));
+}
+
 // forward-x, k-space mix, inverse-x in one pass over NIN input / NOUT output spectra
 template <int NIN, int NOUT, class Mix>
 int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const char* nm, const XfLayout& lay) {
@@ -146,10 +155,7 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
     // (fp32 build, 256-point lines: the 1 -> 1 passes measured 36-37 us in the group-parallel kernel against 39-40 here)
     // (fp32 build, 1024-point lines -- config 5 -- with two lines per lane: every pass, 1 -> 1 included: 205-220 us against 264-272 in
     // the group-parallel kernel at 1024 x 256 x 256, the Lindhard mix 5.8 against 5.9 ms at 1024^3; profiles/r04_x_stride_probe.jsonl)
-    constexpr bool xc_1024_f32 = sizeof(real) == 4;
-    const bool xc_len = (c->n0g == 256 && !(sizeof(real) == 4 && NIN + NOUT == 2)) || c->n0g == 512;
-    if (c->use_xwave == 5 || (c->use_xwave == 6 && NIN + NOUT >= 3) ||
-        (c->use_xwave == 1 && (xc_len || (c->n0g == 1024 && (NIN + NOUT >= 3 || xc_1024_f32))))) {
+    if (xc_serves<NIN, NOUT>(c)) {
         switch (c->n0g) {
             case 128: return launch_xc_t<128, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
             case 256: return launch_xc_t<256, NIN, NOUT, Mix>(c, io, mix, lay, st, nm);
@@ -183,6 +189,5 @@ int xfused(ofdft_ctx* c, const XfIo& io, const Mix& mix, hipStream_t st, const c
     }
     return fail(c, OFDFT_EINVAL, "unsupported fast FFT length %d", c->n0g);
 }
-
 
 }  // namespace eng

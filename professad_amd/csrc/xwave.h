@@ -80,6 +80,8 @@ template <int LEN> struct XwCfg {
 
 // all coefficients of one k-point for a table-driven mix are fetched by ONE call (so that they can be requested early);
 // computed mixes (functions of the integer indices) are evaluated where they are used
+template <class Mix, class = void> struct mix_has_fold : std::false_type {};
+template <class Mix> struct mix_has_fold<Mix, std::void_t<decltype(std::declval<const Mix&>().fold_n0)>> : std::true_type {};
 template <class Mix, class = void> struct mix_coef_count { static constexpr int N = 0; };
 template <class Mix> struct mix_coef_count<Mix, std::void_t<decltype(Mix::kTableReals)>> { static constexpr int N = Mix::kTableReals; };
 

@@ -600,10 +600,12 @@ class DistEngine:
         return ionic_potential(self._f64_stages(), self._box_np.reshape(3, 3), species,
                                pme_order).to(self.stages.dtype).contiguous()
 
-    def close(self):
-        """collective when the ipc transport was attached: every rank lets go of the peers' arenas, the ranks meet, and only
-        then is any arena freed (see ofdft_ipc_detach)"""
-        if self.comm.active and getattr(self.stages, '_ipc_attached', False) and dist.is_initialized():
+    def close(self, sync_peers=False):
+        """sync_peers=True (every rank must then call close, in the same order): with the ipc transport attached, every rank first
+        lets go of the peers' arenas, the ranks meet, and only then is any arena freed (ofdft_ipc_detach) -- for jobs that go on to
+        create another slab engine in the same processes.  The default frees at once and never waits for a peer: a rank that
+        closes because ANOTHER rank failed must not be left in a collective."""
+        if sync_peers and self.comm.active and getattr(self.stages, '_ipc_attached', False) and dist.is_initialized():
             with contextlib.suppress(Exception):
                 self.stages.lib.ofdft_ipc_detach(self.stages._ctx)
                 t = torch.zeros(1, dtype=torch.int32, device=self.stages.device if self.comm.backend == 'nccl' else 'cpu')

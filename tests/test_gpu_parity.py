@@ -176,6 +176,33 @@ def test_bench_workload_energy_mu_and_gradient_match_the_reference_pin(n):
     eng.close()
 
 
+@pytest.mark.parametrize('shape,cell', [((256, 16, 32), ('cubic', 32)), ((256, 32, 16), ('tri', 1.1)), ((512, 8, 16), ('cubic', 16))])
+def test_folded_wgc99_table_reads_change_nothing(shape, cell):
+    """round 5: on cells with orthogonal axes the cross-wave x pass reads the WGC99 table entry of x > n0 / 2 at n0 - x (|k| is
+    even along a line; functionals.py:968-972 depends on |k| only).  Same numbers as with every k-point reading its own entry
+    (OFDFT_OPT_WGC_FOLD = 0) -- to the rounding of |k|^2 of the two representatives -- and as the oracle; a triclinic cell never folds"""
+    from professad_amd import _native as N
+    box = cases.make_cell(cell) if cell[0] == 'tri' else np.diag([7.6 * s / 32.0 * (1.0 + 0.1 * i) for i, s in enumerate(shape)])
+    den = synth.smooth_density(shape, seed=21) * (1 + 0.05 * np.random.default_rng(5).random(shape))
+    vext = synth.random_potential(shape, seed=22)
+    chi = np.sqrt(den)
+    n_elec = float(np.floor(den.mean() * abs(np.linalg.det(box))) + 0.5)
+    names = F.NativeTerms(['ion_electron', 'hartree', 'wgc99', 'pbe']).names
+    out = {}
+    for fold in (1, 0):
+        eng = Engine(shape, DEV).set_cell(dev(box)).set_terms(names).set_option(N.OPT_WGC_FOLD, fold)
+        out[fold] = eng.energy_grad_chi(dev(chi), n_elec, dev(vext))
+        eng.close()
+    (Ea, mua, ga), (Eb, mub, gb) = out[1], out[0]
+    tol = 0.0 if cell[0] == 'tri' else 1e-13
+    assert abs(sum(Ea.values()) - sum(Eb.values())) <= tol * abs(sum(Eb.values())) and abs(mua - mub) <= tol * abs(mub)
+    assert float((ga - gb).abs().max()) <= tol * float(gb.abs().max())
+    if shape[0] == 256:
+        ev = cf.Evaluator(cf.Grid(box, shape))
+        Ec, go, muo = ev.closure(cases.CONFIGS['cfg3'], chi, n_elec, vext)
+        assert abs(sum(Ea.values()) - Ec) <= E_RTOL * max(1.0, abs(Ec)) and relerr(ga.cpu().numpy(), go) < V_RTOL
+
+
 # ------------------------------------------------------------------------------- oracle on seeded inputs
 @pytest.mark.parametrize('shape,cell', [((64, 64, 64), ('cubic', 64)), ((32, 64, 16), ('tri', 1.3)),
                                         ((24, 20, 18), ('tri', 0.8)), ((33, 32, 31), ('cubic', 32))])

@@ -29,6 +29,9 @@ for arg in [a for a in sys.argv[1:] if a[0].isdigit()]:
     eng = Engine(shape, dev, dtype=DT).set_cell(torch.as_tensor(box)).set_terms(CFG3)
     if NOMIXED:
         eng.set_option(9, 0)
+    for a in sys.argv[1:]:          # optK=V: ofdft_set_option(K, V) (A/B of run-time switches, e.g. opt28=0: no folded WGC99 table reads)
+        if a.startswith('opt') and '=' in a:
+            eng.set_option(int(a[3:a.index('=')]), float(a[a.index('=') + 1:]))
     for _ in range(3):
         eng.energy_grad_chi(chi, nel, vext)
     torch.cuda.synchronize()
@@ -44,7 +47,7 @@ for arg in [a for a in sys.argv[1:] if a[0].isdigit()]:
         eng.energy_grad_chi(chi, nel, vext)
     prof = eng.profile()
     npts = float(np.prod(shape))
-    print(json.dumps({'shape': shape, 'terms': 'cfg2' if 'cfg2' in sys.argv[1:] else 'cfg3', 'dtype': str(DT), 'mixed_radix': not NOMIXED, 'ms': round(ms, 3), 'ns_per_point': round(ms * 1e6 / npts, 4),
+    print(json.dumps({'shape': shape, 'opts': [a for a in sys.argv[1:] if a.startswith('opt') and '=' in a], 'terms': 'cfg2' if 'cfg2' in sys.argv[1:] else 'cfg3', 'dtype': str(DT), 'mixed_radix': not NOMIXED, 'ms': round(ms, 3), 'ns_per_point': round(ms * 1e6 / npts, 4),
                       'ps_per_point': {k: round(v[0] / 3 * 1e9 / npts, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}), flush=True)
     eng.close()
     del chi, vext
