@@ -5,6 +5,7 @@
 // System.ecut2shape (system.py:75-89, always odd extents) produces: O(N log N) per line instead of the O(N^2) of the
 // plain DFT kernels (kept for extents above 512).
 #pragma once
+#include "fastmath.h"
 #include "fft_kernels.h"
 
 namespace ofdft {
@@ -21,11 +22,27 @@ struct BsArgs {
 // one launch may cover several arrays (blockIdx.y): the unfused pipeline transforms its spectra in groups of three (gradient,
 // flux, the WGC99 triples) and small grids are bound by their launch count, not by bytes
 constexpr int kBsBatch = 4;
+// Pointwise pre-operation of an r2c pass (round 5): the real rows of array a are f_a(rin[a]) -- the forward transforms of
+// sqrt n (vW), n^e (Wang-Teter) and n^e theta^m / m! (WGC99, theta = n - n_ref) read the density itself, where a separate
+// kernel wrote each of these arrays first (map / wgc_prep: a launch, a read and a write each; on the reference's own 53^3 grid
+// 9 % of the evaluation, which is bound by its launches there).  Same expressions as map_kernel / wgc_prep_kernel.
+enum { BS_PREP_NONE = 0, BS_PREP_SQRT = 1, BS_PREP_POW0 = 2, BS_PREP_POW1 = 3, BS_PREP_POW2 = 4 };
 struct BsIo {
     cplx* spec[kBsBatch];
     const real* rin[kBsBatch];
     real* rout[kBsBatch];
+    int prep[kBsBatch];      // BS_PREP_* of array a (r2c passes)
+    real pe[kBsBatch];       // exponent e of BS_PREP_POW*
+    real pnref;              // n_ref of theta
 };
+__device__ __forceinline__ real bs_prep(real x, int kind, real e, real nref) {
+    if (kind == BS_PREP_NONE) return x;
+    if (kind == BS_PREP_SQRT) return (x != 0.0) ? sqrt(x) : (real)0.0;           // functionals.py:242-243
+    // (the lean exp(e log x) of fastmath.h: with the library's pow -- ~250 fp64 instructions, three arrays each forming it -- the r2c
+    // pass lost more than the separate kernels had cost: 255^3 6.35 -> 6.49 ms)
+    const real a = x > 0.0 ? fm::pow_pos(x, e) : (real)0.0, th = x - nref;       // functionals.py:974-981
+    return kind == BS_PREP_POW0 ? a : (kind == BS_PREP_POW1 ? a * th : (real)0.5 * a * th * th);
+}
 
 // Design of the kernels (round 3, second half; the steps and their A/B measurements: DESIGN.md section 13a):
 //  * a line is owned by the lanes of ONE wavefront (ZPlan<M, 8>: 8 points per lane, 64 lanes for M = 512), so the two M-point
@@ -158,12 +175,16 @@ __attribute__((amdgpu_waves_per_eu(BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>::WAVES, B
     cplx* __restrict__ spec = io.spec[0];
     const real* __restrict__ rin = io.rin[0];
     real* __restrict__ rout = io.rout[0];
+    int prep = io.prep[0];
+    real pe = io.pe[0];
 #pragma unroll
     for (int a = 1; a < kBsBatch; ++a)          // (select without dynamic indexing into the kernel arguments)
         if ((int)blockIdx.y == a) {
             spec = io.spec[a];
             rin = io.rin[a];
             rout = io.rout[a];
+            prep = io.prep[a];
+            pe = io.pe[a];
         }
     const int j = tid % P, l = tid / P;
     const int N = b.N;
@@ -228,6 +249,8 @@ __attribute__((amdgpu_waves_per_eu(BsCfg<M, (KIND != BS_CPLX ? 1 : 0)>::WAVES, B
             } else if (KIND == BS_R2C) {
                 off[q] = in ? (row * (unsigned)g.n2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
                 v[q] = mkc(buf_load_d(rin, off[q]), buf_load_d(rin, in && valid1 ? off[q] + (unsigned)g.n2 * (unsigned)sizeof(real) : kBsOob));
+                if (prep != BS_PREP_NONE)       // (uniform; elements of the zero padding and of a missing second row stay zero)
+                    v[q] = mkc(in ? bs_prep(v[q].x, prep, pe, io.pnref) : (real)0.0, (in && valid1) ? bs_prep(v[q].y, prep, pe, io.pnref) : (real)0.0);
             } else {            // rebuild the Hermitian lines; imaginary parts of k = 0 (and Nyquist) are ignored like irfftn
                 const int k = (e < g.nzc) ? e : N - e;
                 const unsigned idx = k < g.nzm ? ((unsigned)(k >> 3) * (unsigned)g.nrows + row) * 8u + (unsigned)(k & 7)
@@ -471,12 +494,16 @@ __global__ __launch_bounds__(512) void bluestein_zy_kernel(BsIo io, SpecGeom g, 
     cplx* __restrict__ spec = io.spec[0];
     const real* __restrict__ rin = io.rin[0];
     real* __restrict__ rout = io.rout[0];
+    int prep = io.prep[0];
+    real pe = io.pe[0];
 #pragma unroll
     for (int a = 1; a < kBsBatch; ++a)
         if ((int)blockIdx.y == a) {
             spec = io.spec[a];
             rin = io.rin[a];
             rout = io.rout[a];
+            prep = io.prep[a];
+            pe = io.pe[a];
         }
     const int j = tid % P, grp = tid / P;
     const int x = blockIdx.x, N1 = g.n1, N2 = g.n2, nzc = g.nzc, PS = nzc | 1;
@@ -512,6 +539,8 @@ __global__ __launch_bounds__(512) void bluestein_zy_kernel(BsIo io, SpecGeom g, 
                 const int e = j + P * q;
                 const unsigned o = e < N2 ? ((rowx + (unsigned)y0) * (unsigned)N2 + (unsigned)e) * (unsigned)sizeof(real) : kBsOob;
                 v[q] = mkc(buf_load_d(rin, o), buf_load_d(rin, (e < N2 && valid1) ? o + (unsigned)N2 * (unsigned)sizeof(real) : kBsOob));
+                if (prep != BS_PREP_NONE)
+                    v[q] = mkc(e < N2 ? bs_prep(v[q].x, prep, pe, io.pnref) : (real)0.0, (e < N2 && valid1) ? bs_prep(v[q].y, prep, pe, io.pnref) : (real)0.0);
             }
 #pragma unroll
             for (int q = EH; q < E; ++q) v[q] = mkc(0.0, 0.0);

@@ -428,33 +428,53 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         const real* fin[4];
         cplx* fout[4];
         int nf = 0;
+        // chirp-z path with the fused x pass (xm): sqrt n and the powers are formed by the r2c pass as it loads the density
+        // (BsPrep) -- no map launches, no intermediate arrays
+        BsPrep prep;
         if (has_n) {
             fin[nf] = den;
             fout[nf++] = s0;
         }
         if (has_vw) {
-            if (int rc = real_ws(c, "t0", &t_sqrt)) return rc;
             if (int rc = spec_ws(c, "svw", &s_vw)) return rc;
-            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, t_sqrt, npts, 0.0);
-            fin[nf] = t_sqrt;
+            if (xm) {
+                prep.kind[nf] = BS_PREP_SQRT;
+                fin[nf] = den;
+            } else {
+                if (int rc = real_ws(c, "t0", &t_sqrt)) return rc;
+                OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_SQRT>), dim3(pw_grid), dim3(256), 0, den, t_sqrt, npts, 0.0);
+                fin[nf] = t_sqrt;
+            }
             fout[nf++] = s_vw;
         }
         if (has_wt) {
-            if (int rc = real_ws(c, "t1", &t_pb)) return rc;
             if (int rc = spec_ws(c, "swb", &s_wb)) return rc;
-            OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pb, npts, wbe);
-            fin[nf] = t_pb;
+            if (xm) {
+                prep.kind[nf] = BS_PREP_POW0;
+                prep.e[nf] = wbe;
+                fin[nf] = den;
+            } else {
+                if (int rc = real_ws(c, "t1", &t_pb)) return rc;
+                OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pb, npts, wbe);
+                fin[nf] = t_pb;
+            }
             fout[nf++] = s_wb;
             if (wt2) {
-                if (int rc = real_ws(c, "t2", &t_pa)) return rc;
                 if (int rc = spec_ws(c, "swa", &s_wa)) return rc;
-                OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pa, npts, wal);
-                fin[nf] = t_pa;
+                if (xm) {
+                    prep.kind[nf] = BS_PREP_POW0;
+                    prep.e[nf] = wal;
+                    fin[nf] = den;
+                } else {
+                    if (int rc = real_ws(c, "t2", &t_pa)) return rc;
+                    OFDFT_LAUNCH(c, st, "map", (map_kernel<MAP_POW>), dim3(pw_grid), dim3(256), 0, den, t_pa, npts, wal);
+                    fin[nf] = t_pa;
+                }
                 fout[nf++] = s_wa;
             }
         }
         if (nf)
-            if (int rc = (xm ? bluestein_fwd_zy_multi(c, fin, fout, nf, st) : rfftn_internal_multi(c, fin, fout, nf, st))) return rc;
+            if (int rc = (xm ? bluestein_fwd_zy_multi(c, fin, fout, nf, st, &prep) : rfftn_internal_multi(c, fin, fout, nf, st))) return rc;
     }
     // ---- B: spectral multiplies; C: inverse batches (at most kBsBatch arrays each)
     {
@@ -608,16 +628,23 @@ int run_terms_unfused(ofdft_ctx* c, const real* den, const real* vext, double* E
         if (int rc = spec_ws(c, "s2", &s2)) return rc;
         const MixWgc wmix = wgc_tab(c);
         for (int pass = 0; pass < 2; ++pass) {
-            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
-                               nref);
             cplx* sw[3] = {s0, s1, s2};
             const real* tw3[3] = {t0, t1, t2};
-            if (xm) {
-                if (int rc = bluestein_fwd_zy_multi(c, tw3, sw, 3, st)) return rc;
+            if (xm) {          // A = n^e, B = A theta, C = A theta^2 / 2 formed by the r2c pass from the density (BsPrep)
+                const real* d3[3] = {den, den, den};
+                BsPrep prep;
+                for (int k = 0; k < 3; ++k) {
+                    prep.kind[k] = BS_PREP_POW0 + k;
+                    prep.e[k] = pass == 0 ? be : al;
+                }
+                prep.nref = nref;
+                if (int rc = bluestein_fwd_zy_multi(c, d3, sw, 3, st, &prep)) return rc;
                 if (int rc = bluestein_xmix<3, 3>(c, sw, sw, wmix, st)) return rc;
                 if (int rc = bluestein_inv_yz_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;
                 continue;
             }
+            OFDFT_LAUNCH(c, st, "wgc_prep", wgc_prep_kernel, dim3(pw_grid), dim3(256), 0, den, t0, t1, t2, npts, pass == 0 ? be : al,
+                               nref);
             if (int rc = rfftn_internal_multi(c, tw3, sw, 3, st)) return rc;
             OFDFT_LAUNCH(c, st, "spec_wgc_mix", spec_wgc_mix_kernel, dim3(sp_grid), dim3(256), 0, s0, s1, s2, wmix.t01, wmix.t2, wmix.ck, c->g.total);
             if (int rc = irfftn_internal_multi(c, sw, o + 3 * pass, 3, inv_n, st)) return rc;

@@ -328,7 +328,9 @@ int rfftn_internal_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec,
 bool bluestein_xmix_ok(const ofdft_ctx* c);
 template <int NIN, int NOUT, class Mix>
 int bluestein_xmix(ofdft_ctx* c, const cplx* const* in, cplx* const* out, const Mix& mix, hipStream_t st);
-int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st);
+// (prep: pointwise pre-operations of the r2c pass, bluestein.h: BsIo -- array a is transformed as f_a(in[a]))
+struct BsPrep { int kind[kBsBatch] = {0, 0, 0, 0}; double e[kBsBatch] = {0, 0, 0, 0}; double nref = 0.0; };
+int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st, const BsPrep* prep = nullptr);
 int bluestein_inv_yz_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st);
 int irfftn_internal_multi(ofdft_ctx* c, cplx* const* spec, real* const* out, int n, double scale, hipStream_t st);
 int irfftn_internal(ofdft_ctx* c, cplx* spec, real* out, double scale, hipStream_t st);

@@ -374,12 +374,17 @@ static int bluestein_zy(ofdft_ctx* c, int M, const BsIo& io, int narr, double sc
 
 // the z and y passes of `n` (<= kBsBatch) transforms, one launch per pass (small grids: ONE launch for both): the halves of a 3-D
 // transform around the fused x pass
-int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st) {
+int bluestein_fwd_zy_multi(ofdft_ctx* c, const real* const* in, cplx* const* spec, int n, hipStream_t st, const BsPrep* prep) {
     BsIo io{};
     for (int a = 0; a < n; ++a) {
         io.spec[a] = spec[a];
         io.rin[a] = in[a];
+        if (prep) {
+            io.prep[a] = prep->kind[a];
+            io.pe[a] = (real)prep->e[a];
+        }
     }
+    if (prep) io.pnref = (real)prep->nref;
     c->fft_count += n;
     int M;
     if (bluestein_zy_ok(c, &M)) return bluestein_zy<false>(c, M, io, n, 1.0, st);
