@@ -134,7 +134,12 @@ constexpr int BS_R2C = 1;       // real rows -> half spectrum along z
 constexpr int BS_C2R = 2;       // half spectrum -> real rows along z (times `scale`)
 
 __device__ __forceinline__ cplx cmul_cj(cplx a, cplx b) {      // a * conj(b)
+#if defined(OFDFT_REAL_F32) && OFDFT_F32_PK
+    const v2f_t t = (v2f_t){a.x, a.x} * (v2f_t){b.x, -b.y};      // a.x (b.x, -b.y) + a.y (b.y, b.x)
+    return v2c(__builtin_elementwise_fma((v2f_t){a.y, a.y}, (v2f_t){b.y, b.x}, t));
+#else
     return mkc(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
 }
 // the convolution itself: v (element j + P q in slot q, zero beyond the line) -> its N-point DFT, same slots.  The chirp (wch)
 // and the filter spectrum (fl_l, in LDS) are in their FORWARD form; the inverse transform conjugates them where they are used

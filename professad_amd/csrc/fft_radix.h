@@ -60,11 +60,36 @@ __host__ __device__ __forceinline__ cplx mkc(real x, real y) {
     return c;
 }
 
+// fp32 build (round 5): complex arithmetic on the register PAIR -- v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do both components of
+// a complex number in one instruction at the rate of a scalar one (the hardware's 2 x fp32 rate exists only in this form), so a
+// complex product is 2 instructions instead of 4 and a butterfly's add / subtract pair 2 instead of 4.  Written component-wise the
+// compiler found the packed form for about half of the sums and almost none of the products: the fp32 z kernels at 1024-point rows
+// (config 5) spent 60-65 % of their time issuing vector instructions -- the same count as the fp64 build for half the bytes.
+// Measured (profiles/r05_ab_f32_packed.jsonl, one box, two alternations): static vector instructions of zf_density<512, 8> 2 194 ->
+// 1 864, of zi_combine 12 059 -> 10 566; on the device zf_density 3.3 -> 3.0 ps per point and zi_combine 7.6 -> 7.25 at 1024-point rows,
+// zpbe 9.95 -> 9.35 at 256^3 -- but zi_wgc 8.55 -> 9.25, and the chirp-z kernels 67 -> 118 ps per point and pass (255^3 fp32 3.98 ->
+// 6.0 ms): the evaluation gains ~1 % on plan-served grids and loses 50 % on the reference's own odd grids.  OFF by default;
+// OFDFT_F32_PK=1 selects the packed forms.
+#ifndef OFDFT_F32_PK
+#define OFDFT_F32_PK 0
+#endif
+#if defined(OFDFT_REAL_F32) && OFDFT_F32_PK
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t c2v(cplx a) { v2f_t r = {a.x, a.y}; return r; }
+__device__ __forceinline__ cplx v2c(v2f_t v) { return mkc(v.x, v.y); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return v2c(c2v(a) + c2v(b)); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return v2c(c2v(a) - c2v(b)); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {       // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.y (-b.y, b.x) + a.x b
+    const v2f_t t = (v2f_t){a.x, a.x} * c2v(b);
+    return v2c(__builtin_elementwise_fma((v2f_t){a.y, a.y}, (v2f_t){-b.y, b.x}, t));
+}
+#else
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return mkc(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return mkc(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
     return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+#endif
 __device__ __forceinline__ cplx cconj(cplx a) { return mkc(a.x, -a.y); }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) {
@@ -93,7 +118,11 @@ template <int R, int K, bool INV> __device__ __forceinline__ cplx mul_w(cplx a) 
     else {
         constexpr real c = kCos16[idx];
         constexpr real s = INV ? kSin16[idx] : -kSin16[idx];
+#if defined(OFDFT_REAL_F32) && OFDFT_F32_PK
+        return cmul(a, mkc(c, s));
+#else
         return mkc(a.x * c - a.y * s, a.x * s + a.y * c);
+#endif
     }
 }
 
@@ -245,7 +274,11 @@ template <int N, int K, bool INV> __device__ __forceinline__ cplx mul_root(cplx 
     } else {
         constexpr real c = (real)UnitRoots<N>::c[k];
         constexpr real sn = (real)(INV ? UnitRoots<N>::s[k] : -UnitRoots<N>::s[k]);
+#if defined(OFDFT_REAL_F32) && OFDFT_F32_PK
+        return cmul(a, mkc(c, sn));
+#else
         return mkc(a.x * c - a.y * sn, a.x * sn + a.y * c);
+#endif
     }
 }
 template <bool INV> struct Dft<3, INV> {
