@@ -109,6 +109,9 @@ template <int LEN, int NIN, int NOUT> constexpr int xc_waves() {
 #ifndef OFDFT_XC_ST_AUX
 #define OFDFT_XC_ST_AUX 2
 #endif
+#ifndef OFDFT_XC_ST_AUX_HALF
+#define OFDFT_XC_ST_AUX_HALF 0     // stores of tiles narrower than a 128-byte line
+#endif
 
 // NL complex elements that are adjacent in memory by one access (NL = 2: 16 bytes in the fp32 build)
 template <int NL, int AUX> __device__ __forceinline__ void buf_load_cn(cplx (&o)[NL], const cplx* ubase, unsigned voff_bytes) {
@@ -145,6 +148,10 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, (xc_waves<LEN, NIN, NOUT>())) void
     constexpr int A = Cfg::A, S = Cfg::S, E = Cfg::E, LPWV = Cfg::LPWV, LPB = Cfg::LPB, PP = Cfg::PP, RR = Cfg::RR,
                   TPB = Cfg::TPB, WREG = Cfg::WREG, WPT = Cfg::WPT, NL = Cfg::NL, G = NIN > NOUT ? NIN : NOUT;
     constexpr int LDA = (LPB * sizeof(cplx) >= 128) ? OFDFT_XC_LD_AUX : 0;
+    // ... and so are the stores (round 5): a tile of half lines stored nt sent its 64-byte halves to memory on their own -- the
+    // 1024-point fp32 passes wrote 5.1-5.75 GB per launch where 4.3 GB leave the kernel (rocprofv3 WRITE_SIZE,
+    // profiles/r05_1024_f32_cfg2_rocprof_serialised.md); cached, the two halves meet in the L2 of the XCD both workgroups run on
+    constexpr int STA = (LPB * sizeof(cplx) >= 128) ? OFDFT_XC_ST_AUX : OFDFT_XC_ST_AUX_HALF;
     extern __shared__ __attribute__((aligned(16))) real lds[];
     constexpr bool ONEBUF = xc_one_buffer<LEN, NIN, NOUT>();
     cplx* xb = reinterpret_cast<cplx*>(lds);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(XcCfg<LEN>::TPB, (xc_waves<LEN, NIN, NOUT>())) void
 #pragma unroll
                 for (int nl = 0; nl < NL; ++nl) pr[nl] = v[O][nl][q];
                 if (xs.se_out) buf_store_cn<NL, 0>(ub + q * qstep_o, voff_o, pr);
-                else buf_store_cn<NL, OFDFT_XC_ST_AUX>(ub + q * qstep_o, voff_o, pr);
+                else buf_store_cn<NL, STA>(ub + q * qstep_o, voff_o, pr);
             }
         }
     });

@@ -54,7 +54,7 @@ CLASSES = [('cpass_kernel', 'cpass_y'), ('yderiv_kernel', 'yderiv'), ('ypass_xch
            ('MixScale<1>', 'xfused_lap'), ('MixScale<2>', 'xfused_lind'), ('xw_kernel', 'xfused_wgc'),
            ('zi_combine_kernel', 'zi_combine'), ('zi_wgc_kernel', 'zi_wgc'), ('zpbe2_kernel', 'zpbe'), ('zpbe_kernel', 'zpbe'),
            ('zf_powers_kernel', 'zf_powers'), ('zf_density_kernel', 'zf_density'), ('chi_grad_kernel', 'chi_grad'),
-           ('sum_kernel', 'sum'), ('wgc_table_kernel', 'wgc_table'), ('reduce_partials_kernel', 'reduce'),
+           ('sum_kernel', 'sum'), ('wgc_table_kernel', 'wgc_table'), ('reduce_partials_kernel', 'reduce'), ('reduce_rows_kernel', 'reduce'),
            ('closure_scale_kernel', 'reduce'), ('closure_scale_reduce_kernel', 'reduce'), ('axpy_kernel', 'reduce'), ('resident_closure_kernel', 'resident'),
            ('ipc_scatter_kernel', 'ipc_scatter'), ('ipc_wait_kernel', 'ipc_sync'), ('ipc_stamp_kernel', 'ipc_sync'),
            ('ipc_post_kernel', 'ipc_sync'), ('ipc_sum_kernel', 'ipc_sync'), ('ipc_abort_check_kernel', 'ipc_sync'), ('xchg_unpack_kernel', 'xchg_unpack')]
