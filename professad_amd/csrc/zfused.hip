@@ -1,4 +1,10 @@
 // Launchers of the wave-local z kernels with fused real-space physics (zpass.h).  gfx950 only.
+// (fp32 build: this unit's kernels -- the wave-local z kernels -- use the packed complex arithmetic of fft_radix.h: zf_density -9 %,
+// zi_combine -5 %, zpbe -6 %, zi_wgc +8 % at their sizes of BASELINE configs 3 / 5, profiles/r05_ab_f32_packed.jsonl; every other
+// unit keeps the component-wise forms, which the chirp-z kernels of lines.hip need)
+#if defined(OFDFT_REAL_F32) && !defined(OFDFT_F32_PK)
+#define OFDFT_F32_PK 1
+#endif
 #include "engine_ctx.h"
 
 namespace eng {
