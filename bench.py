@@ -235,7 +235,13 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
     tol = 1e-10 if tdtype == torch.double else 5e-6
     chi_d = torch.as_tensor(chi256, dtype=tdtype, device=device)
     vext_d = torch.as_tensor(vext256, dtype=tdtype, device=device)
+    def note(msg):          # progress on stderr (stdout stays ONE line): a long block must not look hung
+        if rank == 0:
+            sys.stderr.write('bench.py: scale_512 [%6.1f s] %s\n' % (time.perf_counter() - t_block, msg))
+            sys.stderr.flush()
+    t_block = time.perf_counter()
     for tr in transports:
+        note('transport %s: set-up' % tr)
         eng, err = None, None
         try:        # everything that can fail on ONE rank only (memory, ipc attach is guarded inside) happens before the ranks meet
             eng = DistEngine((n, n, n), device, dtype=tdtype, transport=tr,
@@ -252,19 +258,23 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
             if eng is not None:
                 eng.close()
             continue
+        note('transport %s: warm-up' % tr)
         for _ in range(2):
             E, mu, g = eng.energy_grad_chi(chi, nel, vext)
         fence()
+        note('transport %s: %d timed evaluations' % (tr, steps))
         t0 = time.perf_counter()
         for _ in range(steps):
             E, mu, g = eng.energy_grad_chi(chi, nel, vext)
         fence()
+        note('transport %s: timed' % tr)
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.double, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if 'compute_only_ms' not in out:
             # a rank's LOCAL wall time per evaluation (kernels, launches, both streams, the small all-reduces; the all-to-alls
             # skipped): the floor the exchange adds to -- measured here, on this node, not taken from a one-GPU emulation
             try:
+                note('local compute without the exchange')
                 for _ in range(2):
                     eng.compute_only(chi, nel, vext)
                 fence()
@@ -284,6 +294,7 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
         del chi, vext, g
     if rank == 0:          # the one-GPU leg: this rank alone on the whole 512^3 grid (the others wait at the barrier below)
         try:
+            note('the same problem on one GPU')
             one = Engine((n, n, n), device, dtype=tdtype).set_cell(box).set_terms(names)
             chi = chi_d.repeat(2, 2, 2).contiguous()
             vext = vext_d.repeat(2, 2, 2).contiguous()

@@ -148,8 +148,8 @@ int  ofdft_ipc_export(ofdft_ctx* ctx, void* handle64, unsigned long long* offset
 int  ofdft_ipc_attach(ofdft_ctx* ctx, int peer_rank, const void* handle64, const unsigned long long* offsets5);
 /* Close every mapping of a peer's arena this rank holds: the first step of tearing a slab job down -- every rank calls it,
  * the host's ranks meet (a barrier), and only then is any context destroyed: ofdft_destroy frees the arena, and device memory
- * must not be freed while a peer process still has it open through hipIpc.  (The arena itself is sized once for the largest
- * term set, so ofdft_set_terms never rebuilds it: csrc/ipc_exchange.inc.h.)  No-op on a context that never attached. */
+ * must not be freed while a peer process still has it open through hipIpc.  (While a job runs nothing exported is freed and nothing
+ * opened is closed: a term set that needs bigger buffers gets a second arena, csrc/ipc_exchange.inc.h.)  No-op on a context that never attached. */
 int  ofdft_ipc_detach(ofdft_ctx* ctx);
 int  ofdft_dist_closure(ofdft_ctx* ctx, const void* chi_local_dev, const void* vext_local_dev, double n_electrons_global,
                         double* E_terms_host, double* mu_host, void* grad_local_dev, void* v_work_local_dev, void* stream);

@@ -32,6 +32,13 @@ struct ofdft_ipc_state {
     size_t arena_bytes = 0, off[5] = {}, bytes[5] = {};
     void* peer_base[16] = {};          // rank p's arena in THIS process' address space (an opened handle)
     hipIpcMemHandle_t peer_handle[16] = {};
+    // Arenas this rank has outgrown and mappings of arenas the peers have outgrown (round 5): kept until the context dies.  A
+    // bigger term set used to FREE the arena while the peers still had it open through hipIpc, and the peers closed their mapping
+    // and opened the replacement right after: one run in ~10 of four ranks failed there (hipIpcOpenMemHandle: invalid device
+    // pointer).  Now nothing exported is freed and nothing opened is closed while the job runs: the replacement is a second
+    // allocation (another address, another handle) and a second mapping.  (Sizing the arena once for the largest term set was
+    // tried instead: at 512^3 on two ranks that is a 15-GB fine-grained allocation per rank, and mapping it did not return.)
+    std::vector<void*> old_arenas, old_peer_bases;
     void* peer[5][16] = {};            // peer[w][p]: rank p's object w (p == me: the local pointer)
     // mailbox layout (this rank's copy): flags [3 kinds][16 ranks] u32 | sums [2 kinds][16 ranks][16] f64
     unsigned* flags = nullptr;
@@ -58,6 +65,8 @@ void ipc_release(ofdft_ctx* c) {
     if (!s) return;
     for (int p = 0; p < 16; ++p)
         if (s->peer_base[p]) (void)hipIpcCloseMemHandle(s->peer_base[p]);
+    for (void* q : s->old_peer_bases) (void)hipIpcCloseMemHandle(q);
+    for (void* q : s->old_arenas) (void)hipFree(q);
     for (const char* nm : {"x:recv0", "x:recv0b", "x:recv1", "x:recv1b"}) {        // the windows into the arena die with it
         auto it = c->ws.find(nm);
         if (it != c->ws.end() && it->second.borrowed) {
@@ -206,17 +215,10 @@ int ipc_arena(ofdft_ctx* c) {
             c->ws.erase(it);
         }
     }
-    if (s->arena) HIP_TRY(c, hipFree(s->arena));
+    if (s->arena) s->old_arenas.push_back(s->arena);       // (peers may still have it open: freed with the context)
     s->arena = nullptr;
-    // Sized ONCE for the largest term set the chains can carry (chain 0: Hartree + three gradient components + the Laplacian
-    // pair + vW = 6 spectra, chain 1: two Wang-Teter powers + six WGC99 spectra = 8; dist_buffer_bytes) -- not for the active one:
-    // a later ofdft_set_terms then never rebuilds the arena.  Rebuilding meant freeing device memory that the peer processes
-    // still had open through hipIpc and opening the replacement right after: one run in ~10 of four ranks failed there
-    // ("hipIpcOpenMemHandle: invalid device pointer"), and closing the peers' mappings first made the re-opened ones stale
-    // (deliveries that never arrived) -- round 5.  An arena is now opened once per peer and closed when the context dies.
-    const size_t unit = sizeof(cplx) * (size_t)c->g.total;
-    const size_t need[5] = {std::max(dist_buffer_bytes(c, 0), 6 * unit), std::max(dist_buffer_bytes(c, 0), 6 * unit),
-                            std::max(dist_buffer_bytes(c, 1), 8 * unit), std::max(dist_buffer_bytes(c, 1), 8 * unit), kIpcMailboxBytes};
+    const size_t need[5] = {dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 0), dist_buffer_bytes(c, 1), dist_buffer_bytes(c, 1),
+                            kIpcMailboxBytes};
     size_t tot = 0;
     for (int w = 0; w < 5; ++w) {
         s->off[w] = tot;
@@ -339,8 +341,8 @@ int ofdft_ipc_attach(ofdft_ctx* c, int peer, const void* handle64, const unsigne
     std::memcpy(&h, handle64, sizeof(h));
     if (!s->peer_base[peer] || std::memcmp(&h, &s->peer_handle[peer], sizeof(h)) != 0) {
         for (int w = 0; w < 5; ++w) s->peer[w][peer] = nullptr;
-        if (s->peer_base[peer]) {
-            (void)hipIpcCloseMemHandle(s->peer_base[peer]);
+        if (s->peer_base[peer]) {          // the peer has outgrown that arena: the mapping stays open until this context dies
+            s->old_peer_bases.push_back(s->peer_base[peer]);
             s->peer_base[peer] = nullptr;
         }
         void* ptr = nullptr;
@@ -379,6 +381,8 @@ int ofdft_ipc_detach(ofdft_ctx* c) {
             }
         }
     }
+    for (void* q : s->old_peer_bases) (void)hipIpcCloseMemHandle(q);
+    s->old_peer_bases.clear();
     return OFDFT_OK;
 }
 
