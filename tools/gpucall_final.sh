@@ -40,7 +40,7 @@ else
   echo "bench 512 done"
   timeout -k 10 300 python bench.py --grid 64 --cfg cfg2 --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench_64_cfg2.json 2> gpurun_out/${TAG}_bench_64_cfg2.err
   echo "bench 64 rc=$?"
-  OFDFT_BENCH_SHARE_GPU=1 OFDFT_BENCH_BACKEND=gloo timeout -k 10 500 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks.json 2> gpurun_out/${TAG}_bench_2ranks.err
+  OFDFT_BENCH_SHARE_GPU=1 OFDFT_BENCH_BACKEND=gloo timeout -k 10 500 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_2ranks.json 2> >(tee gpurun_out/${TAG}_bench_2ranks.err | grep --line-buffered scale_512 >&2)
   echo "two-rank rehearsal rc=$?"
   bash tools/ipc_timeline.sh ${TAG}_ipctl 256 > gpurun_out/${TAG}_ipctl.log 2>&1
   echo "ipc timeline rc=$?"
