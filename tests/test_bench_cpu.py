@@ -121,6 +121,29 @@ def test_bench_workload_is_pinned_to_the_reference():
     assert n_elec == ref['cfg3_128']['n_elec']
 
 
+def test_gradient_pin_of_the_bench_workload_accepts_the_reference_and_rejects_a_wrong_gradient():
+    """round-4 verdict item 7: `reference_check` compares chi.grad of the timed call (L2 norm, sum, eight probes) with the
+    reference's closure output; `grad_stats` forms the statistics from a tensor (whole grid, or one rank's x-slab)"""
+    import torch
+    with open(os.path.join(ROOT, 'tests', 'golden', 'bench_scalars.json')) as fh:
+        r = json.load(fh)['cfg3_64']
+    g = r['grad']
+    ok = bench.reference_check(64, 'cfg3', 'f64', r['E'], r['mu'], dict(g))
+    assert ok['ok'] and ok['grad_rel_dl2'] == 0.0 and ok['grad_probe_max_rel'] == 0.0
+    for key, val in (('l2', g['l2'] * (1 + 1e-7)), ('sum', g['sum'] + 1e-6 * g['l2'] * 64 ** 1.5), ('probes', [p * (1 + 1e-6) for p in g['probes']])):
+        bad = bench.reference_check(64, 'cfg3', 'f64', r['E'], r['mu'], dict(g, **{key: val}))
+        assert not bad['ok'], key
+    assert bench.reference_check(64, 'cfg3', 'f32', r['E'], r['mu'], dict(g, l2=g['l2'] * (1 + 1e-5)))['ok']        # fp32 bar: 5e-4
+    # grad_stats: a whole grid and its two x-slabs give the same probes (each slab contributes the probes that fall into it)
+    t = torch.arange(8 * 6 * 4, dtype=torch.double).reshape(8, 6, 4) * 0.01 - 0.5
+    whole = bench.grad_stats(t)
+    assert abs(whole['sum'] - float(t.sum())) < 1e-12 and abs(whole['l2'] - float((t * t).sum().sqrt())) < 1e-12
+    assert whole['probes'] == [float(t.reshape(-1)[i]) for i in whole['probe_idx']]
+    parts = [bench.grad_stats(t[:4], None, 0, t.numel()), bench.grad_stats(t[4:], None, 4, t.numel())]
+    assert [a + b for a, b in zip(parts[0]['probes'], parts[1]['probes'])] == whole['probes']
+    assert abs(parts[0]['sum'] + parts[1]['sum'] - whole['sum']) < 1e-12
+
+
 def test_oracle_reproduces_the_bench_pin_at_64():
     """the CPU restatement (cpu_baseline leg) on the bench recipe equals the reference's closure energy"""
     import torch
