@@ -98,7 +98,12 @@ template <int LEN, int NIN, int NOUT> constexpr bool xc_one_buffer() {
 #endif
 // waves per SIMD the kernel is compiled for: with one cross buffer twice the workgroups fit the LDS
 template <int LEN, int NIN, int NOUT> constexpr int xc_waves() {
-    return (xc_one_buffer<LEN, NIN, NOUT>() && NIN + NOUT <= 3 && OFDFT_XC_WAVES < 4) ? 2 * OFDFT_XC_WAVES : OFDFT_XC_WAVES;
+    // (the 1 -> 2 pass needs ~144 VGPRs in fp64: compiled for twice the waves it spills 68 bytes per thread.  With A = 4 waves per
+    // workgroup three workgroups fit a CU at its natural register count and the spill-free kernel is 7 % faster (256-point lines:
+    // 5.75 -> 5.35 ps per point); with A = 8 only the capped kernel gets a second workgroup onto the CU and wins by 5 % (512-point
+    // lines: 5.65 against 5.95) -- profiles/r05_ab_spill.jsonl)
+    return (xc_one_buffer<LEN, NIN, NOUT>() && (NIN + NOUT <= 2 || XcWaves<LEN>::A >= 8) && OFDFT_XC_WAVES < 4) ? 2 * OFDFT_XC_WAVES
+                                                                                                                  : OFDFT_XC_WAVES;
 }
 // cache policy of the data loads: a tile of whole 128-byte runs is read once by ONE wave -> nt (256^3: the WGC99 pair 452 -> 405 us);
 // narrower tiles (64-byte runs: the partner workgroup reads the other half of every cache line) keep the lines cached
