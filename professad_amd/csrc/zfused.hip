@@ -120,7 +120,7 @@ int launch_zi_combine(ofdft_ctx* c, const ZCombineArgs& a, int* blocks_out, hipS
     cplx *twM, *twN;
     if (int rc = z_tables(c, &twM, &twN)) return rc;
     SpecGeom gq = c->g;
-    const size_t park = sizeof(double) * 256 * kCombineScalars;
+    const size_t park = sizeof(real) * 256 * kParkSlots;
 #define X(M_)                                                                                                     \
     case M_: {                                                                                                    \
         using W = ZW<M_, ZPick<M_, EZ>::E>;                                                                       \

@@ -26,7 +26,7 @@ namespace ofdft {
 #define OFDFT_Z_PREFETCH 1     // depth-one software pipeline over the spectra a fused z kernel consumes (z_issue_row)
 #endif
 #ifndef OFDFT_Z_PIPE_BIG_F32
-#define OFDFT_Z_PIPE_BIG_F32 1  // fp32 build: the depth-one pipeline of zi_combine also for rows of 1024 points
+#define OFDFT_Z_PIPE_BIG_F32 0  // fp32 build: the depth-one pipeline of zi_combine also for rows of 1024 points (see zi_combine_waves)
 #endif
 #ifndef OFDFT_ZI_ROOTS_ONCE
 #define OFDFT_ZI_ROOTS_ONCE 0   // zi_combine: n^(-1/6) of every point kept in registers for all sections (1) or formed per section (0)
@@ -845,8 +845,21 @@ __device__ __forceinline__ real wgc_row_section(const cplx (&n)[E], cplx (&vacc)
     return e;
 }
 
+// parked energy sums of zi_combine (slot numbers): ion-electron, Hartree, vW, Wang-Teter, WGC99
+constexpr int kParkIe = 0, kParkH = 1, kParkVw = 2, kParkWt = 3, kParkWgc = 4, kParkSlots = 5;
+// waves per SIMD zi_combine is compiled for.  fp32 build, rows of 1024 points, lean instantiation (OFDFT_ZI_WAVES_BIG_F32): with the
+// park area at 5 KB the LDS no longer caps the kernel at three workgroups per CU, and FOUR waves per SIMD without the depth-one
+// pipeline (125 VGPRs) beat three with it (141): 7.1-7.3 -> 6.4-6.5 ps per point at 1024-point rows; the pipeline squeezed into 128
+// registers spills (10.2), five waves spill more (16.2) -- profiles/r05_ab_zi_waves.jsonl
+#ifndef OFDFT_ZI_WAVES_BIG_F32
+#define OFDFT_ZI_WAVES_BIG_F32 4
+#endif
+template <int M, int E, bool WGC_INLINE> constexpr int zi_combine_waves() {
+    if (sizeof(real) == 4 && M >= 512 && E <= 8 && !WGC_INLINE) return OFDFT_ZI_WAVES_BIG_F32;
+    return z_waves<M, E>(2);
+}
 template <int M, int E, bool WGC_INLINE>
-__global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM_g,
+__global__ __launch_bounds__(256, (zi_combine_waves<M, E, WGC_INLINE>())) void zi_combine_kernel(ZCombineArgs a, SpecGeom g, const cplx* __restrict__ twM_g,
                                                          const cplx* __restrict__ twN_g, acc_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) real lds[];
     const cplx *twM, *twN;
@@ -857,9 +870,11 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     // Each energy sum is touched by ONE section only: it is accumulated in a local and parked in the thread's own LDS
     // slots when the section ends (9 live doubles less through the register-hungry WGC99 section; no barrier needed,
     // a thread only reads what it wrote).  The final reduction order is unchanged.
-    acc_t* park = reinterpret_cast<acc_t*>(lds + ZW<M, E>::LDS / sizeof(real)) + threadIdx.x;
+    // (five slots of the grid precision -- the parked values ARE of that precision: 5 KB per workgroup in the fp32 build, where the ten
+    // fp64 slots of rounds 2-4, 20 KB, held the kernel to three workgroups per CU at 1024-point rows)
+    real* park = lds + ZW<M, E>::LDS / sizeof(real) + threadIdx.x;
 #pragma unroll
-    for (int s = 0; s < kCombineScalars; ++s) park[s * 256] = 0.0;
+    for (int s = 0; s < kParkSlots; ++s) park[s * 256] = 0.0;
     cplx n[E], vacc[E], w[E];
     z_load_real<M, E, true>(n, z, a.ds.src);
     z_tw_commit<M, E>(lds, twq, twM_g, twN_g, twM, twN);
@@ -897,9 +912,9 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     // present one before transforming its own (z_issue_row).
     // (not at M = 512 -- rows of 1024 -- where E = 8: the extra row would push the kernel past 256 registers, i.e. from
     // two waves per SIMD to one)
-    // (round 5: the fp32 build keeps the pipeline at M = 512 -- 8 more complex registers are 16 VGPRs there, the kernel stays
-    // at three waves per SIMD, and without it a wave had ONE row of ONE array in flight: 12 waves x 4 KB per CU against the
-    // ~40 KB a CU must keep in flight at 5 TB/s -- zi_combine at 1024-point rows ran at 0.33 of the peak)
+    // (round 5, fp32 build at M = 512: the pipeline costs 16 VGPRs there; with three workgroups per CU -- the old 20-KB park area's
+    // cap -- it lifted the kernel from 0.33 to 0.39 of the peak, but a fourth wave per SIMD without it does better still, 0.43 -> 0.47:
+    // OFDFT_Z_PIPE_BIG_F32 / OFDFT_ZI_WAVES_BIG_F32)
     constexpr bool PIPE = OFDFT_Z_PREFETCH && !WGC_INLINE && (M < 512 || (sizeof(real) == 4 && OFDFT_Z_PIPE_BIG_F32));
     const bool gga = (a.mask & (7u << 10)) != 0;
     const cplx* chain[6] = {(a.mask & 2u) ? a.vh : nullptr,  (a.mask & 8u) ? a.lap : nullptr, (a.mask & 16u) ? a.conv_b : nullptr,
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
             vacc[q].x += x0;
             vacc[q].y += x1;
         }
-        park[1 * 256] = e;
+        park[kParkH * 256] = e;
     }
     if (a.mask & 8u) {                                   // vW  functionals.py:245; tools_for_tests.py:23-26
         take_row(std::integral_constant<int, 1>{}, a.lap);
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
             vacc[q].x += -0.5 * x0 * r0;
             vacc[q].y += -0.5 * x1 * r1;
         }
-        park[3 * 256] = e;
+        park[kParkVw * 256] = e;
     }
     if (a.mask & 16u) {                                  // WT family  functionals.py:650-651; tools_for_tests.py:29-39
         take_row(std::integral_constant<int, 2>{}, a.conv_b);
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
             vacc[q].x += ctf * f * pa1[q].x * x0;
             vacc[q].y += ctf * f * pa1[q].y * x1;
         }
-        park[4 * 256] = e;
+        park[kParkWt * 256] = e;
         if (a.conv_a) {
             take_row(std::integral_constant<int, 3>{}, a.conv_a);
 #pragma unroll
@@ -981,7 +996,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
     }
     if (a.mask & 32u) {                                  // WGC99
         if (WGC_INLINE) {
-            park[5 * 256] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, sc, ctf);
+            park[kParkWgc * 256] = wgc_row_section<M, E>(n, vacc, w, z, a, g, twM, twN, sc, ctf);
         } else if (!a.v_part_deferred) {                 // computed by zi_wgc_kernel on the nonlocal chain's stream
             z_load_real<M, E, true>(w, z, a.v_part);
 #pragma unroll
@@ -1020,7 +1035,7 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
             vacc[q].x += ve[q].x;
             vacc[q].y += ve[q].y;
         }
-        park[0] = e;
+        park[kParkIe * 256] = e;
     }
     acc_t acc[kCombineScalars];
 #pragma unroll
@@ -1054,11 +1069,11 @@ __global__ __launch_bounds__(256, (z_waves<M, E>(2))) void zi_combine_kernel(ZCo
         }
         acc[8] += vacc[q].x * n[q].x + vacc[q].y * n[q].y;
     }
-    acc[0] = park[0];
-    acc[1] = park[1 * 256];
-    acc[3] = park[3 * 256];
-    acc[4] = park[4 * 256];
-    acc[5] = park[5 * 256];
+    acc[0] = park[kParkIe * 256];
+    acc[1] = park[kParkH * 256];
+    acc[3] = park[kParkVw * 256];
+    acc[4] = park[kParkWt * 256];
+    acc[5] = park[kParkWgc * 256];
     if (!z.valid) {
 #pragma unroll
         for (int s = 0; s < kCombineScalars; ++s) acc[s] = 0.0;
