@@ -290,7 +290,7 @@ def scale_512_block(dist, device, backend, rank, world, tdtype, names, box256, c
         out['ms_Ngpu'][tr] = round(float(tt[0]) / steps * 1e3, 4)
         out['xchg_chunks'] = eng.stages.nchunks
         out['rel_dE_vs_8x_256'] = abs(sum(E.values()) - 8.0 * E256) / abs(8.0 * E256)
-        eng.close()
+        eng.close(sync_peers=True)          # (every rank is here: peers let go of each other's arenas before any is freed)
         del chi, vext, g
     if rank == 0:          # the one-GPU leg: this rank alone on the whole 512^3 grid (the others wait at the barrier below)
         try:
@@ -488,11 +488,11 @@ def main():
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if bool(bad[0] > 0.5):
                 transport_probe['ipc']['disagrees_with_collective'] = True
-                cands.pop('ipc')[0].close()
+                cands.pop('ipc')[0].close(sync_peers=True)
         transport = min(cands, key=lambda k: cands[k][1])
         for k in list(cands):
             if k != transport:
-                cands.pop(k)[0].close()
+                cands.pop(k)[0].close(sync_peers=True)          # (the same engines on every rank, in the same order)
         eng = cands[transport][0]
         chi_h, vext_h = np.ascontiguousarray(chi_h[xs]), np.ascontiguousarray(vext_h[xs])
         raw = eng.stages
@@ -675,7 +675,7 @@ def main():
     if world > 1 and (n == 256 or os.environ.get('OFDFT_BENCH_SCALE_ANY_GRID') == '1') and a.cfg == 'cfg3' and os.environ.get('OFDFT_BENCH_NO_SCALE512') != '1':
         # the 512^3 one-GPU / N-GPU pair of the north star, inside this very command (the driver passes no --grid)
         working = [tr for tr, v in (transport_probe or {}).items() if not v.get('failed') and not v.get('disagrees_with_collective')]
-        eng.close()
+        eng.close(sync_peers=True)
         del g
         if rank == 0:       # the primary line survives whatever happens in the optional block (a copy on stderr; stdout stays ONE line)
             sys.stderr.write('bench.py: 256^3 line before the optional scale_512 block: %s\n' % json.dumps(out))
