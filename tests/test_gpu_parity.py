@@ -203,6 +203,33 @@ def test_folded_wgc99_table_reads_change_nothing(shape, cell):
         assert abs(sum(Ea.values()) - Ec) <= E_RTOL * max(1.0, abs(Ec)) and relerr(ga.cpu().numpy(), go) < V_RTOL
 
 
+@pytest.mark.parametrize('dt', [torch.double, torch.float32])
+def test_views_that_are_not_16_byte_aligned_give_the_same_numbers(dt):
+    """chi handed over as a contiguous VIEW into a larger tensor (offsets of 1..3 elements: 4- / 8- / 12-byte alignment): the
+    streaming kernels' 16-byte accesses (round 5) fall back to pairs, everything else takes the pointer as it is"""
+    shape = (64, 64, 64)
+    box = dev(synth.cubic_cell(64))
+    chi_h = np.sqrt(synth.smooth_density(shape, seed=3))
+    vext = torch.as_tensor(synth.random_potential(shape, seed=4), dtype=dt, device=DEV)
+    n = int(np.prod(shape))
+    big = torch.zeros(n + 8, dtype=dt, device=DEV)
+    ref = None
+    for off in (0, 1, 2, 3):
+        chi = big[off:off + n].view(shape)
+        chi.copy_(torch.as_tensor(chi_h, dtype=dt))
+        from professad_amd import _native as N
+        eng = Engine(shape, DEV, dtype=dt).set_cell(box).set_terms(['ion_electron', 'hartree', 'tf', 'vw', 'wgc99_nl', 'pbe_x', 'pbe_c'])
+        eng.set_option(N.OPT_RESIDENT, 0)
+        E, mu, g = eng.energy_grad_chi(chi, 96.0, vext)
+        eng.close()
+        cur = (sum(E.values()), mu, g.double())
+        if ref is None:
+            ref = cur
+        tol = 1e-13 if dt == torch.double else 1e-6
+        assert abs(cur[0] - ref[0]) <= tol * abs(ref[0]) and abs(cur[1] - ref[1]) <= tol * abs(ref[1]), (off, cur[0], ref[0])
+        assert float((cur[2] - ref[2]).abs().max()) <= tol * float(ref[2].abs().max()), off
+
+
 # ------------------------------------------------------------------------------- oracle on seeded inputs
 @pytest.mark.parametrize('shape,cell', [((64, 64, 64), ('cubic', 64)), ((32, 64, 16), ('tri', 1.3)),
                                         ((24, 20, 18), ('tri', 0.8)), ((33, 32, 31), ('cubic', 32))])
