@@ -414,7 +414,10 @@ def main():
         # A slab rank runs three compute streams, two RCCL communicators (one per chain) or two communication streams of the ipc
         # transport: more streams than the runtime's default of four hardware queues per process, and streams that share a queue
         # serialise -- which would couple the chains' exchanges again.  Must be set before the first HIP call of the process.
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+        # (rehearsals with the ranks SHARING one GPU keep the default: four processes x eight queues oversubscribe the card's hardware
+        # queues and the scheduler time-slices them -- a 128^3 evaluation on four ranks took 87 ms instead of 2 ms)
+        if os.environ.get('OFDFT_BENCH_SHARE_GPU') != '1':
+            os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # (a collective that a failed rank never joins must not hold the job for the backend's default ten minutes)
