@@ -82,8 +82,12 @@ def test_slab_decomposed_over_rccl_matches_single_gpu(shape, dtype, tmp_path):
     (raw-pointer tensors), two overlapped chains, device-resident scalars -- against one engine on rank 0's GPU.
     Runs wherever the box has >= 2 GPUs (a one-GPU box cannot host two RCCL ranks)."""
     world = 2 if _gpu_count() < 4 else 4
-    for transport in ('collective', 'ipc'):          # RCCL all-to-alls issued by the host; peer copies issued by the library
-        env = {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_TEST_TRANSPORT': transport}
+    # 'collective2': the opt-in second RCCL communicator for the nonlocal chain (Comm: OFDFT_COMM_TWO_GROUPS=1 with eight hardware
+    # queues per process) -- its first run on real peers happens here, wherever a box with >= 2 GPUs runs this suite
+    for transport in ('collective', 'ipc', 'collective2'):          # RCCL all-to-alls issued by the host; peer copies issued by the library
+        env = {'OFDFT_TEST_BACKEND': 'nccl', 'OFDFT_TEST_TRANSPORT': transport.rstrip('2')}
+        if transport == 'collective2':
+            env.update(OFDFT_COMM_TWO_GROUPS='1', GPU_MAX_HW_QUEUES='8')
         if shape == '64x64x64' and world == 2:       # ... and the kz-chunked exchange against the unchunked one on the same GPUs
             env['OFDFT_TEST_XCHG_CHUNKS'] = '2'      # (256^3 runs chunked by the automatic choice)
         res = _run_workers(world, shape, dtype, str(tmp_path / ('res_%s.json' % transport)), env, timeout=600)
